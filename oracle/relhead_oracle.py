@@ -1,0 +1,464 @@
+"""CPU oracle for the pairwise relation-prediction path.  TEST INFRASTRUCTURE ONLY.
+
+This file is a literal, un-restructured float32 restatement (PyTorch CPU ops + plain Python
+loops) of the reference's algorithm for the hot path.  It is the checker: only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import it.  Nothing under
+``scene_graph_commonsense_amd/`` imports it and the product path never falls back to it.
+
+Parity pinning: ``tests/golden/make_golden.py`` imports the real reference from
+``/root/reference`` (in the build container only) and stores its outputs for seeded inputs under
+``tests/golden/*.npz``; ``tests/test_oracle_golden.py`` checks this restatement against every one
+of those vectors (the reference itself has no tests or golden vectors).
+
+Reference map (all paths relative to the reference repo):
+  build_masks              train_test.py:164-169 (= :365-370, evaluate.py:111-116)
+  super_class_multihot     utils.py:136-149      (quirk: only first and last list entries are set)
+  conv_trunk               model.py:138-150
+  concat_labels            model.py:152-168
+  classifier_forward       model.py:170-186 (hierarchical), model.py:96-102 (flat)
+  bayes_head               model.py:24-34
+  overlap_filter           train_test.py:403-408
+  class_weights            train_test.py:104-105, utils.py:258-268
+  relationship_loss        train_utils.py:116-157, utils.py:28-35
+  direction_step_loss      train_utils.py:64-94
+  run_pair_loop            train_test.py:174-258 (train) / :373-437 (test), train_utils.py:160-196
+  OracleEvaluator          evaluator.py:118-367, :568-583
+  OracleEvaluatorTop3      evaluator.py:639-790
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+
+
+# --------------------------------------------------------------------------- inputs
+def build_masks(bbox: Tensor, feature_size: int) -> Tensor:
+    """[n,4] boxes (x0,x1,y0,y1) -> [n,F,F] bool; int() truncation and slice clipping."""
+    n = bbox.shape[0]
+    mask = torch.zeros(n, feature_size, feature_size, dtype=torch.bool)
+    for j in range(n):
+        x0, x1, y0, y1 = (int(bbox[j][k]) for k in range(4))
+        mask[j, y0:y1, x0:x1] = True
+    return mask
+
+
+def super_class_multihot(s_list: Sequence[Tensor], num_super: int) -> Tensor:
+    """Multi-hot over super-classes; for a k-element list only element 0 and k-1 are set."""
+    out = torch.zeros(len(s_list), num_super, dtype=torch.int64)
+    for r, s in enumerate(s_list):
+        out[r, int(s[0])] += 1
+        k = len(s)
+        if 2 <= k <= 4:
+            out[r, int(s[k - 1])] += 1
+    return out
+
+
+def overlap_filter(mask_g: Tensor, mask_e: Tensor) -> Tensor:
+    """[b,1,F,F] bool x2 -> [b] bool: sum(or)/sum(and), inf->0, >0."""
+    s_or = torch.logical_or(mask_g, mask_e).sum(-1).sum(-1)
+    s_and = torch.logical_and(mask_g, mask_e).sum(-1).sum(-1)
+    r = (s_or / s_and).flatten()
+    r[torch.isinf(r)] = 0
+    return r > 0
+
+
+# --------------------------------------------------------------------------- model
+def conv_trunk(sd: Dict[str, Tensor], h_sub: Tensor, h_obj: Tensor, drop1: Optional[Tensor] = None) -> Tensor:
+    a = torch.tanh(F.conv2d(h_sub, sd["conv1_1.weight"], sd["conv1_1.bias"]))
+    b = torch.tanh(F.conv2d(h_obj, sd["conv1_2.weight"], sd["conv1_2.bias"]))
+    h = torch.cat((a, b), dim=1)
+    h = F.max_pool2d(F.relu(F.conv2d(h, sd["conv2_1.weight"], sd["conv2_1.bias"], padding=1)), 2, 2)
+    h = F.max_pool2d(F.relu(F.conv2d(h, sd["conv3_1.weight"], sd["conv3_1.bias"], padding=1)), 2, 2)
+    h = h.reshape(h.shape[0], -1)
+    h = F.relu(F.linear(h, sd["fc1.weight"], sd["fc1.bias"]))
+    if drop1 is not None:          # injected dropout mask already scaled by 1/(1-p)
+        h = h * drop1
+    return h
+
+
+def concat_labels(h: Tensor, c1: Tensor, c2: Tensor, s1, s2, num_classes: int, num_super: int) -> Tensor:
+    o1 = F.one_hot(c1, num_classes=num_classes)
+    o2 = F.one_hot(c2, num_classes=num_classes)
+    if s1 is not None:
+        m1 = super_class_multihot(s1, num_super)
+        m2 = super_class_multihot(s2, num_super)
+        return torch.cat((h, o1, o2, m1, m2), dim=1)
+    return torch.cat((h, o1, o2), dim=1)
+
+
+def bayes_head(sd: Dict[str, Tensor], p: Tensor, T=(1.0, 1.0, 1.0)):
+    sup = F.log_softmax(F.linear(p, sd["fc5.weight"], sd["fc5.bias"]), dim=1)
+    rels = []
+    for k, name in enumerate(("fc3_1", "fc3_2", "fc3_3")):
+        r = F.linear(p, sd[name + ".weight"], sd[name + ".bias"])
+        rels.append(F.log_softmax(r / T[k], dim=1) + sup[:, k].view(-1, 1))
+    return rels[0], rels[1], rels[2], sup
+
+
+def classifier_forward(sd: Dict[str, Tensor], h_sub: Tensor, h_obj: Tensor, c1: Tensor, c2: Tensor, s1, s2,
+                       num_classes: int = 150, num_super: int = 17, hierarchical: bool = True,
+                       drop1: Optional[Tensor] = None, drop2: Optional[Tensor] = None, T=(1.0, 1.0, 1.0)):
+    """Hierarchical: (rel1, rel2, rel3, super, connectivity[b,1], hidden[b,512]).
+    Flat: (relation[b,R] raw logits, connectivity[b,1], hidden)."""
+    h = conv_trunk(sd, h_sub, h_obj, drop1)
+    hc = concat_labels(h, c1, c2, s1, s2, num_classes, num_super)
+    p = F.relu(F.linear(hc, sd["fc2.weight"], sd["fc2.bias"]))
+    if drop2 is not None:
+        p = p * drop2
+    conn = F.linear(p, sd["fc4.weight"], sd["fc4.bias"])
+    if hierarchical:
+        r1, r2, r3, sup = bayes_head(sd, p, T)
+        return r1, r2, r3, sup, conn, p
+    rel = F.linear(p, sd["fc3.weight"], sd["fc3.bias"])
+    return rel, conn, p
+
+
+# --------------------------------------------------------------------------- loss
+def class_weights(counts: Tensor) -> Tensor:
+    counts = counts.float()
+    return 1 - counts / torch.sum(counts)
+
+
+def relationship_loss(relation: Tensor, super_relation: Optional[Tensor], connected: Tensor, target_row: Tensor,
+                      weights: Tensor, ng: int, npos: int, hierarchical: bool = True) -> Tensor:
+    tgt = target_row[connected]
+    if not hierarchical:
+        return F.cross_entropy(relation[connected], tgt, weight=weights)
+    sup_t = tgt.clone()
+    sup_t[tgt < ng] = 0
+    sup_t[torch.logical_and(tgt >= ng, tgt < ng + npos)] = 1
+    sup_t[tgt >= ng + npos] = 2
+    loss = F.nll_loss(super_relation[connected], sup_t)
+    bounds = [(0, ng), (ng, ng + npos), (ng + npos, relation.shape[1])]
+    for lo, hi in bounds:
+        sel = torch.nonzero(torch.logical_and(tgt >= lo, tgt < hi)).flatten()
+        if sel.numel() > 0:
+            loss = loss + F.nll_loss(relation[:, lo:hi][connected][sel], tgt[sel] - lo, weight=weights[lo:hi])
+    return loss
+
+
+def direction_step_loss(relation, super_relation, conn, rel_row, dir_row, first_direction: bool, weights,
+                        ng, npos, hierarchical=True, lambda_not_connected=1.0):
+    """One (graph_iter, edge_iter, direction) step -> (loss_relationship, loss_connectivity)."""
+    flag = 1 if first_direction else 0
+    not_connected = torch.where(dir_row != flag)[0]
+    connected = torch.where(dir_row == flag)[0]
+    c = conn[:, 0]
+    loss_conn = 0.0
+    if len(not_connected) > 0:     # BCE mean over an empty set is NaN -> 0.0 in the reference
+        loss_conn = lambda_not_connected * F.binary_cross_entropy_with_logits(
+            c[not_connected], torch.zeros(len(not_connected)))
+    loss_rel = 0.0
+    if len(connected) > 0:
+        # overwrite (not add): the not-connected term is dropped whenever the step has a connected pair
+        loss_conn = F.binary_cross_entropy_with_logits(c[connected], torch.ones(len(connected)))
+        loss_rel = relationship_loss(relation, super_relation, connected, rel_row, weights, ng, npos, hierarchical)
+    return loss_rel, loss_conn, connected, not_connected
+
+
+# --------------------------------------------------------------------------- pair loop
+def run_pair_loop(sd: Dict[str, Tensor], batch, cfg, mode: str = "eval", evaluator=None, evaluator_top3=None,
+                  weights: Optional[Tensor] = None, lambda_connectivity: float = 0.1,
+                  lambda_not_connected: float = 1.0, overlap_filtering: Optional[bool] = None,
+                  max_steps: Optional[int] = None, step_filter=None):
+    """The reference's nested (graph_iter, edge_iter) x 2-direction loop.
+
+    mode 'eval' mirrors ``testing()`` (overlap filter on, steps with no overlapping image skipped),
+    mode 'train' mirrors ``training()`` (iou_mask all ones, loss with the running-sum quirk; dropout
+    is not applied - parity is checked in eval-mode numerics).
+    Returns dict(records=[per direction-step dict], losses=scalar tensor or None).
+    """
+    Fs = cfg.feature_size
+    B = batch.image_feature.shape[0]
+    hier = cfg.hierarchical
+    ng, npos = cfg.num_geometric, cfg.num_possessive
+    if overlap_filtering is None:
+        overlap_filtering = (mode == "eval")
+    masks = [build_masks(b, Fs) for b in batch.bbox]
+    n_obj = torch.as_tensor([len(m) for m in masks])
+    relations_target, direction_target = [], []
+    for g in range(int(n_obj.max()) - 1):
+        keep = torch.nonzero(n_obj - 1 > g).view(-1)
+        relations_target.append(torch.vstack([batch.relationships[i][g] for i in keep]).T)
+        direction_target.append(torch.vstack([batch.subj_or_obj[i][g] for i in keep]).T)
+
+    records = []
+    losses = 0.0
+    run_rel, run_conn = 0.0, 0.0
+    nsteps = 0
+    for g in range(int(n_obj.max())):
+        keep = torch.nonzero(n_obj > g).view(-1)
+        gm = torch.stack([masks[i][g].unsqueeze(0) for i in keep])
+        h_graph = torch.cat((batch.image_feature[keep] * gm, batch.image_depth[keep] * gm), dim=1)
+        cat_g = torch.tensor([int(batch.categories[i][g]) for i in keep])
+        sp_g = [batch.super_categories[i][g] for i in keep] if batch.super_categories is not None else None
+        bb_g = torch.stack([batch.bbox[i][g] for i in keep])
+        for e in range(g):
+            if max_steps is not None and nsteps >= max_steps:
+                break
+            if step_filter is not None and not step_filter(g, e):
+                continue
+            em = torch.stack([masks[i][e].unsqueeze(0) for i in keep])
+            h_edge = torch.cat((batch.image_feature[keep] * em, batch.image_depth[keep] * em), dim=1)
+            cat_e = torch.tensor([int(batch.categories[i][e]) for i in keep])
+            sp_e = [batch.super_categories[i][e] for i in keep] if batch.super_categories is not None else None
+            bb_e = torch.stack([batch.bbox[i][e] for i in keep])
+            if overlap_filtering:
+                iou_mask = overlap_filter(gm, em)
+                if torch.sum(iou_mask) == 0:
+                    continue
+            else:
+                iou_mask = torch.ones(len(keep), dtype=torch.bool)
+            nsteps += 1
+            for first in (True, False):
+                hs, ho = (h_graph, h_edge) if first else (h_edge, h_graph)
+                cs, co = (cat_g, cat_e) if first else (cat_e, cat_g)
+                ss, so = (sp_g, sp_e) if first else (sp_e, sp_g)
+                bs, bo = (bb_g, bb_e) if first else (bb_e, bb_g)
+                out = classifier_forward(sd, hs, ho, cs, co, ss, so, cfg.num_classes, cfg.num_super_classes, hier)
+                if hier:
+                    r1, r2, r3, sup, conn, hidden = out
+                    relation = torch.cat((r1, r2, r3), dim=1)
+                else:
+                    relation, conn, hidden = out
+                    sup = None
+                rel_row = relations_target[g - 1][e]
+                dir_row = direction_target[g - 1][e]
+                flag = 1 if first else 0
+                not_connected = torch.where(dir_row != flag)[0]
+                directed = rel_row.clone()
+                directed[not_connected] = -1
+                if mode == "train":
+                    lr_, lc_, _, _ = direction_step_loss(relation, sup, conn, rel_row, dir_row, first, weights, ng,
+                                                         npos, hier, lambda_not_connected)
+                    run_rel = run_rel + lr_
+                    run_conn = run_conn + lc_
+                    losses = losses + run_rel + lambda_connectivity * run_conn
+                logsig = torch.log(torch.sigmoid(conn[:, 0]))
+                if evaluator is not None:
+                    evaluator.accumulate(keep, relation.detach(), directed, None if sup is None else sup.detach(),
+                                         logsig.detach(), cs, co, cs, co, bs, bo, bs, bo, iou_mask)
+                if evaluator_top3 is not None and hier:
+                    evaluator_top3.accumulate(keep, relation.detach(), directed, sup.detach(), logsig.detach(),
+                                              cs, co, cs, co, bs, bo, bs, bo, iou_mask)
+                records.append(dict(g=g, e=e, first=first, keep=keep.clone(), relation=relation.detach(),
+                                    super_relation=None if sup is None else sup.detach(),
+                                    connectivity=conn.detach()[:, 0], hidden=hidden.detach(),
+                                    iou_mask=iou_mask.clone(), target=directed))
+    return dict(records=records, losses=losses if mode == "train" else None)
+
+
+# --------------------------------------------------------------------------- evaluator
+def grid_iou(bt, bp, feature_size: int) -> float:
+    """Rectangles rasterised with int() truncation on the FxF grid; union==0 -> 0."""
+    mp = torch.zeros(feature_size, feature_size)
+    mp[int(bp[2]):int(bp[3]), int(bp[0]):int(bp[1])] = 1
+    mt = torch.zeros(feature_size, feature_size)
+    mt[int(bt[2]):int(bt[3]), int(bt[0]):int(bt[1])] = 1
+    inter = torch.sum(torch.logical_and(mt, mp))
+    union = torch.sum(torch.logical_or(mt, mp))
+    return 0 if union == 0 else float(inter) / float(union)
+
+
+class OracleEvaluator:
+    """Recall@K with three candidates per directed pair (hierarchical) or one (flat).
+
+    Deviation from the reference, on purpose and documented in DESIGN.md: the per-image ranking
+    uses a *stable* descending sort (ties keep append order); the reference's ``torch.argsort`` is
+    unstable on ties, so index parity is only defined under a stable order.
+    """
+
+    def __init__(self, cfg, top_k=(20, 50, 100), iou_thresh=0.5, zero_shot_triplets=None, train_triplets=None):
+        self.cfg = cfg
+        self.hier = cfg.hierarchical
+        self.top_k = list(top_k)
+        self.iou_thresh = iou_thresh
+        self.R = cfg.num_relations
+        self.zero_shot = set(zero_shot_triplets) if zero_shot_triplets is not None else None
+        self.train_triplets = train_triplets
+        self.result_dict = {k: 0.0 for k in self.top_k}
+        self.result_per_class = {k: torch.zeros(self.R) for k in self.top_k}
+        self.num_connected_target = 0.0
+        self.num_conn_target_per_class = torch.zeros(self.R)
+        self.result_dict_zs = {k: 0.0 for k in self.top_k}
+        self.result_per_class_zs = {k: torch.zeros(self.R) for k in self.top_k}
+        self.num_connected_target_zs = 0.0
+        self.num_conn_target_per_class_zs = torch.zeros(self.R)
+        self.clear_data()
+
+    def clear_data(self):
+        self.which, self.conf, self.conn, self.pred = [], [], [], []
+        self.scat, self.ocat, self.sbox, self.obox = [], [], [], []
+        self.which_t, self.rel_t, self.scat_t, self.ocat_t, self.sbox_t, self.obox_t = [], [], [], [], [], []
+        self.last_sorted = {}
+
+    def accumulate(self, which_in_batch, relation_pred, relation_target, super_relation_pred, connectivity,
+                   subject_cat_pred, object_cat_pred, subject_cat_target, object_cat_target,
+                   subject_bbox_pred, object_bbox_pred, subject_bbox_target, object_bbox_target, iou_mask,
+                   predcls=True, cat_subject_confidence=None, cat_object_confidence=None):
+        ng, npos = self.cfg.num_geometric, self.cfg.num_possessive
+        if self.hier:
+            segs = [(0, ng), (ng, ng + npos), (ng + npos, relation_pred.shape[1])]
+            conf = torch.hstack([torch.max(relation_pred[:, lo:hi], dim=1)[0] for lo, hi in segs])
+            pred = torch.hstack([torch.argmax(relation_pred[:, lo:hi], dim=1) + lo for lo, hi in segs])
+            rep = 3
+        else:
+            conf = torch.max(relation_pred, dim=1)[0].clone()
+            pred = torch.argmax(relation_pred, dim=1)
+            rep = 1
+        if not predcls:
+            conf = conf + (cat_subject_confidence + cat_object_confidence).repeat(rep)
+        conf = conf.clone()
+        conf[~iou_mask.repeat(rep)] = -math.inf
+        self.which.append(which_in_batch.repeat(rep)); self.conf.append(conf); self.pred.append(pred)
+        self.conn.append(connectivity.repeat(rep))
+        self.scat.append(subject_cat_pred.repeat(rep)); self.ocat.append(object_cat_pred.repeat(rep))
+        self.sbox.append(subject_bbox_pred.repeat(rep, 1)); self.obox.append(object_bbox_pred.repeat(rep, 1))
+        if predcls:
+            self.which_t.append(which_in_batch); self.rel_t.append(relation_target)
+            self.scat_t.append(subject_cat_target); self.ocat_t.append(object_cat_target)
+            self.sbox_t.append(subject_bbox_target); self.obox_t.append(object_bbox_target)
+
+    def flat_state(self):
+        cat = torch.hstack
+        return dict(which=cat(self.which), conf=cat(self.conf), conn=cat(self.conn), pred=cat(self.pred),
+                    scat=cat(self.scat), ocat=cat(self.ocat), sbox=torch.vstack(self.sbox),
+                    obox=torch.vstack(self.obox), which_t=cat(self.which_t), rel_t=cat(self.rel_t),
+                    scat_t=cat(self.scat_t), ocat_t=cat(self.ocat_t), sbox_t=torch.vstack(self.sbox_t),
+                    obox_t=torch.vstack(self.obox_t))
+
+    def compute(self, per_class=False):
+        if len(self.which) == 0:
+            return self._ratios()
+        s = self.flat_state()
+        conf = s["conf"] + s["conn"]
+        Fs = self.cfg.feature_size
+        for image in torch.unique(s["which"]):
+            cur = s["which"] == image
+            cur_t = s["which_t"] == image
+            c = conf[cur]
+            order = torch.sort(c, descending=True, stable=True)[1]
+            this_k = min(self.top_k[-1], len(c))
+            keep = order[:this_k]
+            self.last_sorted[int(image)] = keep.clone()
+            pred, scat, ocat = s["pred"][cur][keep], s["scat"][cur][keep], s["ocat"][cur][keep]
+            sbox, obox = s["sbox"][cur][keep], s["obox"][cur][keep]
+            rel_t, scat_t, ocat_t = s["rel_t"][cur_t], s["scat_t"][cur_t], s["ocat_t"][cur_t]
+            sbox_t, obox_t = s["sbox_t"][cur_t], s["obox_t"][cur_t]
+            for i in range(len(rel_t)):
+                if rel_t[i] == -1:
+                    continue
+                trip = "%d_%d_%d" % (int(scat_t[i]), int(rel_t[i]), int(ocat_t[i]))
+                is_zs = self.zero_shot is not None and trip in self.zero_shot
+                for j in range(this_k):
+                    if scat_t[i] == scat[j] and ocat_t[i] == ocat[j]:
+                        if grid_iou(sbox_t[i], sbox[j], Fs) >= self.iou_thresh and \
+                                grid_iou(obox_t[i], obox[j], Fs) >= self.iou_thresh:
+                            if rel_t[i] == pred[j]:
+                                for k in self.top_k:
+                                    if j >= k:
+                                        continue
+                                    self.result_dict[k] += 1.0
+                                    if per_class:
+                                        self.result_per_class[k][rel_t[i]] += 1.0
+                                    if is_zs:
+                                        self.result_dict_zs[k] += 1.0
+                                        if per_class:
+                                            self.result_per_class_zs[k][rel_t[i]] += 1.0
+                                break
+                self.num_connected_target += 1.0
+                self.num_conn_target_per_class[rel_t[i]] += 1.0
+                if is_zs:
+                    self.num_connected_target_zs += 1.0
+                    self.num_conn_target_per_class_zs[rel_t[i]] += 1.0
+        return self._ratios()
+
+    def _ratios(self):
+        rk = [self.result_dict[k] / max(self.num_connected_target, 1e-3) for k in self.top_k]
+        rpc = [self.result_per_class[k] / self.num_conn_target_per_class for k in self.top_k]
+        mrk = [torch.nanmean(r) for r in rpc]
+        rk_zs = rpc_zs = mrk_zs = None
+        if self.cfg.dataset == "vg":
+            rk_zs = [self.result_dict_zs[k] / max(self.num_connected_target_zs, 1e-3) for k in self.top_k]
+            rpc_zs = [self.result_per_class_zs[k] / self.num_conn_target_per_class_zs for k in self.top_k]
+            mrk_zs = [torch.nanmean(r) for r in rpc_zs]
+        return rk, rpc, mrk, rk_zs, rpc_zs, mrk_zs
+
+
+class OracleEvaluatorTop3:
+    """Recall@K*: one candidate per directed pair; a hit if the target equals any of the three
+    per-super-category argmaxes; counted for k with ``j < max(k, num_target)``."""
+
+    def __init__(self, cfg, top_k=(20, 50, 100), iou_thresh=0.5):
+        self.cfg = cfg
+        self.top_k = list(top_k)
+        self.iou_thresh = iou_thresh
+        self.R = cfg.num_relations
+        self.result_dict = {k: 0.0 for k in self.top_k}
+        self.result_per_class = {k: torch.zeros(self.R) for k in self.top_k}
+        self.num_connected_target = 0.0
+        self.num_conn_target_per_class = torch.zeros(self.R)
+        self.clear_data()
+
+    def clear_data(self):
+        self.which, self.conf, self.conn, self.rel, self.rel_t = [], [], [], [], []
+        self.scat, self.ocat, self.sbox, self.obox = [], [], [], []
+
+    def accumulate(self, which_in_batch, relation_pred, relation_target, super_relation_pred, connectivity,
+                   subject_cat_pred, object_cat_pred, subject_cat_target, object_cat_target,
+                   subject_bbox_pred, object_bbox_pred, subject_bbox_target, object_bbox_target, iou_mask):
+        ng, npos = self.cfg.num_geometric, self.cfg.num_possessive
+        segs = [(0, ng), (ng, ng + npos), (ng + npos, relation_pred.shape[1])]
+        conf = torch.max(torch.vstack([torch.max(relation_pred[:, lo:hi], dim=1)[0] for lo, hi in segs]), dim=0)[0]
+        conf = conf.clone()
+        conf[~iou_mask] = -math.inf
+        self.which.append(which_in_batch); self.conf.append(conf); self.conn.append(connectivity)
+        self.rel.append(relation_pred); self.rel_t.append(relation_target)
+        self.scat.append(subject_cat_pred); self.ocat.append(object_cat_pred)
+        self.sbox.append(subject_bbox_pred); self.obox.append(object_bbox_pred)
+
+    def compute(self, per_class=False):
+        if len(self.which) > 0:
+            ng, npos = self.cfg.num_geometric, self.cfg.num_possessive
+            which, conf = torch.hstack(self.which), torch.hstack(self.conf) + torch.hstack(self.conn)
+            rel, rel_t = torch.vstack(self.rel), torch.hstack(self.rel_t)
+            scat, ocat = torch.hstack(self.scat), torch.hstack(self.ocat)
+            sbox, obox = torch.vstack(self.sbox), torch.vstack(self.obox)
+            Fs = self.cfg.feature_size
+            for image in torch.unique(which):
+                cur = which == image
+                order = torch.sort(conf[cur], descending=True, stable=True)[1]
+                this_k = min(self.top_k[-1], int(cur.sum()))
+                keep = order[:this_k]
+                r_c, t_c = rel[cur], rel_t[cur]
+                sc, oc, sb, ob = scat[cur], ocat[cur], sbox[cur], obox[cur]
+                num_target = int(torch.sum(t_c != -1))
+                for i in range(len(t_c)):
+                    if t_c[i] == -1:
+                        continue
+                    for jj in range(this_k):
+                        j = int(keep[jj])
+                        if sc[i] == sc[j] and oc[i] == oc[j] and \
+                                grid_iou(sb[i], sb[j], Fs) >= self.iou_thresh and \
+                                grid_iou(ob[i], ob[j], Fs) >= self.iou_thresh:
+                            a1 = int(torch.argmax(r_c[j][:ng]))
+                            a2 = int(torch.argmax(r_c[j][ng:ng + npos])) + ng
+                            a3 = int(torch.argmax(r_c[j][ng + npos:])) + ng + npos
+                            if int(t_c[i]) in (a1, a2, a3):
+                                for k in self.top_k:
+                                    if jj >= max(k, num_target):
+                                        continue
+                                    self.result_dict[k] += 1.0
+                                    if per_class:
+                                        self.result_per_class[k][t_c[i]] += 1.0
+                                break
+                    self.num_connected_target += 1.0
+                    self.num_conn_target_per_class[t_c[i]] += 1.0
+        rk = [self.result_dict[k] / max(self.num_connected_target, 1e-3) for k in self.top_k]
+        rpc = [self.result_per_class[k] / self.num_conn_target_per_class for k in self.top_k]
+        return rk, rpc, [torch.nanmean(r) for r in rpc]

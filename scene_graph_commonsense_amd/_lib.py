@@ -1,0 +1,51 @@
+"""ctypes binding of the C-ABI library (include/sgc_relhead.h).  Fails loudly: there is no CPU fallback."""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_LIB = None
+
+
+class HipExtensionMissing(RuntimeError):
+    pass
+
+
+def lib_path() -> str:
+    from .build import lib_path as _p
+    return _p()
+
+
+def load(build_if_missing: bool = True) -> ctypes.CDLL:
+    """Load libsgc_relhead.so (building it in-tree with hipcc when absent)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        if not build_if_missing:
+            raise HipExtensionMissing(path + " is missing; run `python -m scene_graph_commonsense_amd.build`")
+        from .build import build
+        build()
+    try:
+        _LIB = ctypes.CDLL(path)
+    except OSError as e:  # pragma: no cover
+        raise HipExtensionMissing("cannot load %s: %s" % (path, e))
+    return _LIB
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        raise RuntimeError("%s failed with status %d (1=bad argument, 2=launch error)" % (what, status))
+
+
+def ptr(t):
+    """Device (or host) pointer of a torch tensor / None as a void*."""
+    if t is None:
+        return ctypes.c_void_p(0)
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,61 @@
+// Shared device helpers for the gfx950 (CDNA4) relation-head kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef _Float16 f16;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16;
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+enum { ELEM_F16 = 0, ELEM_BF16 = 1 };
+
+__device__ __forceinline__ u16 f32_to_bf16_bits(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u16)((u >> 16) | 0x40);   // NaN
+    u += 0x7fffu + ((u >> 16) & 1u);                                       // round to nearest even
+    return (u16)(u >> 16);
+}
+__device__ __forceinline__ float bf16_bits_to_f32(u16 h) { return __uint_as_float(((uint32_t)h) << 16); }
+__device__ __forceinline__ u16 f32_to_f16_bits(float f) {
+    f16 h = (f16)f;
+    return *reinterpret_cast<u16*>(&h);
+}
+__device__ __forceinline__ float f16_bits_to_f32(u16 b) {
+    f16 h = *reinterpret_cast<f16*>(&b);
+    return (float)h;
+}
+template <int ELEM> __device__ __forceinline__ u16 to_elem(float f) {
+    if constexpr (ELEM == ELEM_F16) return f32_to_f16_bits(f); else return f32_to_bf16_bits(f);
+}
+template <int ELEM> __device__ __forceinline__ float from_elem(u16 b) {
+    if constexpr (ELEM == ELEM_F16) return f16_bits_to_f32(b); else return bf16_bits_to_f32(b);
+}
+
+// Counter-based hash shared with scene_graph_commonsense_amd/synthetic.py (lowbias32).
+__device__ __host__ __forceinline__ uint32_t lowbias32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+// Dropout keep-bit for element idx of a stream: p = 0.5 (reference model.py:120-121).
+__device__ __host__ __forceinline__ bool dropout_keep(uint32_t seed, uint32_t idx) {
+    return (lowbias32(idx ^ (seed * 0x9E3779B1U + 0x7F4A7C15U)) >> 16) & 1U;
+}
+
+#define SGC_OK 0
+#define SGC_ERR_ARG 1
+#define SGC_ERR_LAUNCH 2
+
+#define SGC_CHECK_LAUNCH()                                   \
+    do {                                                     \
+        hipError_t e__ = hipGetLastError();                  \
+        if (e__ != hipSuccess) return SGC_ERR_LAUNCH;        \
+    } while (0)

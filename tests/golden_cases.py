@@ -1,0 +1,35 @@
+"""Shared description of the golden cases (must match tests/golden/make_golden.py:CASES)."""
+import os
+
+import numpy as np
+
+from scene_graph_commonsense_amd.synthetic import HeadConfig, make_scene_batch, make_state_dict
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+CASES = {
+    "vg_full": (dict(), (5, 4, 3), 1, 6.0, 0.5, True),
+    "vg_flat": (dict(hierarchical=False), (4, 3), 2, 6.0, 0.5, False),
+    "oiv6_full": (dict(dataset="oiv6", num_classes=601, num_super_classes=0, num_geometric=4, num_possessive=2,
+                       num_semantic=24), (4, 3), 3, 6.0, 0.5, False),
+    "vg_small": (dict(hidden_dim=16, feature_size=8), (7, 6, 6, 2), 4, 6.0, 0.4, True),
+    "vg_bert_small": (dict(hidden_dim=16, feature_size=8, num_geometric=12, num_possessive=25, num_semantic=13),
+                      (5, 5), 5, 6.0, 0.4, False),
+}
+FULL = ("vg_full", "vg_flat", "oiv6_full")
+SMALL = ("vg_small", "vg_bert_small")
+
+
+def load_case(name):
+    kw, nobj, seed, gain, cfrac, edge = CASES[name]
+    cfg = HeadConfig(**kw)
+    sd = make_state_dict(cfg, seed=seed, head_gain=gain)
+    batch = make_scene_batch(cfg, nobj, seed=seed, connect_frac=cfrac, edge_boxes=edge)
+    gold = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+    return cfg, sd, batch, gold
+
+
+def zero_shot_list():
+    import torch
+    p = os.path.join(GOLDEN, "ref_fixtures", "zero_shot_triplets.pt")
+    return torch.load(p)

@@ -1,0 +1,126 @@
+"""GPU tests of the two MFMA GEMM engines (csrc/gemm_nt.h, csrc/gemm_tn.h) through the debug C-ABI hooks.
+Reference = torch fp32 matmul of the same 16-bit-rounded operands; tolerance covers f32 accumulation order."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _lib():
+    from scene_graph_commonsense_amd import _lib
+    return _lib.load(), _lib
+
+
+def _rand(shape, dtype, seed):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.rand(shape, generator=g) * 2 - 1).to(dtype).cuda()
+
+
+def _window_major_index(S):
+    """row m = 4*W + q  ->  (y, x) of the SxS image."""
+    m = torch.arange(S * S)
+    W, q = m // 4, m % 4
+    py, px = W // (S // 2), W % (S // 2)
+    return 2 * py + q // 2, 2 * px + q % 2
+
+
+@pytest.mark.parametrize("dtype,elem", [(torch.float16, 0), (torch.bfloat16, 1)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 256, 192), (1000, 512, 4096)])
+def test_gemm_nt_plain(dtype, elem, M, N, K):
+    lib, L = _lib()
+    A, B = _rand((M, K), dtype, 1), _rand((N, K), dtype, 2)
+    bias = _rand((N,), torch.float32, 3)
+    C = torch.empty(M, N, dtype=dtype, device="cuda")
+    st = lib.sgc_dbg_gemm_nt(elem, L.ptr(A), L.ptr(B), L.ptr(C), M, N, K, ctypes.c_long(K), ctypes.c_long(K),
+                             ctypes.c_long(N), L.ptr(bias), L.stream_ptr())
+    assert st == 0
+    torch.cuda.synchronize()
+    ref = A.float() @ B.float().t() + bias
+    err = (C.float() - ref).abs().max().item()
+    tol = (2e-3 if elem == 0 else 1.6e-2) * ref.abs().max().item()
+    assert err <= tol, (err, tol)
+
+
+def _conv_inputs(n_img, S, Cin, N, dtype):
+    x = _rand((n_img, Cin, S, S), dtype, 5)
+    w = (_rand((N, Cin, 3, 3), dtype, 6).float() * 0.1).to(dtype)
+    xp = torch.zeros(n_img, S + 2, S + 2, Cin, dtype=dtype, device="cuda")
+    xp[:, 1:-1, 1:-1, :] = x.permute(0, 2, 3, 1)
+    wr = w.permute(0, 2, 3, 1).contiguous().reshape(N, 9 * Cin)
+    return x, w, xp.contiguous(), wr
+
+
+@pytest.mark.parametrize("dtype,elem", [(torch.float16, 0), (torch.bfloat16, 1)])
+@pytest.mark.parametrize("n_img,lgS,Cin,N", [(3, 4, 128, 128), (2, 5, 128, 256), (5, 4, 512, 128)])
+def test_conv_nt(dtype, elem, n_img, lgS, Cin, N):
+    lib, L = _lib()
+    S = 1 << lgS
+    x, w, xp, wr = _conv_inputs(n_img, S, Cin, N, dtype)
+    bias = _rand((N,), torch.float32, 7)
+    C = torch.empty(n_img * S * S, N, dtype=dtype, device="cuda")
+    st = lib.sgc_dbg_conv_nt(elem, L.ptr(xp), L.ptr(wr), L.ptr(C), n_img, lgS, Cin, N, L.ptr(bias), L.stream_ptr())
+    assert st == 0
+    torch.cuda.synchronize()
+    ref = torch.nn.functional.conv2d(x.float(), w.float(), bias, padding=1)      # [n,N,S,S]
+    yy, xx = _window_major_index(S)
+    ref_rows = ref[:, :, yy, xx].permute(0, 2, 1).reshape(n_img * S * S, N)
+    err = (C.float() - ref_rows).abs().max().item()
+    tol = (2e-3 if elem == 0 else 1.6e-2) * ref_rows.abs().max().item()
+    assert err <= tol, (err, tol)
+
+
+def test_tr_probe_layout():
+    """Document what ds_read_b64_tr_b16 returns for the linear address pattern the TN kernel uses."""
+    lib, L = _lib()
+    lane = torch.arange(64)
+    t, grp = lane % 16, lane // 16
+    addr = (grp * 128 + (t // 4) * 32 + (t % 4) * 8).int().cuda()
+    out = torch.zeros(64 * 4, dtype=torch.int16, device="cuda")
+    assert lib.sgc_dbg_tr_probe(L.ptr(addr), L.ptr(out), L.stream_ptr()) == 0
+    torch.cuda.synchronize()
+    got = out.view(64, 4).cpu()
+    # expectation: lane t of group g receives column t of the 4x16 block g: elements g*64 + j*16 + t
+    exp = torch.stack([grp * 64 + j * 16 + t for j in range(4)], dim=1).to(torch.int16)
+    print("tr probe lanes 0..3, 16..17:", got[:4].tolist(), got[16:18].tolist())
+    assert torch.equal(got, exp), got[:20].tolist()
+
+
+@pytest.mark.parametrize("dtype,elem", [(torch.float16, 0), (torch.bfloat16, 1)])
+@pytest.mark.parametrize("M,N,K,splits", [(128, 128, 64, 1), (256, 384, 640, 3), (512, 128, 4096, 8)])
+def test_gemm_tn_plain(dtype, elem, M, N, K, splits):
+    lib, L = _lib()
+    A, B = _rand((K, M), dtype, 11), _rand((K, N), dtype, 12)
+    C = torch.zeros(splits, M, N, dtype=torch.float32, device="cuda")
+    slabs = ctypes.c_int(0)
+    st = lib.sgc_dbg_gemm_tn(elem, L.ptr(A), L.ptr(B), L.ptr(C), M, N, K, ctypes.c_long(M), ctypes.c_long(N), splits,
+                             ctypes.byref(slabs), L.stream_ptr())
+    assert st == 0
+    torch.cuda.synchronize()
+    got = C[:slabs.value].sum(0)
+    ref = A.float().t() @ B.float()
+    err = (got - ref).abs().max().item()
+    assert err <= 1e-3 * ref.abs().max().item() + 1e-4, err
+
+
+@pytest.mark.parametrize("n_img,lgS,Cin,M,splits", [(2, 4, 128, 128, 2), (3, 5, 128, 256, 4), (2, 4, 512, 128, 1)])
+def test_conv_tn(n_img, lgS, Cin, M, splits):
+    lib, L = _lib()
+    dtype, elem = torch.bfloat16, 1
+    S = 1 << lgS
+    x, _, xp, _ = _conv_inputs(n_img, S, Cin, 128, dtype)
+    dy = _rand((n_img, M, S, S), dtype, 21)                       # grad wrt conv output [n, M, S, S]
+    yy, xx = _window_major_index(S)
+    dy_rows = dy[:, :, yy, xx].permute(0, 2, 1).reshape(n_img * S * S, M).contiguous()
+    C = torch.zeros(splits, M, 9 * Cin, dtype=torch.float32, device="cuda")
+    slabs = ctypes.c_int(0)
+    st = lib.sgc_dbg_conv_tn(elem, L.ptr(dy_rows), L.ptr(xp), L.ptr(C), M, n_img, lgS, Cin, splits,
+                             ctypes.byref(slabs), L.stream_ptr())
+    assert st == 0
+    torch.cuda.synchronize()
+    got = C[:slabs.value].sum(0).view(M, 3, 3, Cin).permute(0, 3, 1, 2)       # -> [M, Cin, 3, 3]
+    ref = torch.nn.grad.conv2d_weight(x.float(), (M, Cin, 3, 3), dy.float(), padding=1)
+    err = (got - ref).abs().max().item()
+    assert err <= 1e-3 * ref.abs().max().item() + 1e-4, err
