@@ -1,0 +1,298 @@
+// Forward-path HBM-bound kernels of the pairwise relation head (gfx950) and their C-ABI launchers.
+// Layout conventions (all channels-last, 16-bit):
+//   x        [n_img*1024][XC=384]   packed cat(feature, depth), pixel-major rows (y*32+x), zero padded channels
+//   a_img    [n_img*1024][128]      tanh(conv1) per role
+//   a_pad    [n_obj][34][34][128]   per-object masked map, zero border (conv2 halo)
+//   U, V     [n_obj*1024][512]      per-object conv2 halves, rows window-major (m = 4*(Y*16+X) + dy*2+dx)
+//   z_pad    [n_pair][18][18][512]  relu/maxpool(U_i + V_j), zero border (conv3 halo)
+//   y        [n_pair*64][1024]      conv3 output after relu+pool, rows = pooled window py*8+px
+#include "common.h"
+#include "gemm_nt.h"
+
+// ------------------------------------------------------------------------------------------------ pack
+// cat(feature, depth) f32 NCHW -> f16 [img*HW][XC] (reference train_test.py:194-195 builds the same concat).
+__global__ __launch_bounds__(256) void pack_nhwc_kernel(const float* __restrict__ f0, int C0, const float* __restrict__ f1,
+                                                        int C1, u16* __restrict__ out, int HW, int XC) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    u16* tile = reinterpret_cast<u16*>(smem);          // [64][XC+8]
+    const int ldt = XC + 8;
+    const int img = blockIdx.y, p0 = blockIdx.x * 64;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int c = w; c < XC; c += 4) {
+        float v = 0.f;
+        if (c < C0) v = f0[((long)img * C0 + c) * HW + p0 + lane];
+        else if (c < C0 + C1) v = f1[((long)img * C1 + (c - C0)) * HW + p0 + lane];
+        tile[lane * ldt + c] = f32_to_f16_bits(v);
+    }
+    __syncthreads();
+    const int chunks = XC / 8;
+    for (int i = threadIdx.x; i < 64 * chunks; i += 256) {
+        const int r = i / chunks, ch = i - r * chunks;
+        const uint4 v = *reinterpret_cast<const uint4*>(tile + r * ldt + ch * 8);
+        *reinterpret_cast<uint4*>(out + ((long)img * HW + p0 + r) * XC + ch * 8) = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ masks
+// a_pad[o][py][px][:] = border ? 0 : (inside bbox ? a_img[img[o]][y*F+x][:] : cst[:])
+// (reference train_test.py:166-168 mask build + :194-195 multiply, with tanh(conv1(0)) = tanh(bias) outside.)
+__global__ __launch_bounds__(256) void mask_objects_kernel(const u16* __restrict__ a_img, const int* __restrict__ obj_img,
+                                                           const int* __restrict__ bbox, const u16* __restrict__ cst,
+                                                           u16* __restrict__ a_pad, int n_obj, int F, int D) {
+    const int P = F + 2;
+    const int cpp = D / 8;                              // 16-byte chunks per pixel
+    const long total = (long)n_obj * P * P * cpp;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int ch = (int)(i % cpp);
+        long r = i / cpp;
+        const int px = (int)(r % P); r /= P;
+        const int py = (int)(r % P);
+        const int o = (int)(r / P);
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (px > 0 && px <= F && py > 0 && py <= F) {
+            const int x = px - 1, y = py - 1;
+            const int* b = bbox + 4 * o;                // x0,x1,y0,y1 (already normalised to slice semantics)
+            if (x >= b[0] && x < b[1] && y >= b[2] && y < b[3])
+                v = *reinterpret_cast<const uint4*>(a_img + ((long)obj_img[o] * F * F + y * F + x) * D + ch * 8);
+            else
+                v = *reinterpret_cast<const uint4*>(cst + ch * 8);
+        }
+        *reinterpret_cast<uint4*>(a_pad + i * 8) = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ expansion
+// z_pad[p][Y+1][X+1][c] = max_q relu(U[sub[p]][4W+q][c] + V[obj[p]][4W+q][c]),  W = Y*16+X
+// (reference model.py:141-144: cat -> conv2_1 -> relu -> maxpool, with conv2_1(cat(a,b)) = U + V.)
+// One wavefront per (pair, window): lane l owns channels 8l..8l+7 (16-byte loads/stores, 1 KiB per wave row).
+template <int ELEM_OUT>
+__global__ __launch_bounds__(256) void pair_expand_kernel(const u16* __restrict__ U, const u16* __restrict__ V,
+                                                          const int* __restrict__ sub, const int* __restrict__ obj,
+                                                          u16* __restrict__ z, long n_items) {
+    const int lane = threadIdx.x & 63;
+    for (long it = (long)blockIdx.x * 4 + (threadIdx.x >> 6); it < n_items; it += (long)gridDim.x * 4) {
+        const int p = (int)(it >> 8), W = (int)(it & 255);
+        const u16* up = U + ((long)sub[p] * 1024 + 4 * W) * 512 + lane * 8;
+        const u16* vp = V + ((long)obj[p] * 1024 + 4 * W) * 512 + lane * 8;
+        float best[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) best[k] = 0.f;      // relu floor
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint4 a = *reinterpret_cast<const uint4*>(up + q * 512);
+            const uint4 b = *reinterpret_cast<const uint4*>(vp + q * 512);
+            const u16* ah = reinterpret_cast<const u16*>(&a);
+            const u16* bh = reinterpret_cast<const u16*>(&b);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) best[k] = fmaxf(best[k], f16_bits_to_f32(ah[k]) + f16_bits_to_f32(bh[k]));
+        }
+        uint4 o;
+        u16* oh = reinterpret_cast<u16*>(&o);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) oh[k] = to_elem<ELEM_OUT>(best[k]);
+        const int Y = W >> 4, X = W & 15;
+        *reinterpret_cast<uint4*>(z + (((long)p * 18 + Y + 1) * 18 + X + 1) * 512 + lane * 8) = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ head
+// Hierarchical Bayesian head + candidate reduction (reference model.py:176-184, evaluator.py:160-174).
+// Wt is [512][64] f32 (column r = output row r): rows [0,R) fine relations (three segments), R..R+2 super
+// logits (fc5), R+3 connectivity (fc4).  One wavefront per pair, lane r owns output row r; segment
+// max / sum / argmax are wavefront shuffle reductions.
+struct HeadParams {
+    const float* p; const float* Wt; const float* bias; int n_pairs;
+    int ng, np, ns; int hier; float invT1, invT2, invT3;
+    float* rel; float* sup; float* conn; float* cand_conf; int* cand_pred; const unsigned char* iou_mask;
+};
+
+__device__ __forceinline__ float wave_max_pred(float v, bool in) {
+    float x = in ? v : -INFINITY;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x = fmaxf(x, __shfl_xor(x, o));
+    return x;
+}
+__device__ __forceinline__ float wave_sum_pred(float v, bool in) {
+    float x = in ? v : 0.f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+    return x;
+}
+__device__ __forceinline__ int wave_min_int(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
+    return v;
+}
+
+__global__ __launch_bounds__(256) void bayes_head_kernel(const HeadParams hp) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* Wl = reinterpret_cast<float*>(smem);             // [512][64]
+    float* pl = Wl + 512 * 64;                              // [4 waves][512]
+    for (int i = threadIdx.x; i < 512 * 64; i += 256) Wl[i] = hp.Wt[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int R = hp.ng + hp.np + hp.ns;
+    float* pw = pl + w * 512;
+    const float bias = hp.bias[lane];
+    for (int pr = blockIdx.x * 4 + w; pr < hp.n_pairs; pr += gridDim.x * 4) {
+        const float* prow = hp.p + (long)pr * 512;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) pw[lane + 64 * k] = prow[lane + 64 * k];
+        __builtin_amdgcn_wave_barrier();
+        float acc = 0.f;
+#pragma unroll 8
+        for (int k = 0; k < 512; ++k) acc = fmaf(pw[k], Wl[k * 64 + lane], acc);
+        acc += bias;
+        __builtin_amdgcn_wave_barrier();
+        const bool is_conn = lane == (hp.hier ? R + 3 : R);
+        if (is_conn) hp.conn[pr] = acc;
+        const bool masked = hp.iou_mask && !hp.iou_mask[pr];
+        if (hp.hier) {
+            const bool in_sup = lane >= R && lane < R + 3;
+            const float smax = wave_max_pred(acc, in_sup);
+            const float ssum = wave_sum_pred(expf(acc - smax), in_sup);
+            const float slog = acc - smax - logf(ssum);             // valid on the three super lanes
+            if (in_sup) hp.sup[(long)pr * 3 + (lane - R)] = slog;
+            const int seg = lane < hp.ng ? 0 : (lane < hp.ng + hp.np ? 1 : 2);
+            const int lo = seg == 0 ? 0 : (seg == 1 ? hp.ng : hp.ng + hp.np);
+            const float invT = seg == 0 ? hp.invT1 : (seg == 1 ? hp.invT2 : hp.invT3);
+            const float x = acc * invT;
+            float out = 0.f;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const bool in = lane < R && seg == s;
+                const float m = wave_max_pred(x, in);
+                const float sm = wave_sum_pred(expf(x - m), in);
+                const float sl = __shfl(slog, R + s);
+                const float lp = x - m - logf(sm) + sl;
+                if (in) out = lp;
+                // candidate: max log-prob of the segment and its first argmax (evaluator.py:160-174)
+                const float cm = wave_max_pred(lp, in);
+                const int am = wave_min_int((in && lp == cm) ? lane : 1 << 20);
+                if (lane == 0) {
+                    hp.cand_conf[(long)pr * 3 + s] = masked ? -INFINITY : cm;
+                    hp.cand_pred[(long)pr * 3 + s] = am;
+                }
+                (void)lo;
+            }
+            if (lane < R) hp.rel[(long)pr * R + lane] = out;
+        } else {
+            const bool in = lane < R;
+            if (in) hp.rel[(long)pr * R + lane] = acc;
+            const float cm = wave_max_pred(acc, in);
+            const int am = wave_min_int((in && acc == cm) ? lane : 1 << 20);
+            if (lane == 0) {
+                hp.cand_conf[pr] = masked ? -INFINITY : cm;
+                hp.cand_pred[pr] = am;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ C ABI
+extern "C" {
+
+int sgc_pack_image_nhwc(const float* f0, int C0, const float* f1, int C1, void* x_out, int n_img, int HW, int XC,
+                        void* stream) {
+    if (HW % 64 || XC % 8 || C0 + C1 > XC) return SGC_ERR_ARG;
+    if (n_img <= 0) return SGC_OK;
+    hipLaunchKernelGGL(pack_nhwc_kernel, dim3(HW / 64, n_img), dim3(256), 64 * (XC + 8) * 2, (hipStream_t)stream,
+                       f0, C0, f1, C1, (u16*)x_out, HW, XC);
+    SGC_CHECK_LAUNCH();
+    return SGC_OK;
+}
+
+int sgc_conv1_tanh(const void* x, const void* w1r, const float* b1, void* a_img, int n_rows, int XC, void* stream) {
+    NtParams p{};
+    p.A = (const u16*)x; p.B = (const u16*)w1r; p.C = a_img; p.M = n_rows; p.N = 128; p.K = XC;
+    p.lda = XC; p.ldb = XC; p.ldc = 128; p.bias = b1;
+    return launch_gemm_nt<ELEM_F16, AMODE_PLAIN, EPI_BIAS_TANH>(p, (hipStream_t)stream);
+}
+
+int sgc_object_masked_maps(const void* a_img, const int* obj_img, const int* bbox, const void* cst, void* a_pad,
+                           int n_obj, int F, int D, void* stream) {
+    if (D % 8) return SGC_ERR_ARG;
+    if (n_obj <= 0) return SGC_OK;
+    const long total = (long)n_obj * (F + 2) * (F + 2) * (D / 8);
+    const int blocks = (int)((total + 255) / 256 > 65536 ? 65536 : (total + 255) / 256);
+    hipLaunchKernelGGL(mask_objects_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const u16*)a_img, obj_img,
+                       bbox, (const u16*)cst, (u16*)a_pad, n_obj, F, D);
+    SGC_CHECK_LAUNCH();
+    return SGC_OK;
+}
+
+// U (or V) [n_obj*1024][512] = conv3x3(a_pad, w2r[512][9][128]) (+ bias for the object role)
+int sgc_conv2_object(const void* a_pad, const void* w2r, const float* bias, void* out, int n_obj, void* stream) {
+    NtParams p{};
+    p.A = (const u16*)a_pad; p.B = (const u16*)w2r; p.C = out; p.M = n_obj * 1024; p.N = 512; p.K = 9 * 128;
+    p.ldb = 9 * 128; p.ldc = 512; p.lgS = 5; p.Cin = 128; p.bias = bias;
+    return launch_gemm_nt<ELEM_F16, AMODE_CONV, EPI_STORE>(p, (hipStream_t)stream);
+}
+
+int sgc_pair_expand(const void* U, const void* V, const int* sub_idx, const int* obj_idx, void* z_pad, int n_pairs,
+                    int out_elem, void* stream) {
+    if (n_pairs <= 0) return SGC_OK;
+    const long items = (long)n_pairs * 256;
+    const long want = (items + 3) / 4;
+    const int blocks = (int)(want > 262144 ? 262144 : want);
+    if (out_elem == ELEM_F16)
+        hipLaunchKernelGGL(pair_expand_kernel<ELEM_F16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const u16*)U,
+                           (const u16*)V, sub_idx, obj_idx, (u16*)z_pad, items);
+    else
+        hipLaunchKernelGGL(pair_expand_kernel<ELEM_BF16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const u16*)U,
+                           (const u16*)V, sub_idx, obj_idx, (u16*)z_pad, items);
+    SGC_CHECK_LAUNCH();
+    return SGC_OK;
+}
+
+// y [n_pairs*64][1024] (+argmax u8) = maxpool2(relu(conv3x3(z_pad, w3r[1024][9][512]) + b3))
+int sgc_conv3_relu_pool(const void* z_pad, const void* w3r, const float* b3, void* y, unsigned char* argmax, int n_pairs,
+                        void* stream) {
+    NtParams p{};
+    p.A = (const u16*)z_pad; p.B = (const u16*)w3r; p.C = y; p.M = n_pairs * 256; p.N = 1024; p.K = 9 * 512;
+    p.ldb = 9 * 512; p.ldc = 1024; p.lgS = 4; p.Cin = 512; p.bias = b3; p.argmax = argmax;
+    return launch_gemm_nt<ELEM_F16, AMODE_CONV, EPI_POOL>(p, (hipStream_t)stream);
+}
+
+// h1 [n_pairs][4096] = dropout(relu(y[n_pairs][65536] * w1p^T + b))
+int sgc_fc1_relu(const void* y, const void* w1p, const float* b, void* h1, int n_pairs, int K, int drop_enable,
+                 unsigned drop_seed, void* stream) {
+    NtParams p{};
+    p.A = (const u16*)y; p.B = (const u16*)w1p; p.C = h1; p.M = n_pairs; p.N = 4096; p.K = K;
+    p.lda = K; p.ldb = K; p.ldc = 4096; p.bias = b; p.drop_enable = drop_enable; p.drop_seed = drop_seed; p.scale = 2.f;
+    return launch_gemm_nt<ELEM_F16, AMODE_PLAIN, EPI_BIAS_RELU>(p, (hipStream_t)stream);
+}
+
+// p [n_pairs][512] f32 = dropout(relu(h1 * w2m^T + b + Lsub[sub_idx] + Lobj[obj_idx]))
+int sgc_fc2_labels_relu(const void* h1, const void* w2m, const float* b, const float* lsub, const float* lobj,
+                        const int* sub_idx, const int* obj_idx, float* p_out, int n_pairs, int drop_enable,
+                        unsigned drop_seed, void* stream) {
+    NtParams p{};
+    p.A = (const u16*)h1; p.B = (const u16*)w2m; p.C = p_out; p.M = n_pairs; p.N = 512; p.K = 4096;
+    p.lda = 4096; p.ldb = 4096; p.ldc = 512; p.bias = b; p.lsub = lsub; p.lobj = lobj; p.sub_idx = sub_idx;
+    p.obj_idx = obj_idx; p.drop_enable = drop_enable; p.drop_seed = drop_seed; p.scale = 2.f;
+    return launch_gemm_nt<ELEM_F16, AMODE_PLAIN, EPI_FC2>(p, (hipStream_t)stream);
+}
+
+int sgc_bayes_head(const float* p, const float* Wt, const float* bias, int n_pairs, int ng, int np, int ns, int hier,
+                   float T1, float T2, float T3, float* rel, float* sup, float* conn, float* cand_conf, int* cand_pred,
+                   const unsigned char* iou_mask, void* stream) {
+    if (ng + np + ns + 4 > 64 || ng <= 0) return SGC_ERR_ARG;
+    if (n_pairs <= 0) return SGC_OK;
+    HeadParams hp{p, Wt, bias, n_pairs, ng, np, ns, hier, 1.f / T1, 1.f / T2, 1.f / T3, rel, sup, conn, cand_conf,
+                  cand_pred, iou_mask};
+    static bool attr_set = false;
+    const int lds = (512 * 64 + 4 * 512) * 4;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bayes_head_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    int blocks = (n_pairs + 3) / 4;
+    if (blocks > 256) blocks = 256;
+    hipLaunchKernelGGL(bayes_head_kernel, dim3(blocks), dim3(256), lds, (hipStream_t)stream, hp);
+    SGC_CHECK_LAUNCH();
+    return SGC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,142 @@
+"""Host-side pair enumeration and ragged-annotation flattening for the fused path.
+
+The reference enumerates pairs with two nested Python loops and runs the classifier once per
+(graph_iter, edge_iter, direction) on a batch of *images* (``train_test.py:189-258``).  The fused path
+scores every ordered pair of every image in one pass, so the loops become index arrays, emitted in
+exactly the reference's order (SURVEY §8a'): for g in 1..maxN-1, for e in 0..g-1, direction 1
+(subject g, object e) then direction 2 (subject e, object g); inside a step, images in
+``keep_in_batch`` order (images with more than g objects, ascending).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+
+@dataclass
+class PairIndex:
+    """All ordered pairs of a minibatch in reference call order (host numpy arrays, length P)."""
+    image: np.ndarray        # minibatch-local image index (= which_in_batch)
+    g: np.ndarray            # graph_iter of the step
+    e: np.ndarray            # edge_iter of the step
+    first: np.ndarray        # True for direction 1 (subject = object g)
+    sub: np.ndarray          # flattened object index of the subject
+    obj: np.ndarray          # flattened object index of the object
+    step: np.ndarray         # direction-step ordinal t (0-based) of the reference loop
+    call_sizes: np.ndarray   # pairs per direction-step, in order
+    obj_offset: np.ndarray   # [B+1] prefix sum of objects per image
+
+    @property
+    def n_pairs(self) -> int:
+        return int(self.image.shape[0])
+
+
+def enumerate_pairs(num_objects: Sequence[int]) -> PairIndex:
+    n = np.asarray(num_objects, dtype=np.int64)
+    off = np.concatenate([[0], np.cumsum(n)])
+    img, gg, ee, ff, ss, oo, st, sizes = [], [], [], [], [], [], [], []
+    t = 0
+    for g in range(1, int(n.max()) if len(n) else 0):
+        keep = np.nonzero(n > g)[0]
+        if len(keep) == 0:
+            continue
+        for e in range(g):
+            for first in (True, False):
+                s = off[keep] + (g if first else e)
+                o = off[keep] + (e if first else g)
+                img.append(keep); gg.append(np.full(len(keep), g)); ee.append(np.full(len(keep), e))
+                ff.append(np.full(len(keep), first)); ss.append(s); oo.append(o)
+                st.append(np.full(len(keep), t)); sizes.append(len(keep))
+                t += 1
+    cat = lambda xs, dt: (np.concatenate(xs).astype(dt) if xs else np.zeros(0, dtype=dt))
+    return PairIndex(cat(img, np.int64), cat(gg, np.int64), cat(ee, np.int64), cat(ff, bool), cat(ss, np.int32),
+                     cat(oo, np.int32), cat(st, np.int64), np.asarray(sizes, dtype=np.int64), off)
+
+
+def slice_norm(i: int, F: int) -> int:
+    """Python slice-bound semantics of ``mask[int(a):int(b)]`` on an axis of length F."""
+    i = int(i)
+    if i < 0:
+        i += F
+        return max(i, 0)
+    return min(i, F)
+
+
+def normalise_boxes(bbox: torch.Tensor, F: int) -> np.ndarray:
+    """[n,4] (x0,x1,y0,y1), int or float -> int32 with int() truncation and slice clipping applied."""
+    b = bbox.detach().cpu().numpy()
+    out = np.zeros((b.shape[0], 4), dtype=np.int32)
+    for r in range(b.shape[0]):
+        for k in range(4):
+            out[r, k] = slice_norm(int(b[r, k]), F)
+    return out
+
+
+def super_multihot(super_categories: Optional[List[List[torch.Tensor]]], num_super: int) -> Optional[np.ndarray]:
+    """Multi-hot rows in flattened object order with the reference quirk (``utils.py:136-149``): for a
+    k-element list only element 0 and element k-1 are set (k = 2..4); longer lists keep element 0 only."""
+    if super_categories is None:
+        return None
+    rows = []
+    for per_img in super_categories:
+        for s in per_img:
+            s = [int(v) for v in (s.tolist() if hasattr(s, "tolist") else s)]
+            r = np.zeros(num_super, dtype=np.float32)
+            r[s[0]] += 1
+            if 2 <= len(s) <= 4:
+                r[s[-1]] += 1
+            rows.append(r)
+    return np.stack(rows) if rows else np.zeros((0, num_super), dtype=np.float32)
+
+
+def pair_targets(relationships, subj_or_obj, pidx: PairIndex):
+    """Directed targets per ordered pair (``train_utils.py:169-187``): predicate where the stored direction
+    matches the pair's direction, else -1.  Also returns the raw (undirected) predicate row entry."""
+    P = pidx.n_pairs
+    directed = np.full(P, -1, dtype=np.int64)
+    raw = np.full(P, -1, dtype=np.int64)
+    for k in range(P):
+        b, g, e = int(pidx.image[k]), int(pidx.g[k]), int(pidx.e[k])
+        r = int(relationships[b][g - 1][e])
+        d = float(subj_or_obj[b][g - 1][e])
+        raw[k] = r
+        flag = 1.0 if pidx.first[k] else 0.0
+        if d == flag:
+            directed[k] = r
+    return directed, raw
+
+
+@dataclass
+class DeviceScene:
+    """A minibatch flattened for the fused path (device tensors) plus its host pair index."""
+    image_feature: torch.Tensor     # [B,256,32,32] f32
+    image_depth: torch.Tensor       # [B,1,32,32] f32
+    obj_img: torch.Tensor           # [n_obj] int32
+    bbox: torch.Tensor              # [n_obj,4] int32 (slice-normalised x0,x1,y0,y1)
+    cats: torch.Tensor              # [n_obj] int64
+    super_mh: Optional[torch.Tensor]  # [n_obj,S] f32 or None
+    sub_idx: torch.Tensor           # [P] int32
+    obj_idx: torch.Tensor           # [P] int32
+    pidx: PairIndex
+    bbox_raw: np.ndarray            # [n_obj,4] as given (evaluator records)
+
+
+def flatten_scene(cfg, batch, device) -> DeviceScene:
+    """SceneBatch (reference data contract) -> DeviceScene with all ordered pairs in reference order."""
+    n = [int(b.shape[0]) for b in batch.bbox]
+    pidx = enumerate_pairs(n)
+    obj_img = np.concatenate([np.full(k, i, dtype=np.int32) for i, k in enumerate(n)])
+    F = cfg.feature_size
+    bb = np.concatenate([normalise_boxes(b, F) for b in batch.bbox])
+    raw = np.concatenate([b.detach().cpu().numpy() for b in batch.bbox])
+    cats = torch.cat([c.reshape(-1) for c in batch.categories]).to(torch.int64)
+    mh = super_multihot(batch.super_categories, cfg.num_super_classes) if cfg.dataset == "vg" else None
+    dev = torch.device(device)
+    return DeviceScene(batch.image_feature.to(dev, torch.float32).contiguous(),
+                       batch.image_depth.to(dev, torch.float32).contiguous(),
+                       torch.from_numpy(obj_img).to(dev), torch.from_numpy(bb).to(dev), cats.to(dev),
+                       None if mh is None else torch.from_numpy(mh).to(dev),
+                       torch.from_numpy(pidx.sub).to(dev), torch.from_numpy(pidx.obj).to(dev), pidx, raw)

@@ -1,0 +1,96 @@
+"""GPU parity of the fused forward path (HIP kernels via the C-ABI) against
+  (a) golden vectors produced by the real reference (tests/golden/*.npz) and
+  (b) the CPU oracle on the same seeded inputs.
+Tolerance (BASELINE.json north_star): 1e-3 relative on the super-category and fine-relation outputs.  The
+contractions run in f16 with f32 accumulation, so we bound the max abs error by 1e-3 x the output's max
+magnitude (relative to scale) and report the per-element relative error on the log-probs as well."""
+import numpy as np
+import pytest
+import torch
+
+from tests.golden_cases import load_case
+
+pytestmark = pytest.mark.gpu
+REL_TOL = 1e-3
+
+
+def _engine(cfg, sd):
+    from scene_graph_commonsense_amd.engine import RelHeadEngine
+    eng = RelHeadEngine(cfg, "cuda:0")
+    eng.load_weights(sd)
+    return eng
+
+
+def _forward(cfg, sd, batch):
+    from scene_graph_commonsense_amd.pairs import flatten_scene
+    eng = _engine(cfg, sd)
+    sc = flatten_scene(cfg, batch, "cuda:0")
+    out = eng.forward_pairs(sc.image_feature, sc.image_depth, sc.obj_img, sc.bbox, sc.cats, sc.super_mh, sc.sub_idx,
+                            sc.obj_idx)
+    torch.cuda.synchronize()
+    return sc, out
+
+
+def _rel_err(a, ref):
+    a, ref = np.asarray(a, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    return np.abs(a - ref).max() / max(np.abs(ref).max(), 1e-12)
+
+
+@pytest.mark.parametrize("name", ["vg_full", "oiv6_full", "vg_flat"])
+def test_forward_matches_reference_golden(name):
+    cfg, sd, batch, gold = load_case(name)
+    sc, out = _forward(cfg, sd, batch)
+    pidx = sc.pidx
+    rows = []
+    for (g, e) in gold["eval_steps"].tolist():
+        for first in (True, False):
+            sel = np.nonzero((pidx.g == g) & (pidx.e == e) & (pidx.first == first))[0]
+            rows.append(sel)
+    rows = np.concatenate(rows)
+    assert len(rows) == int(gold["eval_call_sizes"].sum())
+    rel = out.relation.cpu().numpy()[rows]
+    conn = out.connectivity.cpu().numpy()[rows]
+    hid = out.hidden.cpu().numpy()[rows]
+    if cfg.hierarchical:
+        gold_rel = np.concatenate([gold["eval_rel1"], gold["eval_rel2"], gold["eval_rel3"]], axis=1)
+        sup = out.super_relation.cpu().numpy()[rows]
+        e_sup = _rel_err(sup, gold["eval_super"])
+        assert e_sup <= REL_TOL, e_sup
+        assert np.abs(sup / gold["eval_super"] - 1).max() <= 5e-3          # per-element, log-probs are O(1)
+    else:
+        gold_rel = gold["eval_rel"]
+    e_rel, e_conn, e_hid = _rel_err(rel, gold_rel), _rel_err(conn, gold["eval_conn"][:, 0]), _rel_err(hid, gold["eval_hidden"])
+    print(name, "rel err (rel-to-scale): relation %.2e conn %.2e hidden %.2e" % (e_rel, e_conn, e_hid))
+    assert e_rel <= REL_TOL and e_conn <= REL_TOL and e_hid <= REL_TOL
+    # integer outputs: per-super-category argmax must be exact wherever the reference's top-2 gap is resolvable
+    if cfg.hierarchical:
+        segs = [(0, cfg.num_geometric), (cfg.num_geometric, cfg.num_geometric + cfg.num_possessive),
+                (cfg.num_geometric + cfg.num_possessive, cfg.num_relations)]
+        pred = out.cand_pred.cpu().numpy()[rows]
+        for s, (lo, hi) in enumerate(segs):
+            ref_seg = gold_rel[:, lo:hi]
+            ref_arg = ref_seg.argmax(1) + lo
+            top2 = np.sort(ref_seg, axis=1)[:, -2:]
+            resolvable = (top2[:, 1] - top2[:, 0]) > 2 * REL_TOL * np.abs(gold_rel).max()
+            assert (pred[resolvable, s] == ref_arg[resolvable]).all()
+            assert (pred[:, s] == ref_arg).mean() >= 0.95
+
+
+def test_forward_matches_oracle_all_pairs():
+    """All ordered pairs of a ragged minibatch (incl. edge-case boxes) against the CPU oracle."""
+    from oracle import relhead_oracle as O
+    from scene_graph_commonsense_amd.synthetic import HeadConfig, make_scene_batch, make_state_dict
+    cfg = HeadConfig()
+    sd = make_state_dict(cfg, seed=11, head_gain=6.0)
+    batch = make_scene_batch(cfg, (4, 2, 3), seed=11, connect_frac=0.5, edge_boxes=True)
+    sc, out = _forward(cfg, sd, batch)
+    with torch.no_grad():
+        ref = O.run_pair_loop(sd, batch, cfg, mode="eval", overlap_filtering=False)
+    rel = torch.cat([r["relation"] for r in ref["records"]]).numpy()
+    sup = torch.cat([r["super_relation"] for r in ref["records"]]).numpy()
+    conn = torch.cat([r["connectivity"] for r in ref["records"]]).numpy()
+    assert rel.shape[0] == sc.pidx.n_pairs
+    for nm, a, b in (("relation", out.relation, rel), ("super", out.super_relation, sup), ("conn", out.connectivity, conn)):
+        e = _rel_err(a.cpu().numpy(), b)
+        print(nm, "%.2e" % e)
+        assert e <= REL_TOL, (nm, e)
