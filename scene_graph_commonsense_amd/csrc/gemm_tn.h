@@ -21,10 +21,11 @@ struct TnParams {
     long lda, ldb, ldc;
     long slab_stride;            // elements between split-K slabs
     int lgS, Cin;                // BMODE_CONV
+    int CinA;                    // ACONV: A rows are the centre pixels of a zero-padded image with CinA channels
     int tiles_m, tiles_n, ktiles_per_split;
 };
 
-template <int ELEM, int BMODE>
+template <int ELEM, int BMODE, int ACONV>
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TILE_BYTES = 64 * 128 * 2;   // 16 KiB per operand per buffer
@@ -55,7 +56,9 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int k = kt * 64 + (wid * 4 + i) * 4 + kr;
-            const u16* ap = p.A + (long)k * p.lda + m0 + mo;
+            const u16* ap;
+            if constexpr (ACONV) ap = p.A + conv_row_base(k, p.lgS, p.CinA) + (long)((1 << p.lgS) + 3) * p.CinA + m0 + mo;
+            else ap = p.A + (long)k * p.lda + m0 + mo;
             const u16* bp;
             if constexpr (BMODE == BMODE_CONV) bp = p.B + conv_row_base(k, p.lgS, p.Cin) + boff_tap + bcol0 + mo;
             else bp = p.B + (long)k * p.ldb + n0 + mo;
@@ -128,7 +131,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
         }
 }
 
-template <int ELEM, int BMODE>
+template <int ELEM, int BMODE, int ACONV = 0>
 static int launch_gemm_tn(TnParams p, int splits, int* slabs_out, hipStream_t stream) {
     if ((p.K & 63) || (p.N & 127) || (p.M & 127) || p.K <= 0) return SGC_ERR_ARG;
     if (BMODE == BMODE_CONV && ((p.Cin & 127) || p.N != 9 * p.Cin)) return SGC_ERR_ARG;
@@ -140,7 +143,7 @@ static int launch_gemm_tn(TnParams p, int splits, int* slabs_out, hipStream_t st
     p.ktiles_per_split = (nk + splits - 1) / splits;
     splits = (nk + p.ktiles_per_split - 1) / p.ktiles_per_split;
     static bool attr_set = false;
-    auto kern = gemm_tn_kernel<ELEM, BMODE>;
+    auto kern = gemm_tn_kernel<ELEM, BMODE, ACONV>;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
         attr_set = true;

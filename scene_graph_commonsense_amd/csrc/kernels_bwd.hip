@@ -1,0 +1,569 @@
+// Backward-path kernels of the pairwise relation head (gfx950) and their C-ABI launchers.
+// Gradient tensors are bf16 (range of f32; the reference's running-sum loss quirk spreads per-pair loss
+// weights over >3 decades), accumulation is f32.  Layouts as in kernels_fwd.hip, plus
+//   dy3_pad  [n_pair][18][18][1024]  grad wrt conv3 pre-pool output, zero border
+//   dz       [n_pair*256][512]       grad wrt z, rows window-major over the 16x16 map
+//   dU_pad   [n_obj][34][34][512]    grad wrt U (or V), zero border (halo for the conv2 dgrad)
+#include "common.h"
+#include "gemm_nt.h"
+#include "gemm_tn.h"
+
+// ------------------------------------------------------------------------------------------------ head + loss
+// Per pair: dL/dlogits of the hierarchical NLL / BCE loss (reference train_utils.py:64-94,116-157 with the
+// per-step weights of train_test.py:219-258 folded into the coefficients by the host), the pair's loss
+// value, and dL/d(fc2 pre-activation) through the head weights and the ReLU/dropout mask.
+struct HeadBwdParams {
+    const float* rel; const float* sup; const float* conn; const float* p;
+    const int* tgt; const float* coef_a; const float* coef_b; const float* coef_c; const float* conn_y;
+    const float* W;            // [64][512] rows as in the forward head
+    int n_pairs, ng, np, ns, hier; float invT1, invT2, invT3; float drop_scale;
+    float* dl; float* loss; u16* dpre;
+};
+
+__device__ __forceinline__ float wave_max_f(float x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x = fmaxf(x, __shfl_xor(x, o));
+    return x;
+}
+__device__ __forceinline__ float wave_sum_f(float x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+    return x;
+}
+__device__ __forceinline__ float softplusf(float x) { return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x))); }
+
+__global__ __launch_bounds__(256) void head_loss_bwd_kernel(const HeadBwdParams hp) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* Wl = reinterpret_cast<float*>(smem);          // [64][512]
+    float* dls = Wl + 64 * 512;                          // [4][64]
+    for (int i = threadIdx.x; i < 64 * 512; i += 256) Wl[i] = hp.W[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int R = hp.ng + hp.np + hp.ns;
+    float* dlw = dls + w * 64;
+    for (int pr = blockIdx.x * 4 + w; pr < hp.n_pairs; pr += gridDim.x * 4) {
+        const int t = hp.tgt[pr];
+        const float a = hp.coef_a[pr], b = hp.coef_b[pr], cc = hp.coef_c[pr], y = hp.conn_y[pr];
+        const float cn = hp.conn[pr];
+        float dl = 0.f, lossv = 0.f;
+        if (cc != 0.f) lossv += cc * (y > 0.5f ? softplusf(-cn) : softplusf(cn));
+        const float sig = 1.f / (1.f + expf(-cn));
+        if (hp.hier) {
+            if (lane == R + 3) dl = cc * (sig - y);
+            if (t >= 0) {
+                const int st = t < hp.ng ? 0 : (t < hp.ng + hp.np ? 1 : 2);
+                const float invT = st == 0 ? hp.invT1 : (st == 1 ? hp.invT2 : hp.invT3);
+                const float sst = hp.sup[(long)pr * 3 + st];
+                if (lane < R) {
+                    const int seg = lane < hp.ng ? 0 : (lane < hp.ng + hp.np ? 1 : 2);
+                    if (seg == st) dl = b * invT * (expf(hp.rel[(long)pr * R + lane] - sst) - (lane == t ? 1.f : 0.f));
+                } else if (lane < R + 3) {
+                    dl = (a + b) * (expf(hp.sup[(long)pr * 3 + lane - R]) - ((lane - R) == st ? 1.f : 0.f));
+                }
+                lossv += -a * sst - b * hp.rel[(long)pr * R + t];
+            }
+        } else {
+            if (lane == R) dl = cc * (sig - y);
+            if (t >= 0) {                                   // weighted cross-entropy on raw logits
+                const float x = lane < R ? hp.rel[(long)pr * R + lane] : -INFINITY;
+                const float m = wave_max_f(x);
+                const float e = lane < R ? expf(x - m) : 0.f;
+                const float s = wave_sum_f(e);
+                if (lane < R) dl = b * (e / s - (lane == t ? 1.f : 0.f));
+                const float xt = hp.rel[(long)pr * R + t];
+                lossv += -b * (xt - m - logf(s));
+            }
+        }
+        hp.dl[(long)pr * 64 + lane] = dl;
+        if (lane == 0) hp.loss[pr] = lossv;
+        dlw[lane] = dl;
+        __builtin_amdgcn_wave_barrier();
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+        const int nrow = hp.hier ? R + 4 : R + 1;
+        for (int r = 0; r < nrow; ++r) {
+            const float d = dlw[r];
+            if (d != 0.f) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] = fmaf(d, Wl[r * 512 + lane + 64 * j], acc[j]);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = lane + 64 * j;
+            const float pv = hp.p[(long)pr * 512 + k];
+            hp.dpre[(long)pr * 512 + k] = f32_to_bf16_bits(pv > 0.f ? acc[j] * hp.drop_scale : 0.f);
+        }
+    }
+}
+
+// dW[r][k] partial = sum over a chunk of pairs dl[p][r] * p[p][k];  column 512 holds the bias gradient.
+__global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict__ dl, const float* __restrict__ p,
+                                                         float* __restrict__ part, int n_pairs, int chunk) {
+    __shared__ float dls[64];
+    const int k0 = threadIdx.x, k1 = threadIdx.x + 256;
+    float a0[64], a1[64];
+#pragma unroll
+    for (int r = 0; r < 64; ++r) { a0[r] = 0.f; a1[r] = 0.f; }
+    float ab = 0.f;
+    const int pb = blockIdx.x * chunk;
+    const int pe = min(n_pairs, pb + chunk);
+    for (int pr = pb; pr < pe; ++pr) {
+        __syncthreads();
+        if (threadIdx.x < 64) dls[threadIdx.x] = dl[(long)pr * 64 + threadIdx.x];
+        __syncthreads();
+        const float v0 = p[(long)pr * 512 + k0], v1 = p[(long)pr * 512 + k1];
+        if (threadIdx.x < 64) ab += dls[threadIdx.x];
+#pragma unroll
+        for (int r = 0; r < 64; ++r) {
+            const float d = dls[r];
+            a0[r] = fmaf(d, v0, a0[r]);
+            a1[r] = fmaf(d, v1, a1[r]);
+        }
+    }
+    float* out = part + (long)blockIdx.x * 64 * 513;
+#pragma unroll
+    for (int r = 0; r < 64; ++r) { out[r * 513 + k0] = a0[r]; out[r * 513 + k1] = a1[r]; }
+    if (threadIdx.x < 64) out[threadIdx.x * 513 + 512] = ab;
+}
+
+// ------------------------------------------------------------------------------------------------ small reductions
+// out[n] (+)= sum_s in[s][n]
+__global__ void slab_sum_kernel(const float* __restrict__ in, float* __restrict__ out, long n, int slabs, int accumulate) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        float s = accumulate ? out[i] : 0.f;
+        for (int k = 0; k < slabs; ++k) s += in[(long)k * n + i];
+        out[i] = s;
+    }
+}
+
+// column sums of a 16-bit matrix: part[blockIdx.y][cols] = sum over this block's rows
+template <int ELEM>
+__global__ __launch_bounds__(256) void colsum_kernel(const u16* __restrict__ X, float* __restrict__ part, long rows, int cols,
+                                                     long rows_per_block) {
+    const int c = (blockIdx.x * 256 + threadIdx.x) * 8;
+    if (c >= cols) return;
+    const long r0 = blockIdx.y * rows_per_block;
+    const long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+    float acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+    for (long r = r0; r < r1; ++r) {
+        const uint4 v = *reinterpret_cast<const uint4*>(X + r * cols + c);
+        const u16* h = reinterpret_cast<const u16*>(&v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] += from_elem<ELEM>(h[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) part[(long)blockIdx.y * cols + c + k] = acc[k];
+}
+
+// out[o][:] = sum over pairs in list[ptr[o]..ptr[o+1]) of X[pair][:]  (label-column gradients of fc2)
+__global__ __launch_bounds__(64) void segment_sum_rows_kernel(const u16* __restrict__ X, const int* __restrict__ ptr,
+                                                              const int* __restrict__ list, float* __restrict__ out, int cols) {
+    const int o = blockIdx.x, c = threadIdx.x * 8;
+    if (c >= cols) return;
+    float acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+    for (int i = ptr[o]; i < ptr[o + 1]; ++i) {
+        const uint4 v = *reinterpret_cast<const uint4*>(X + (long)list[i] * cols + c);
+        const u16* h = reinterpret_cast<const u16*>(&v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] += bf16_bits_to_f32(h[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) out[(long)o * cols + c + k] = acc[k];
+}
+
+__global__ void convert_f16_bf16_kernel(const u16* __restrict__ in, u16* __restrict__ out, long n8) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+        const uint4 v = reinterpret_cast<const uint4*>(in)[i];
+        const u16* h = reinterpret_cast<const u16*>(&v);
+        uint4 o;
+        u16* oh = reinterpret_cast<u16*>(&o);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) oh[k] = f32_to_bf16_bits(f16_bits_to_f32(h[k]));
+        reinterpret_cast<uint4*>(out)[i] = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ un-pool (conv3 output)
+// dy3_pad[p][2py+dy+1][2px+dx+1][c] = (argmax[p][W][c] == dy*2+dx) ? dy[p][W][c] : 0 ; db3[c] += routed dy
+__global__ __launch_bounds__(256) void unpool_kernel(const u16* __restrict__ dy, const unsigned char* __restrict__ am,
+                                                     u16* __restrict__ dy3, float* __restrict__ dbias, long n_win) {
+    const int ch = threadIdx.x & 127;                    // 128 chunks of 8 channels
+    const int sub = threadIdx.x >> 7;                    // 2 windows per block iteration
+    float bs[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) bs[k] = 0.f;
+    for (long wdx = (long)blockIdx.x * 2 + sub; wdx < n_win; wdx += (long)gridDim.x * 2) {
+        const long p = wdx >> 6;
+        const int W = (int)(wdx & 63), py = W >> 3, px = W & 7;
+        const uint4 g = *reinterpret_cast<const uint4*>(dy + wdx * 1024 + ch * 8);
+        const uint2 a = *reinterpret_cast<const uint2*>(am + wdx * 1024 + ch * 8);
+        const u16* gh = reinterpret_cast<const u16*>(&g);
+        const unsigned char* ab = reinterpret_cast<const unsigned char*>(&a);
+        uint4 o[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            u16* oh = reinterpret_cast<u16*>(&o[q]);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) oh[k] = (ab[k] == q) ? gh[k] : (u16)0;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) if (ab[k] < 4) bs[k] += bf16_bits_to_f32(gh[k]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int Y = 2 * py + (q >> 1) + 1, X = 2 * px + (q & 1) + 1;
+            *reinterpret_cast<uint4*>(dy3 + ((p * 18 + Y) * 18 + X) * 1024 + ch * 8) = o[q];
+        }
+    }
+    if (dbias) {                                         // per-block partial: dbias[blockIdx.x][1024]
+        __shared__ float red[2][1024];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) red[sub][ch * 8 + k] = bs[k];
+        __syncthreads();
+        for (int c = threadIdx.x; c < 1024; c += 256) dbias[(long)blockIdx.x * 1024 + c] = red[0][c] + red[1][c];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ pair expansion (training)
+// Forward expansion that also records which of the four positions won (0..3, 4 = none positive): the
+// routing mask of relu+maxpool for the contraction below.
+template <int ELEM_OUT>
+__global__ __launch_bounds__(256) void pair_expand_train_kernel(const u16* __restrict__ U, const u16* __restrict__ V,
+                                                                const int* __restrict__ sub, const int* __restrict__ obj,
+                                                                u16* __restrict__ z, unsigned char* __restrict__ amz,
+                                                                long n_items) {
+    const int lane = threadIdx.x & 63;
+    for (long it = (long)blockIdx.x * 4 + (threadIdx.x >> 6); it < n_items; it += (long)gridDim.x * 4) {
+        const int p = (int)(it >> 8), W = (int)(it & 255);
+        const u16* up = U + ((long)sub[p] * 1024 + 4 * W) * 512 + lane * 8;
+        const u16* vp = V + ((long)obj[p] * 1024 + 4 * W) * 512 + lane * 8;
+        float best[8];
+        unsigned char arg[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { best[k] = 0.f; arg[k] = 4; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint4 a = *reinterpret_cast<const uint4*>(up + q * 512);
+            const uint4 b = *reinterpret_cast<const uint4*>(vp + q * 512);
+            const u16* ah = reinterpret_cast<const u16*>(&a);
+            const u16* bh = reinterpret_cast<const u16*>(&b);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float s = f16_bits_to_f32(ah[k]) + f16_bits_to_f32(bh[k]);
+                if (s > best[k]) { best[k] = s; arg[k] = (unsigned char)q; }
+            }
+        }
+        if (z) {
+            uint4 o;
+            u16* oh = reinterpret_cast<u16*>(&o);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) oh[k] = to_elem<ELEM_OUT>(best[k]);
+            const int Y = W >> 4, X = W & 15;
+            *reinterpret_cast<uint4*>(z + (((long)p * 18 + Y + 1) * 18 + X + 1) * 512 + lane * 8) = o;
+        }
+        if (amz) {
+            uint2 ao;
+            unsigned char* ab = reinterpret_cast<unsigned char*>(&ao);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) ab[k] = arg[k];
+            *reinterpret_cast<uint2*>(amz + it * 512 + lane * 8) = ao;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ pair contraction
+// dU_pad[o][2Y+dy+1][2X+dx+1][c] = sum over pairs p in list(o):  (amz[p][W][c] == dy*2+dx) ? dz[p][m3(W)][c] : 0
+// (the transpose of the expansion: dU_i = sum_j g_ij, dV_j = sum_i g_ij; one wavefront owns one (object, window),
+//  so the segmented reduction needs no atomics.)
+__global__ __launch_bounds__(256) void pair_contract_kernel(const u16* __restrict__ dz, const unsigned char* __restrict__ amz,
+                                                            const int* __restrict__ ptr, const int* __restrict__ list,
+                                                            u16* __restrict__ dU, long n_items) {
+    const int lane = threadIdx.x & 63;
+    for (long it = (long)blockIdx.x * 4 + (threadIdx.x >> 6); it < n_items; it += (long)gridDim.x * 4) {
+        const int o = (int)(it >> 8), W = (int)(it & 255);
+        const int Y = W >> 4, X = W & 15;
+        const int m3 = 4 * ((Y >> 1) * 8 + (X >> 1)) + (Y & 1) * 2 + (X & 1);
+        float acc[4][8];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[q][k] = 0.f;
+        const int i0 = ptr[o], i1 = ptr[o + 1];
+        for (int i = i0; i < i1; ++i) {
+            const long p = list[i];
+            const uint4 g = *reinterpret_cast<const uint4*>(dz + (p * 256 + m3) * 512 + lane * 8);
+            const uint2 a = *reinterpret_cast<const uint2*>(amz + (p * 256 + W) * 512 + lane * 8);
+            const u16* gh = reinterpret_cast<const u16*>(&g);
+            const unsigned char* ab = reinterpret_cast<const unsigned char*>(&a);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float v = bf16_bits_to_f32(gh[k]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q][k] += (ab[k] == q) ? v : 0.f;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            uint4 ov;
+            u16* oh = reinterpret_cast<u16*>(&ov);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) oh[k] = f32_to_bf16_bits(acc[q][k]);
+            const int yy = 2 * Y + (q >> 1) + 1, xx = 2 * X + (q & 1) + 1;
+            *reinterpret_cast<uint4*>(dU + (((long)o * 34 + yy) * 34 + xx) * 512 + lane * 8) = ov;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ mask backward
+// dA[img][pix][c] = sum_{o in img, pix in box_o} da[o][m(pix)][c];  dcst[c] += sum_{o, pix not in box_o} da[...]
+__global__ __launch_bounds__(256) void mask_objects_bwd_kernel(const u16* __restrict__ da, const int* __restrict__ img_ptr,
+                                                               const int* __restrict__ bbox, float* __restrict__ dA,
+                                                               float* __restrict__ dcst, int F, int D) {
+    __shared__ float outs[256];
+    const int cpp = D / 8;                                 // 16 chunks
+    const int img = blockIdx.y;
+    const int item = blockIdx.x * 256 + threadIdx.x;       // (pixel, chunk)
+    const int pix = item / cpp, ch = item - pix * cpp;
+    if (threadIdx.x < D) outs[threadIdx.x] = 0.f;
+    __syncthreads();
+    const int y = pix / F, x = pix - y * F;
+    const int m = 4 * ((y >> 1) * (F >> 1) + (x >> 1)) + (y & 1) * 2 + (x & 1);
+    float in[8], out[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { in[k] = 0.f; out[k] = 0.f; }
+    if (pix < F * F) {
+        for (int o = img_ptr[img]; o < img_ptr[img + 1]; ++o) {
+            const uint4 v = *reinterpret_cast<const uint4*>(da + ((long)o * F * F + m) * D + ch * 8);
+            const u16* h = reinterpret_cast<const u16*>(&v);
+            const int* b = bbox + 4 * o;
+            const bool inside = x >= b[0] && x < b[1] && y >= b[2] && y < b[3];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float f = bf16_bits_to_f32(h[k]);
+                if (inside) in[k] += f; else out[k] += f;
+            }
+        }
+        float* dst = dA + ((long)img * F * F + pix) * D + ch * 8;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) dst[k] = in[k];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) atomicAdd(&outs[ch * 8 + k], out[k]);
+    }
+    __syncthreads();
+    if (threadIdx.x < D) atomicAdd(dcst + threadIdx.x, outs[threadIdx.x]);
+}
+
+// dpre = dA * (1 - a^2)  (tanh backward), 16-bit out for the conv1 weight-gradient GEMM
+__global__ void tanh_bwd_kernel(const float* __restrict__ dA, const u16* __restrict__ a, u16* __restrict__ dpre, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float t = f16_bits_to_f32(a[i]);
+        dpre[i] = f32_to_bf16_bits(dA[i] * (1.f - t * t));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ C ABI
+static inline int grid_for(long items, long per_block, int cap) {
+    long b = (items + per_block - 1) / per_block;
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+extern "C" {
+
+int sgc_head_loss_bwd(const float* rel, const float* sup, const float* conn, const float* p, const int* tgt,
+                      const float* coef_a, const float* coef_b, const float* coef_c, const float* conn_y,
+                      const float* W, int n_pairs, int ng, int np, int ns, int hier, float T1, float T2, float T3,
+                      float drop_scale, float* dl, float* loss, void* dpre, void* stream) {
+    if (n_pairs <= 0) return SGC_OK;
+    HeadBwdParams hp{rel, sup, conn, p, tgt, coef_a, coef_b, coef_c, conn_y, W, n_pairs, ng, np, ns, hier,
+                     1.f / T1, 1.f / T2, 1.f / T3, drop_scale, dl, loss, (u16*)dpre};
+    const int lds = (64 * 512 + 4 * 64) * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(head_loss_bwd_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(head_loss_bwd_kernel, dim3(grid_for(n_pairs, 4, 256)), dim3(256), lds, (hipStream_t)stream, hp);
+    SGC_CHECK_LAUNCH();
+    return SGC_OK;
+}
+
+// part: [n_blocks][64][513] f32, n_blocks = ceil(n_pairs / chunk)
+int sgc_head_wgrad(const float* dl, const float* p, float* part, int n_pairs, int chunk, void* stream) {
+    if (n_pairs <= 0) return SGC_OK;
+    const int nb = (n_pairs + chunk - 1) / chunk;
+    hipLaunchKernelGGL(head_wgrad_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, dl, p, part, n_pairs, chunk);
+    SGC_CHECK_LAUNCH();
+    return SGC_OK;
+}
+
+int sgc_slab_sum(const float* in, float* out, long n, int slabs, int accumulate, void* stream) {
+    if (n <= 0) return SGC_OK;
+    hipLaunchKernelGGL(slab_sum_kernel, dim3(grid_for(n, 256, 65536)), dim3(256), 0, (hipStream_t)stream, in, out, n, slabs,
+                       accumulate);
+    SGC_CHECK_LAUNCH();
+    return SGC_OK;
+}
+
+// part [row_blocks][cols] f32; returns row_blocks through *n_parts
+int sgc_colsum(int elem, const void* X, float* part, long rows, int cols, int row_blocks, void* stream) {
+    if (cols % 8 || row_blocks < 1) return SGC_ERR_ARG;
+    if (rows <= 0) return SGC_OK;
+    const long rpb = (rows + row_blocks - 1) / row_blocks;
+    dim3 grid((cols / 8 + 255) / 256, row_blocks);
+    if (elem == ELEM_F16)
+        hipLaunchKernelGGL(colsum_kernel<ELEM_F16>, grid, dim3(256), 0, (hipStream_t)stream, (const u16*)X, part, rows, cols, rpb);
+    else
+        hipLaunchKernelGGL(colsum_kernel<ELEM_BF16>, grid, dim3(256), 0, (hipStream_t)stream, (const u16*)X, part, rows, cols, rpb);
+    SGC_CHECK_LAUNCH();
+    return SGC_OK;
+}
+
+int sgc_segment_sum_rows(const void* X, const int* ptr, const int* list, float* out, int n_seg, int cols, void* stream) {
+    if (cols != 512) return SGC_ERR_ARG;
+    if (n_seg <= 0) return SGC_OK;
+    hipLaunchKernelGGL(segment_sum_rows_kernel, dim3(n_seg), dim3(64), 0, (hipStream_t)stream, (const u16*)X, ptr, list, out, cols);
+    SGC_CHECK_LAUNCH();
+    return SGC_OK;
+}
+
+int sgc_convert_f16_bf16(const void* in, void* out, long n, void* stream) {
+    if (n % 8) return SGC_ERR_ARG;
+    if (n <= 0) return SGC_OK;
+    hipLaunchKernelGGL(convert_f16_bf16_kernel, dim3(grid_for(n / 8, 256, 65536)), dim3(256), 0, (hipStream_t)stream,
+                       (const u16*)in, (u16*)out, n / 8);
+    SGC_CHECK_LAUNCH();
+    return SGC_OK;
+}
+
+// ---- fc2
+// dh1 [n_pairs][4096] bf16 = (dpre [n_pairs][512] * w2mT[4096][512]^T) masked by h1 > 0 (x drop_scale)
+int sgc_fc2_dgrad(const void* dpre, const void* w2mT, const void* h1, void* dh1, int n_pairs, float drop_scale, void* stream) {
+    NtParams p{};
+    p.A = (const u16*)dpre; p.B = (const u16*)w2mT; p.C = dh1; p.M = n_pairs; p.N = 4096; p.K = 512;
+    p.lda = 512; p.ldb = 512; p.ldc = 4096; p.mask_src = (const u16*)h1; p.scale = drop_scale;
+    return launch_gemm_nt<ELEM_BF16, AMODE_PLAIN, EPI_RELUMASK>(p, (hipStream_t)stream);
+}
+// slabs [splits][512][4096] f32 = dpre^T * h1_bf16 over n_rows (multiple of 64, zero padded)
+int sgc_fc2_wgrad(const void* dpre, const void* h1_bf16, float* slabs, int n_rows, int splits, int* n_slabs, void* stream) {
+    TnParams p{};
+    p.A = (const u16*)dpre; p.B = (const u16*)h1_bf16; p.C = slabs; p.M = 512; p.N = 4096; p.K = n_rows;
+    p.lda = 512; p.ldb = 4096; p.ldc = 4096; p.slab_stride = 512L * 4096;
+    return launch_gemm_tn<ELEM_BF16, BMODE_PLAIN>(p, splits, n_slabs, (hipStream_t)stream);
+}
+// ---- fc1
+// dy [n_pairs][K] bf16 = dh1 [n_pairs][4096] * w1pT[K][4096]^T
+int sgc_fc1_dgrad(const void* dh1, const void* w1pT, void* dy, int n_pairs, int K, void* stream) {
+    NtParams p{};
+    p.A = (const u16*)dh1; p.B = (const u16*)w1pT; p.C = dy; p.M = n_pairs; p.N = K; p.K = 4096;
+    p.lda = 4096; p.ldb = 4096; p.ldc = K;
+    return launch_gemm_nt<ELEM_BF16, AMODE_PLAIN, EPI_STORE>(p, (hipStream_t)stream);
+}
+// dW1p [4096][K] f32 = dh1^T * y_bf16 over n_rows (multiple of 64, zero padded); no split (16384 tiles)
+int sgc_fc1_wgrad(const void* dh1, const void* y_bf16, float* dw, int n_rows, int K, void* stream) {
+    TnParams p{};
+    p.A = (const u16*)dh1; p.B = (const u16*)y_bf16; p.C = dw; p.M = 4096; p.N = K; p.K = n_rows;
+    p.lda = 4096; p.ldb = K; p.ldc = K; p.slab_stride = 0;
+    return launch_gemm_tn<ELEM_BF16, BMODE_PLAIN>(p, 1, nullptr, (hipStream_t)stream);
+}
+// ---- conv3
+// dbias_part: [*n_parts][1024] f32 per-block partial sums of the routed gradient (conv3 bias gradient)
+int sgc_unpool_relu_bwd(const void* dy, const unsigned char* argmax, void* dy3_pad, float* dbias_part, int* n_parts,
+                        int n_pairs, void* stream) {
+    if (n_pairs <= 0) { if (n_parts) *n_parts = 0; return SGC_OK; }
+    const long n_win = (long)n_pairs * 64;
+    const int blocks = grid_for(n_win, 2, 2048);
+    if (n_parts) *n_parts = blocks;
+    hipLaunchKernelGGL(unpool_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const u16*)dy, argmax,
+                       (u16*)dy3_pad, dbias_part, n_win);
+    SGC_CHECK_LAUNCH();
+    return SGC_OK;
+}
+// dz [n_pairs*256][512] bf16 = conv3x3(dy3_pad, wd3[512][9][1024])
+int sgc_conv3_dgrad(const void* dy3_pad, const void* wd3, void* dz, int n_pairs, void* stream) {
+    NtParams p{};
+    p.A = (const u16*)dy3_pad; p.B = (const u16*)wd3; p.C = dz; p.M = n_pairs * 256; p.N = 512; p.K = 9 * 1024;
+    p.ldb = 9 * 1024; p.ldc = 512; p.lgS = 4; p.Cin = 1024;
+    return launch_gemm_nt<ELEM_BF16, AMODE_CONV, EPI_STORE>(p, (hipStream_t)stream);
+}
+// slabs [splits][1024][9*512] f32 = sum_pix dy3[pix][n] * z_pad_bf16[pix+tap][c]
+int sgc_conv3_wgrad(const void* dy3_pad, const void* z_pad_bf16, float* slabs, int n_pairs, int splits, int* n_slabs, void* stream) {
+    TnParams p{};
+    p.A = (const u16*)dy3_pad; p.B = (const u16*)z_pad_bf16; p.C = slabs; p.M = 1024; p.N = 9 * 512; p.K = n_pairs * 256;
+    p.ldc = 9 * 512; p.slab_stride = 1024L * 9 * 512; p.lgS = 4; p.Cin = 512; p.CinA = 1024;
+    return launch_gemm_tn<ELEM_BF16, BMODE_CONV, 1>(p, splits, n_slabs, (hipStream_t)stream);
+}
+// ---- expansion / contraction
+int sgc_pair_expand_train(const void* U, const void* V, const int* sub_idx, const int* obj_idx, void* z_pad, unsigned char* amz,
+                          int n_pairs, int out_elem, void* stream) {
+    if (n_pairs <= 0) return SGC_OK;
+    const long items = (long)n_pairs * 256;
+    const int blocks = grid_for(items, 4, 262144);
+    if (out_elem == ELEM_F16)
+        hipLaunchKernelGGL(pair_expand_train_kernel<ELEM_F16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const u16*)U,
+                           (const u16*)V, sub_idx, obj_idx, (u16*)z_pad, amz, items);
+    else
+        hipLaunchKernelGGL(pair_expand_train_kernel<ELEM_BF16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const u16*)U,
+                           (const u16*)V, sub_idx, obj_idx, (u16*)z_pad, amz, items);
+    SGC_CHECK_LAUNCH();
+    return SGC_OK;
+}
+int sgc_pair_contract(const void* dz, const unsigned char* amz, const int* ptr, const int* list, void* dU_pad, int n_obj,
+                      void* stream) {
+    if (n_obj <= 0) return SGC_OK;
+    const long items = (long)n_obj * 256;
+    hipLaunchKernelGGL(pair_contract_kernel, dim3(grid_for(items, 4, 262144)), dim3(256), 0, (hipStream_t)stream, (const u16*)dz,
+                       amz, ptr, list, (u16*)dU_pad, items);
+    SGC_CHECK_LAUNCH();
+    return SGC_OK;
+}
+// ---- conv2 (per role)
+// da [n_obj*1024][128] bf16 = conv3x3(dU_pad, wd2[128][9][512])
+int sgc_conv2_dgrad(const void* dU_pad, const void* wd2, void* da, int n_obj, void* stream) {
+    NtParams p{};
+    p.A = (const u16*)dU_pad; p.B = (const u16*)wd2; p.C = da; p.M = n_obj * 1024; p.N = 128; p.K = 9 * 512;
+    p.ldb = 9 * 512; p.ldc = 128; p.lgS = 5; p.Cin = 512;
+    return launch_gemm_nt<ELEM_BF16, AMODE_CONV, EPI_STORE>(p, (hipStream_t)stream);
+}
+// slabs [splits][512][9*128] f32 = sum_pix dU[pix][n] * a_pad_bf16[pix+tap][c]
+int sgc_conv2_wgrad(const void* dU_pad, const void* a_pad_bf16, float* slabs, int n_obj, int splits, int* n_slabs, void* stream) {
+    TnParams p{};
+    p.A = (const u16*)dU_pad; p.B = (const u16*)a_pad_bf16; p.C = slabs; p.M = 512; p.N = 9 * 128; p.K = n_obj * 1024;
+    p.ldc = 9 * 128; p.slab_stride = 512L * 9 * 128; p.lgS = 5; p.Cin = 128; p.CinA = 512;
+    return launch_gemm_tn<ELEM_BF16, BMODE_CONV, 1>(p, splits, n_slabs, (hipStream_t)stream);
+}
+// ---- masks / conv1
+int sgc_object_masked_maps_bwd(const void* da, const int* img_ptr, const int* bbox, float* dA, float* dcst, int n_img, int F,
+                               int D, void* stream) {
+    if (D != 128) return SGC_ERR_ARG;
+    if (n_img <= 0) return SGC_OK;
+    const int items = F * F * (D / 8);
+    hipLaunchKernelGGL(mask_objects_bwd_kernel, dim3((items + 255) / 256, n_img), dim3(256), 0, (hipStream_t)stream,
+                       (const u16*)da, img_ptr, bbox, dA, dcst, F, D);
+    SGC_CHECK_LAUNCH();
+    return SGC_OK;
+}
+int sgc_tanh_bwd(const float* dA, const void* a_img, void* dpre, long n, void* stream) {
+    if (n <= 0) return SGC_OK;
+    hipLaunchKernelGGL(tanh_bwd_kernel, dim3(grid_for(n, 256, 65536)), dim3(256), 0, (hipStream_t)stream, dA, (const u16*)a_img,
+                       (u16*)dpre, n);
+    SGC_CHECK_LAUNCH();
+    return SGC_OK;
+}
+// slabs [splits][128][XC] f32 = dpre^T * x_bf16 over n_rows image pixels
+int sgc_conv1_wgrad(const void* dpre, const void* x_bf16, float* slabs, int n_rows, int XC, int splits, int* n_slabs, void* stream) {
+    TnParams p{};
+    p.A = (const u16*)dpre; p.B = (const u16*)x_bf16; p.C = slabs; p.M = 128; p.N = XC; p.K = n_rows;
+    p.lda = 128; p.ldb = XC; p.ldc = XC; p.slab_stride = 128L * XC;
+    return launch_gemm_tn<ELEM_BF16, BMODE_PLAIN>(p, splits, n_slabs, (hipStream_t)stream);
+}
+
+}  // extern "C"
