@@ -1,0 +1,154 @@
+#!/usr/bin/env python3
+"""Benchmark of the pairwise relation head on MI355X: ordered object-pairs/sec, forward + backward.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one minibatch of synthetic input already resident in HBM:
+8 images x 64 objects per GPU -> 32 256 ordered pairs: per-image conv1, per-object conv2 halves, pair
+expansion, conv3, fc1, fc2, Bayesian head, hierarchical loss, full backward, (N>1: RCCL gradient all-reduce),
+SGD-momentum update of the f32 master weights and re-derivation of the 16-bit compute copies.  Weak scaling:
+every rank owns 8 images.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+from scene_graph_commonsense_amd import distributed as sgd_dist  # noqa: E402
+from scene_graph_commonsense_amd.synthetic import HeadConfig, make_scene_batch, make_state_dict, predicate_counts  # noqa: E402
+
+MFMA_PEAK_TFLOPS = 2500.0      # dense bf16/f16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def cpu_baseline(cfg, sd, budget_s=20.0):
+    """The CPU oracle (literal reference restatement) timed on this host: fwd + loss + bwd of the reference's
+    per-step calls (b = 8 images per call), bounded sample, all host cores."""
+    from oracle import relhead_oracle as O
+    batch = make_scene_batch(cfg, [6] * 8, seed=123, connect_frac=0.3)
+    w = O.class_weights(predicate_counts(cfg))
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    t0 = time.time()
+    out = O.run_pair_loop(sdr, batch, cfg, mode="train", weights=w, max_steps=1)
+    out["losses"].backward()
+    one = time.time() - t0                         # warm-up + cost estimate of one (g,e) step = 2 calls of b=8
+    steps = int(max(1, min(12, budget_s / max(one, 1e-3))))
+    for p in sdr.values():
+        p.grad = None
+    t0 = time.time()
+    out = O.run_pair_loop(sdr, batch, cfg, mode="train", weights=w, max_steps=steps)
+    out["losses"].backward()
+    dt = time.time() - t0
+    pairs = sum(len(r["keep"]) for r in out["records"])
+    return {"value": pairs / dt, "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d reference calls of b=8 pairs (fwd+loss+bwd, f32, %.1f s)" % (len(out["records"]), dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--objects", type=int, default=64)
+    ap.add_argument("--images", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--forward-only", action="store_true")
+    args = ap.parse_args()
+
+    rank, world, local = sgd_dist.init_from_env()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    from scene_graph_commonsense_amd.model import BayesianRelationClassifier
+    from scene_graph_commonsense_amd.pairs import flatten_scene, pair_targets_fast
+    cfg = HeadConfig()
+    sd = make_state_dict(cfg, seed=0)
+    model = BayesianRelationClassifier(cfg.args(run_mode="train")).to(dev)
+    model.load_state_dict(sd)
+    model.train()
+    opt = torch.optim.SGD(model.parameters(), lr=1e-5, momentum=0.9, weight_decay=1e-4)
+    batch = make_scene_batch(cfg, [args.objects] * args.images, seed=1000 + rank, connect_frac=0.02)
+    scene = flatten_scene(cfg, batch, dev)
+    directed = pair_targets_fast(batch.relationships, batch.subj_or_obj, scene.pidx)
+    P = scene.pidx.n_pairs
+    reducer = sgd_dist.GradReducer(world)
+    eng = model.engine()
+    eng.timers = {}
+
+    def step():
+        if args.forward_only:
+            model.forward_pairs(scene)
+            return None
+        opt.zero_grad(set_to_none=True)
+        loss = model.training_step(scene, directed=directed, grad_hook=reducer.hook)
+        reducer.finish(list(model.named_parameters()))
+        opt.step()
+        return loss
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    eng.timers = {}
+    barrier()
+    t0 = time.time()
+    loss = None
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    dt = time.time() - t0
+    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    dt = float(t.item())
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        value = P * world * args.steps / dt
+        kern = {}
+        for name, evs in eng.timers.items():
+            kern[name] = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+        flops = {"conv3_fwd": 2.0 * P * 256 * 1024 * 4608, "conv3_dgrad": 2.0 * P * 256 * 512 * 9216,
+                 "conv3_wgrad": 2.0 * P * 256 * 1024 * 4608, "fc1_fwd": 2.0 * P * 65536 * 4096,
+                 "fc1_dgrad": 2.0 * P * 65536 * 4096, "fc1_wgrad": 2.0 * P * 65536 * 4096}
+        dom = "conv3_fwd"
+        roof = None
+        if dom in kern and kern[dom] > 0:
+            ach = flops[dom] / (kern[dom] * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": "gemm_nt_kernel<f16,conv3x3,relu+pool> (sgc_conv3_relu_pool)",
+                    "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None, "ms_per_launch": round(kern[dom], 3)}
+        out = {
+            "metric": "ordered object-pairs/sec (relation head fwd+bwd), batch=%d, N=%d" % (args.images, args.objects)
+                      if not args.forward_only else "ordered object-pairs/sec (relation head forward only)",
+            "value": round(value, 1), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16 fwd / bf16 bwd (f32 accumulate, f32 master weights)", "data": "synthetic",
+            "config": {"workload": "VG PredCLS synthetic, %d images x %d objects per GPU = %d ordered pairs per GPU per step"
+                                   % (args.images, args.objects, P), "parallelism": "dp%d" % world},
+            "loss": None if loss is None else float(loss),
+            "roofline": roof,
+            "kernels_ms": {k: round(v, 3) for k, v in sorted(kern.items())},
+            "kernels_tflops": {k: round(flops[k] / (kern[k] * 1e-3) / 1e12, 1) for k in kern if k in flops and kern[k] > 0},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, sd)
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,116 @@
+/* C-ABI of libsgc_relhead.so: the MI355X (gfx950) kernels of the pairwise relation-prediction path.
+ *
+ * The reference (bowen-upenn/scene_graph_commonsense) is pure PyTorch and has no FFI; every entry point
+ * below replaces a *stock PyTorch op sequence* of its hot path and cites it (paths relative to the reference
+ * repo).  Conventions:
+ *   - all pointers are DEVICE pointers unless stated; the library owns no memory and never synchronises;
+ *   - `stream` is a hipStream_t passed as void* (0 = default stream); kernels are enqueued on it;
+ *   - return 0 = ok, 1 = bad argument (shape/alignment contract violated), 2 = launch error;
+ *   - "f16"/"bf16" tensors are raw 16-bit storage; accumulation is always f32;
+ *   - layouts are channels-last.  Pixel rows of conv outputs are "window-major": row m of an SxS map is
+ *     m = 4*(py*(S/2)+px) + (dy*2+dx), i.e. the four pixels of a 2x2 pooling window are adjacent.
+ * Sizes are specialised to the reference defaults hidden_dim=128 (D), feature_size=32 (F): C = 2D+1 = 257 input
+ * channels zero-padded to XC=384, conv2 512 ch, conv3 1024 ch, fc1 65536->4096, fc2 ->512.
+ * The Python binding is scene_graph_commonsense_amd/_lib.py (ctypes); INTEGRATION.md shows the call sites.
+ */
+#ifndef SGC_RELHEAD_H
+#define SGC_RELHEAD_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ----------------------------------------------------------------------------------------------- forward */
+
+/* cat(image_feature, image_depth) NCHW f32 -> f16 [n_img*HW][XC]   (train_test.py:194-195 `torch.cat((feat*mask, depth*mask), dim=1)`;
+ * the mask is applied later, after conv1).  f1 may be NULL with C1 = 0 (already concatenated 257-channel input). */
+int sgc_pack_image_nhwc(const float* f0, int C0, const float* f1, int C1, void* x_out, int n_img, int HW, int XC, void* stream);
+
+/* a_img [n_rows][128] f16 = tanh(x [n_rows][XC] * w1r[128][XC]^T + b1)   (model.py:139-140, conv1_1 / conv1_2 + tanh; once per image and role) */
+int sgc_conv1_tanh(const void* x, const void* w1r, const float* b1, void* a_img, int n_rows, int XC, void* stream);
+
+/* a_pad [n_obj][F+2][F+2][D] f16: inside bbox (x0,x1,y0,y1, slice semantics) the image map, outside tanh(b1), zero border
+ * (train_test.py:164-169 mask build + :194-195,202-203 masked gather; tanh(conv1(0)) = tanh(bias) outside the box). */
+int sgc_object_masked_maps(const void* a_img, const int* obj_img, const int* bbox, const void* cst, void* a_pad, int n_obj, int F, int D, void* stream);
+
+/* U or V [n_obj*1024][512] f16 = conv3x3(a_pad, w2r[512][9][128]) (+bias)   (model.py:141-143: conv2_1 over the channel concat
+ * is the sum of a subject half U_i and an object half V_j; bias goes with V). */
+int sgc_conv2_object(const void* a_pad, const void* w2r, const float* bias, void* out, int n_obj, void* stream);
+
+/* z_pad [n_pairs][18][18][512] = maxpool2(relu(U[sub_idx] + V[obj_idx]))   (model.py:143-144 ReLU + maxpool; the pair expansion).
+ * out_elem: 0 = f16, 1 = bf16. */
+int sgc_pair_expand(const void* U, const void* V, const int* sub_idx, const int* obj_idx, void* z_pad, int n_pairs, int out_elem, void* stream);
+
+/* y [n_pairs*64][1024] f16 (+ argmax u8, may be NULL) = maxpool2(relu(conv3x3(z_pad, w3r[1024][9][512]) + b3))   (model.py:145-146) */
+int sgc_conv3_relu_pool(const void* z_pad, const void* w3r, const float* b3, void* y, unsigned char* argmax, int n_pairs, void* stream);
+
+/* h1 [n_pairs][4096] f16 = dropout(relu(y[n_pairs][K] * w1p[4096][K]^T + b))   (model.py:148-149; columns of w1p in (window, channel) order) */
+int sgc_fc1_relu(const void* y, const void* w1p, const float* b, void* h1, int n_pairs, int K, int drop_enable, unsigned drop_seed, void* stream);
+
+/* p [n_pairs][512] f32 = dropout(relu(h1 * w2m[512][4096]^T + b + Lsub[sub_idx] + Lobj[obj_idx]))
+ * (model.py:152-168 one-hot/multi-hot concat + :175 fc2: the label columns of fc2 become per-object row vectors). */
+int sgc_fc2_labels_relu(const void* h1, const void* w2m, const float* b, const float* lsub, const float* lobj, const int* sub_idx,
+                        const int* obj_idx, float* p_out, int n_pairs, int drop_enable, unsigned drop_seed, void* stream);
+
+/* Hierarchical Bayesian head + candidate reduction   (model.py:176-184 = BayesianHead model.py:24-34; flat: model.py:99-101;
+ * candidates evaluator.py:160-174: per super-category max log-prob / first argmax, -inf where iou_mask == 0).
+ * Wt [512][64] f32 (column r = output row r: R relation rows, then 3 super rows and the connectivity row (hier) or the
+ * connectivity row (flat)), bias [64].  rel [n_pairs][R], sup [n_pairs][3] (hier), conn [n_pairs],
+ * cand_conf/cand_pred [n_pairs][3] (hier) or [n_pairs] (flat).  iou_mask may be NULL. */
+int sgc_bayes_head(const float* p, const float* Wt, const float* bias, int n_pairs, int ng, int np, int ns, int hier, float T1, float T2,
+                   float T3, float* rel, float* sup, float* conn, float* cand_conf, int* cand_pred, const unsigned char* iou_mask, void* stream);
+
+/* Per-image stable descending top-K over the accumulated candidates   (evaluator.py:292-316: confidence += connectivity, argsort, top 100).
+ * conf [n_cand] f32 (already including the connectivity term), seg_ptr [n_img+1]; out_idx [n_img][K] image-local candidate
+ * indices (-1 padded), out_count [n_img]. */
+int sgc_topk_per_image(const float* conf, const int* seg_ptr, int n_img, int K, int* out_idx, int* out_count, void* stream);
+
+/* "iou_mask" of testing(): the two boxes overlap on the FxF grid   (train_test.py:403-408).  bbox [n_obj][4], out u8 [n_pairs]. */
+int sgc_overlap_filter(const int* bbox, const int* sub_idx, const int* obj_idx, unsigned char* out, int n_pairs, void* stream);
+
+/* ----------------------------------------------------------------------------------------------- backward */
+
+/* Forward expansion that also records the relu/maxpool routing (amz u8 [n_pairs*256][512]: winning position 0..3, 4 = none);
+ * z_pad or amz may be NULL. */
+int sgc_pair_expand_train(const void* U, const void* V, const int* sub_idx, const int* obj_idx, void* z_pad, unsigned char* amz, int n_pairs,
+                          int out_elem, void* stream);
+
+/* Loss + head backward per pair   (train_utils.py:64-94,116-157, utils.py:28-35 with the step weights of train_test.py:219-258 folded
+ * into per-pair coefficients by the host): loss_i = -a*super[st] - b*rel[t] + c*BCE(conn, y).
+ * W [64][512] f32 head rows; dl [n_pairs][64] dL/dlogits; loss [n_pairs]; dpre [n_pairs][512] bf16 = dL/d(fc2 pre-activation). */
+int sgc_head_loss_bwd(const float* rel, const float* sup, const float* conn, const float* p, const int* tgt, const float* coef_a,
+                      const float* coef_b, const float* coef_c, const float* conn_y, const float* W, int n_pairs, int ng, int np, int ns,
+                      int hier, float T1, float T2, float T3, float drop_scale, float* dl, float* loss, void* dpre, void* stream);
+/* part [ceil(n_pairs/chunk)][64][513] f32 partial head weight (cols 0..511) and bias (col 512) gradients */
+int sgc_head_wgrad(const float* dl, const float* p, float* part, int n_pairs, int chunk, void* stream);
+
+int sgc_slab_sum(const float* in, float* out, long n, int slabs, int accumulate, void* stream);          /* out[n] (+)= sum_s in[s][n] */
+int sgc_colsum(int elem, const void* X, float* part, long rows, int cols, int row_blocks, void* stream);  /* bias gradients */
+int sgc_segment_sum_rows(const void* X, const int* ptr, const int* list, float* out, int n_seg, int cols, void* stream); /* label-column grads */
+int sgc_convert_f16_bf16(const void* in, void* out, long n, void* stream);
+
+int sgc_fc2_dgrad(const void* dpre, const void* w2mT, const void* h1, void* dh1, int n_pairs, float drop_scale, void* stream);
+int sgc_fc2_wgrad(const void* dpre, const void* h1_bf16, float* slabs, int n_rows, int splits, int* n_slabs, void* stream);
+int sgc_fc1_dgrad(const void* dh1, const void* w1pT, void* dy, int n_pairs, int K, void* stream);
+int sgc_fc1_wgrad(const void* dh1, const void* y_bf16, float* dw, int n_rows, int K, void* stream);
+int sgc_unpool_relu_bwd(const void* dy, const unsigned char* argmax, void* dy3_pad, float* dbias_part, int* n_parts, int n_pairs, void* stream);
+int sgc_conv3_dgrad(const void* dy3_pad, const void* wd3, void* dz, int n_pairs, void* stream);
+int sgc_conv3_wgrad(const void* dy3_pad, const void* z_pad_bf16, float* slabs, int n_pairs, int splits, int* n_slabs, void* stream);
+/* dU_pad [n_obj][34][34][512] bf16 = sum over the pairs listed for each object of the routed dz  (transpose of the expansion) */
+int sgc_pair_contract(const void* dz, const unsigned char* amz, const int* ptr, const int* list, void* dU_pad, int n_obj, void* stream);
+int sgc_conv2_dgrad(const void* dU_pad, const void* wd2, void* da, int n_obj, void* stream);
+int sgc_conv2_wgrad(const void* dU_pad, const void* a_pad_bf16, float* slabs, int n_obj, int splits, int* n_slabs, void* stream);
+int sgc_object_masked_maps_bwd(const void* da, const int* img_ptr, const int* bbox, float* dA, float* dcst, int n_img, int F, int D, void* stream);
+int sgc_tanh_bwd(const float* dA, const void* a_img, void* dpre, long n, void* stream);
+int sgc_conv1_wgrad(const void* dpre, const void* x_bf16, float* slabs, int n_rows, int XC, int splits, int* n_slabs, void* stream);
+
+/* ----------------------------------------------------------------------------------------------- test hooks (raw GEMM engines) */
+int sgc_dbg_gemm_nt(int elem, const void* A, const void* B, void* C, int M, int N, int K, long lda, long ldb, long ldc, const float* bias, void* stream);
+int sgc_dbg_conv_nt(int elem, const void* A, const void* B, void* C, int n_img, int lgS, int Cin, int N, const float* bias, void* stream);
+int sgc_dbg_gemm_tn(int elem, const void* A, const void* B, float* C, int M, int N, int K, long lda, long ldb, int splits, int* slabs, void* stream);
+int sgc_dbg_conv_tn(int elem, const void* A, const void* B, float* C, int M, int n_img, int lgS, int Cin, int splits, int* slabs, void* stream);
+int sgc_dbg_tr_probe(const int* addr, short* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,128 @@
+// Evaluation-side kernels: overlap filter (K10) and per-image stable top-K ranking (K9).
+#include "common.h"
+
+// iou_mask of testing(): reference train_test.py:403-408 computes sum(mask_g | mask_e) / sum(mask_g & mask_e),
+// maps inf -> 0 and keeps ratio > 0, i.e. "the two rectangles share at least one grid cell"
+// (0/0 = NaN and x/0 = inf both end up False).
+__global__ void overlap_filter_kernel(const int* __restrict__ bbox, const int* __restrict__ sub, const int* __restrict__ obj,
+                                      unsigned char* __restrict__ out, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int* a = bbox + 4 * sub[i];
+    const int* b = bbox + 4 * obj[i];
+    const int w = min(a[1], b[1]) - max(a[0], b[0]);
+    const int h = min(a[3], b[3]) - max(a[2], b[2]);
+    const bool a_ok = a[1] > a[0] && a[3] > a[2], b_ok = b[1] > b[0] && b[3] > b[2];
+    out[i] = (a_ok && b_ok && w > 0 && h > 0) ? 1 : 0;
+}
+
+__device__ __forceinline__ unsigned order_key(float f) {      // ascending uint order == ascending float order
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// One workgroup per image: radix-select the K-th largest confidence (4 x 8-bit LDS histograms), gather everything
+// above it plus the earliest ties (ordered compaction with wavefront ballots), bitonic-sort the <=128 survivors
+// by (confidence desc, index asc).  Equivalent to a stable descending argsort truncated to K
+// (reference evaluator.py:304,315-316 uses an unstable argsort; ties are resolved by append order here).
+__global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ conf, const int* __restrict__ seg_ptr, int K,
+                                                   int* __restrict__ out_idx, int* __restrict__ out_count) {
+    __shared__ unsigned hist[256];
+    __shared__ unsigned s_prefix, s_mask;
+    __shared__ int s_remaining, s_cnt, s_base, wave_cnt[4];
+    __shared__ unsigned long long keys[128];
+    const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int b = seg_ptr[img], n = seg_ptr[img + 1] - b;
+    const int k = min(K, n);
+    const float* c = conf + b;
+    if (tid < 128) keys[tid] = ~0ull;
+    if (tid == 0) { s_prefix = 0; s_mask = 0; s_remaining = k; s_cnt = 0; out_count[img] = k; }
+    __syncthreads();
+    if (k > 0) {
+        for (int pass = 3; pass >= 0; --pass) {
+            hist[tid] = 0;
+            __syncthreads();
+            const unsigned prefix = s_prefix, mask = s_mask;
+            for (int i = tid; i < n; i += 256) {
+                const unsigned key = order_key(c[i]);
+                if ((key & mask) == prefix) atomicAdd(&hist[(key >> (8 * pass)) & 255u], 1u);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int cum = 0, rem = s_remaining;
+                for (int bk = 255; bk >= 0; --bk) {
+                    const int hv = (int)hist[bk];
+                    if (cum + hv >= rem) {
+                        s_prefix = prefix | ((unsigned)bk << (8 * pass));
+                        s_mask = mask | (0xffu << (8 * pass));
+                        s_remaining = rem - cum;
+                        break;
+                    }
+                    cum += hv;
+                }
+            }
+            __syncthreads();
+        }
+        const unsigned thr = s_prefix;
+        for (int i = tid; i < n; i += 256) {
+            const unsigned key = order_key(c[i]);
+            if (key > thr) {
+                const int pos = atomicAdd(&s_cnt, 1);
+                keys[pos] = ((unsigned long long)(~key) << 32) | (unsigned)i;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) s_base = s_cnt;
+        __syncthreads();
+        for (int c0 = 0; c0 < n; c0 += 256) {
+            if (s_base >= k) break;
+            const int i = c0 + tid;
+            const bool flag = i < n && order_key(c[i]) == thr;
+            const unsigned long long bal = __ballot(flag);
+            const int within = __popcll(bal & ((1ull << lane) - 1ull));
+            if (lane == 0) wave_cnt[wv] = __popcll(bal);
+            __syncthreads();
+            int off = s_base + within;
+            for (int w2 = 0; w2 < wv; ++w2) off += wave_cnt[w2];
+            if (flag && off < k) keys[off] = ((unsigned long long)(~thr) << 32) | (unsigned)i;
+            __syncthreads();
+            if (tid == 0) s_base += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+            __syncthreads();
+        }
+        // bitonic sort of 128 keys, ascending ( = confidence descending, index ascending)
+        for (int size = 2; size <= 128; size <<= 1) {
+            for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                __syncthreads();
+                if (tid < 64) {
+                    const int lo = 2 * tid - (tid & (stride - 1));
+                    const int hi = lo + stride;
+                    const bool up = ((lo & size) == 0);
+                    const unsigned long long a = keys[lo], bb = keys[hi];
+                    if ((a > bb) == up) { keys[lo] = bb; keys[hi] = a; }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    for (int j = tid; j < K; j += 256) out_idx[(long)img * K + j] = (j < k) ? (int)(keys[j] & 0xffffffffull) : -1;
+}
+
+extern "C" {
+
+int sgc_overlap_filter(const int* bbox, const int* sub_idx, const int* obj_idx, unsigned char* out, int n_pairs, void* stream) {
+    if (n_pairs <= 0) return SGC_OK;
+    hipLaunchKernelGGL(overlap_filter_kernel, dim3((n_pairs + 255) / 256), dim3(256), 0, (hipStream_t)stream, bbox, sub_idx, obj_idx,
+                       out, n_pairs);
+    SGC_CHECK_LAUNCH();
+    return SGC_OK;
+}
+
+int sgc_topk_per_image(const float* conf, const int* seg_ptr, int n_img, int K, int* out_idx, int* out_count, void* stream) {
+    if (K < 1 || K > 128) return SGC_ERR_ARG;
+    if (n_img <= 0) return SGC_OK;
+    hipLaunchKernelGGL(topk_kernel, dim3(n_img), dim3(256), 0, (hipStream_t)stream, conf, seg_ptr, K, out_idx, out_count);
+    SGC_CHECK_LAUNCH();
+    return SGC_OK;
+}
+
+}  // extern "C"

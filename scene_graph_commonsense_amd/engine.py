@@ -73,6 +73,18 @@ class RelHeadEngine:
         self.ws = Workspace(self.device)
         self.w: Dict[str, torch.Tensor] = {}
         self.T = (1.0, 1.0, 1.0)
+        self.timers = None          # optional {name: [(start_event, end_event), ...]} filled by bench.py
+
+    def _timed(self, name, fn):
+        """Run one launch, bracketing it with HIP events on the current stream when bench timers are on."""
+        if self.timers is None:
+            return fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        r = fn()
+        b.record()
+        self.timers.setdefault(name, []).append((a, b))
+        return r
 
     # ------------------------------------------------------------------ weights
     def load_weights(self, sd: Dict[str, torch.Tensor]):
@@ -160,9 +172,9 @@ class RelHeadEngine:
                                                   _lib.ptr(self.w["cst"][r]), _lib.ptr(a_pad), n_obj, 32, 128,
                                                   self._st()), "sgc_object_masked_maps")
             uv = ws.get("uv_%d" % r, n_obj * 1024 * 512, torch.float16)
-            _lib.check(lib.sgc_conv2_object(_lib.ptr(a_pad), _lib.ptr(self.w["w2r"][r]),
+            self._timed("conv2_fwd", lambda: _lib.check(lib.sgc_conv2_object(_lib.ptr(a_pad), _lib.ptr(self.w["w2r"][r]),
                                             _lib.ptr(self.w["b2"]) if r == 1 else None, _lib.ptr(uv), n_obj, self._st()),
-                       "sgc_conv2_object")
+                       "sgc_conv2_object"))
             res[r] = uv
         return res
 
@@ -172,19 +184,19 @@ class RelHeadEngine:
         P = int(sub_idx.shape[0])
         Ppad = (P + 63) // 64 * 64
         z = ws.get("z_pad", P * 18 * 18 * 512, torch.float16)      # border stays zero: only interiors are written
-        _lib.check(lib.sgc_pair_expand(_lib.ptr(U), _lib.ptr(V), _lib.ptr(sub_idx), _lib.ptr(obj_idx), _lib.ptr(z), P,
-                                       ELEM_F16, self._st()), "sgc_pair_expand")
+        self._timed("expand", lambda: _lib.check(lib.sgc_pair_expand(_lib.ptr(U), _lib.ptr(V), _lib.ptr(sub_idx), _lib.ptr(obj_idx), _lib.ptr(z), P,
+                                       ELEM_F16, self._st()), "sgc_pair_expand"))
         y = ws.get("y", Ppad * 65536, torch.float16)
         am = ws.get("argmax", P * 65536, torch.uint8) if keep_argmax else None
-        _lib.check(lib.sgc_conv3_relu_pool(_lib.ptr(z), _lib.ptr(self.w["w3r"]), _lib.ptr(self.w["b3"]), _lib.ptr(y),
-                                           _lib.ptr(am), P, self._st()), "sgc_conv3_relu_pool")
+        self._timed("conv3_fwd", lambda: _lib.check(lib.sgc_conv3_relu_pool(_lib.ptr(z), _lib.ptr(self.w["w3r"]), _lib.ptr(self.w["b3"]), _lib.ptr(y),
+                                           _lib.ptr(am), P, self._st()), "sgc_conv3_relu_pool"))
         h1 = ws.get("h1", Ppad * 4096, torch.float16)
-        _lib.check(lib.sgc_fc1_relu(_lib.ptr(y), _lib.ptr(self.w["w1p"]), _lib.ptr(self.w["bf1"]), _lib.ptr(h1), P, 65536,
-                                    int(train), ctypes.c_uint(seeds[0]), self._st()), "sgc_fc1_relu")
+        self._timed("fc1_fwd", lambda: _lib.check(lib.sgc_fc1_relu(_lib.ptr(y), _lib.ptr(self.w["w1p"]), _lib.ptr(self.w["bf1"]), _lib.ptr(h1), P, 65536,
+                                    int(train), ctypes.c_uint(seeds[0]), self._st()), "sgc_fc1_relu"))
         p = ws.get("p", Ppad * 512, torch.float32)
-        _lib.check(lib.sgc_fc2_labels_relu(_lib.ptr(h1), _lib.ptr(self.w["w2m"]), _lib.ptr(self.w["bf2"]), _lib.ptr(lsub),
+        self._timed("fc2_fwd", lambda: _lib.check(lib.sgc_fc2_labels_relu(_lib.ptr(h1), _lib.ptr(self.w["w2m"]), _lib.ptr(self.w["bf2"]), _lib.ptr(lsub),
                                            _lib.ptr(lobj), _lib.ptr(sub_idx), _lib.ptr(obj_idx), _lib.ptr(p), P,
-                                           int(train), ctypes.c_uint(seeds[1]), self._st()), "sgc_fc2_labels_relu")
+                                           int(train), ctypes.c_uint(seeds[1]), self._st()), "sgc_fc2_labels_relu"))
         return self.head(p, P, iou_mask)
 
     def head(self, p, P, iou_mask=None) -> PairOutputs:
@@ -301,7 +313,8 @@ def _colsum(self, X, rows, cols, elem=ELEM_BF16, blocks=64):
 
 def _to_bf16(self, name, src, n):
     dst = self.ws.get(name, n, torch.bfloat16)
-    _lib.check(self.lib.sgc_convert_f16_bf16(_lib.ptr(src), _lib.ptr(dst), _c_long(n), self._st()), "sgc_convert_f16_bf16")
+    self._timed("convert", lambda: _lib.check(self.lib.sgc_convert_f16_bf16(_lib.ptr(src), _lib.ptr(dst), _c_long(n), self._st()),
+                                              "sgc_convert_f16_bf16"))
     return dst
 
 
@@ -322,25 +335,25 @@ def train_forward(self, image_feature, image_depth, obj_img, bbox, cats, super_m
     ctx.lsub, ctx.lobj = self.label_vectors(cats, super_mh)
     z = ws.get("z_pad", P * 18 * 18 * 512, torch.float16)
     amz = ws.get("amz", P * 256 * 512, torch.uint8)
-    _lib.check(lib.sgc_pair_expand_train(_lib.ptr(ctx.uv[0]), _lib.ptr(ctx.uv[1]), _lib.ptr(sub_idx), _lib.ptr(obj_idx),
-                                         _lib.ptr(z), _lib.ptr(amz), P, ELEM_F16, self._st()), "sgc_pair_expand_train")
+    self._timed("expand_train", lambda: _lib.check(lib.sgc_pair_expand_train(_lib.ptr(ctx.uv[0]), _lib.ptr(ctx.uv[1]), _lib.ptr(sub_idx), _lib.ptr(obj_idx),
+                                         _lib.ptr(z), _lib.ptr(amz), P, ELEM_F16, self._st()), "sgc_pair_expand_train"))
     y = ws.get("y", Ppad * 65536, torch.float16)
     am = ws.get("argmax", P * 65536, torch.uint8)
-    _lib.check(lib.sgc_conv3_relu_pool(_lib.ptr(z), _lib.ptr(self.w["w3r"]), _lib.ptr(self.w["b3"]), _lib.ptr(y), _lib.ptr(am),
-                                       P, self._st()), "sgc_conv3_relu_pool")
+    self._timed("conv3_fwd", lambda: _lib.check(lib.sgc_conv3_relu_pool(_lib.ptr(z), _lib.ptr(self.w["w3r"]), _lib.ptr(self.w["b3"]), _lib.ptr(y), _lib.ptr(am),
+                                       P, self._st()), "sgc_conv3_relu_pool"))
     h1 = ws.get("h1", Ppad * 4096, torch.float16)
-    _lib.check(lib.sgc_fc1_relu(_lib.ptr(y), _lib.ptr(self.w["w1p"]), _lib.ptr(self.w["bf1"]), _lib.ptr(h1), P, 65536,
-                                int(dropout), ctypes.c_uint(seeds[0]), self._st()), "sgc_fc1_relu")
+    self._timed("fc1_fwd", lambda: _lib.check(lib.sgc_fc1_relu(_lib.ptr(y), _lib.ptr(self.w["w1p"]), _lib.ptr(self.w["bf1"]), _lib.ptr(h1), P, 65536,
+                                int(dropout), ctypes.c_uint(seeds[0]), self._st()), "sgc_fc1_relu"))
     p = ws.get("p", Ppad * 512, torch.float32)
-    _lib.check(lib.sgc_fc2_labels_relu(_lib.ptr(h1), _lib.ptr(self.w["w2m"]), _lib.ptr(self.w["bf2"]), _lib.ptr(ctx.lsub),
+    self._timed("fc2_fwd", lambda: _lib.check(lib.sgc_fc2_labels_relu(_lib.ptr(h1), _lib.ptr(self.w["w2m"]), _lib.ptr(self.w["bf2"]), _lib.ptr(ctx.lsub),
                                        _lib.ptr(ctx.lobj), _lib.ptr(sub_idx), _lib.ptr(obj_idx), _lib.ptr(p), P, int(dropout),
-                                       ctypes.c_uint(seeds[1]), self._st()), "sgc_fc2_labels_relu")
+                                       ctypes.c_uint(seeds[1]), self._st()), "sgc_fc2_labels_relu"))
     ctx.z, ctx.amz, ctx.y, ctx.am, ctx.h1, ctx.p = z, amz, y, am, h1, p
     ctx.out = self.head(p, P)
     return ctx
 
 
-def train_backward(self, ctx: "TrainContext", coefs, sub_csr, obj_csr, img_ptr, splits=8):
+def train_backward(self, ctx: "TrainContext", coefs, sub_csr, obj_csr, img_ptr, splits=8, grad_hook=None):
     """Backward of the whole path.  Returns (loss scalar tensor, {reference parameter name: f32 gradient})."""
     lib, ws, cfg, dev, w = self.lib, self.ws, self.cfg, self.device, self.w
     P, Ppad, n_obj, n_img = ctx.P, ctx.Ppad, ctx.n_obj, ctx.n_img
@@ -383,8 +396,8 @@ def train_backward(self, ctx: "TrainContext", coefs, sub_csr, obj_csr, img_ptr, 
     # ---- fc2
     h1_bf = _to_bf16(self, "h1_bf", ctx.h1, Ppad * 4096)
     sl = ws.get("slabs", max(splits * 512 * 4096, splits * 1024 * 4608), torch.float32)
-    _lib.check(lib.sgc_fc2_wgrad(_lib.ptr(dpre), _lib.ptr(h1_bf), _lib.ptr(sl), Ppad, splits, ctypes.byref(slabs_n), st()),
-               "sgc_fc2_wgrad")
+    self._timed("fc2_wgrad", lambda: _lib.check(lib.sgc_fc2_wgrad(_lib.ptr(dpre), _lib.ptr(h1_bf), _lib.ptr(sl), Ppad, splits, ctypes.byref(slabs_n), st()),
+               "sgc_fc2_wgrad"))
     dW2m = _slab_sum(self, sl, 512 * 4096, slabs_n.value).view(512, 4096)
     gfc2 = torch.zeros_like(w["fc2_full"])
     gfc2[:, :4096] = dW2m
@@ -406,52 +419,54 @@ def train_backward(self, ctx: "TrainContext", coefs, sub_csr, obj_csr, img_ptr, 
     dh1 = ws.get("dh1", Ppad * 4096, torch.bfloat16)
     if Ppad > P:
         dh1[P * 4096:].zero_()
-    _lib.check(lib.sgc_fc2_dgrad(_lib.ptr(dpre), _lib.ptr(w["w2mT"]), _lib.ptr(ctx.h1), _lib.ptr(dh1), P, f(scale), st()),
-               "sgc_fc2_dgrad")
+    self._timed("fc2_dgrad", lambda: _lib.check(lib.sgc_fc2_dgrad(_lib.ptr(dpre), _lib.ptr(w["w2mT"]), _lib.ptr(ctx.h1), _lib.ptr(dh1), P, f(scale), st()),
+               "sgc_fc2_dgrad"))
 
     # ---- fc1
     y_bf = _to_bf16(self, "y_bf", ctx.y, Ppad * 65536)
     dW1p = ws.get("dW1p", 4096 * 65536, torch.float32)
-    _lib.check(lib.sgc_fc1_wgrad(_lib.ptr(dh1), _lib.ptr(y_bf), _lib.ptr(dW1p), Ppad, 65536, st()), "sgc_fc1_wgrad")
+    self._timed("fc1_wgrad", lambda: _lib.check(lib.sgc_fc1_wgrad(_lib.ptr(dh1), _lib.ptr(y_bf), _lib.ptr(dW1p), Ppad, 65536, st()), "sgc_fc1_wgrad"))
     grads["fc1.weight"] = dW1p.view(4096, 64, 1024).permute(0, 2, 1).reshape(4096, 65536)
+    if grad_hook is not None:          # largest gradient (97 % of the bytes) is ready first: overlap its all-reduce
+        grad_hook("fc1.weight", grads["fc1.weight"])
     grads["fc1.bias"] = _colsum(self, dh1, Ppad, 4096)
     dy = ws.get("dy", Ppad * 65536, torch.bfloat16)
-    _lib.check(lib.sgc_fc1_dgrad(_lib.ptr(dh1), _lib.ptr(w["w1pT"]), _lib.ptr(dy), P, 65536, st()), "sgc_fc1_dgrad")
+    self._timed("fc1_dgrad", lambda: _lib.check(lib.sgc_fc1_dgrad(_lib.ptr(dh1), _lib.ptr(w["w1pT"]), _lib.ptr(dy), P, 65536, st()), "sgc_fc1_dgrad"))
 
     # ---- conv3
     dy3 = ws.get("dy3_pad", P * 18 * 18 * 1024, torch.bfloat16)
     bpart = ws.get("b3_part", 2048 * 1024, torch.float32)
     nparts = ctypes.c_int(0)
-    _lib.check(lib.sgc_unpool_relu_bwd(_lib.ptr(dy), _lib.ptr(ctx.am), _lib.ptr(dy3), _lib.ptr(bpart), ctypes.byref(nparts), P, st()),
-               "sgc_unpool_relu_bwd")
+    self._timed("unpool", lambda: _lib.check(lib.sgc_unpool_relu_bwd(_lib.ptr(dy), _lib.ptr(ctx.am), _lib.ptr(dy3), _lib.ptr(bpart), ctypes.byref(nparts), P, st()),
+               "sgc_unpool_relu_bwd"))
     grads["conv3_1.bias"] = _slab_sum(self, bpart, 1024, nparts.value)
     z_bf = ws.get("z_pad_bf", P * 18 * 18 * 512, torch.bfloat16)
-    _lib.check(lib.sgc_pair_expand_train(_lib.ptr(ctx.uv[0]), _lib.ptr(ctx.uv[1]), _lib.ptr(ctx.sub_idx), _lib.ptr(ctx.obj_idx),
-                                         _lib.ptr(z_bf), None, P, ELEM_BF16, st()), "sgc_pair_expand_train")
-    _lib.check(lib.sgc_conv3_wgrad(_lib.ptr(dy3), _lib.ptr(z_bf), _lib.ptr(sl), P, splits, ctypes.byref(slabs_n), st()),
-               "sgc_conv3_wgrad")
+    self._timed("expand_train", lambda: _lib.check(lib.sgc_pair_expand_train(_lib.ptr(ctx.uv[0]), _lib.ptr(ctx.uv[1]), _lib.ptr(ctx.sub_idx), _lib.ptr(ctx.obj_idx),
+                                         _lib.ptr(z_bf), None, P, ELEM_BF16, st()), "sgc_pair_expand_train"))
+    self._timed("conv3_wgrad", lambda: _lib.check(lib.sgc_conv3_wgrad(_lib.ptr(dy3), _lib.ptr(z_bf), _lib.ptr(sl), P, splits, ctypes.byref(slabs_n), st()),
+               "sgc_conv3_wgrad"))
     dW3r = _slab_sum(self, sl, 1024 * 4608, slabs_n.value)
     grads["conv3_1.weight"] = dW3r.view(1024, 3, 3, 512).permute(0, 3, 1, 2).contiguous()
     dz = ws.get("dz", P * 256 * 512, torch.bfloat16)
-    _lib.check(lib.sgc_conv3_dgrad(_lib.ptr(dy3), _lib.ptr(w["wd3"]), _lib.ptr(dz), P, st()), "sgc_conv3_dgrad")
+    self._timed("conv3_dgrad", lambda: _lib.check(lib.sgc_conv3_dgrad(_lib.ptr(dy3), _lib.ptr(w["wd3"]), _lib.ptr(dz), P, st()), "sgc_conv3_dgrad"))
 
     # ---- pair contraction + conv2 + masks + conv1
     gc2 = torch.empty(512, 256, 3, 3, dtype=torch.float32, device=dev)
     x_bf = _to_bf16(self, "x_bf", ctx.x, n_img * 1024 * XC)
     for r, csr in ((0, sub_csr), (1, obj_csr)):
         dU = ws.get("dU_pad_%d" % r, n_obj * 34 * 34 * 512, torch.bfloat16)
-        _lib.check(lib.sgc_pair_contract(_lib.ptr(dz), _lib.ptr(ctx.amz), _lib.ptr(csr[0]), _lib.ptr(csr[1]), _lib.ptr(dU), n_obj, st()),
-                   "sgc_pair_contract")
+        self._timed("contract", lambda: _lib.check(lib.sgc_pair_contract(_lib.ptr(dz), _lib.ptr(ctx.amz), _lib.ptr(csr[0]), _lib.ptr(csr[1]), _lib.ptr(dU), n_obj, st()),
+                   "sgc_pair_contract"))
         a_pad = ws.get("a_pad_%d" % r, n_obj * 34 * 34 * 128, torch.float16)
         a_bf = _to_bf16(self, "a_pad_bf", a_pad, n_obj * 34 * 34 * 128)
-        _lib.check(lib.sgc_conv2_wgrad(_lib.ptr(dU), _lib.ptr(a_bf), _lib.ptr(sl), n_obj, splits, ctypes.byref(slabs_n), st()),
-                   "sgc_conv2_wgrad")
+        self._timed("conv2_wgrad", lambda: _lib.check(lib.sgc_conv2_wgrad(_lib.ptr(dU), _lib.ptr(a_bf), _lib.ptr(sl), n_obj, splits, ctypes.byref(slabs_n), st()),
+                   "sgc_conv2_wgrad"))
         dW2r = _slab_sum(self, sl, 512 * 1152, slabs_n.value)
         gc2[:, r * 128:(r + 1) * 128] = dW2r.view(512, 3, 3, 128).permute(0, 3, 1, 2)
         if r == 1:
             grads["conv2_1.bias"] = _colsum(self, dU, n_obj * 34 * 34, 512)
         da = ws.get("da", n_obj * 1024 * 128, torch.bfloat16)
-        _lib.check(lib.sgc_conv2_dgrad(_lib.ptr(dU), _lib.ptr(w["wd2"][r]), _lib.ptr(da), n_obj, st()), "sgc_conv2_dgrad")
+        self._timed("conv2_dgrad", lambda: _lib.check(lib.sgc_conv2_dgrad(_lib.ptr(dU), _lib.ptr(w["wd2"][r]), _lib.ptr(da), n_obj, st()), "sgc_conv2_dgrad"))
         dA = ws.get("dA", n_img * 1024 * 128, torch.float32)
         dcst = torch.zeros(128, dtype=torch.float32, device=dev)
         _lib.check(lib.sgc_object_masked_maps_bwd(_lib.ptr(da), _lib.ptr(img_ptr), _lib.ptr(ctx.bbox), _lib.ptr(dA), _lib.ptr(dcst),

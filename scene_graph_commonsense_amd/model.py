@@ -1,0 +1,258 @@
+"""Drop-in modules for the reference's ``model.py`` backed by the gfx950 kernels.
+
+Same class names, constructor arguments, parameter names/shapes (reference checkpoints load with
+``load_state_dict``, including the DDP ``module.`` prefix via ``strip_ddp_prefix``) and ``forward`` signatures
+and return tuples as the reference (``model.py:9-34, 37-102, 105-186``).  Two entry points:
+
+* ``forward(h_sub, h_obj, c1, c2, s1, s2, rank, h_sub_aug=None, h_obj_aug=None)`` - the reference's per-step
+  call on pre-masked ``[b,257,32,32]`` inputs, so the reference's own pair loops run unchanged;
+* ``forward_pairs(...)`` / ``training_step(...)`` - the fused path: one call per minibatch over all ordered
+  pairs, in the reference's candidate order.
+
+There is no CPU or eager-PyTorch fallback: the HIP extension must load and the module must live on a GPU.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .engine import PairOutputs, RelHeadEngine, csr_by, loss_coefficients
+from .pairs import DeviceScene, pair_targets_fast, super_multihot
+from .synthetic import HeadConfig, predicate_counts
+
+
+def strip_ddp_prefix(state_dict: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """Reference checkpoints are saved from the DDP wrapper (``train_test.py:322``; ``utils.py:207-214``)."""
+    return {k.replace("module.", ""): v for k, v in state_dict.items()}
+
+
+class _RelationBase(nn.Module):
+    hierarchical = True
+
+    def _build_trunk(self, args, input_dim, feature_size, num_classes, num_super_classes):
+        self.input_dim = input_dim
+        self.feature_size = feature_size
+        self.num_classes = num_classes
+        self.num_super_classes = num_super_classes
+        self.dataset = args["dataset"]["dataset"]
+        self.conv1_1 = nn.Conv2d(2 * input_dim + 1, input_dim, kernel_size=1, stride=1, padding=0)
+        self.conv1_2 = nn.Conv2d(2 * input_dim + 1, input_dim, kernel_size=1, stride=1, padding=0)
+        self.conv2_1 = nn.Conv2d(2 * input_dim, 4 * input_dim, kernel_size=3, stride=1, padding=1)
+        self.conv3_1 = nn.Conv2d(4 * input_dim, 8 * input_dim, kernel_size=3, stride=1, padding=1)
+        self.dropout1 = nn.Dropout(p=0.5)     # kept for state/API parity; dropout itself runs in the kernels
+        self.dropout2 = nn.Dropout(p=0.5)
+        self.maxpool = nn.MaxPool2d(kernel_size=2, stride=2)
+        self.fc1 = nn.Linear(8 * input_dim * (feature_size // 4) ** 2, 4096)
+        if self.dataset == "vg":
+            self.fc2 = nn.Linear(4096 + 2 * (num_classes + num_super_classes), 512)
+        else:
+            self.fc2 = nn.Linear(4096 + 2 * num_classes, 512)
+        self._engine: Optional[RelHeadEngine] = None
+        self._weights_version = None
+        self._step = 0
+        self.dropout_seed = 0x5EED
+
+    # ------------------------------------------------------------------ engine plumbing
+    def head_config(self) -> HeadConfig:
+        raise NotImplementedError
+
+    def engine(self) -> RelHeadEngine:
+        dev = self.fc1.weight.device
+        if dev.type != "cuda":
+            raise RuntimeError("the relation head runs only on a GPU through its HIP kernels (no CPU fallback); "
+                               "move the module to a cuda device")
+        if self._engine is None or self._engine.device != dev:
+            self._engine = RelHeadEngine(self.head_config(), dev)
+            self._engine.T = (float(getattr(self, "T1", 1)), float(getattr(self, "T2", 1)), float(getattr(self, "T3", 1)))
+            self._weights_version = None
+        return self._engine
+
+    def _version(self):
+        return tuple(p._version for p in self.parameters()) + tuple(p.data_ptr() for p in self.parameters())
+
+    def refresh_weights(self, backward: bool = False):
+        """Re-derive the 16-bit compute copies when the f32 master parameters changed."""
+        eng = self.engine()
+        v = (self._version(), backward)
+        if self._weights_version is None or self._weights_version[0] != v[0] or (backward and not self._weights_version[1]):
+            sd = {k: p for k, p in self.named_parameters()}
+            with torch.no_grad():
+                eng.load_weights(sd)
+                if backward:
+                    eng.prep_bwd_weights(sd)
+            self._weights_version = v
+        return eng
+
+    # ------------------------------------------------------------------ fused path
+    def forward_pairs(self, scene: DeviceScene, iou_mask: Optional[torch.Tensor] = None) -> PairOutputs:
+        """All ordered pairs of a minibatch in one pass (eval numerics unless ``self.training``)."""
+        eng = self.refresh_weights()
+        seeds = self._next_seeds() if self.training else (0, 0)
+        with torch.no_grad():
+            return eng.forward_pairs(scene.image_feature, scene.image_depth, scene.obj_img, scene.bbox, scene.cats,
+                                     scene.super_mh, scene.sub_idx, scene.obj_idx, train=self.training, seeds=seeds,
+                                     iou_mask=iou_mask)
+
+    def _next_seeds(self):
+        self._step += 1
+        return ((self.dropout_seed * 2654435761 + 2 * self._step) & 0xFFFFFFFF,
+                (self.dropout_seed * 2654435761 + 2 * self._step + 1) & 0xFFFFFFFF)
+
+    def training_step(self, scene: DeviceScene, relationships=None, subj_or_obj=None, directed: Optional[np.ndarray] = None,
+                      lambda_connectivity: float = 0.1, lambda_not_connected: float = 1.0, class_weight=None,
+                      grad_hook=None):
+        """Forward + loss + backward over all ordered pairs; gradients land in ``param.grad`` (accumulating like
+        autograd).  Loss follows ``train_test.py:189-258`` / ``train_utils.py:64-157`` (hierarchical NLL, BCE on
+        connectivity, running-sum step weights); the contrastive and commonsense terms are out of scope."""
+        cfg = self.head_config()
+        eng = self.refresh_weights(backward=True)
+        pidx = scene.pidx
+        dev = eng.device
+        if directed is None:
+            directed = pair_targets_fast(relationships, subj_or_obj, pidx)
+        if class_weight is None:
+            counts = predicate_counts(cfg).numpy()
+            class_weight = 1 - counts / counts.sum()
+        coefs = loss_coefficients(cfg, pidx.step, len(pidx.call_sizes), directed, np.asarray(class_weight),
+                                  lambda_connectivity, lambda_not_connected)
+        coefs_d = tuple(torch.from_numpy(c).to(dev, non_blocking=True) for c in coefs)
+        n_obj = int(scene.obj_img.shape[0])
+        if getattr(scene, "_csr", None) is None:
+            scene._csr = (tuple(torch.from_numpy(a).to(dev) for a in csr_by(pidx.sub, n_obj)),
+                          tuple(torch.from_numpy(a).to(dev) for a in csr_by(pidx.obj, n_obj)),
+                          torch.from_numpy(pidx.obj_offset.astype(np.int32)).to(dev))
+        sub_csr, obj_csr, img_ptr = scene._csr
+        with torch.no_grad():
+            ctx = eng.train_forward(scene.image_feature, scene.image_depth, scene.obj_img, scene.bbox, scene.cats,
+                                    scene.super_mh, scene.sub_idx, scene.obj_idx,
+                                    seeds=self._next_seeds() if self.training else (0, 0), dropout=self.training)
+            loss, grads = eng.train_backward(ctx, coefs_d, sub_csr, obj_csr, img_ptr, grad_hook=grad_hook)
+            for name, p in self.named_parameters():
+                g = grads[name].view_as(p)
+                if p.grad is None:
+                    p.grad = g if g.is_contiguous() else g.contiguous()
+                else:
+                    p.grad.add_(g)
+        self.last_outputs = ctx.out
+        return loss
+
+    # ------------------------------------------------------------------ reference per-step call
+    def _compat_forward(self, h_sub, h_obj, c1, c2, s1, s2):
+        """Reference semantics for arbitrary pre-masked inputs: each of the b rows is one (subject, object) pair."""
+        cfg = self.head_config()
+        eng = self.refresh_weights()
+        dev = eng.device
+        b = int(h_sub.shape[0])
+        with torch.no_grad():
+            hs = h_sub.to(dev, torch.float32).contiguous()
+            ho = h_obj.to(dev, torch.float32).contiguous()
+            a_s = eng.image_maps(hs, None, roles=(0,), tag="cs")
+            a_o = eng.image_maps(ho, None, roles=(1,), tag="co")
+            full = torch.tensor([[0, 32, 0, 32]], dtype=torch.int32, device=dev).repeat(b, 1).contiguous()
+            ids = torch.arange(b, dtype=torch.int32, device=dev)
+            U = eng.object_halves({0: a_s[0]}, ids, full, roles=(0,))[0]
+            V = eng.object_halves({1: a_o[1]}, ids, full, roles=(1,))[1]
+            mh1 = mh2 = None
+            if s1 is not None:
+                mh1 = torch.from_numpy(super_multihot([list(s1)], cfg.num_super_classes)).to(dev)
+                mh2 = torch.from_numpy(super_multihot([list(s2)], cfg.num_super_classes)).to(dev)
+            lsub, _ = eng.label_vectors(c1.to(dev).long(), mh1)
+            _, lobj = eng.label_vectors(c2.to(dev).long(), mh2)
+            seeds = self._next_seeds() if self.training else (0, 0)
+            return eng.pair_trunk(U, V, ids, ids, lsub, lobj, train=self.training, seeds=seeds)
+
+
+class BayesianRelationClassifier(_RelationBase):
+    """Hierarchical (Bayesian) local predictor - drop-in for reference ``model.py:105-186``."""
+    hierarchical = True
+
+    def __init__(self, args, input_dim=128, feature_size=32, num_classes=150, num_super_classes=17, num_geometric=15,
+                 num_possessive=11, num_semantic=24, T1=1, T2=1, T3=1):
+        super().__init__()
+        self._build_trunk(args, input_dim, feature_size, num_classes, num_super_classes)
+        self.num_geometric, self.num_possessive, self.num_semantic = num_geometric, num_possessive, num_semantic
+        self.fc3_1 = nn.Linear(512, num_geometric)
+        self.fc3_2 = nn.Linear(512, num_possessive)
+        self.fc3_3 = nn.Linear(512, num_semantic)
+        self.fc4 = nn.Linear(512, 1)
+        self.fc5 = nn.Linear(512, 3)
+        self.T1, self.T2, self.T3 = T1, T2, T3
+
+    def head_config(self) -> HeadConfig:
+        return HeadConfig(dataset=self.dataset, hidden_dim=self.input_dim, feature_size=self.feature_size,
+                          num_classes=self.num_classes, num_super_classes=self.num_super_classes,
+                          num_geometric=self.num_geometric, num_possessive=self.num_possessive,
+                          num_semantic=self.num_semantic, hierarchical=True)
+
+    def forward(self, h_sub, h_obj, c1, c2, s1, s2, rank, h_sub_aug=None, h_obj_aug=None):
+        out = self._compat_forward(h_sub, h_obj, c1, c2, s1, s2)
+        ng, npos = self.num_geometric, self.num_possessive
+        rel = out.relation
+        pred_aug = None
+        if h_sub_aug is not None:      # second (augmented) view: same trunk, hidden only (model.py:172)
+            pred_aug = self._compat_forward(h_sub_aug, h_obj_aug, c1, c2, s1, s2).hidden.clone()
+        return (rel[:, :ng], rel[:, ng:ng + npos], rel[:, ng + npos:], out.super_relation,
+                out.connectivity.view(-1, 1), out.hidden.clone(), pred_aug)
+
+
+class FlatRelationClassifier(_RelationBase):
+    """Flat-classification ablation - drop-in for reference ``model.py:37-102``."""
+    hierarchical = False
+
+    def __init__(self, args, input_dim=128, output_dim=50, feature_size=32, num_classes=150, num_super_classes=17):
+        super().__init__()
+        self._build_trunk(args, input_dim, feature_size, num_classes, num_super_classes)
+        self.output_dim = output_dim
+        self.fc3 = nn.Linear(512, output_dim)
+        self.fc4 = nn.Linear(512, 1)
+
+    def head_config(self) -> HeadConfig:
+        return HeadConfig(dataset=self.dataset, hidden_dim=self.input_dim, feature_size=self.feature_size,
+                          num_classes=self.num_classes, num_super_classes=self.num_super_classes,
+                          num_geometric=self.output_dim, num_possessive=0, num_semantic=0, hierarchical=False)
+
+    def forward(self, h_sub, h_obj, c1, c2, s1, s2, rank, h_sub_aug=None, h_obj_aug=None, one_hot=True):
+        out = self._compat_forward(h_sub, h_obj, c1, c2, s1, s2)
+        pred_aug = None
+        if h_sub_aug is not None:
+            pred_aug = self._compat_forward(h_sub_aug, h_obj_aug, c1, c2, s1, s2).hidden.clone()
+        return out.relation, out.connectivity.view(-1, 1), out.hidden.clone(), pred_aug
+
+
+class BayesianHead(nn.Module):
+    """Plug-and-play hierarchical head on ``[M,512]`` features - drop-in for reference ``model.py:9-34``."""
+
+    def __init__(self, input_dim=512, num_geometric=15, num_possessive=11, num_semantic=24, T1=1, T2=1, T3=1):
+        super().__init__()
+        if input_dim != 512:
+            raise NotImplementedError("the head kernel is specialised to 512 input features")
+        self.fc3_1 = nn.Linear(input_dim, num_geometric)
+        self.fc3_2 = nn.Linear(input_dim, num_possessive)
+        self.fc3_3 = nn.Linear(input_dim, num_semantic)
+        self.fc5 = nn.Linear(input_dim, 3)
+        self.T1, self.T2, self.T3 = T1, T2, T3
+        self.ng, self.np_, self.ns = num_geometric, num_possessive, num_semantic
+        self._eng = None
+
+    def forward(self, h):
+        dev = h.device
+        if dev.type != "cuda":
+            raise RuntimeError("BayesianHead runs only on a GPU through its HIP kernel (no CPU fallback)")
+        cfg = HeadConfig(num_geometric=self.ng, num_possessive=self.np_, num_semantic=self.ns)
+        if self._eng is None or self._eng.device != dev:
+            self._eng = RelHeadEngine(cfg, dev)
+        eng = self._eng
+        eng.T = (float(self.T1), float(self.T2), float(self.T3))
+        with torch.no_grad():
+            rows = torch.cat([self.fc3_1.weight, self.fc3_2.weight, self.fc3_3.weight, self.fc5.weight])
+            Wc = torch.zeros(64, 512, device=dev)
+            Wc[:rows.shape[0]] = rows
+            bc = torch.zeros(64, device=dev)
+            bc[:rows.shape[0]] = torch.cat([self.fc3_1.bias, self.fc3_2.bias, self.fc3_3.bias, self.fc5.bias])
+            eng.w["head_wt"], eng.w["head_b"] = Wc.t().contiguous(), bc
+            out = eng.head(h.float().contiguous().view(-1), int(h.shape[0]))
+        rel = out.relation
+        return rel[:, :self.ng], rel[:, self.ng:self.ng + self.np_], rel[:, self.ng + self.np_:], out.super_relation

@@ -140,3 +140,20 @@ def flatten_scene(cfg, batch, device) -> DeviceScene:
                        torch.from_numpy(obj_img).to(dev), torch.from_numpy(bb).to(dev), cats.to(dev),
                        None if mh is None else torch.from_numpy(mh).to(dev),
                        torch.from_numpy(pidx.sub).to(dev), torch.from_numpy(pidx.obj).to(dev), pidx, raw)
+
+
+def pair_targets_fast(relationships, subj_or_obj, pidx: PairIndex) -> np.ndarray:
+    """Vectorised ``pair_targets`` (directed targets only)."""
+    n = np.diff(pidx.obj_offset).astype(np.int64)
+    sq_off = np.concatenate([[0], np.cumsum(n * n)])
+    rel = np.full(int(sq_off[-1]), -1, dtype=np.int64)
+    dirs = np.full(int(sq_off[-1]), -1.0, dtype=np.float32)
+    for b in range(len(n)):
+        nb = int(n[b])
+        for g in range(1, nb):
+            base = int(sq_off[b]) + g * nb
+            rel[base:base + g] = np.asarray(relationships[b][g - 1])
+            dirs[base:base + g] = np.asarray(subj_or_obj[b][g - 1])
+    idx = sq_off[pidx.image] + pidx.g * n[pidx.image] + pidx.e
+    flag = np.where(pidx.first, 1.0, 0.0).astype(np.float32)
+    return np.where(dirs[idx] == flag, rel[idx], -1).astype(np.int64)
