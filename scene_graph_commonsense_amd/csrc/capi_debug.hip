@@ -55,7 +55,7 @@ __global__ void tr_probe_kernel(const int* addr, short* out) {
     for (int j = 0; j < 4; ++j) out[threadIdx.x * 4 + j] = v[j];
 }
 int sgc_dbg_tr_probe(const int* addr, short* out, void* stream) {
-    hipLaunchKernelGGL(tr_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, addr, out);
+    SGC_LAUNCH(tr_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, addr, out);
     SGC_CHECK_LAUNCH();
     return SGC_OK;
 }

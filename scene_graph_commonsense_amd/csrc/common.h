@@ -59,3 +59,7 @@ __device__ __host__ __forceinline__ bool dropout_keep(uint32_t seed, uint32_t id
         hipError_t e__ = hipGetLastError();                  \
         if (e__ != hipSuccess) return SGC_ERR_LAUNCH;        \
     } while (0)
+
+// hipGetLastError() also reports stale errors of unrelated earlier runtime calls (e.g. a benign failed pointer
+// query made by the host framework); clear it before our launch so the check after it is about OUR launch.
+#define SGC_LAUNCH(...) do { (void)hipGetLastError(); hipLaunchKernelGGL(__VA_ARGS__); } while (0)

@@ -212,7 +212,7 @@ static int launch_gemm_nt(NtParams p, hipStream_t stream) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(256), 65536, stream, p);
+    SGC_LAUNCH(kern, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(256), 65536, stream, p);
     SGC_CHECK_LAUNCH();
     return SGC_OK;
 }

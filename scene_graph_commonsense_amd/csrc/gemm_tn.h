@@ -148,7 +148,7 @@ static int launch_gemm_tn(TnParams p, int splits, int* slabs_out, hipStream_t st
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)(p.tiles_m * p.tiles_n), (unsigned)splits), dim3(256), 65536, stream, p);
+    SGC_LAUNCH(kern, dim3((unsigned)(p.tiles_m * p.tiles_n), (unsigned)splits), dim3(256), 65536, stream, p);
     SGC_CHECK_LAUNCH();
     if (slabs_out) *slabs_out = splits;
     return SGC_OK;

@@ -391,7 +391,7 @@ int sgc_head_loss_bwd(const float* rel, const float* sup, const float* conn, con
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL(head_loss_bwd_kernel, dim3(grid_for(n_pairs, 4, 256)), dim3(256), lds, (hipStream_t)stream, hp);
+    SGC_LAUNCH(head_loss_bwd_kernel, dim3(grid_for(n_pairs, 4, 256)), dim3(256), lds, (hipStream_t)stream, hp);
     SGC_CHECK_LAUNCH();
     return SGC_OK;
 }
@@ -400,14 +400,14 @@ int sgc_head_loss_bwd(const float* rel, const float* sup, const float* conn, con
 int sgc_head_wgrad(const float* dl, const float* p, float* part, int n_pairs, int chunk, void* stream) {
     if (n_pairs <= 0) return SGC_OK;
     const int nb = (n_pairs + chunk - 1) / chunk;
-    hipLaunchKernelGGL(head_wgrad_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, dl, p, part, n_pairs, chunk);
+    SGC_LAUNCH(head_wgrad_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, dl, p, part, n_pairs, chunk);
     SGC_CHECK_LAUNCH();
     return SGC_OK;
 }
 
 int sgc_slab_sum(const float* in, float* out, long n, int slabs, int accumulate, void* stream) {
     if (n <= 0) return SGC_OK;
-    hipLaunchKernelGGL(slab_sum_kernel, dim3(grid_for(n, 256, 65536)), dim3(256), 0, (hipStream_t)stream, in, out, n, slabs,
+    SGC_LAUNCH(slab_sum_kernel, dim3(grid_for(n, 256, 65536)), dim3(256), 0, (hipStream_t)stream, in, out, n, slabs,
                        accumulate);
     SGC_CHECK_LAUNCH();
     return SGC_OK;
@@ -420,9 +420,9 @@ int sgc_colsum(int elem, const void* X, float* part, long rows, int cols, int ro
     const long rpb = (rows + row_blocks - 1) / row_blocks;
     dim3 grid((cols / 8 + 255) / 256, row_blocks);
     if (elem == ELEM_F16)
-        hipLaunchKernelGGL(colsum_kernel<ELEM_F16>, grid, dim3(256), 0, (hipStream_t)stream, (const u16*)X, part, rows, cols, rpb);
+        SGC_LAUNCH(colsum_kernel<ELEM_F16>, grid, dim3(256), 0, (hipStream_t)stream, (const u16*)X, part, rows, cols, rpb);
     else
-        hipLaunchKernelGGL(colsum_kernel<ELEM_BF16>, grid, dim3(256), 0, (hipStream_t)stream, (const u16*)X, part, rows, cols, rpb);
+        SGC_LAUNCH(colsum_kernel<ELEM_BF16>, grid, dim3(256), 0, (hipStream_t)stream, (const u16*)X, part, rows, cols, rpb);
     SGC_CHECK_LAUNCH();
     return SGC_OK;
 }
@@ -430,7 +430,7 @@ int sgc_colsum(int elem, const void* X, float* part, long rows, int cols, int ro
 int sgc_segment_sum_rows(const void* X, const int* ptr, const int* list, float* out, int n_seg, int cols, void* stream) {
     if (cols != 512) return SGC_ERR_ARG;
     if (n_seg <= 0) return SGC_OK;
-    hipLaunchKernelGGL(segment_sum_rows_kernel, dim3(n_seg), dim3(64), 0, (hipStream_t)stream, (const u16*)X, ptr, list, out, cols);
+    SGC_LAUNCH(segment_sum_rows_kernel, dim3(n_seg), dim3(64), 0, (hipStream_t)stream, (const u16*)X, ptr, list, out, cols);
     SGC_CHECK_LAUNCH();
     return SGC_OK;
 }
@@ -438,7 +438,7 @@ int sgc_segment_sum_rows(const void* X, const int* ptr, const int* list, float* 
 int sgc_convert_f16_bf16(const void* in, void* out, long n, void* stream) {
     if (n % 8) return SGC_ERR_ARG;
     if (n <= 0) return SGC_OK;
-    hipLaunchKernelGGL(convert_f16_bf16_kernel, dim3(grid_for(n / 8, 256, 65536)), dim3(256), 0, (hipStream_t)stream,
+    SGC_LAUNCH(convert_f16_bf16_kernel, dim3(grid_for(n / 8, 256, 65536)), dim3(256), 0, (hipStream_t)stream,
                        (const u16*)in, (u16*)out, n / 8);
     SGC_CHECK_LAUNCH();
     return SGC_OK;
@@ -482,7 +482,7 @@ int sgc_unpool_relu_bwd(const void* dy, const unsigned char* argmax, void* dy3_p
     const long n_win = (long)n_pairs * 64;
     const int blocks = grid_for(n_win, 2, 2048);
     if (n_parts) *n_parts = blocks;
-    hipLaunchKernelGGL(unpool_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const u16*)dy, argmax,
+    SGC_LAUNCH(unpool_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const u16*)dy, argmax,
                        (u16*)dy3_pad, dbias_part, n_win);
     SGC_CHECK_LAUNCH();
     return SGC_OK;
@@ -508,10 +508,10 @@ int sgc_pair_expand_train(const void* U, const void* V, const int* sub_idx, cons
     const long items = (long)n_pairs * 256;
     const int blocks = grid_for(items, 4, 262144);
     if (out_elem == ELEM_F16)
-        hipLaunchKernelGGL(pair_expand_train_kernel<ELEM_F16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const u16*)U,
+        SGC_LAUNCH(pair_expand_train_kernel<ELEM_F16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const u16*)U,
                            (const u16*)V, sub_idx, obj_idx, (u16*)z_pad, amz, items);
     else
-        hipLaunchKernelGGL(pair_expand_train_kernel<ELEM_BF16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const u16*)U,
+        SGC_LAUNCH(pair_expand_train_kernel<ELEM_BF16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const u16*)U,
                            (const u16*)V, sub_idx, obj_idx, (u16*)z_pad, amz, items);
     SGC_CHECK_LAUNCH();
     return SGC_OK;
@@ -520,7 +520,7 @@ int sgc_pair_contract(const void* dz, const unsigned char* amz, const int* ptr, 
                       void* stream) {
     if (n_obj <= 0) return SGC_OK;
     const long items = (long)n_obj * 256;
-    hipLaunchKernelGGL(pair_contract_kernel, dim3(grid_for(items, 4, 262144)), dim3(256), 0, (hipStream_t)stream, (const u16*)dz,
+    SGC_LAUNCH(pair_contract_kernel, dim3(grid_for(items, 4, 262144)), dim3(256), 0, (hipStream_t)stream, (const u16*)dz,
                        amz, ptr, list, (u16*)dU_pad, items);
     SGC_CHECK_LAUNCH();
     return SGC_OK;
@@ -546,14 +546,14 @@ int sgc_object_masked_maps_bwd(const void* da, const int* img_ptr, const int* bb
     if (D != 128) return SGC_ERR_ARG;
     if (n_img <= 0) return SGC_OK;
     const int items = F * F * (D / 8);
-    hipLaunchKernelGGL(mask_objects_bwd_kernel, dim3((items + 255) / 256, n_img), dim3(256), 0, (hipStream_t)stream,
+    SGC_LAUNCH(mask_objects_bwd_kernel, dim3((items + 255) / 256, n_img), dim3(256), 0, (hipStream_t)stream,
                        (const u16*)da, img_ptr, bbox, dA, dcst, F, D);
     SGC_CHECK_LAUNCH();
     return SGC_OK;
 }
 int sgc_tanh_bwd(const float* dA, const void* a_img, void* dpre, long n, void* stream) {
     if (n <= 0) return SGC_OK;
-    hipLaunchKernelGGL(tanh_bwd_kernel, dim3(grid_for(n, 256, 65536)), dim3(256), 0, (hipStream_t)stream, dA, (const u16*)a_img,
+    SGC_LAUNCH(tanh_bwd_kernel, dim3(grid_for(n, 256, 65536)), dim3(256), 0, (hipStream_t)stream, dA, (const u16*)a_img,
                        (u16*)dpre, n);
     SGC_CHECK_LAUNCH();
     return SGC_OK;

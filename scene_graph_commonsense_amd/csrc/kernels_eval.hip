@@ -111,7 +111,7 @@ extern "C" {
 
 int sgc_overlap_filter(const int* bbox, const int* sub_idx, const int* obj_idx, unsigned char* out, int n_pairs, void* stream) {
     if (n_pairs <= 0) return SGC_OK;
-    hipLaunchKernelGGL(overlap_filter_kernel, dim3((n_pairs + 255) / 256), dim3(256), 0, (hipStream_t)stream, bbox, sub_idx, obj_idx,
+    SGC_LAUNCH(overlap_filter_kernel, dim3((n_pairs + 255) / 256), dim3(256), 0, (hipStream_t)stream, bbox, sub_idx, obj_idx,
                        out, n_pairs);
     SGC_CHECK_LAUNCH();
     return SGC_OK;
@@ -120,7 +120,7 @@ int sgc_overlap_filter(const int* bbox, const int* sub_idx, const int* obj_idx, 
 int sgc_topk_per_image(const float* conf, const int* seg_ptr, int n_img, int K, int* out_idx, int* out_count, void* stream) {
     if (K < 1 || K > 128) return SGC_ERR_ARG;
     if (n_img <= 0) return SGC_OK;
-    hipLaunchKernelGGL(topk_kernel, dim3(n_img), dim3(256), 0, (hipStream_t)stream, conf, seg_ptr, K, out_idx, out_count);
+    SGC_LAUNCH(topk_kernel, dim3(n_img), dim3(256), 0, (hipStream_t)stream, conf, seg_ptr, K, out_idx, out_count);
     SGC_CHECK_LAUNCH();
     return SGC_OK;
 }

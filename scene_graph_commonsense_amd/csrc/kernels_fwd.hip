@@ -196,7 +196,7 @@ int sgc_pack_image_nhwc(const float* f0, int C0, const float* f1, int C1, void* 
                         void* stream) {
     if (HW % 64 || XC % 8 || C0 + C1 > XC) return SGC_ERR_ARG;
     if (n_img <= 0) return SGC_OK;
-    hipLaunchKernelGGL(pack_nhwc_kernel, dim3(HW / 64, n_img), dim3(256), 64 * (XC + 8) * 2, (hipStream_t)stream,
+    SGC_LAUNCH(pack_nhwc_kernel, dim3(HW / 64, n_img), dim3(256), 64 * (XC + 8) * 2, (hipStream_t)stream,
                        f0, C0, f1, C1, (u16*)x_out, HW, XC);
     SGC_CHECK_LAUNCH();
     return SGC_OK;
@@ -215,7 +215,7 @@ int sgc_object_masked_maps(const void* a_img, const int* obj_img, const int* bbo
     if (n_obj <= 0) return SGC_OK;
     const long total = (long)n_obj * (F + 2) * (F + 2) * (D / 8);
     const int blocks = (int)((total + 255) / 256 > 65536 ? 65536 : (total + 255) / 256);
-    hipLaunchKernelGGL(mask_objects_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const u16*)a_img, obj_img,
+    SGC_LAUNCH(mask_objects_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const u16*)a_img, obj_img,
                        bbox, (const u16*)cst, (u16*)a_pad, n_obj, F, D);
     SGC_CHECK_LAUNCH();
     return SGC_OK;
@@ -236,10 +236,10 @@ int sgc_pair_expand(const void* U, const void* V, const int* sub_idx, const int*
     const long want = (items + 3) / 4;
     const int blocks = (int)(want > 262144 ? 262144 : want);
     if (out_elem == ELEM_F16)
-        hipLaunchKernelGGL(pair_expand_kernel<ELEM_F16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const u16*)U,
+        SGC_LAUNCH(pair_expand_kernel<ELEM_F16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const u16*)U,
                            (const u16*)V, sub_idx, obj_idx, (u16*)z_pad, items);
     else
-        hipLaunchKernelGGL(pair_expand_kernel<ELEM_BF16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const u16*)U,
+        SGC_LAUNCH(pair_expand_kernel<ELEM_BF16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const u16*)U,
                            (const u16*)V, sub_idx, obj_idx, (u16*)z_pad, items);
     SGC_CHECK_LAUNCH();
     return SGC_OK;
@@ -290,7 +290,7 @@ int sgc_bayes_head(const float* p, const float* Wt, const float* bias, int n_pai
     }
     int blocks = (n_pairs + 3) / 4;
     if (blocks > 256) blocks = 256;
-    hipLaunchKernelGGL(bayes_head_kernel, dim3(blocks), dim3(256), lds, (hipStream_t)stream, hp);
+    SGC_LAUNCH(bayes_head_kernel, dim3(blocks), dim3(256), lds, (hipStream_t)stream, hp);
     SGC_CHECK_LAUNCH();
     return SGC_OK;
 }
