@@ -69,10 +69,10 @@ int sgc_overlap_filter(const int* bbox, const int* sub_idx, const int* obj_idx, 
 
 /* ----------------------------------------------------------------------------------------------- backward */
 
-/* Forward expansion that also records the relu/maxpool routing (amz u8 [n_pairs*256][512]: winning position 0..3, 4 = none);
- * z_pad or amz may be NULL. */
-int sgc_pair_expand_train(const void* U, const void* V, const int* sub_idx, const int* obj_idx, void* z_pad, unsigned char* amz, int n_pairs,
-                          int out_elem, void* stream);
+/* Forward expansion for training: writes z in f16 (conv3 forward operand) and bf16 (conv3 weight-gradient operand) and records
+ * the relu/maxpool routing (amz u8 [n_pairs*256][512]: winning position 0..3, 4 = none).  Any output may be NULL. */
+int sgc_pair_expand_train(const void* U, const void* V, const int* sub_idx, const int* obj_idx, void* z_pad_f16, void* z_pad_bf16,
+                          unsigned char* amz, int n_pairs, void* stream);
 
 /* Loss + head backward per pair   (train_utils.py:64-94,116-157, utils.py:28-35 with the step weights of train_test.py:219-258 folded
  * into per-pair coefficients by the host): loss_i = -a*super[st] - b*rel[t] + c*BCE(conn, y).

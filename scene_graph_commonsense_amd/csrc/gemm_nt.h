@@ -53,27 +53,37 @@ __device__ __forceinline__ long conv_row_base(int m, int lgS, int Cin) {
     return ((long)(img * (S + 2) + y) * (S + 2) + x) * Cin;
 }
 
-template <int ELEM, int AMODE, int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NtParams p) {
+// Block configuration: WR x WC wavefronts, each owning a (TM*32) x (TN*32) output tile.
+//   small: 2x2 waves of 64x64   -> 128x128 block, 64 KiB LDS, 2 blocks/CU  (small problems, N % 256 != 0)
+//   big  : 2x4 waves of 128x64  -> 256x256 block, 128 KiB LDS, 1 block/CU  (half the LDS bytes per MFMA)
+template <int ELEM, int AMODE, int EPI, int WR, int WC, int TM, int TN>
+__global__ __launch_bounds__(WR * WC * 64, 2) void gemm_nt_kernel(const NtParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int BM = 128, BN = 128;
-    constexpr int TILE_BYTES = BM * 64 * 2;   // 16 KiB per operand per buffer
+    constexpr int NW = WR * WC;
+    constexpr int BM = WR * TM * 32, BN = WC * TN * 32;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, BUF_BYTES = A_BYTES + B_BYTES;
+    constexpr int AI = BM / (8 * NW), BI = BN / (8 * NW);      // global_load_lds instructions per wave per K tile
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tn = blockIdx.x % p.tiles_n, tm = blockIdx.x / p.tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
 
-    // ---- loader addresses: wave w stages rows w*32 .. w*32+31 of both operands, 8 rows per instruction
+    // ---- loader addresses: wave w stages rows w*AI*8 .. of A and w*BI*8 .. of B, 8 rows (1 KiB) per instruction
     const int lrow = lane >> 3, cpos = lane & 7;
-    const u16* a_ptr[4];
-    const u16* b_ptr[4];
+    const u16* a_ptr[AI];
+    const u16* b_ptr[BI];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = wid * 32 + i * 8 + lrow;
+    for (int i = 0; i < AI; ++i) {
+        const int row = wid * AI * 8 + i * 8 + lrow;
         const int chunk = cpos ^ ((row >> 1) & 7);
         int m = m0 + row; if (m > p.M - 1) m = p.M - 1;
         if constexpr (AMODE == AMODE_CONV) a_ptr[i] = p.A + conv_row_base(m, p.lgS, p.Cin) + chunk * 8;
         else a_ptr[i] = p.A + (long)m * p.lda + chunk * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+        const int row = wid * BI * 8 + i * 8 + lrow;
+        const int chunk = cpos ^ ((row >> 1) & 7);
         b_ptr[i] = p.B + (long)(n0 + row) * p.ldb + chunk * 8;
     }
     const int cpt = (AMODE == AMODE_CONV) ? (p.Cin >> 6) : 1;
@@ -89,31 +99,35 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NtParams p) {
             aoff = (long)kt << 6;
         }
         const long boff = (long)kt << 6;
-        char* abase = smem + buf * 2 * TILE_BYTES + wid * 4096;
-        char* bbase = abase + TILE_BYTES;
+        char* abase = smem + buf * BUF_BYTES + wid * (AI * 1024);
+        char* bbase = smem + buf * BUF_BYTES + A_BYTES + wid * (BI * 1024);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < AI; ++i)
             __builtin_amdgcn_global_load_lds(GLB_PTR(a_ptr[i] + aoff), LDS_PTR(abase + i * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < BI; ++i)
             __builtin_amdgcn_global_load_lds(GLB_PTR(b_ptr[i] + boff), LDS_PTR(bbase + i * 1024), 16, 0, 0);
-        }
     };
 
     // ---- fragment read addresses
-    const int wr = wid >> 1, wc = wid & 1;
+    const int wr = wid / WC, wc = wid % WC;
     const int kh = lane >> 5;
-    int a_off[2], a_sw[2], b_off[2], b_sw[2];
+    int a_off[TM], a_sw[TM], b_off[TN], b_sw[TN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int ra = wr * 64 + i * 32 + (lane & 31);
-        const int rb = wc * 64 + i * 32 + (lane & 31);
+    for (int i = 0; i < TM; ++i) {
+        const int ra = wr * TM * 32 + i * 32 + (lane & 31);
         a_off[i] = ra * 128; a_sw[i] = (ra >> 1) & 7;
+    }
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+        const int rb = wc * TN * 32 + i * 32 + (lane & 31);
         b_off[i] = rb * 128; b_sw[i] = (rb >> 1) & 7;
     }
-    f32x16 acc[2][2];
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -123,32 +137,31 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NtParams p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
-        const char* ab = smem + (kt & 1) * 2 * TILE_BYTES;
-        const char* bb = ab + TILE_BYTES;
+        const char* ab = smem + (kt & 1) * BUF_BYTES;
+        const char* bb = ab + A_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int c = ks * 2 + kh;
-            s16x8 af[2], bf[2];
+            s16x8 af[TM], bf[TN];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                af[i] = *reinterpret_cast<const s16x8*>(ab + a_off[i] + ((c ^ a_sw[i]) << 4));
-                bf[i] = *reinterpret_cast<const s16x8*>(bb + b_off[i] + ((c ^ b_sw[i]) << 4));
-            }
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const s16x8*>(ab + a_off[i] + ((c ^ a_sw[i]) << 4));
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < TN; ++i) bf[i] = *reinterpret_cast<const s16x8*>(bb + b_off[i] + ((c ^ b_sw[i]) << 4));
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = mfma32<ELEM>(af[i], bf[j], acc[i][j]);
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = mfma32<ELEM>(af[i], bf[j], acc[i][j]);
         }
     }
 
     // ---- epilogue
     const int h = lane >> 5, cl = lane & 31;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < TM; ++i) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = n0 + wc * 64 + j * 32 + cl;
-            const int rbase = m0 + wr * 64 + i * 32;
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wc * TN * 32 + j * 32 + cl;
+            const int rbase = m0 + wr * TM * 32 + i * 32;
             const float bias = p.bias ? p.bias[col] : 0.f;
             if constexpr (EPI == EPI_POOL) {
                 u16* out = reinterpret_cast<u16*>(p.C);
@@ -199,20 +212,37 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NtParams p) {
     }
 }
 
+inline int sgc_gemm_cfg() {       // test hook: SGC_GEMM_CFG=1 forces the 128x128 block, =2 the 256x256 block
+    static int cfg = -1;
+    if (cfg < 0) { const char* e = getenv("SGC_GEMM_CFG"); cfg = e ? atoi(e) : 0; }
+    return cfg;
+}
+
+template <int ELEM, int AMODE, int EPI, int WR, int WC, int TM, int TN>
+static int launch_gemm_nt_cfg(NtParams p, hipStream_t stream) {
+    constexpr int BM = WR * TM * 32, BN = WC * TN * 32;
+    constexpr int LDS = 2 * (BM + BN) * 128;
+    p.tiles_m = (p.M + BM - 1) / BM;
+    p.tiles_n = p.N / BN;
+    static bool attr_set = false;
+    auto kern = gemm_nt_kernel<ELEM, AMODE, EPI, WR, WC, TM, TN>;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set = true;
+    }
+    SGC_LAUNCH(kern, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(WR * WC * 64), LDS, stream, p);
+    SGC_CHECK_LAUNCH();
+    return SGC_OK;
+}
+
 template <int ELEM, int AMODE, int EPI>
 static int launch_gemm_nt(NtParams p, hipStream_t stream) {
     if (p.M <= 0) return SGC_OK;
     if ((p.K & 63) || (p.N & 127) || p.K <= 0) return SGC_ERR_ARG;
     if (AMODE == AMODE_CONV && ((p.Cin & 63) || p.K != 9 * p.Cin)) return SGC_ERR_ARG;
-    p.tiles_m = (p.M + 127) / 128;
-    p.tiles_n = p.N / 128;
-    static bool attr_set = false;
-    auto kern = gemm_nt_kernel<ELEM, AMODE, EPI>;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-        attr_set = true;
-    }
-    SGC_LAUNCH(kern, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(256), 65536, stream, p);
-    SGC_CHECK_LAUNCH();
-    return SGC_OK;
+    const int cfg = sgc_gemm_cfg();
+    const bool big_ok = (p.N % 256) == 0;
+    const bool big = big_ok && (cfg == 2 || (cfg == 0 && (long)p.M * p.N >= 256L * 256 * 256));
+    if (big) return launch_gemm_nt_cfg<ELEM, AMODE, EPI, 2, 4, 4, 2>(p, stream);
+    return launch_gemm_nt_cfg<ELEM, AMODE, EPI, 2, 2, 2, 2>(p, stream);
 }

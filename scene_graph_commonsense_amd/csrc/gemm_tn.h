@@ -25,20 +25,25 @@ struct TnParams {
     int tiles_m, tiles_n, ktiles_per_split;
 };
 
-template <int ELEM, int BMODE, int ACONV>
-__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
+template <int ELEM, int BMODE, int ACONV, int WR, int WC, int TM, int TN>
+__global__ __launch_bounds__(WR * WC * 64, 2) void gemm_tn_kernel(const TnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int TILE_BYTES = 64 * 128 * 2;   // 16 KiB per operand per buffer
+    constexpr int NW = WR * WC;
+    constexpr int BM = WR * TM * 32, BN = WC * TN * 32;
+    constexpr int MB16 = BM / 16, NB16 = BN / 16;             // 4x16 sub-blocks (128 B) per 4-row k block
+    constexpr int A_BYTES = 64 * BM * 2, B_BYTES = 64 * BN * 2, BUF_BYTES = A_BYTES + B_BYTES;
+    constexpr int AI = A_BYTES / 1024 / NW, BI = B_BYTES / 1024 / NW;   // global_load_lds instructions per wave
+    constexpr int APK = MB16 / 8, BPK = NB16 / 8;             // instructions per k block row
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tn = blockIdx.x % p.tiles_n, tm = blockIdx.x / p.tiles_n;
-    const int m0 = tm * 128, n0 = tn * 128;
+    const int m0 = tm * BM, n0 = tn * BN;
     const int kt_begin = blockIdx.y * p.ktiles_per_split;
     int kt_end = kt_begin + p.ktiles_per_split;
     const int nk_total = p.K >> 6;
     if (kt_end > nk_total) kt_end = nk_total;
 
-    // loader: instruction i of wave w fills k-block kb = w*4+i (4 k rows) x 128 columns
+    // loader: one instruction fills 8 sub-blocks = 4 k rows x 128 columns
     const int kr = (lane >> 1) & 3;
     const int mo = ((lane >> 3) * 2 + (lane & 1)) * 8;
     long boff_tap = 0;
@@ -51,36 +56,43 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
     }
 
     auto stage = [&](int buf, int kt) {
-        char* abase = smem + buf * 2 * TILE_BYTES + wid * 4096;
-        char* bbase = abase + TILE_BYTES;
+        char* abase = smem + buf * BUF_BYTES + wid * (AI * 1024);
+        char* bbase = smem + buf * BUF_BYTES + A_BYTES + wid * (BI * 1024);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int k = kt * 64 + (wid * 4 + i) * 4 + kr;
+        for (int i = 0; i < AI; ++i) {
+            const int q = wid * AI + i;
+            const int k = kt * 64 + (q / APK) * 4 + kr;
+            const int mcol = (q % APK) * 128 + mo;
             const u16* ap;
-            if constexpr (ACONV) ap = p.A + conv_row_base(k, p.lgS, p.CinA) + (long)((1 << p.lgS) + 3) * p.CinA + m0 + mo;
-            else ap = p.A + (long)k * p.lda + m0 + mo;
-            const u16* bp;
-            if constexpr (BMODE == BMODE_CONV) bp = p.B + conv_row_base(k, p.lgS, p.Cin) + boff_tap + bcol0 + mo;
-            else bp = p.B + (long)k * p.ldb + n0 + mo;
+            if constexpr (ACONV) ap = p.A + conv_row_base(k, p.lgS, p.CinA) + (long)((1 << p.lgS) + 3) * p.CinA + m0 + mcol;
+            else ap = p.A + (long)k * p.lda + m0 + mcol;
             __builtin_amdgcn_global_load_lds(GLB_PTR(ap), LDS_PTR(abase + i * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < BI; ++i) {
+            const int q = wid * BI + i;
+            const int k = kt * 64 + (q / BPK) * 4 + kr;
+            const int ncol = (q % BPK) * 128 + mo;
+            const u16* bp;
+            if constexpr (BMODE == BMODE_CONV) bp = p.B + conv_row_base(k, p.lgS, p.Cin) + boff_tap + bcol0 + ncol;
+            else bp = p.B + (long)k * p.ldb + n0 + ncol;
             __builtin_amdgcn_global_load_lds(GLB_PTR(bp), LDS_PTR(bbase + i * 1024), 16, 0, 0);
         }
     };
 
-    const int wr = wid >> 1, wc = wid & 1;
+    const int wr = wid / WC, wc = wid % WC;
     const int g = (lane >> 4) & 1, kh = lane >> 5, t = lane & 15;
     const int lane_off = (t >> 2) * 32 + (t & 3) * 8;
-    int a_blk[2], b_blk[2];
+    int a_blk[TM], b_blk[TN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        a_blk[i] = (wr * 4 + i * 2 + g) * 128 + lane_off;
-        b_blk[i] = (wc * 4 + i * 2 + g) * 128 + lane_off;
-    }
-    f32x16 acc[2][2];
+    for (int i = 0; i < TM; ++i) a_blk[i] = (wr * TM * 2 + i * 2 + g) * 128 + lane_off;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TN; ++i) b_blk[i] = (wc * TN * 2 + i * 2 + g) * 128 + lane_off;
+    f32x16 acc[TM][TN];
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -90,66 +102,80 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (kt + 1 < kt_end) stage((it + 1) & 1, kt + 1);
-        const char* ab = smem + (it & 1) * 2 * TILE_BYTES;
-        const char* bb = ab + TILE_BYTES;
+        const char* ab = smem + (it & 1) * BUF_BYTES;
+        const char* bb = ab + A_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int kb = ks * 4 + kh * 2;          // first of two 4-row k blocks
-            s16x8 af[2], bf[2];
+            s16x8 af[TM], bf[TN];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < TM; ++i) {
                 const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) s16x4*)(ab + kb * 1024 + a_blk[i]));
+                    (__attribute__((address_space(3))) s16x4*)(ab + kb * (MB16 * 128) + a_blk[i]));
                 const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) s16x4*)(ab + (kb + 1) * 1024 + a_blk[i]));
-                const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) s16x4*)(bb + kb * 1024 + b_blk[i]));
-                const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) s16x4*)(bb + (kb + 1) * 1024 + b_blk[i]));
+                    (__attribute__((address_space(3))) s16x4*)(ab + (kb + 1) * (MB16 * 128) + a_blk[i]));
                 af[i] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+                const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4*)(bb + kb * (NB16 * 128) + b_blk[i]));
+                const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4*)(bb + (kb + 1) * (NB16 * 128) + b_blk[i]));
                 bf[i] = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = mfma32<ELEM>(af[i], bf[j], acc[i][j]);
+                for (int j = 0; j < TN; ++j) acc[i][j] = mfma32<ELEM>(af[i], bf[j], acc[i][j]);
         }
     }
 
     float* C = p.C + (long)blockIdx.y * p.slab_stride;
     const int h = lane >> 5, cl = lane & 31;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = n0 + wc * 64 + j * 32 + cl;
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wc * TN * 32 + j * 32 + cl;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int row = m0 + wr * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 C[(long)row * p.ldc + col] = acc[i][j][r];
             }
         }
 }
 
-template <int ELEM, int BMODE, int ACONV = 0>
-static int launch_gemm_tn(TnParams p, int splits, int* slabs_out, hipStream_t stream) {
-    if ((p.K & 63) || (p.N & 127) || (p.M & 127) || p.K <= 0) return SGC_ERR_ARG;
-    if (BMODE == BMODE_CONV && ((p.Cin & 127) || p.N != 9 * p.Cin)) return SGC_ERR_ARG;
-    p.tiles_m = p.M / 128;
-    p.tiles_n = p.N / 128;
+template <int ELEM, int BMODE, int ACONV, int WR, int WC, int TM, int TN>
+static int launch_gemm_tn_cfg(TnParams p, int splits, int* slabs_out, hipStream_t stream) {
+    constexpr int BM = WR * TM * 32, BN = WC * TN * 32;
+    constexpr int LDS = 2 * 64 * (BM + BN) * 2;
+    p.tiles_m = p.M / BM;
+    p.tiles_n = p.N / BN;
     const int nk = p.K >> 6;
     if (splits < 1) splits = 1;
     if (splits > nk) splits = nk;
     p.ktiles_per_split = (nk + splits - 1) / splits;
     splits = (nk + p.ktiles_per_split - 1) / p.ktiles_per_split;
     static bool attr_set = false;
-    auto kern = gemm_tn_kernel<ELEM, BMODE, ACONV>;
+    auto kern = gemm_tn_kernel<ELEM, BMODE, ACONV, WR, WC, TM, TN>;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;
     }
-    SGC_LAUNCH(kern, dim3((unsigned)(p.tiles_m * p.tiles_n), (unsigned)splits), dim3(256), 65536, stream, p);
+    SGC_LAUNCH(kern, dim3((unsigned)(p.tiles_m * p.tiles_n), (unsigned)splits), dim3(WR * WC * 64), LDS, stream, p);
     SGC_CHECK_LAUNCH();
     if (slabs_out) *slabs_out = splits;
     return SGC_OK;
+}
+
+template <int ELEM, int BMODE, int ACONV = 0>
+static int launch_gemm_tn(TnParams p, int splits, int* slabs_out, hipStream_t stream) {
+    if ((p.K & 63) || (p.N & 127) || (p.M & 127) || p.K <= 0) return SGC_ERR_ARG;
+    if (BMODE == BMODE_CONV && ((p.Cin & 127) || p.N != 9 * p.Cin)) return SGC_ERR_ARG;
+    const int cfg = sgc_gemm_cfg();
+    const bool big_ok = (p.N % 256) == 0 && (p.M % 256) == 0 && (BMODE != BMODE_CONV || (p.Cin % 256) == 0);
+    const bool big = big_ok && (cfg == 2 || (cfg == 0 && (long)p.M * p.N >= 512L * 512));
+    if (big) return launch_gemm_tn_cfg<ELEM, BMODE, ACONV, 2, 4, 4, 2>(p, splits, slabs_out, stream);
+    return launch_gemm_tn_cfg<ELEM, BMODE, ACONV, 2, 2, 2, 2>(p, splits, slabs_out, stream);
 }

@@ -233,11 +233,10 @@ __global__ __launch_bounds__(256) void unpool_kernel(const u16* __restrict__ dy,
 // ------------------------------------------------------------------------------------------------ pair expansion (training)
 // Forward expansion that also records which of the four positions won (0..3, 4 = none positive): the
 // routing mask of relu+maxpool for the contraction below.
-template <int ELEM_OUT>
 __global__ __launch_bounds__(256) void pair_expand_train_kernel(const u16* __restrict__ U, const u16* __restrict__ V,
                                                                 const int* __restrict__ sub, const int* __restrict__ obj,
-                                                                u16* __restrict__ z, unsigned char* __restrict__ amz,
-                                                                long n_items) {
+                                                                u16* __restrict__ z, u16* __restrict__ zb,
+                                                                unsigned char* __restrict__ amz, long n_items) {
     const int lane = threadIdx.x & 63;
     for (long it = (long)blockIdx.x * 4 + (threadIdx.x >> 6); it < n_items; it += (long)gridDim.x * 4) {
         const int p = (int)(it >> 8), W = (int)(it & 255);
@@ -259,13 +258,21 @@ __global__ __launch_bounds__(256) void pair_expand_train_kernel(const u16* __res
                 if (s > best[k]) { best[k] = s; arg[k] = (unsigned char)q; }
             }
         }
-        if (z) {
+        const int Y = W >> 4, X = W & 15;
+        const long zo = (((long)p * 18 + Y + 1) * 18 + X + 1) * 512 + lane * 8;
+        if (z) {                                               // f16 copy: conv3 forward operand
             uint4 o;
             u16* oh = reinterpret_cast<u16*>(&o);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) oh[k] = to_elem<ELEM_OUT>(best[k]);
-            const int Y = W >> 4, X = W & 15;
-            *reinterpret_cast<uint4*>(z + (((long)p * 18 + Y + 1) * 18 + X + 1) * 512 + lane * 8) = o;
+            for (int k = 0; k < 8; ++k) oh[k] = f32_to_f16_bits(best[k]);
+            *reinterpret_cast<uint4*>(z + zo) = o;
+        }
+        if (zb) {                                              // bf16 copy: conv3 weight-gradient operand
+            uint4 o;
+            u16* oh = reinterpret_cast<u16*>(&o);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) oh[k] = f32_to_bf16_bits(best[k]);
+            *reinterpret_cast<uint4*>(zb + zo) = o;
         }
         if (amz) {
             uint2 ao;
@@ -502,17 +509,13 @@ int sgc_conv3_wgrad(const void* dy3_pad, const void* z_pad_bf16, float* slabs, i
     return launch_gemm_tn<ELEM_BF16, BMODE_CONV, 1>(p, splits, n_slabs, (hipStream_t)stream);
 }
 // ---- expansion / contraction
-int sgc_pair_expand_train(const void* U, const void* V, const int* sub_idx, const int* obj_idx, void* z_pad, unsigned char* amz,
-                          int n_pairs, int out_elem, void* stream) {
+int sgc_pair_expand_train(const void* U, const void* V, const int* sub_idx, const int* obj_idx, void* z_pad_f16, void* z_pad_bf16,
+                          unsigned char* amz, int n_pairs, void* stream) {
     if (n_pairs <= 0) return SGC_OK;
     const long items = (long)n_pairs * 256;
     const int blocks = grid_for(items, 4, 262144);
-    if (out_elem == ELEM_F16)
-        SGC_LAUNCH(pair_expand_train_kernel<ELEM_F16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const u16*)U,
-                           (const u16*)V, sub_idx, obj_idx, (u16*)z_pad, amz, items);
-    else
-        SGC_LAUNCH(pair_expand_train_kernel<ELEM_BF16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const u16*)U,
-                           (const u16*)V, sub_idx, obj_idx, (u16*)z_pad, amz, items);
+    SGC_LAUNCH(pair_expand_train_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const u16*)U, (const u16*)V, sub_idx,
+               obj_idx, (u16*)z_pad_f16, (u16*)z_pad_bf16, amz, items);
     SGC_CHECK_LAUNCH();
     return SGC_OK;
 }

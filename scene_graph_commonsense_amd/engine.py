@@ -334,9 +334,11 @@ def train_forward(self, image_feature, image_depth, obj_img, bbox, cats, super_m
     ctx.uv = self.object_halves(ctx.a_img, obj_img, bbox)
     ctx.lsub, ctx.lobj = self.label_vectors(cats, super_mh)
     z = ws.get("z_pad", P * 18 * 18 * 512, torch.float16)
+    z_bf = ws.get("z_pad_bf", P * 18 * 18 * 512, torch.bfloat16)
     amz = ws.get("amz", P * 256 * 512, torch.uint8)
     self._timed("expand_train", lambda: _lib.check(lib.sgc_pair_expand_train(_lib.ptr(ctx.uv[0]), _lib.ptr(ctx.uv[1]), _lib.ptr(sub_idx), _lib.ptr(obj_idx),
-                                         _lib.ptr(z), _lib.ptr(amz), P, ELEM_F16, self._st()), "sgc_pair_expand_train"))
+                                         _lib.ptr(z), _lib.ptr(z_bf), _lib.ptr(amz), P, self._st()), "sgc_pair_expand_train"))
+    ctx.z_bf = z_bf
     y = ws.get("y", Ppad * 65536, torch.float16)
     am = ws.get("argmax", P * 65536, torch.uint8)
     self._timed("conv3_fwd", lambda: _lib.check(lib.sgc_conv3_relu_pool(_lib.ptr(z), _lib.ptr(self.w["w3r"]), _lib.ptr(self.w["b3"]), _lib.ptr(y), _lib.ptr(am),
@@ -395,8 +397,8 @@ def train_backward(self, ctx: "TrainContext", coefs, sub_csr, obj_csr, img_ptr, 
 
     # ---- fc2
     h1_bf = _to_bf16(self, "h1_bf", ctx.h1, Ppad * 4096)
-    sl = ws.get("slabs", max(splits * 512 * 4096, splits * 1024 * 4608), torch.float32)
-    self._timed("fc2_wgrad", lambda: _lib.check(lib.sgc_fc2_wgrad(_lib.ptr(dpre), _lib.ptr(h1_bf), _lib.ptr(sl), Ppad, splits, ctypes.byref(slabs_n), st()),
+    sl = ws.get("slabs", 32 * 1024 * 4608, torch.float32)      # split-K slabs (largest user: conv3 wgrad)
+    self._timed("fc2_wgrad", lambda: _lib.check(lib.sgc_fc2_wgrad(_lib.ptr(dpre), _lib.ptr(h1_bf), _lib.ptr(sl), Ppad, 32, ctypes.byref(slabs_n), st()),
                "sgc_fc2_wgrad"))
     dW2m = _slab_sum(self, sl, 512 * 4096, slabs_n.value).view(512, 4096)
     gfc2 = torch.zeros_like(w["fc2_full"])
@@ -440,10 +442,8 @@ def train_backward(self, ctx: "TrainContext", coefs, sub_csr, obj_csr, img_ptr, 
     self._timed("unpool", lambda: _lib.check(lib.sgc_unpool_relu_bwd(_lib.ptr(dy), _lib.ptr(ctx.am), _lib.ptr(dy3), _lib.ptr(bpart), ctypes.byref(nparts), P, st()),
                "sgc_unpool_relu_bwd"))
     grads["conv3_1.bias"] = _slab_sum(self, bpart, 1024, nparts.value)
-    z_bf = ws.get("z_pad_bf", P * 18 * 18 * 512, torch.bfloat16)
-    self._timed("expand_train", lambda: _lib.check(lib.sgc_pair_expand_train(_lib.ptr(ctx.uv[0]), _lib.ptr(ctx.uv[1]), _lib.ptr(ctx.sub_idx), _lib.ptr(ctx.obj_idx),
-                                         _lib.ptr(z_bf), None, P, ELEM_BF16, st()), "sgc_pair_expand_train"))
-    self._timed("conv3_wgrad", lambda: _lib.check(lib.sgc_conv3_wgrad(_lib.ptr(dy3), _lib.ptr(z_bf), _lib.ptr(sl), P, splits, ctypes.byref(slabs_n), st()),
+    z_bf = ctx.z_bf
+    self._timed("conv3_wgrad", lambda: _lib.check(lib.sgc_conv3_wgrad(_lib.ptr(dy3), _lib.ptr(z_bf), _lib.ptr(sl), P, 32, ctypes.byref(slabs_n), st()),
                "sgc_conv3_wgrad"))
     dW3r = _slab_sum(self, sl, 1024 * 4608, slabs_n.value)
     grads["conv3_1.weight"] = dW3r.view(1024, 3, 3, 512).permute(0, 3, 1, 2).contiguous()
@@ -459,7 +459,7 @@ def train_backward(self, ctx: "TrainContext", coefs, sub_csr, obj_csr, img_ptr, 
                    "sgc_pair_contract"))
         a_pad = ws.get("a_pad_%d" % r, n_obj * 34 * 34 * 128, torch.float16)
         a_bf = _to_bf16(self, "a_pad_bf", a_pad, n_obj * 34 * 34 * 128)
-        self._timed("conv2_wgrad", lambda: _lib.check(lib.sgc_conv2_wgrad(_lib.ptr(dU), _lib.ptr(a_bf), _lib.ptr(sl), n_obj, splits, ctypes.byref(slabs_n), st()),
+        self._timed("conv2_wgrad", lambda: _lib.check(lib.sgc_conv2_wgrad(_lib.ptr(dU), _lib.ptr(a_bf), _lib.ptr(sl), n_obj, 16, ctypes.byref(slabs_n), st()),
                    "sgc_conv2_wgrad"))
         dW2r = _slab_sum(self, sl, 512 * 1152, slabs_n.value)
         gc2[:, r * 128:(r + 1) * 128] = dW2r.view(512, 3, 3, 128).permute(0, 3, 1, 2)
@@ -474,7 +474,7 @@ def train_backward(self, ctx: "TrainContext", coefs, sub_csr, obj_csr, img_ptr, 
         dp1 = ws.get("dpre1", n_img * 1024 * 128, torch.bfloat16)
         _lib.check(lib.sgc_tanh_bwd(_lib.ptr(dA), _lib.ptr(ctx.a_img[r]), _lib.ptr(dp1), _c_long(n_img * 1024 * 128), st()),
                    "sgc_tanh_bwd")
-        _lib.check(lib.sgc_conv1_wgrad(_lib.ptr(dp1), _lib.ptr(x_bf), _lib.ptr(sl), n_img * 1024, XC, splits, ctypes.byref(slabs_n), st()),
+        _lib.check(lib.sgc_conv1_wgrad(_lib.ptr(dp1), _lib.ptr(x_bf), _lib.ptr(sl), n_img * 1024, XC, 16, ctypes.byref(slabs_n), st()),
                    "sgc_conv1_wgrad")
         dW1 = _slab_sum(self, sl, 128 * XC, slabs_n.value).view(128, XC)
         nm = "conv1_%d" % (r + 1)
