@@ -32,7 +32,7 @@ int sgc_conv1_tanh(const void* x, const void* w1r, const float* b1, void* a_img,
  * (train_test.py:164-169 mask build + :194-195,202-203 masked gather; tanh(conv1(0)) = tanh(bias) outside the box). */
 int sgc_object_masked_maps(const void* a_img, const int* obj_img, const int* bbox, const void* cst, void* a_pad, int n_obj, int F, int D, void* stream);
 
-/* U or V [n_obj*1024][512] f16 = conv3x3(a_pad, w2r[512][9][128]) (+bias)   (model.py:141-143: conv2_1 over the channel concat
+/* U or V [n_obj*1024][512] f16 = conv3x3(a_pad, w2r[512][2][9][64]) (+bias)   (model.py:141-143: conv2_1 over the channel concat
  * is the sum of a subject half U_i and an object half V_j; bias goes with V). */
 int sgc_conv2_object(const void* a_pad, const void* w2r, const float* bias, void* out, int n_obj, void* stream);
 
@@ -40,7 +40,7 @@ int sgc_conv2_object(const void* a_pad, const void* w2r, const float* bias, void
  * out_elem: 0 = f16, 1 = bf16. */
 int sgc_pair_expand(const void* U, const void* V, const int* sub_idx, const int* obj_idx, void* z_pad, int n_pairs, int out_elem, void* stream);
 
-/* y [n_pairs*64][1024] f16 (+ argmax u8, may be NULL) = maxpool2(relu(conv3x3(z_pad, w3r[1024][9][512]) + b3))   (model.py:145-146) */
+/* y [n_pairs*64][1024] f16 (+ argmax u8, may be NULL) = maxpool2(relu(conv3x3(z_pad, w3r[1024][8][9][64]) + b3))   (model.py:145-146) */
 int sgc_conv3_relu_pool(const void* z_pad, const void* w3r, const float* b3, void* y, unsigned char* argmax, int n_pairs, void* stream);
 
 /* h1 [n_pairs][4096] f16 = dropout(relu(y[n_pairs][K] * w1p[4096][K]^T + b))   (model.py:148-149; columns of w1p in (window, channel) order) */

@@ -13,7 +13,7 @@ int sgc_dbg_gemm_nt(int elem, const void* A, const void* B, void* C, int M, int 
     return launch_gemm_nt<ELEM_BF16, AMODE_PLAIN, EPI_STORE>(p, (hipStream_t)stream);
 }
 
-// A: zero-padded channels-last images [n_img][S+2][S+2][Cin]; B: [N][9][Cin]; C: [n_img*S*S][N] window-major rows
+// A: zero-padded channels-last images [n_img][S+2][S+2][Cin]; B: [N][Cin/64][9][64]; C: [n_img*S*S][N] window-major rows
 int sgc_dbg_conv_nt(int elem, const void* A, const void* B, void* C, int n_img, int lgS, int Cin, int N,
                     const float* bias, void* stream) {
     NtParams p{};

@@ -6,7 +6,7 @@
 //    ((row>>1)&7), conflict-free for the 4x16-lane groups of ds_read_b128 at a 128-byte row pitch) is
 //    applied to the per-lane SOURCE address and again on the fragment read.
 //  * AMODE_CONV turns the A operand into an implicit 3x3 convolution over a zero-padded channels-last
-//    image [img][S+2][S+2][Cin]: K index = (tap, c); every A row is a pixel whose address is shifted by
+//    image [img][S+2][S+2][Cin]: K index = (c/64, tap, c%64); every A row is a pixel whose address is shifted by
 //    the tap, so no im2col buffer exists.  Rows are enumerated window-major (m = 4*window + q,
 //    q = dy*2+dx inside a 2x2 pooling window) so that a 2x2 max-pool is a pure in-register max over the
 //    four accumulator registers a lane holds for one window (MFMA C layout: row = (reg&3) + 8*(reg>>2)
@@ -86,15 +86,16 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void gemm_nt_kernel(const NtParams
         const int chunk = cpos ^ ((row >> 1) & 7);
         b_ptr[i] = p.B + (long)(n0 + row) * p.ldb + chunk * 8;
     }
-    const int cpt = (AMODE == AMODE_CONV) ? (p.Cin >> 6) : 1;
     const int Wp = (1 << p.lgS) + 2;
 
     auto stage = [&](int buf, int kt) {
         long aoff;
         if constexpr (AMODE == AMODE_CONV) {
-            const int tap = kt / cpt, c0 = (kt - tap * cpt) << 6;
+            // K order = (64-channel chunk, tap, channel): the nine taps of one chunk are consecutive K tiles, so
+            // the shifted re-reads of a pixel row hit L2 (working set 18x18x64 ch per block) instead of the fabric.
+            const int cc = kt / 9, tap = kt - cc * 9;
             const int ky = tap / 3, kx = tap - 3 * ky;
-            aoff = (long)(ky * Wp + kx) * p.Cin + c0;
+            aoff = (long)(ky * Wp + kx) * p.Cin + (cc << 6);
         } else {
             aoff = (long)kt << 6;
         }

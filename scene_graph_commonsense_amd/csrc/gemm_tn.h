@@ -22,7 +22,7 @@ struct TnParams {
     long slab_stride;            // elements between split-K slabs
     int lgS, Cin;                // BMODE_CONV
     int CinA;                    // ACONV: A rows are the centre pixels of a zero-padded image with CinA channels
-    int tiles_m, tiles_n, ktiles_per_split;
+    int tiles_m, tiles_n, ktiles_per_split, splits;
 };
 
 template <int ELEM, int BMODE, int ACONV, int WR, int WC, int TM, int TN>
@@ -36,9 +36,15 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void gemm_tn_kernel(const TnParams
     constexpr int APK = MB16 / 8, BPK = NB16 / 8;             // instructions per k block row
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tn = blockIdx.x % p.tiles_n, tm = blockIdx.x / p.tiles_n;
+    // Work mapping: N tile fastest, then M tile, then K split.  Blocks that run concurrently sit at the same K
+    // position of neighbouring tiles, so their A/B rows are shared through L2.  (An XCD-grouped mapping - all N
+    // tiles of one (M tile, split) on one XCD - was measured 9 % slower on the conv3 weight gradient: the tail of
+    // each group starts out of phase with its head and re-fetches the slices.)
+    const int tn = blockIdx.x % p.tiles_n;
+    const int tm = (blockIdx.x / p.tiles_n) % p.tiles_m;
+    const int split = blockIdx.x / (p.tiles_n * p.tiles_m);
     const int m0 = tm * BM, n0 = tn * BN;
-    const int kt_begin = blockIdx.y * p.ktiles_per_split;
+    const int kt_begin = split * p.ktiles_per_split;
     int kt_end = kt_begin + p.ktiles_per_split;
     const int nk_total = p.K >> 6;
     if (kt_end > nk_total) kt_end = nk_total;
@@ -104,6 +110,9 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void gemm_tn_kernel(const TnParams
         if (kt + 1 < kt_end) stage((it + 1) & 1, kt + 1);
         const char* ab = smem + (it & 1) * BUF_BYTES;
         const char* bb = ab + A_BYTES;
+        // The compiler groups the 12 transpose reads of a k-step ahead of its 8 MFMAs.  Forcing a finer
+        // read/MFMA interleave with sched_group_barrier was measured 8 % SLOWER on the conv3 weight gradient
+        // (84.3 vs 77.8 ms), so the schedule is left to hipcc.
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int kb = ks * 4 + kh * 2;          // first of two 4-row k blocks
@@ -131,7 +140,7 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void gemm_tn_kernel(const TnParams
         }
     }
 
-    float* C = p.C + (long)blockIdx.y * p.slab_stride;
+    float* C = p.C + (long)split * p.slab_stride;
     const int h = lane >> 5, cl = lane & 31;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -163,7 +172,8 @@ static int launch_gemm_tn_cfg(TnParams p, int splits, int* slabs_out, hipStream_
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;
     }
-    SGC_LAUNCH(kern, dim3((unsigned)(p.tiles_m * p.tiles_n), (unsigned)splits), dim3(WR * WC * 64), LDS, stream, p);
+    p.splits = splits;
+    SGC_LAUNCH(kern, dim3((unsigned)(p.tiles_m * p.tiles_n * splits)), dim3(WR * WC * 64), LDS, stream, p);
     SGC_CHECK_LAUNCH();
     if (slabs_out) *slabs_out = splits;
     return SGC_OK;

@@ -139,25 +139,39 @@ __global__ void slab_sum_kernel(const float* __restrict__ in, float* __restrict_
     }
 }
 
-// column sums of a 16-bit matrix: part[blockIdx.y][cols] = sum over this block's rows
+// column sums of a 16-bit matrix: part[blockIdx.y][cols] = sum over this block's rows.
+// Block = 32 column chunks (8 columns, 16 B each) x 8 row lanes; row lanes are reduced through LDS.
 template <int ELEM>
 __global__ __launch_bounds__(256) void colsum_kernel(const u16* __restrict__ X, float* __restrict__ part, long rows, int cols,
                                                      long rows_per_block) {
-    const int c = (blockIdx.x * 256 + threadIdx.x) * 8;
-    if (c >= cols) return;
+    __shared__ float red[8][32][9];
+    const int cc = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int c = (blockIdx.x * 32 + cc) * 8;
     const long r0 = blockIdx.y * rows_per_block;
     const long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
     float acc[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) acc[k] = 0.f;
-    for (long r = r0; r < r1; ++r) {
-        const uint4 v = *reinterpret_cast<const uint4*>(X + r * cols + c);
-        const u16* h = reinterpret_cast<const u16*>(&v);
+    if (c < cols) {
+        for (long r = r0 + rl; r < r1; r += 8) {
+            const uint4 v = *reinterpret_cast<const uint4*>(X + r * cols + c);
+            const u16* h = reinterpret_cast<const u16*>(&v);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) acc[k] += from_elem<ELEM>(h[k]);
+            for (int k = 0; k < 8; ++k) acc[k] += from_elem<ELEM>(h[k]);
+        }
     }
 #pragma unroll
-    for (int k = 0; k < 8; ++k) part[(long)blockIdx.y * cols + c + k] = acc[k];
+    for (int k = 0; k < 8; ++k) red[rl][cc][k] = acc[k];
+    __syncthreads();
+    if (rl == 0 && c < cols) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float s2 = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) s2 += red[q][cc][k];
+            part[(long)blockIdx.y * cols + c + k] = s2;
+        }
+    }
 }
 
 // out[o][:] = sum over pairs in list[ptr[o]..ptr[o+1]) of X[pair][:]  (label-column gradients of fc2)
@@ -425,7 +439,7 @@ int sgc_colsum(int elem, const void* X, float* part, long rows, int cols, int ro
     if (cols % 8 || row_blocks < 1) return SGC_ERR_ARG;
     if (rows <= 0) return SGC_OK;
     const long rpb = (rows + row_blocks - 1) / row_blocks;
-    dim3 grid((cols / 8 + 255) / 256, row_blocks);
+    dim3 grid((cols / 8 + 31) / 32, row_blocks);
     if (elem == ELEM_F16)
         SGC_LAUNCH(colsum_kernel<ELEM_F16>, grid, dim3(256), 0, (hipStream_t)stream, (const u16*)X, part, rows, cols, rpb);
     else

@@ -221,7 +221,7 @@ int sgc_object_masked_maps(const void* a_img, const int* obj_img, const int* bbo
     return SGC_OK;
 }
 
-// U (or V) [n_obj*1024][512] = conv3x3(a_pad, w2r[512][9][128]) (+ bias for the object role)
+// U (or V) [n_obj*1024][512] = conv3x3(a_pad, w2r[512][2][9][64]) (+ bias for the object role)
 int sgc_conv2_object(const void* a_pad, const void* w2r, const float* bias, void* out, int n_obj, void* stream) {
     NtParams p{};
     p.A = (const u16*)a_pad; p.B = (const u16*)w2r; p.C = out; p.M = n_obj * 1024; p.N = 512; p.K = 9 * 128;
@@ -245,7 +245,7 @@ int sgc_pair_expand(const void* U, const void* V, const int* sub_idx, const int*
     return SGC_OK;
 }
 
-// y [n_pairs*64][1024] (+argmax u8) = maxpool2(relu(conv3x3(z_pad, w3r[1024][9][512]) + b3))
+// y [n_pairs*64][1024] (+argmax u8) = maxpool2(relu(conv3x3(z_pad, w3r[1024][8][9][64]) + b3))
 int sgc_conv3_relu_pool(const void* z_pad, const void* w3r, const float* b3, void* y, unsigned char* argmax, int n_pairs,
                         void* stream) {
     NtParams p{};

@@ -29,6 +29,13 @@ def _c_long(v):
     return ctypes.c_long(int(v))
 
 
+def conv_k_layout(w: torch.Tensor) -> torch.Tensor:
+    """[N, C, 3, 3] conv weight -> [N, 9*C] with K ordered (C/64 chunk, tap, 64 channels): the K order of the
+    implicit-GEMM A operand (csrc/gemm_nt.h), chosen so the nine taps of a channel chunk are consecutive."""
+    N, C = w.shape[0], w.shape[1]
+    return w.reshape(N, C // 64, 64, 9).permute(0, 1, 3, 2).reshape(N, 9 * C)
+
+
 @dataclass
 class PairOutputs:
     relation: torch.Tensor                  # [P, R] log-probs (hier) or raw logits (flat)
@@ -99,10 +106,9 @@ class RelHeadEngine:
         w["b1"] = torch.stack([g("conv1_1.bias"), g("conv1_2.bias")]).contiguous()
         w["cst"] = torch.tanh(w["b1"]).half().contiguous()                  # tanh(conv1(0)) outside the box
         c2 = g("conv2_1.weight")
-        w["w2r"] = torch.stack([c2[:, r * 128:(r + 1) * 128].permute(0, 2, 3, 1).reshape(512, 1152) for r in (0, 1)]
-                               ).half().contiguous()
+        w["w2r"] = torch.stack([conv_k_layout(c2[:, r * 128:(r + 1) * 128]) for r in (0, 1)]).half().contiguous()
         w["b2"] = g("conv2_1.bias").contiguous()
-        w["w3r"] = g("conv3_1.weight").permute(0, 2, 3, 1).reshape(1024, 4608).half().contiguous()
+        w["w3r"] = conv_k_layout(g("conv3_1.weight")).half().contiguous()
         w["b3"] = g("conv3_1.bias").contiguous()
         w["w1p"] = g("fc1.weight").view(4096, 1024, 64).permute(0, 2, 1).reshape(4096, 65536).half().contiguous()
         w["bf1"] = g("fc1.bias").contiguous()
@@ -288,9 +294,9 @@ def _prep_bwd_weights(self, sd):
     w = self.w
     w["w2mT"] = w["fc2_full"][:, :4096].t().contiguous().to(torch.bfloat16)
     w["w1pT"] = g("fc1.weight").view(4096, 1024, 64).permute(2, 1, 0).reshape(65536, 4096).to(torch.bfloat16).contiguous()
-    w["wd3"] = g("conv3_1.weight").flip(2, 3).permute(1, 2, 3, 0).reshape(512, 9 * 1024).to(torch.bfloat16).contiguous()
+    w["wd3"] = conv_k_layout(g("conv3_1.weight").flip(2, 3).permute(1, 0, 2, 3)).to(torch.bfloat16).contiguous()
     c2 = g("conv2_1.weight")
-    w["wd2"] = torch.stack([c2[:, r * 128:(r + 1) * 128].flip(2, 3).permute(1, 2, 3, 0).reshape(128, 9 * 512)
+    w["wd2"] = torch.stack([conv_k_layout(c2[:, r * 128:(r + 1) * 128].flip(2, 3).permute(1, 0, 2, 3))
                             for r in (0, 1)]).to(torch.bfloat16).contiguous()
     rows = self.head_rows
     Wc = torch.zeros(64, 512, device=dev)
@@ -304,7 +310,9 @@ def _slab_sum(self, slabs, n, count):
     return out
 
 
-def _colsum(self, X, rows, cols, elem=ELEM_BF16, blocks=64):
+def _colsum(self, X, rows, cols, elem=ELEM_BF16, blocks=None):
+    if blocks is None:
+        blocks = max(1, min(512, rows // 64))
     blocks = int(max(1, min(blocks, rows)))
     part = self.ws.get("colsum_part", blocks * cols, torch.float32)
     _lib.check(self.lib.sgc_colsum(elem, _lib.ptr(X), _lib.ptr(part), _c_long(rows), cols, blocks, self._st()), "sgc_colsum")

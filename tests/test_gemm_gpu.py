@@ -49,7 +49,7 @@ def _conv_inputs(n_img, S, Cin, N, dtype):
     w = (_rand((N, Cin, 3, 3), dtype, 6).float() * 0.1).to(dtype)
     xp = torch.zeros(n_img, S + 2, S + 2, Cin, dtype=dtype, device="cuda")
     xp[:, 1:-1, 1:-1, :] = x.permute(0, 2, 3, 1)
-    wr = w.permute(0, 2, 3, 1).contiguous().reshape(N, 9 * Cin)
+    wr = w.reshape(N, Cin // 64, 64, 9).permute(0, 1, 3, 2).contiguous().reshape(N, 9 * Cin)   # K = (c/64, tap, c%64)
     return x, w, xp.contiguous(), wr
 
 
@@ -89,7 +89,8 @@ def test_tr_probe_layout():
 
 
 @pytest.mark.parametrize("dtype,elem", [(torch.float16, 0), (torch.bfloat16, 1)])
-@pytest.mark.parametrize("M,N,K,splits", [(128, 128, 64, 1), (256, 384, 640, 3), (512, 128, 4096, 8)])
+@pytest.mark.parametrize("M,N,K,splits", [(128, 128, 64, 1), (256, 384, 640, 3), (512, 128, 4096, 8), (512, 512, 4096, 8),
+                                          (1024, 768, 2048, 16)])
 def test_gemm_tn_plain(dtype, elem, M, N, K, splits):
     lib, L = _lib()
     A, B = _rand((K, M), dtype, 11), _rand((K, N), dtype, 12)
@@ -105,7 +106,8 @@ def test_gemm_tn_plain(dtype, elem, M, N, K, splits):
     assert err <= 1e-3 * ref.abs().max().item() + 1e-4, err
 
 
-@pytest.mark.parametrize("n_img,lgS,Cin,M,splits", [(2, 4, 128, 128, 2), (3, 5, 128, 256, 4), (2, 4, 512, 128, 1)])
+@pytest.mark.parametrize("n_img,lgS,Cin,M,splits", [(2, 4, 128, 128, 2), (3, 5, 128, 256, 4), (2, 4, 512, 128, 1),
+                                                    (8, 4, 512, 1024, 8), (16, 4, 256, 512, 16)])
 def test_conv_tn(n_img, lgS, Cin, M, splits):
     lib, L = _lib()
     dtype, elem = torch.bfloat16, 1
