@@ -13,6 +13,22 @@ int sgc_dbg_gemm_nt(int elem, const void* A, const void* B, void* C, int M, int 
     return launch_gemm_nt<ELEM_BF16, AMODE_PLAIN, EPI_STORE>(p, (hipStream_t)stream);
 }
 
+// ablation hook for tools/gemm_microbench.py (bf16, 256x256 block): abl as documented at gemm_nt_kernel
+int sgc_dbg_gemm_nt_abl(int abl, const void* A, const void* B, void* C, int M, int N, int K, void* stream) {
+    NtParams p{};
+    p.A = (const u16*)A; p.B = (const u16*)B; p.C = C; p.M = M; p.N = N; p.K = K;
+    p.lda = K; p.ldb = K; p.ldc = N;
+    if ((N % 256) || (K % 64)) return SGC_ERR_ARG;
+    switch (abl) {
+        case 0: return launch_gemm_nt_cfg<ELEM_BF16, AMODE_PLAIN, EPI_STORE, 2, 4, 4, 2, 0>(p, (hipStream_t)stream);
+        case 1: return launch_gemm_nt_cfg<ELEM_BF16, AMODE_PLAIN, EPI_STORE, 2, 4, 4, 2, 1>(p, (hipStream_t)stream);
+        case 2: return launch_gemm_nt_cfg<ELEM_BF16, AMODE_PLAIN, EPI_STORE, 2, 4, 4, 2, 2>(p, (hipStream_t)stream);
+        case 3: return launch_gemm_nt_cfg<ELEM_BF16, AMODE_PLAIN, EPI_STORE, 2, 4, 4, 2, 3>(p, (hipStream_t)stream);
+        case 4: return launch_gemm_nt_ring<ELEM_BF16, AMODE_PLAIN, EPI_STORE>(p, (hipStream_t)stream);
+    }
+    return SGC_ERR_ARG;
+}
+
 // A: zero-padded channels-last images [n_img][S+2][S+2][Cin]; B: [N][Cin/64][9][64]; C: [n_img*S*S][N] window-major rows
 int sgc_dbg_conv_nt(int elem, const void* A, const void* B, void* C, int n_img, int lgS, int Cin, int N,
                     const float* bias, void* stream) {

@@ -53,10 +53,71 @@ __device__ __forceinline__ long conv_row_base(int m, int lgS, int Cin) {
     return ((long)(img * (S + 2) + y) * (S + 2) + x) * Cin;
 }
 
+template <int ELEM, int EPI, int TM, int TN>
+__device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wr, int wc, int lane) {
+    const int h = lane >> 5, cl = lane & 31;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wc * TN * 32 + j * 32 + cl;
+            const int rbase = m0 + wr * TM * 32 + i * 32;
+            const float bias = p.bias ? p.bias[col] : 0.f;
+            if constexpr (EPI == EPI_POOL) {
+                u16* out = reinterpret_cast<u16*>(p.C);
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    float v = acc[i][j][4 * w];
+                    int am = 0;
+#pragma unroll
+                    for (int q = 1; q < 4; ++q) {
+                        const float t = acc[i][j][4 * w + q];
+                        if (t > v) { v = t; am = q; }
+                    }
+                    v += bias;
+                    const int prow = (rbase >> 2) + 2 * w + h;
+                    if (prow * 4 < p.M) {
+                        if (!(v > 0.f)) { v = 0.f; am = 4; }        // ReLU killed: no gradient path
+                        out[(long)prow * p.ldc + col] = to_elem<ELEM>(v);
+                        if (p.argmax) p.argmax[(long)prow * p.ldc + col] = (unsigned char)am;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rbase + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (row >= p.M) continue;
+                    float v = acc[i][j][r];
+                    const long o = (long)row * p.ldc + col;
+                    if constexpr (EPI == EPI_STORE) {
+                        reinterpret_cast<u16*>(p.C)[o] = to_elem<ELEM>(v + bias);
+                    } else if constexpr (EPI == EPI_BIAS_TANH) {
+                        reinterpret_cast<u16*>(p.C)[o] = to_elem<ELEM>(tanhf(v + bias));
+                    } else if constexpr (EPI == EPI_BIAS_RELU) {
+                        v = fmaxf(v + bias, 0.f);
+                        if (p.drop_enable) v = dropout_keep(p.drop_seed, (uint32_t)(row * p.N + col)) ? v * p.scale : 0.f;
+                        reinterpret_cast<u16*>(p.C)[o] = to_elem<ELEM>(v);
+                    } else if constexpr (EPI == EPI_FC2) {
+                        v += bias + p.lsub[(long)p.sub_idx[row] * p.N + col] + p.lobj[(long)p.obj_idx[row] * p.N + col];
+                        v = fmaxf(v, 0.f);
+                        if (p.drop_enable) v = dropout_keep(p.drop_seed, (uint32_t)(row * p.N + col)) ? v * p.scale : 0.f;
+                        reinterpret_cast<float*>(p.C)[o] = v;
+                    } else if constexpr (EPI == EPI_RELUMASK) {
+                        const float f = from_elem<ELEM_F16>(p.mask_src[o]);   // forward activations are f16
+                        reinterpret_cast<u16*>(p.C)[o] = to_elem<ELEM>(f > 0.f ? v * p.scale : 0.f);
+                    }
+                }
+            }
+        }
+    }
+}
+
 // Block configuration: WR x WC wavefronts, each owning a (TM*32) x (TN*32) output tile.
 //   small: 2x2 waves of 64x64   -> 128x128 block, 64 KiB LDS, 2 blocks/CU  (small problems, N % 256 != 0)
 //   big  : 2x4 waves of 128x64  -> 256x256 block, 128 KiB LDS, 1 block/CU  (half the LDS bytes per MFMA)
-template <int ELEM, int AMODE, int EPI, int WR, int WC, int TM, int TN>
+// ABL (test hook only): 0 = normal; 1 = no global loads inside the K loop; 2 = no loads and no barriers;
+// 3 = loads and barriers only (no LDS reads / MFMA).  Used by tools/gemm_microbench.py to attribute time.
+template <int ELEM, int AMODE, int EPI, int WR, int WC, int TM, int TN, int ABL = 0>
 __global__ __launch_bounds__(WR * WC * 64, 2) void gemm_nt_kernel(const NtParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NW = WR * WC;
@@ -135,11 +196,14 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void gemm_nt_kernel(const NtParams
     const int nk = p.K >> 6;
     stage(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+        if (ABL != 2) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        if ((ABL == 0 || ABL == 3) && kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
         const char* ab = smem + (kt & 1) * BUF_BYTES;
         const char* bb = ab + A_BYTES;
+        if (ABL == 3) continue;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int c = ks * 2 + kh;
@@ -155,83 +219,157 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void gemm_nt_kernel(const NtParams
         }
     }
 
-    // ---- epilogue
-    const int h = lane >> 5, cl = lane & 31;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int col = n0 + wc * TN * 32 + j * 32 + cl;
-            const int rbase = m0 + wr * TM * 32 + i * 32;
-            const float bias = p.bias ? p.bias[col] : 0.f;
-            if constexpr (EPI == EPI_POOL) {
-                u16* out = reinterpret_cast<u16*>(p.C);
-#pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    float v = acc[i][j][4 * w];
-                    int am = 0;
-#pragma unroll
-                    for (int q = 1; q < 4; ++q) {
-                        const float t = acc[i][j][4 * w + q];
-                        if (t > v) { v = t; am = q; }
-                    }
-                    v += bias;
-                    const int prow = (rbase >> 2) + 2 * w + h;
-                    if (prow * 4 < p.M) {
-                        if (!(v > 0.f)) { v = 0.f; am = 4; }        // ReLU killed: no gradient path
-                        out[(long)prow * p.ldc + col] = to_elem<ELEM>(v);
-                        if (p.argmax) p.argmax[(long)prow * p.ldc + col] = (unsigned char)am;
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = rbase + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (row >= p.M) continue;
-                    float v = acc[i][j][r];
-                    const long o = (long)row * p.ldc + col;
-                    if constexpr (EPI == EPI_STORE) {
-                        reinterpret_cast<u16*>(p.C)[o] = to_elem<ELEM>(v + bias);
-                    } else if constexpr (EPI == EPI_BIAS_TANH) {
-                        reinterpret_cast<u16*>(p.C)[o] = to_elem<ELEM>(tanhf(v + bias));
-                    } else if constexpr (EPI == EPI_BIAS_RELU) {
-                        v = fmaxf(v + bias, 0.f);
-                        if (p.drop_enable) v = dropout_keep(p.drop_seed, (uint32_t)(row * p.N + col)) ? v * p.scale : 0.f;
-                        reinterpret_cast<u16*>(p.C)[o] = to_elem<ELEM>(v);
-                    } else if constexpr (EPI == EPI_FC2) {
-                        v += bias + p.lsub[(long)p.sub_idx[row] * p.N + col] + p.lobj[(long)p.obj_idx[row] * p.N + col];
-                        v = fmaxf(v, 0.f);
-                        if (p.drop_enable) v = dropout_keep(p.drop_seed, (uint32_t)(row * p.N + col)) ? v * p.scale : 0.f;
-                        reinterpret_cast<float*>(p.C)[o] = v;
-                    } else if constexpr (EPI == EPI_RELUMASK) {
-                        const float f = from_elem<ELEM_F16>(p.mask_src[o]);   // forward activations are f16
-                        reinterpret_cast<u16*>(p.C)[o] = to_elem<ELEM>(f > 0.f ? v * p.scale : 0.f);
-                    }
-                }
-            }
-        }
-    }
+    nt_epilogue<ELEM, EPI, TM, TN>(p, acc, m0, n0, wr, wc, lane);
 }
 
-inline int sgc_gemm_cfg() {       // test hook: SGC_GEMM_CFG=1 forces the 128x128 block, =2 the 256x256 block
+inline int sgc_gemm_ring() {      // SGC_GEMM_RING=1 selects the 4-stage ring kernel (A/B hook; default off, see below)
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("SGC_GEMM_RING"); v = e ? atoi(e) : 0; }
+    return v;
+}
+
+inline int sgc_gemm_cfg() {       // test hook: SGC_GEMM_CFG=1 forces the 128x128 block, =2 the 2-stage 256x256 block, =3 the 4-stage ring
     static int cfg = -1;
     if (cfg < 0) { const char* e = getenv("SGC_GEMM_CFG"); cfg = e ? atoi(e) : 0; }
     return cfg;
 }
 
-template <int ELEM, int AMODE, int EPI, int WR, int WC, int TM, int TN>
+template <int ELEM, int AMODE, int EPI, int WR, int WC, int TM, int TN, int ABL = 0>
 static int launch_gemm_nt_cfg(NtParams p, hipStream_t stream) {
     constexpr int BM = WR * TM * 32, BN = WC * TN * 32;
     constexpr int LDS = 2 * (BM + BN) * 128;
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = p.N / BN;
     static bool attr_set = false;
-    auto kern = gemm_nt_kernel<ELEM, AMODE, EPI, WR, WC, TM, TN>;
+    auto kern = gemm_nt_kernel<ELEM, AMODE, EPI, WR, WC, TM, TN, ABL>;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;
     }
     SGC_LAUNCH(kern, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(WR * WC * 64), LDS, stream, p);
+    SGC_CHECK_LAUNCH();
+    return SGC_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// 4-stage ring variant of the 256x256 block (BK = 32 per stage, 32 KiB per stage, 128 KiB LDS): global_load_lds for
+// stage kt+3 is issued while stage kt is being multiplied, a COUNTED s_waitcnt vmcnt leaves two stages in flight
+// across the raw s_barrier (a __syncthreads() would drain them).  Measured motivation (tools/gemm_microbench.py,
+// 32768x4096x8192 bf16): with the 2-stage loop the load round trip of one 64 KiB stage is 1.36 us against 1.5 us of
+// LDS-read + MFMA work per stage and the two overlap poorly (2.1 us per stage); the ring keeps 64-96 KiB of loads in
+// flight per CU.  RESULT: correct (tests run it with SGC_GEMM_CFG=3) but 5-10 % SLOWER than the 2-stage loop (995 vs
+// 1105 TFLOP/s on that GEMM; conv3 fwd 70.5 vs 69.0 ms): the load path is bandwidth- not latency-bound (loads-only
+// ablation: 12.4 TB/s of L2->LDS traffic), so deeper prefetch buys nothing and BK=32 doubles the barrier count.
+// Kept off by default as a documented experiment.  64-byte rows: chunk swizzle c ^ ((row>>2)&3) keeps the ds_read_b128 lane groups conflict-free.
+template <int ELEM, int AMODE, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_nt_ring_kernel(const NtParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int WR = 2, WC = 4, TM = 4, TN = 2, NS = 4;
+    constexpr int BM = 256, BN = 256;
+    constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64, BUF_BYTES = A_BYTES + B_BYTES;   // 32 KiB per stage
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tn = blockIdx.x % p.tiles_n, tm = blockIdx.x / p.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    // loader: one instruction = 16 rows x 64 B; wave w stages rows w*32 .. w*32+31 of A and of B (2 + 2 instructions)
+    const int lrow = lane >> 2, cpos = lane & 3;
+    const u16* a_ptr[2];
+    const u16* b_ptr[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = wid * 32 + i * 16 + lrow;
+        const int chunk = cpos ^ ((row >> 2) & 3);
+        int m = m0 + row; if (m > p.M - 1) m = p.M - 1;
+        if constexpr (AMODE == AMODE_CONV) a_ptr[i] = p.A + conv_row_base(m, p.lgS, p.Cin) + chunk * 8;
+        else a_ptr[i] = p.A + (long)m * p.lda + chunk * 8;
+        b_ptr[i] = p.B + (long)(n0 + row) * p.ldb + chunk * 8;
+    }
+    const int Wp = (1 << p.lgS) + 2;
+    auto stage = [&](int buf, int kt) {            // kt counts 32-wide K tiles
+        long aoff;
+        if constexpr (AMODE == AMODE_CONV) {
+            const int k64 = kt >> 1;
+            const int cc = k64 / 9, tap = k64 - cc * 9;
+            const int ky = tap / 3, kx = tap - 3 * ky;
+            aoff = (long)(ky * Wp + kx) * p.Cin + (cc << 6) + ((kt & 1) << 5);
+        } else {
+            aoff = (long)kt << 5;
+        }
+        const long boff = (long)kt << 5;
+        char* abase = smem + buf * BUF_BYTES + wid * 2048;
+        char* bbase = abase + A_BYTES;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            __builtin_amdgcn_global_load_lds(GLB_PTR(a_ptr[i] + aoff), LDS_PTR(abase + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GLB_PTR(b_ptr[i] + boff), LDS_PTR(bbase + i * 1024), 16, 0, 0);
+        }
+    };
+
+    const int wr = wid / WC, wc = wid % WC;
+    const int kh = lane >> 5;
+    int a_off[TM], a_sw[TM], b_off[TN], b_sw[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int ra = wr * TM * 32 + i * 32 + (lane & 31);
+        a_off[i] = ra * 64; a_sw[i] = (ra >> 2) & 3;
+    }
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+        const int rb = wc * TN * 32 + i * 32 + (lane & 31);
+        b_off[i] = rb * 64; b_sw[i] = (rb >> 2) & 3;
+    }
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = p.K >> 5;
+    stage(0, 0);
+    if (nk > 1) stage(1, 1);
+    if (nk > 2) stage(2, 2);
+    for (int kt = 0; kt < nk; ++kt) {
+        // stage kt must have landed; the (up to) two younger stages stay in flight: 4 loads per stage per lane
+        if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();              // every wave's share of stage kt is in LDS; stage kt-1 is fully consumed
+        if (kt + 3 < nk) stage((kt + 3) & 3, kt + 3);
+        const char* ab = smem + (kt & 3) * BUF_BYTES;
+        const char* bb = ab + A_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int c = ks * 2 + kh;
+            s16x8 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const s16x8*>(ab + a_off[i] + ((c ^ a_sw[i]) << 4));
+#pragma unroll
+            for (int i = 0; i < TN; ++i) bf[i] = *reinterpret_cast<const s16x8*>(bb + b_off[i] + ((c ^ b_sw[i]) << 4));
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = mfma32<ELEM>(af[i], bf[j], acc[i][j]);
+        }
+    }
+    nt_epilogue<ELEM, EPI, TM, TN>(p, acc, m0, n0, wr, wc, lane);
+}
+
+template <int ELEM, int AMODE, int EPI>
+static int launch_gemm_nt_ring(NtParams p, hipStream_t stream) {
+    constexpr int LDS = 4 * 512 * 64;
+    p.tiles_m = (p.M + 255) / 256;
+    p.tiles_n = p.N / 256;
+    static bool attr_set = false;
+    auto kern = gemm_nt_ring_kernel<ELEM, AMODE, EPI>;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set = true;
+    }
+    SGC_LAUNCH(kern, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(512), LDS, stream, p);
     SGC_CHECK_LAUNCH();
     return SGC_OK;
 }
@@ -243,7 +381,8 @@ static int launch_gemm_nt(NtParams p, hipStream_t stream) {
     if (AMODE == AMODE_CONV && ((p.Cin & 63) || p.K != 9 * p.Cin)) return SGC_ERR_ARG;
     const int cfg = sgc_gemm_cfg();
     const bool big_ok = (p.N % 256) == 0;
-    const bool big = big_ok && (cfg == 2 || (cfg == 0 && (long)p.M * p.N >= 256L * 256 * 256));
+    const bool big = big_ok && (cfg == 2 || cfg == 3 || (cfg == 0 && (long)p.M * p.N >= 256L * 256 * 256));
+    if (big && (cfg == 3 || (cfg == 0 && sgc_gemm_ring()))) return launch_gemm_nt_ring<ELEM, AMODE, EPI>(p, stream);
     if (big) return launch_gemm_nt_cfg<ELEM, AMODE, EPI, 2, 4, 4, 2>(p, stream);
     return launch_gemm_nt_cfg<ELEM, AMODE, EPI, 2, 2, 2, 2>(p, stream);
 }

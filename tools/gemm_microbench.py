@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Attribute the time of the 256x256 NT GEMM main loop (GPU box): normal vs no-loads vs no-loads-no-barrier vs
+loads-only.  Random bf16 operands (zero-filled data inflates clocks)."""
+import ctypes
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from scene_graph_commonsense_amd import _lib
+
+lib = _lib.load()
+M, N, K = 32768, 4096, 8192
+A = (torch.rand(M, K, device="cuda") * 2 - 1).bfloat16()
+B = (torch.rand(N, K, device="cuda") * 2 - 1).bfloat16()
+C = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+names = {0: "normal", 1: "no global loads", 2: "no loads, no barriers", 3: "loads + barriers only", 4: "4-stage ring BK=32"}
+for rep in range(2):
+    for abl in (0, 1, 2, 3, 4):
+        for _ in range(2):
+            lib.sgc_dbg_gemm_nt_abl(abl, _lib.ptr(A), _lib.ptr(B), _lib.ptr(C), M, N, K, _lib.stream_ptr())
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(5):
+            lib.sgc_dbg_gemm_nt_abl(abl, _lib.ptr(A), _lib.ptr(B), _lib.ptr(C), M, N, K, _lib.stream_ptr())
+        b.record()
+        torch.cuda.synchronize()
+        ms = a.elapsed_time(b) / 5
+        print("abl=%d %-24s %8.3f ms  %7.1f TFLOP/s-equivalent" % (abl, names[abl], ms, 2.0 * M * N * K / ms / 1e9))
