@@ -95,6 +95,89 @@ __global__ __launch_bounds__(256) void pair_expand_kernel(const u16* __restrict_
     }
 }
 
+// ------------------------------------------------------------------------------------------------ dense expansion
+// All ordered pairs of one image at once.  One workgroup owns (image, window W, 64-channel chunk): it stages the
+// U and V rows of EVERY object of the image for that window/chunk in LDS once (2 x n x 512 B), then each 8-lane
+// group keeps one subject row U_i in registers and streams the object rows V_j from LDS, writing z_ij (and, for
+// training, the bf16 copy and the relu/maxpool routing byte).  HBM traffic is the algorithmic minimum: every U/V
+// element is read once per minibatch and every z element written once - the generic pair-list kernel above re-reads
+// 8 KiB of U/V per (pair, window) through L2 (66 GB per step at N=64, B=8).
+// Object stride in LDS is 528 B (512 + 16) so that the two 8-lane groups of a 16-lane ds_read_b128 group hit
+// different banks when their object indices differ.
+__global__ __launch_bounds__(256) void pair_expand_dense_kernel(const u16* __restrict__ U, const u16* __restrict__ V,
+                                                                const int* __restrict__ img_ptr, const int* __restrict__ pid,
+                                                                int pid_ld, u16* __restrict__ z, u16* __restrict__ zb,
+                                                                unsigned char* __restrict__ amz) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int OS = 528;
+    const int W = blockIdx.x, cq = blockIdx.y, img = blockIdx.z;
+    const int o0 = img_ptr[img], n = img_ptr[img + 1] - o0;
+    char* su = smem;
+    char* sv = smem + n * OS;
+    for (int it = threadIdx.x; it < n * 64; it += 256) {
+        const int role = it >= n * 32;
+        const int r = it - role * n * 32;
+        const int o = r >> 5, part = r & 31, q = part >> 3, l8 = part & 7;
+        const u16* src = (role ? V : U) + ((long)(o0 + o) * 1024 + 4 * W + q) * 512 + cq * 64 + l8 * 8;
+        *reinterpret_cast<uint4*>((role ? sv : su) + o * OS + q * 128 + l8 * 16) = *reinterpret_cast<const uint4*>(src);
+    }
+    __syncthreads();
+    const int grp = threadIdx.x >> 3, l8 = threadIdx.x & 7;
+    const int Y = W >> 4, X = W & 15;
+    const long zoff = ((long)(Y + 1) * 18 + X + 1) * 512 + cq * 64 + l8 * 8;
+    const long aoff = (long)W * 512 + cq * 64 + l8 * 8;
+    for (int i = grp; i < n; i += 32) {
+        float uf[4][8];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint4 a = *reinterpret_cast<const uint4*>(su + i * OS + q * 128 + l8 * 16);
+            const u16* ah = reinterpret_cast<const u16*>(&a);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) uf[q][k] = f16_bits_to_f32(ah[k]);
+        }
+        const int* prow = pid + (long)(o0 + i) * pid_ld;
+        for (int j = 0; j < n; ++j) {
+            const int p = prow[j];
+            if (p < 0) continue;                       // diagonal (or a pair that is not requested)
+            float best[8];
+            unsigned char arg[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { best[k] = 0.f; arg[k] = 4; }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint4 b = *reinterpret_cast<const uint4*>(sv + j * OS + q * 128 + l8 * 16);
+                const u16* bh = reinterpret_cast<const u16*>(&b);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float sm = uf[q][k] + f16_bits_to_f32(bh[k]);
+                    if (sm > best[k]) { best[k] = sm; arg[k] = (unsigned char)q; }
+                }
+            }
+            if (z) {
+                uint4 o;
+                u16* oh = reinterpret_cast<u16*>(&o);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) oh[k] = f32_to_f16_bits(best[k]);
+                *reinterpret_cast<uint4*>(z + (long)p * (18 * 18 * 512) + zoff) = o;
+            }
+            if (zb) {
+                uint4 o;
+                u16* oh = reinterpret_cast<u16*>(&o);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) oh[k] = f32_to_bf16_bits(best[k]);
+                *reinterpret_cast<uint4*>(zb + (long)p * (18 * 18 * 512) + zoff) = o;
+            }
+            if (amz) {
+                uint2 ao;
+                unsigned char* ab = reinterpret_cast<unsigned char*>(&ao);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) ab[k] = arg[k];
+                *reinterpret_cast<uint2*>(amz + (long)p * (256 * 512) + aoff) = ao;
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ head
 // Hierarchical Bayesian head + candidate reduction (reference model.py:176-184, evaluator.py:160-174).
 // Wt is [512][64] f32 (column r = output row r): rows [0,R) fine relations (three segments), R..R+2 super
@@ -241,6 +324,26 @@ int sgc_pair_expand(const void* U, const void* V, const int* sub_idx, const int*
     else
         SGC_LAUNCH(pair_expand_kernel<ELEM_BF16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const u16*)U,
                            (const u16*)V, sub_idx, obj_idx, (u16*)z_pad, items);
+    SGC_CHECK_LAUNCH();
+    return SGC_OK;
+}
+
+// Dense form of the expansion: every ordered pair (i, j) of every image, pair index looked up in pid[n_obj][pid_ld]
+// (-1 = skip).  img_ptr [n_img+1] object ranges; max_n = largest object count of an image (<= 150).
+// Any of z_pad_f16 / z_pad_bf16 / amz may be NULL.
+int sgc_pair_expand_dense(const void* U, const void* V, const int* img_ptr, const int* pid, int pid_ld, int n_img, int max_n,
+                          void* z_pad_f16, void* z_pad_bf16, unsigned char* amz, void* stream) {
+    if (max_n > 150 || max_n < 1) return SGC_ERR_ARG;
+    if (n_img <= 0) return SGC_OK;
+    const int lds = 2 * max_n * 528;
+    static int attr_lds = 0;
+    if (lds > attr_lds) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pair_expand_dense_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 150 * 528);
+        attr_lds = 2 * 150 * 528;
+    }
+    SGC_LAUNCH(pair_expand_dense_kernel, dim3(256, 8, n_img), dim3(256), lds, (hipStream_t)stream, (const u16*)U, (const u16*)V,
+               img_ptr, pid, pid_ld, (u16*)z_pad_f16, (u16*)z_pad_bf16, amz);
     SGC_CHECK_LAUNCH();
     return SGC_OK;
 }

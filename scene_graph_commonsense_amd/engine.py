@@ -184,14 +184,30 @@ class RelHeadEngine:
             res[r] = uv
         return res
 
+    def expand(self, U, V, sub_idx, obj_idx, P, z, z_bf=None, amz=None, dense=None):
+        """Pair expansion: dense LDS-staged kernel when the pair list is "all ordered pairs of every image"
+        (dense = (img_ptr, pid, max_n)), generic pair-list kernel otherwise."""
+        lib = self.lib
+        if dense is not None and 0 < dense[2] <= 150:
+            img_ptr, pid, max_n = dense
+            self._timed("expand_dense", lambda: _lib.check(lib.sgc_pair_expand_dense(
+                _lib.ptr(U), _lib.ptr(V), _lib.ptr(img_ptr), _lib.ptr(pid), int(pid.shape[1]), int(img_ptr.shape[0]) - 1, max_n,
+                _lib.ptr(z), _lib.ptr(z_bf), _lib.ptr(amz), self._st()), "sgc_pair_expand_dense"))
+        elif z_bf is None and amz is None:
+            self._timed("expand", lambda: _lib.check(lib.sgc_pair_expand(_lib.ptr(U), _lib.ptr(V), _lib.ptr(sub_idx), _lib.ptr(obj_idx),
+                                                                       _lib.ptr(z), P, ELEM_F16, self._st()), "sgc_pair_expand"))
+        else:
+            self._timed("expand_train", lambda: _lib.check(lib.sgc_pair_expand_train(
+                _lib.ptr(U), _lib.ptr(V), _lib.ptr(sub_idx), _lib.ptr(obj_idx), _lib.ptr(z), _lib.ptr(z_bf), _lib.ptr(amz), P,
+                self._st()), "sgc_pair_expand_train"))
+
     def pair_trunk(self, U, V, sub_idx, obj_idx, lsub, lobj, train=False, seeds=(0, 0), keep_argmax=False,
-                   iou_mask=None) -> PairOutputs:
+                   iou_mask=None, dense=None) -> PairOutputs:
         lib, ws, cfg = self.lib, self.ws, self.cfg
         P = int(sub_idx.shape[0])
         Ppad = (P + 63) // 64 * 64
         z = ws.get("z_pad", P * 18 * 18 * 512, torch.float16)      # border stays zero: only interiors are written
-        self._timed("expand", lambda: _lib.check(lib.sgc_pair_expand(_lib.ptr(U), _lib.ptr(V), _lib.ptr(sub_idx), _lib.ptr(obj_idx), _lib.ptr(z), P,
-                                       ELEM_F16, self._st()), "sgc_pair_expand"))
+        self.expand(U, V, sub_idx, obj_idx, P, z, dense=dense)
         y = ws.get("y", Ppad * 65536, torch.float16)
         am = ws.get("argmax", P * 65536, torch.uint8) if keep_argmax else None
         self._timed("conv3_fwd", lambda: _lib.check(lib.sgc_conv3_relu_pool(_lib.ptr(z), _lib.ptr(self.w["w3r"]), _lib.ptr(self.w["b3"]), _lib.ptr(y),
@@ -226,13 +242,13 @@ class RelHeadEngine:
 
     # ------------------------------------------------------------------ fused entry
     def forward_pairs(self, image_feature, image_depth, obj_img, bbox, cats, super_mh, sub_idx, obj_idx, train=False,
-                      seeds=(0, 0), keep_argmax=False, iou_mask=None) -> PairOutputs:
+                      seeds=(0, 0), keep_argmax=False, iou_mask=None, dense=None) -> PairOutputs:
         """One call per minibatch: image maps -> per-object halves -> all pairs."""
         a_img = self.image_maps(image_feature, image_depth)
         uv = self.object_halves(a_img, obj_img, bbox)
         lsub, lobj = self.label_vectors(cats, super_mh)
         self._lsub, self._lobj = lsub, lobj
-        return self.pair_trunk(uv[0], uv[1], sub_idx, obj_idx, lsub, lobj, train, seeds, keep_argmax, iou_mask)
+        return self.pair_trunk(uv[0], uv[1], sub_idx, obj_idx, lsub, lobj, train, seeds, keep_argmax, iou_mask, dense)
 
 
 # ====================================================================================== training (fwd + bwd)
@@ -327,7 +343,7 @@ def _to_bf16(self, name, src, n):
 
 
 def train_forward(self, image_feature, image_depth, obj_img, bbox, cats, super_mh, sub_idx, obj_idx, seeds=(0, 0),
-                  dropout=True) -> "TrainContext":
+                  dropout=True, dense=None) -> "TrainContext":
     """Forward that keeps what the backward needs (pool argmaxes, expansion routing mask)."""
     lib, ws = self.lib, self.ws
     ctx = TrainContext()
@@ -344,8 +360,7 @@ def train_forward(self, image_feature, image_depth, obj_img, bbox, cats, super_m
     z = ws.get("z_pad", P * 18 * 18 * 512, torch.float16)
     z_bf = ws.get("z_pad_bf", P * 18 * 18 * 512, torch.bfloat16)
     amz = ws.get("amz", P * 256 * 512, torch.uint8)
-    self._timed("expand_train", lambda: _lib.check(lib.sgc_pair_expand_train(_lib.ptr(ctx.uv[0]), _lib.ptr(ctx.uv[1]), _lib.ptr(sub_idx), _lib.ptr(obj_idx),
-                                         _lib.ptr(z), _lib.ptr(z_bf), _lib.ptr(amz), P, self._st()), "sgc_pair_expand_train"))
+    self.expand(ctx.uv[0], ctx.uv[1], sub_idx, obj_idx, P, z, z_bf, amz, dense=dense)
     ctx.z_bf = z_bf
     y = ws.get("y", Ppad * 65536, torch.float16)
     am = ws.get("argmax", P * 65536, torch.uint8)

@@ -24,6 +24,13 @@ from .pairs import DeviceScene, pair_targets_fast, super_multihot
 from .synthetic import HeadConfig, predicate_counts
 
 
+def _dense(scene):
+    """(img_ptr, pid, max_n) when the scene carries the all-pairs lookup table (flatten_scene builds it)."""
+    if getattr(scene, "pid", None) is None or scene.max_n <= 0:
+        return None
+    return (scene.img_ptr, scene.pid, scene.max_n)
+
+
 def strip_ddp_prefix(state_dict: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
     """Reference checkpoints are saved from the DDP wrapper (``train_test.py:322``; ``utils.py:207-214``)."""
     return {k.replace("module.", ""): v for k, v in state_dict.items()}
@@ -94,7 +101,7 @@ class _RelationBase(nn.Module):
         with torch.no_grad():
             return eng.forward_pairs(scene.image_feature, scene.image_depth, scene.obj_img, scene.bbox, scene.cats,
                                      scene.super_mh, scene.sub_idx, scene.obj_idx, train=self.training, seeds=seeds,
-                                     iou_mask=iou_mask)
+                                     iou_mask=iou_mask, dense=_dense(scene))
 
     def _next_seeds(self):
         self._step += 1
@@ -128,7 +135,8 @@ class _RelationBase(nn.Module):
         with torch.no_grad():
             ctx = eng.train_forward(scene.image_feature, scene.image_depth, scene.obj_img, scene.bbox, scene.cats,
                                     scene.super_mh, scene.sub_idx, scene.obj_idx,
-                                    seeds=self._next_seeds() if self.training else (0, 0), dropout=self.training)
+                                    seeds=self._next_seeds() if self.training else (0, 0), dropout=self.training,
+                                    dense=_dense(scene))
             loss, grads = eng.train_backward(ctx, coefs_d, sub_csr, obj_csr, img_ptr, grad_hook=grad_hook)
             for name, p in self.named_parameters():
                 g = grads[name].view_as(p)

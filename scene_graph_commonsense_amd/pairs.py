@@ -122,6 +122,9 @@ class DeviceScene:
     obj_idx: torch.Tensor           # [P] int32
     pidx: PairIndex
     bbox_raw: np.ndarray            # [n_obj,4] as given (evaluator records)
+    img_ptr: Optional[torch.Tensor] = None   # [B+1] int32 object ranges per image
+    pid: Optional[torch.Tensor] = None       # [n_obj, max_n] int32: (subject, object-in-image) -> pair index or -1
+    max_n: int = 0
 
 
 def flatten_scene(cfg, batch, device) -> DeviceScene:
@@ -135,11 +138,15 @@ def flatten_scene(cfg, batch, device) -> DeviceScene:
     cats = torch.cat([c.reshape(-1) for c in batch.categories]).to(torch.int64)
     mh = super_multihot(batch.super_categories, cfg.num_super_classes) if cfg.dataset == "vg" else None
     dev = torch.device(device)
+    max_n = max(n) if n else 0
+    pid = np.full((int(sum(n)), max(max_n, 1)), -1, dtype=np.int32)
+    pid[pidx.sub, pidx.obj - pidx.obj_offset[pidx.image]] = np.arange(pidx.n_pairs, dtype=np.int32)
     return DeviceScene(batch.image_feature.to(dev, torch.float32).contiguous(),
                        batch.image_depth.to(dev, torch.float32).contiguous(),
                        torch.from_numpy(obj_img).to(dev), torch.from_numpy(bb).to(dev), cats.to(dev),
                        None if mh is None else torch.from_numpy(mh).to(dev),
-                       torch.from_numpy(pidx.sub).to(dev), torch.from_numpy(pidx.obj).to(dev), pidx, raw)
+                       torch.from_numpy(pidx.sub).to(dev), torch.from_numpy(pidx.obj).to(dev), pidx, raw,
+                       torch.from_numpy(pidx.obj_offset.astype(np.int32)).to(dev), torch.from_numpy(pid).to(dev), int(max_n))
 
 
 def pair_targets_fast(relationships, subj_or_obj, pidx: PairIndex) -> np.ndarray:

@@ -1,0 +1,161 @@
+"""GPU tests at BASELINE.json's sizes through size-independent properties (the CPU oracle would need hours there):
+dense vs generic expansion bit-equality, batch-independence of per-pair rows, ranking sortedness, the pair contraction
+as exact transpose of the expansion routing, linearity of the backward in the loss coefficients, and the OpenImages
+N=100 stress configuration."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(cfg, seed=0, train=False):
+    from scene_graph_commonsense_amd.model import BayesianRelationClassifier
+    from scene_graph_commonsense_amd.synthetic import make_state_dict
+    m = BayesianRelationClassifier(cfg.args(), num_classes=cfg.num_classes, num_super_classes=cfg.num_super_classes,
+                                   num_geometric=cfg.num_geometric, num_possessive=cfg.num_possessive,
+                                   num_semantic=cfg.num_semantic).cuda()
+    m.load_state_dict(make_state_dict(cfg, seed=seed, head_gain=4.0))
+    m.train(train)
+    return m
+
+
+def test_dense_expansion_equals_generic_bitwise():
+    from scene_graph_commonsense_amd import _lib
+    from scene_graph_commonsense_amd.pairs import flatten_scene
+    from scene_graph_commonsense_amd.synthetic import HeadConfig, make_scene_batch
+    lib = _lib.load()
+    cfg = HeadConfig()
+    for nobj in ((5, 2, 9), (64,), (100, 3)):
+        batch = make_scene_batch(cfg, nobj, seed=7)
+        sc = flatten_scene(cfg, batch, "cuda:0")
+        n_obj, P = int(sc.obj_img.shape[0]), sc.pidx.n_pairs
+        g = torch.Generator(device="cpu").manual_seed(1)
+        U = (torch.randn(n_obj * 1024, 512, generator=g)).half().cuda()
+        V = (torch.randn(n_obj * 1024, 512, generator=g)).half().cuda()
+        outs = []
+        for dense in (False, True):
+            z = torch.zeros(P * 324 * 512, dtype=torch.float16, device="cuda")
+            zb = torch.zeros(P * 324 * 512, dtype=torch.bfloat16, device="cuda")
+            am = torch.full((P * 256 * 512,), 9, dtype=torch.uint8, device="cuda")
+            if dense:
+                st = lib.sgc_pair_expand_dense(_lib.ptr(U), _lib.ptr(V), _lib.ptr(sc.img_ptr), _lib.ptr(sc.pid), int(sc.pid.shape[1]),
+                                               len(nobj), sc.max_n, _lib.ptr(z), _lib.ptr(zb), _lib.ptr(am), _lib.stream_ptr())
+            else:
+                st = lib.sgc_pair_expand_train(_lib.ptr(U), _lib.ptr(V), _lib.ptr(sc.sub_idx), _lib.ptr(sc.obj_idx), _lib.ptr(z),
+                                               _lib.ptr(zb), _lib.ptr(am), P, _lib.stream_ptr())
+            assert st == 0
+            outs.append((z, zb, am))
+        torch.cuda.synchronize()
+        for a, b in zip(*outs):
+            assert torch.equal(a, b)
+        # reference semantics on a sample of pairs: maxpool2(relu(U_i + V_j)) in window-major order
+        z = outs[1][0].view(P, 18, 18, 512)
+        for p in (0, P // 2, P - 1):
+            s = U[int(sc.sub_idx[p]) * 1024:(int(sc.sub_idx[p]) + 1) * 1024].float() + \
+                V[int(sc.obj_idx[p]) * 1024:(int(sc.obj_idx[p]) + 1) * 1024].float()
+            ref = torch.relu(s.view(256, 4, 512).max(dim=1)[0]).half().view(16, 16, 512)
+            assert torch.equal(z[p, 1:17, 1:17], ref)
+            assert float(z[p, 0].abs().max()) == 0 and float(z[p, :, 17].abs().max()) == 0      # halo stays zero
+
+
+def test_fullsize_rows_do_not_depend_on_the_rest_of_the_batch():
+    """N=64, B=8 (the metric's configuration): the rows of image 3 equal those of a batch holding image 3 alone."""
+    from scene_graph_commonsense_amd.pairs import flatten_scene
+    from scene_graph_commonsense_amd.synthetic import HeadConfig, SceneBatch, make_scene_batch
+    cfg = HeadConfig()
+    model = _model(cfg)
+    batch = make_scene_batch(cfg, [64] * 8, seed=5)
+    sc = flatten_scene(cfg, batch, "cuda:0")
+    out = model.forward_pairs(sc)
+    rel_all, cand_all = out.relation.clone(), out.cand_pred.clone()
+    assert sc.pidx.n_pairs == 32256 and torch.isfinite(rel_all).all()
+    k = 3
+    one = SceneBatch(batch.image_feature[k:k + 1], batch.image_depth[k:k + 1], [batch.bbox[k]], [batch.categories[k]],
+                     [batch.super_categories[k]], [batch.relationships[k]], [batch.subj_or_obj[k]], [64])
+    sc1 = flatten_scene(cfg, one, "cuda:0")
+    out1 = model.forward_pairs(sc1)
+    rows = torch.from_numpy(np.nonzero(sc.pidx.image == k)[0]).cuda()
+    assert torch.equal(rel_all[rows], out1.relation)                 # bit-exact: K order does not depend on the row
+    assert torch.equal(cand_all[rows], out1.cand_pred)
+    # log-softmax sanity at full size: each super-category block and the super head are normalised
+    p = rel_all.exp()
+    tot = p.sum(1)
+    assert torch.allclose(tot, torch.ones_like(tot), atol=1e-4)
+
+
+def test_fullsize_ranking_is_sorted_and_stable():
+    from scene_graph_commonsense_amd.evaluator import rank_topk
+    g = torch.Generator().manual_seed(3)
+    which = torch.arange(8).repeat_interleave(12096)                  # 3 candidates x 4032 pairs per image
+    conf = torch.randn(which.numel(), generator=g)
+    conf[torch.rand(conf.numel(), generator=g) < 0.5] = -float("inf")
+    images, order, seg, top, cnt = rank_topk(conf.cuda(), which.cuda(), 100)
+    for r in range(8):
+        c = conf[which == images[r]]
+        vals = c[top[r]]
+        assert (vals[:-1] >= vals[1:]).all()
+        ties = vals[:-1] == vals[1:]
+        assert (top[r][:-1][ties.numpy()] < top[r][1:][ties.numpy()]).all()      # ties in append order
+        assert float(vals[-1]) >= float(torch.topk(c, 100)[0][-1]) - 0.0
+
+
+def test_contraction_is_the_transpose_of_the_expansion_routing():
+    from scene_graph_commonsense_amd import _lib
+    from scene_graph_commonsense_amd.engine import csr_by
+    from scene_graph_commonsense_amd.pairs import flatten_scene
+    from scene_graph_commonsense_amd.synthetic import HeadConfig, make_scene_batch
+    lib = _lib.load()
+    cfg = HeadConfig()
+    batch = make_scene_batch(cfg, (6, 4), seed=2)
+    sc = flatten_scene(cfg, batch, "cuda:0")
+    n_obj, P = 10, sc.pidx.n_pairs
+    g = torch.Generator().manual_seed(4)
+    amz = torch.randint(0, 5, (P, 256, 512), generator=g, dtype=torch.uint8).cuda()
+    dz_std = torch.randint(-3, 4, (P, 16, 16, 512), generator=g).float()         # small integers: exact in bf16 / f32 sums
+    m3 = torch.zeros(16, 16, dtype=torch.long)
+    for Y in range(16):
+        for X in range(16):
+            m3[Y, X] = 4 * ((Y >> 1) * 8 + (X >> 1)) + (Y & 1) * 2 + (X & 1)
+    dz = torch.zeros(P, 256, 512)
+    dz[:, m3.view(-1)] = dz_std.view(P, 256, 512)
+    dz = dz.bfloat16().cuda()
+    for idx in (sc.pidx.sub, sc.pidx.obj):
+        ptr, lst = (torch.from_numpy(a).cuda() for a in csr_by(idx, n_obj))
+        dU = torch.zeros(n_obj, 34, 34, 512, dtype=torch.bfloat16, device="cuda")
+        assert lib.sgc_pair_contract(_lib.ptr(dz), _lib.ptr(amz), _lib.ptr(ptr), _lib.ptr(lst), _lib.ptr(dU), n_obj, _lib.stream_ptr()) == 0
+        torch.cuda.synchronize()
+        ref = torch.zeros(n_obj, 32, 32, 512)
+        a = amz.cpu().view(P, 16, 16, 512)
+        for p in range(P):
+            for q in range(4):
+                ref[idx[p], (q >> 1)::2, (q & 1)::2] += torch.where(a[p] == q, dz_std[p], torch.zeros(()))
+        assert torch.equal(dU[:, 1:33, 1:33].float().cpu(), ref)
+
+
+def test_backward_is_linear_in_the_loss_coefficients_and_configs_run():
+    """configs[1] (N=36) scaled down in B, and the OpenImages N=100 stress shape: finite outputs and gradients, and
+    doubling every loss coefficient doubles every gradient (the backward is linear in dL/dlogits)."""
+    from scene_graph_commonsense_amd.pairs import flatten_scene
+    from scene_graph_commonsense_amd.synthetic import HeadConfig, make_scene_batch
+    for cfg, nobj in ((HeadConfig(), (36, 36)),
+                      (HeadConfig(dataset="oiv6", num_classes=601, num_super_classes=0, num_geometric=4, num_possessive=2,
+                                  num_semantic=24), (100,))):
+        model = _model(cfg)
+        batch = make_scene_batch(cfg, nobj, seed=9, connect_frac=0.05)
+        sc = flatten_scene(cfg, batch, "cuda:0")
+        grads = []
+        for lam in (0.1, 0.2):
+            model.zero_grad(set_to_none=True)
+            loss = model.training_step(sc, batch.relationships, batch.subj_or_obj, lambda_connectivity=lam,
+                                       class_weight=None)
+            assert torch.isfinite(loss)
+            grads.append({n: p.grad.clone() for n, p in model.named_parameters()})
+        out = model.last_outputs
+        assert torch.isfinite(out.relation).all() and int(out.cand_pred.min()) >= 0
+        assert int(out.cand_pred.max()) < cfg.num_relations
+        for n in grads[0]:
+            assert torch.isfinite(grads[0][n]).all(), n
+        # connectivity-only parameters scale exactly with lambda (fc4 sees only the BCE term)
+        r = grads[1]["fc4.weight"].norm() / grads[0]["fc4.weight"].norm()
+        assert abs(float(r) - 2.0) < 1e-3
