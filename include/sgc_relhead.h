@@ -93,6 +93,10 @@ int sgc_slab_sum(const float* in, float* out, long n, int slabs, int accumulate,
 int sgc_colsum(int elem, const void* X, float* part, long rows, int cols, int row_blocks, void* stream);  /* bias gradients */
 int sgc_segment_sum_rows(const void* X, const int* ptr, const int* list, float* out, int n_seg, int cols, void* stream); /* label-column grads */
 int sgc_convert_f16_bf16(const void* in, void* out, long n, void* stream);
+/* 64x64 tile transposes with conversion (weight-copy derivation / gradient layout): dst[a*sa_d + b*sb_d + j*ds_j + i] =
+ * convert(src[a*sa_s + b*sb_s + i*ss_i + j]) for a < na, b < nb, i,j < 64; out_kind 0 f16, 1 bf16, 2 f32. */
+int sgc_transpose_cast(const float* src, void* dst, int out_kind, int na, int nb, long sa_s, long sb_s, long ss_i, long sa_d,
+                       long sb_d, long ds_j, void* stream);
 
 int sgc_fc2_dgrad(const void* dpre, const void* w2mT, const void* h1, void* dh1, int n_pairs, float drop_scale, void* stream);
 int sgc_fc2_wgrad(const void* dpre, const void* h1_bf16, float* slabs, int n_rows, int splits, int* n_slabs, void* stream);

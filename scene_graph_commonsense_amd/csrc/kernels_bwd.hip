@@ -204,6 +204,35 @@ __global__ void convert_f16_bf16_kernel(const u16* __restrict__ in, u16* __restr
     }
 }
 
+// ------------------------------------------------------------------------------------------------ layout transforms
+// 64x64 tile transpose with type conversion: dst[base_d + j*ds_j + i] = convert(src[base_s + i*ss_i + j]), i,j < 64,
+// one tile per workgroup, tiles enumerated by (blockIdx.x, blockIdx.y) with independent source/destination strides.
+// Used to derive the fc1 compute copies from the f32 master ([n][c*64+w] -> f16 [n][w*1024+c] and bf16 [w*1024+c][n])
+// and to bring the fc1 weight gradient back to the reference layout.  OUT: 0 f16, 1 bf16, 2 f32.
+template <int OUT>
+__global__ __launch_bounds__(256) void transpose_cast_kernel(const float* __restrict__ src, void* __restrict__ dst, long sa_s, long sb_s,
+                                                             long ss_i, long sa_d, long sb_d, long ds_j) {
+    __shared__ float tile[64][65];
+    const long bs = blockIdx.x * sa_s + blockIdx.y * sb_s;
+    const long bd = blockIdx.x * sa_d + blockIdx.y * sb_d;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int i = r * 4 + w;
+        tile[i][lane] = src[bs + i * ss_i + lane];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int j = r * 4 + w;
+        const float v = tile[lane][j];
+        const long o = bd + j * ds_j + lane;
+        if constexpr (OUT == 0) reinterpret_cast<u16*>(dst)[o] = f32_to_f16_bits(v);
+        else if constexpr (OUT == 1) reinterpret_cast<u16*>(dst)[o] = f32_to_bf16_bits(v);
+        else reinterpret_cast<float*>(dst)[o] = v;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ un-pool (conv3 output)
 // dy3_pad[p][2py+dy+1][2px+dx+1][c] = (argmax[p][W][c] == dy*2+dx) ? dy[p][W][c] : 0 ; db3[c] += routed dy
 __global__ __launch_bounds__(256) void unpool_kernel(const u16* __restrict__ dy, const unsigned char* __restrict__ am,
@@ -452,6 +481,18 @@ int sgc_segment_sum_rows(const void* X, const int* ptr, const int* list, float* 
     if (cols != 512) return SGC_ERR_ARG;
     if (n_seg <= 0) return SGC_OK;
     SGC_LAUNCH(segment_sum_rows_kernel, dim3(n_seg), dim3(64), 0, (hipStream_t)stream, (const u16*)X, ptr, list, out, cols);
+    SGC_CHECK_LAUNCH();
+    return SGC_OK;
+}
+
+int sgc_transpose_cast(const float* src, void* dst, int out_kind, int na, int nb, long sa_s, long sb_s, long ss_i, long sa_d,
+                       long sb_d, long ds_j, void* stream) {
+    if (na <= 0 || nb <= 0) return SGC_OK;
+    dim3 grid(na, nb);
+    if (out_kind == 0) SGC_LAUNCH(transpose_cast_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, src, dst, sa_s, sb_s, ss_i, sa_d, sb_d, ds_j);
+    else if (out_kind == 1) SGC_LAUNCH(transpose_cast_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, src, dst, sa_s, sb_s, ss_i, sa_d, sb_d, ds_j);
+    else if (out_kind == 2) SGC_LAUNCH(transpose_cast_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, src, dst, sa_s, sb_s, ss_i, sa_d, sb_d, ds_j);
+    else return SGC_ERR_ARG;
     SGC_CHECK_LAUNCH();
     return SGC_OK;
 }

@@ -110,7 +110,8 @@ class RelHeadEngine:
         w["b2"] = g("conv2_1.bias").contiguous()
         w["w3r"] = conv_k_layout(g("conv3_1.weight")).half().contiguous()
         w["b3"] = g("conv3_1.bias").contiguous()
-        w["w1p"] = g("fc1.weight").view(4096, 1024, 64).permute(0, 2, 1).reshape(4096, 65536).half().contiguous()
+        w1 = g("fc1.weight").contiguous()
+        w["w1p"] = self._transpose_cast(w1, "w1p", torch.float16, 0, 4096, 16, 65536, 4096, 64, 65536, 64, 1024)
         w["bf1"] = g("fc1.bias").contiguous()
         fc2 = g("fc2.weight")
         w["fc2_full"] = fc2
@@ -133,6 +134,13 @@ class RelHeadEngine:
         self.head_rows = rc.shape[0]
 
     # ------------------------------------------------------------------ helpers
+    def _transpose_cast(self, src, name, dtype, kind, na, nb, sa_s, sb_s, ss_i, sa_d, sb_d, ds_j):
+        dst = self.ws.get(name, src.numel(), dtype)
+        _lib.check(self.lib.sgc_transpose_cast(_lib.ptr(src), _lib.ptr(dst), kind, na, nb, _c_long(sa_s), _c_long(sb_s),
+                                               _c_long(ss_i), _c_long(sa_d), _c_long(sb_d), _c_long(ds_j), self._st()),
+                   "sgc_transpose_cast")
+        return dst
+
     def _st(self):
         return _lib.stream_ptr()
 
@@ -309,7 +317,8 @@ def _prep_bwd_weights(self, sd):
     g = lambda k: sd[k].detach().to(dev, torch.float32)
     w = self.w
     w["w2mT"] = w["fc2_full"][:, :4096].t().contiguous().to(torch.bfloat16)
-    w["w1pT"] = g("fc1.weight").view(4096, 1024, 64).permute(2, 1, 0).reshape(65536, 4096).to(torch.bfloat16).contiguous()
+    w["w1pT"] = self._transpose_cast(g("fc1.weight").contiguous(), "w1pT", torch.bfloat16, 1, 64, 1024, 64 * 65536, 64, 65536,
+                                     64, 4096, 1024 * 4096)
     w["wd3"] = conv_k_layout(g("conv3_1.weight").flip(2, 3).permute(1, 0, 2, 3)).to(torch.bfloat16).contiguous()
     c2 = g("conv2_1.weight")
     w["wd2"] = torch.stack([conv_k_layout(c2[:, r * 128:(r + 1) * 128].flip(2, 3).permute(1, 0, 2, 3))
@@ -451,7 +460,11 @@ def train_backward(self, ctx: "TrainContext", coefs, sub_csr, obj_csr, img_ptr, 
     y_bf = _to_bf16(self, "y_bf", ctx.y, Ppad * 65536)
     dW1p = ws.get("dW1p", 4096 * 65536, torch.float32)
     self._timed("fc1_wgrad", lambda: _lib.check(lib.sgc_fc1_wgrad(_lib.ptr(dh1), _lib.ptr(y_bf), _lib.ptr(dW1p), Ppad, 65536, st()), "sgc_fc1_wgrad"))
-    grads["fc1.weight"] = dW1p.view(4096, 64, 1024).permute(0, 2, 1).reshape(4096, 65536)
+    # back to the reference column order (c*64 + window): 64x64 tile transposes, f32 -> f32
+    gfc1 = torch.empty(4096, 65536, dtype=torch.float32, device=dev)
+    _lib.check(lib.sgc_transpose_cast(_lib.ptr(dW1p), _lib.ptr(gfc1), 2, 4096, 16, _c_long(65536), _c_long(64), _c_long(1024),
+                                      _c_long(65536), _c_long(4096), _c_long(64), st()), "sgc_transpose_cast")
+    grads["fc1.weight"] = gfc1
     if grad_hook is not None:          # largest gradient (97 % of the bytes) is ready first: overlap its all-reduce
         grad_hook("fc1.weight", grads["fc1.weight"])
     grads["fc1.bias"] = _colsum(self, dh1, Ppad, 4096)
