@@ -26,6 +26,24 @@ from scene_graph_commonsense_amd.synthetic import HeadConfig, make_scene_batch, 
 
 MFMA_PEAK_TFLOPS = 2500.0      # dense bf16/f16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
+DOMINANT_KERNEL = "gemm_nt_kernel<0, 1, 3"        # conv3 forward: f16, implicit 3x3 conv, ReLU + max-pool epilogue
+
+
+def pmc_traffic():
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (separate FETCH_SIZE
+    and WRITE_SIZE runs, profiles/r01_final_pmc_{f,w}.csv).  FETCH_SIZE is doubled: gfx950 counts 128-B requests of
+    wide coalesced reads as 64 B (MI355X_MICROARCH.md, HBM section); both counters are KiB."""
+    vals = {}
+    for tag, ctr in (("f", "FETCH_SIZE"), ("w", "WRITE_SIZE")):
+        path = os.path.join(REPO, "profiles", "r01_final_pmc_%s.csv" % tag)
+        if not os.path.exists(path):
+            return None
+        for line in open(path):
+            if DOMINANT_KERNEL in line and "," + ctr + "," in line:
+                vals[ctr] = float(line.rsplit(",", 1)[1])
+    if len(vals) != 2:
+        return None
+    return int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024)
 
 
 def cpu_baseline(cfg, sd, budget_s=20.0):
@@ -137,7 +155,10 @@ def main():
             ach = flops[dom] / (kern[dom] * 1e-3) / 1e12
             roof = {"bound": "mfma", "kernel": "gemm_nt_kernel<f16,conv3x3,relu+pool> (sgc_conv3_relu_pool)",
                     "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None, "ms_per_launch": round(kern[dom], 3)}
+                    "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic() if P == 32256 else None,
+                    "traffic_note": "bytes/launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from profiles/r01_final_pmc_{f,w}.csv "
+                                    "(separate rocprofv3 --pmc passes at this workload); algorithmic 17.0e9",
+                    "ms_per_launch": round(kern[dom], 3)}
         out = {
             "metric": "ordered object-pairs/sec (relation head fwd+bwd), batch=%d, N=%d" % (args.images, args.objects)
                       if not args.forward_only else "ordered object-pairs/sec (relation head forward only)",
