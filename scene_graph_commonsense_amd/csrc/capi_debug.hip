@@ -24,6 +24,7 @@ int sgc_dbg_gemm_nt_abl(int abl, const void* A, const void* B, void* C, int M, i
         case 1: return launch_gemm_nt_cfg<ELEM_BF16, AMODE_PLAIN, EPI_STORE, 2, 4, 4, 2, 1>(p, (hipStream_t)stream);
         case 2: return launch_gemm_nt_cfg<ELEM_BF16, AMODE_PLAIN, EPI_STORE, 2, 4, 4, 2, 2>(p, (hipStream_t)stream);
         case 3: return launch_gemm_nt_cfg<ELEM_BF16, AMODE_PLAIN, EPI_STORE, 2, 4, 4, 2, 3>(p, (hipStream_t)stream);
+        case 5: return launch_gemm_nt_cfg<ELEM_BF16, AMODE_PLAIN, EPI_STORE, 2, 4, 4, 2, 5>(p, (hipStream_t)stream);
         case 4: return launch_gemm_nt_ring<ELEM_BF16, AMODE_PLAIN, EPI_STORE>(p, (hipStream_t)stream);
     }
     return SGC_ERR_ARG;

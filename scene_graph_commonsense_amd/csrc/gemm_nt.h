@@ -163,9 +163,11 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void gemm_nt_kernel(const NtParams
         const long boff = (long)kt << 6;
         char* abase = smem + buf * BUF_BYTES + wid * (AI * 1024);
         char* bbase = smem + buf * BUF_BYTES + A_BYTES + wid * (BI * 1024);
+        if (ABL != 5 || (kt % 9) == 0) {       // ABL 5: A staged on one K tile in nine (timing model of halo reuse)
 #pragma unroll
-        for (int i = 0; i < AI; ++i)
-            __builtin_amdgcn_global_load_lds(GLB_PTR(a_ptr[i] + aoff), LDS_PTR(abase + i * 1024), 16, 0, 0);
+            for (int i = 0; i < AI; ++i)
+                __builtin_amdgcn_global_load_lds(GLB_PTR(a_ptr[i] + aoff), LDS_PTR(abase + i * 1024), 16, 0, 0);
+        }
 #pragma unroll
         for (int i = 0; i < BI; ++i)
             __builtin_amdgcn_global_load_lds(GLB_PTR(b_ptr[i] + boff), LDS_PTR(bbase + i * 1024), 16, 0, 0);
@@ -200,7 +202,7 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void gemm_nt_kernel(const NtParams
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
-        if ((ABL == 0 || ABL == 3) && kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+        if ((ABL == 0 || ABL == 3 || ABL == 5) && kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
         const char* ab = smem + (kt & 1) * BUF_BYTES;
         const char* bb = ab + A_BYTES;
         if (ABL == 3) continue;
@@ -228,7 +230,7 @@ inline int sgc_gemm_ring() {      // SGC_GEMM_RING=1 selects the 4-stage ring ke
     return v;
 }
 
-inline int sgc_gemm_cfg() {       // test hook: SGC_GEMM_CFG=1 forces the 128x128 block, =2 the 2-stage 256x256 block, =3 the 4-stage ring
+inline int sgc_gemm_cfg() {       // test hook: SGC_GEMM_CFG=1 forces the 128x128 block, =2 the 2-stage 256x256 block, =3 the 4-stage ring, =4 the halo-staged conv
     static int cfg = -1;
     if (cfg < 0) { const char* e = getenv("SGC_GEMM_CFG"); cfg = e ? atoi(e) : 0; }
     return cfg;
@@ -374,6 +376,151 @@ static int launch_gemm_nt_ring(NtParams p, hipStream_t stream) {
     return SGC_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Halo-staged implicit 3x3 convolution for 16x16 maps (conv3 forward and data gradient): one workgroup = one image
+// (256 pixels) x 256 output channels.  For every 64-channel chunk the 18x18 zero-padded patch of the image is staged
+// in LDS ONCE (41 KiB) and the nine taps read their A fragments from it at shifted pixel rows; only the weight tile
+// (32 KiB) is staged per (chunk, tap).  L2->LDS traffic per K step falls from 64 KiB to 36.6 KiB (-43 %), which is
+// what limits the plain implicit GEMM (tools/gemm_microbench.py: the load stream and the LDS-read+MFMA loop overlap
+// poorly; staging A on one K tile in nine was measured +10 %).
+// Patch row r = py*18 + px (128 B per row); 16-B chunk swizzle c ^ f(py,px), f = ((px>>1) + 4*(py&1)) & 7, keeps every
+// ds_read_b128 lane group (pixels of windows {0,3,5,6} / {1,2,4,7} on two image rows) conflict-free for all nine taps.
+template <int ELEM, int EPI>
+__global__ __launch_bounds__(512, 2) void conv16_halo_kernel(const NtParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int WC = 4, TM = 4, TN = 2;
+    constexpr int A_BYTES = 328 * 128;            // 324 patch rows, padded to 41 x 8 rows
+    constexpr int B_BYTES = 256 * 128;
+    char* const abuf0 = smem;
+    char* const bbuf0 = smem + 2 * A_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tn = blockIdx.x % p.tiles_n, img = blockIdx.x / p.tiles_n;
+    const int m0 = img * 256, n0 = tn * 256;
+    const int Cin = p.Cin;
+
+    // ---- A patch loader: 41 instructions of 8 rows; wave w issues instructions w, w+8, ... (<= 6)
+    const int lrow = lane >> 3, cpos = lane & 7;
+    int a_off[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        int r = (wid + 8 * i) * 8 + lrow;
+        if (r > 323) r = 323;
+        const int py = r / 18, px = r - py * 18;
+        const int f = ((px >> 1) + 4 * (py & 1)) & 7;
+        a_off[i] = r * Cin + ((cpos ^ f) << 3);
+    }
+    const u16* const a_img = p.A + (long)img * (324L * Cin);
+    auto stage_a = [&](int buf, int cc) {
+        char* base = abuf0 + buf * A_BYTES;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int t = wid + 8 * i;
+            if (t < 41)
+                __builtin_amdgcn_global_load_lds(GLB_PTR(a_img + a_off[i] + (cc << 6)), LDS_PTR(base + t * 1024), 16, 0, 0);
+        }
+    };
+    // ---- B (weight) loader: as in the plain kernel
+    const u16* b_ptr[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = wid * 32 + i * 8 + lrow;
+        b_ptr[i] = p.B + (long)(n0 + row) * p.ldb + ((cpos ^ ((row >> 1) & 7)) << 3);
+    }
+    auto stage_b = [&](int buf, int step) {
+        char* base = bbuf0 + buf * B_BYTES + wid * 4096;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds(GLB_PTR(b_ptr[i] + ((long)step << 6)), LDS_PTR(base + i * 1024), 16, 0, 0);
+    };
+
+    // ---- fragment addressing
+    const int wr = wid / WC, wc = wid % WC;
+    const int kh = lane >> 5;
+    int a_row[TM], a_px[TM], a_py[TM], b_off[TN], b_sw[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = wr * 128 + i * 32 + (lane & 31);
+        const int W = m >> 2, q = m & 3;
+        a_py[i] = 2 * (W >> 3) + (q >> 1);
+        a_px[i] = 2 * (W & 7) + (q & 1);
+        a_row[i] = a_py[i] * 18 + a_px[i];
+    }
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+        const int rb = wc * TN * 32 + i * 32 + (lane & 31);
+        b_off[i] = rb * 128; b_sw[i] = (rb >> 1) & 7;
+    }
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int ncc = Cin >> 6;
+    const int nsteps = ncc * 9;
+    stage_a(0, 0);
+    stage_b(0, 0);
+    int step = 0;
+    for (int cc = 0; cc < ncc; ++cc) {
+        const char* ab = abuf0 + (cc & 1) * A_BYTES;
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap, ++step) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (step + 1 < nsteps) stage_b((step + 1) & 1, step + 1);
+            if (tap == 0 && cc + 1 < ncc) stage_a((cc + 1) & 1, cc + 1);
+            const char* bb = bbuf0 + (step & 1) * B_BYTES;
+            const int ky = tap / 3, kx = tap - 3 * ky;
+            int ar[TM], af_sw[TM];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                ar[i] = (a_row[i] + ky * 18 + kx) * 128;
+                af_sw[i] = (((a_px[i] + kx) >> 1) + 4 * ((a_py[i] + ky) & 1)) & 7;
+            }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int c = ks * 2 + kh;
+                s16x8 af[TM], bf[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const s16x8*>(ab + ar[i] + ((c ^ af_sw[i]) << 4));
+#pragma unroll
+                for (int i = 0; i < TN; ++i) bf[i] = *reinterpret_cast<const s16x8*>(bb + b_off[i] + ((c ^ b_sw[i]) << 4));
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = mfma32<ELEM>(af[i], bf[j], acc[i][j]);
+            }
+        }
+    }
+    nt_epilogue<ELEM, EPI, TM, TN>(p, acc, m0, n0, wr, wc, lane);
+}
+
+template <int ELEM, int EPI>
+static int launch_conv16_halo(NtParams p, hipStream_t stream) {
+    constexpr int LDS = 2 * 328 * 128 + 2 * 256 * 128;
+    p.tiles_m = p.M / 256;
+    p.tiles_n = p.N / 256;
+    static bool attr_set = false;
+    auto kern = conv16_halo_kernel<ELEM, EPI>;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set = true;
+    }
+    SGC_LAUNCH(kern, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(512), LDS, stream, p);
+    SGC_CHECK_LAUNCH();
+    return SGC_OK;
+}
+
+inline int sgc_conv_halo() {      // SGC_CONV_HALO=0 falls back to the plain implicit GEMM (A/B hook)
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("SGC_CONV_HALO"); v = e ? atoi(e) : 1; }
+    return v;
+}
+
 template <int ELEM, int AMODE, int EPI>
 static int launch_gemm_nt(NtParams p, hipStream_t stream) {
     if (p.M <= 0) return SGC_OK;
@@ -381,6 +528,10 @@ static int launch_gemm_nt(NtParams p, hipStream_t stream) {
     if (AMODE == AMODE_CONV && ((p.Cin & 63) || p.K != 9 * p.Cin)) return SGC_ERR_ARG;
     const int cfg = sgc_gemm_cfg();
     const bool big_ok = (p.N % 256) == 0;
+    if constexpr (AMODE == AMODE_CONV && (EPI == EPI_POOL || EPI == EPI_STORE)) {
+        if (p.lgS == 4 && big_ok && (p.M % 256) == 0 && (cfg == 4 || (cfg == 0 && sgc_conv_halo() && (long)p.M * p.N >= 256L * 256 * 256)))
+            return launch_conv16_halo<ELEM, EPI>(p, stream);
+    }
     const bool big = big_ok && (cfg == 2 || cfg == 3 || (cfg == 0 && (long)p.M * p.N >= 256L * 256 * 256));
     if (big && (cfg == 3 || (cfg == 0 && sgc_gemm_ring()))) return launch_gemm_nt_ring<ELEM, AMODE, EPI>(p, stream);
     if (big) return launch_gemm_nt_cfg<ELEM, AMODE, EPI, 2, 4, 4, 2>(p, stream);

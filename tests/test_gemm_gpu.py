@@ -54,7 +54,8 @@ def _conv_inputs(n_img, S, Cin, N, dtype):
 
 
 @pytest.mark.parametrize("dtype,elem", [(torch.float16, 0), (torch.bfloat16, 1)])
-@pytest.mark.parametrize("n_img,lgS,Cin,N", [(3, 4, 128, 128), (2, 5, 128, 256), (5, 4, 512, 128)])
+@pytest.mark.parametrize("n_img,lgS,Cin,N", [(3, 4, 128, 128), (2, 5, 128, 256), (5, 4, 512, 128), (3, 4, 128, 256),
+                                             (2, 4, 512, 512), (2, 4, 1024, 256)])
 def test_conv_nt(dtype, elem, n_img, lgS, Cin, N):
     lib, L = _lib()
     S = 1 << lgS
