@@ -61,29 +61,38 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void gemm_tn_kernel(const TnParams
         boff_tap = (long)(ky * ((1 << p.lgS) + 2) + kx) * p.Cin;
     }
 
+    // Row addresses split into a per-lane constant (row inside a 64-row K tile, computed once) and a wave-uniform
+    // per-tile offset (scalar ALU): a K tile of 64 window-major rows starts at window column 0, so the padded-pixel
+    // offset of row kt*64 + l is conv_row_base(kt*64) + conv_row_base(l).
+    long a_loc[AI], b_loc[BI];
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+        const int q = wid * AI + i;
+        const int kl = (q / APK) * 4 + kr;
+        const int mcol = (q % APK) * 128 + mo;
+        if constexpr (ACONV) a_loc[i] = conv_row_base(kl, p.lgS, p.CinA) + (long)((1 << p.lgS) + 3) * p.CinA + m0 + mcol;
+        else a_loc[i] = (long)kl * p.lda + m0 + mcol;
+    }
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+        const int q = wid * BI + i;
+        const int kl = (q / BPK) * 4 + kr;
+        const int ncol = (q % BPK) * 128 + mo;
+        if constexpr (BMODE == BMODE_CONV) b_loc[i] = conv_row_base(kl, p.lgS, p.Cin) + boff_tap + bcol0 + ncol;
+        else b_loc[i] = (long)kl * p.ldb + n0 + ncol;
+    }
     auto stage = [&](int buf, int kt) {
         char* abase = smem + buf * BUF_BYTES + wid * (AI * 1024);
         char* bbase = smem + buf * BUF_BYTES + A_BYTES + wid * (BI * 1024);
+        long ta, tb;
+        if constexpr (ACONV) ta = conv_row_base(kt * 64, p.lgS, p.CinA); else ta = (long)kt * 64 * p.lda;
+        if constexpr (BMODE == BMODE_CONV) tb = conv_row_base(kt * 64, p.lgS, p.Cin); else tb = (long)kt * 64 * p.ldb;
 #pragma unroll
-        for (int i = 0; i < AI; ++i) {
-            const int q = wid * AI + i;
-            const int k = kt * 64 + (q / APK) * 4 + kr;
-            const int mcol = (q % APK) * 128 + mo;
-            const u16* ap;
-            if constexpr (ACONV) ap = p.A + conv_row_base(k, p.lgS, p.CinA) + (long)((1 << p.lgS) + 3) * p.CinA + m0 + mcol;
-            else ap = p.A + (long)k * p.lda + m0 + mcol;
-            __builtin_amdgcn_global_load_lds(GLB_PTR(ap), LDS_PTR(abase + i * 1024), 16, 0, 0);
-        }
+        for (int i = 0; i < AI; ++i)
+            __builtin_amdgcn_global_load_lds(GLB_PTR(p.A + ta + a_loc[i]), LDS_PTR(abase + i * 1024), 16, 0, 0);
 #pragma unroll
-        for (int i = 0; i < BI; ++i) {
-            const int q = wid * BI + i;
-            const int k = kt * 64 + (q / BPK) * 4 + kr;
-            const int ncol = (q % BPK) * 128 + mo;
-            const u16* bp;
-            if constexpr (BMODE == BMODE_CONV) bp = p.B + conv_row_base(k, p.lgS, p.Cin) + boff_tap + bcol0 + ncol;
-            else bp = p.B + (long)k * p.ldb + n0 + ncol;
-            __builtin_amdgcn_global_load_lds(GLB_PTR(bp), LDS_PTR(bbase + i * 1024), 16, 0, 0);
-        }
+        for (int i = 0; i < BI; ++i)
+            __builtin_amdgcn_global_load_lds(GLB_PTR(p.B + tb + b_loc[i]), LDS_PTR(bbase + i * 1024), 16, 0, 0);
     };
 
     const int wr = wid / WC, wc = wid % WC;
