@@ -73,6 +73,12 @@ int sgc_topk_per_image(const float* conf, const int* seg_ptr, int n_img, int K, 
 /* "iou_mask" of testing(): the two boxes overlap on the FxF grid   (train_test.py:403-408).  bbox [n_obj][4], out u8 [n_pairs]. */
 int sgc_overlap_filter(const int* bbox, const int* sub_idx, const int* obj_idx, unsigned char* out, int n_pairs, void* stream);
 
+/* Commonsense filter of eval_cs/train_cs (evaluator.py:189-194,261-266: `tuple(...) in commonsense_violated_triplets` /
+ * `not in commonsense_aligned_triplets` per candidate -> confidence = -inf): bit lookups in C*R*C-bit device bitmaps
+ * (bit index (sub*R + rel)*C + obj).  scat/pred/ocat int64 [n], conf f32 [n] updated in place. */
+int sgc_commonsense_filter(const long* scat, const long* pred, const long* ocat, float* conf, int n, const unsigned* aligned,
+                           const unsigned* violated, int C, int R, void* stream);
+
 /* ----------------------------------------------------------------------------------------------- backward */
 
 /* Forward expansion for training: writes z in f16 (conv3 forward operand) and bf16 (conv3 weight-gradient operand) and records

@@ -107,7 +107,35 @@ __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ con
     for (int j = tid; j < K; j += 256) out_idx[(long)img * K + j] = (j < k) ? (int)(keys[j] & 0xffffffffull) : -1;
 }
 
+// Commonsense filter of eval_cs / train_cs (reference evaluator.py:189-194,261-266): a candidate whose
+// (subject class, predicate, object class) triplet is in the "violated" set or is not in the "aligned" set gets
+// confidence -inf.  The Python-set membership tests become two bit lookups in C*R*C-bit device bitmaps.
+__global__ void commonsense_filter_kernel(const long* __restrict__ scat, const long* __restrict__ pred, const long* __restrict__ ocat,
+                                          float* __restrict__ conf, int n, const unsigned* __restrict__ aligned,
+                                          const unsigned* __restrict__ violated, int C, int R) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const long s = scat[i], r = pred[i], o = ocat[i];
+    bool keep = false;
+    if (s >= 0 && s < C && o >= 0 && o < C && r >= 0 && r < R) {
+        const long bit = (s * R + r) * C + o;
+        const bool in_yes = (aligned[bit >> 5] >> (bit & 31)) & 1u;
+        const bool in_no = (violated[bit >> 5] >> (bit & 31)) & 1u;
+        keep = in_yes && !in_no;
+    }
+    if (!keep) conf[i] = -INFINITY;
+}
+
 extern "C" {
+
+int sgc_commonsense_filter(const long* scat, const long* pred, const long* ocat, float* conf, int n, const unsigned* aligned,
+                           const unsigned* violated, int C, int R, void* stream) {
+    if (n <= 0) return SGC_OK;
+    SGC_LAUNCH(commonsense_filter_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, scat, pred, ocat, conf, n,
+               aligned, violated, C, R);
+    SGC_CHECK_LAUNCH();
+    return SGC_OK;
+}
 
 int sgc_overlap_filter(const int* bbox, const int* sub_idx, const int* obj_idx, unsigned char* out, int n_pairs, void* stream) {
     if (n_pairs <= 0) return SGC_OK;

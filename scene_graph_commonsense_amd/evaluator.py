@@ -128,6 +128,15 @@ class Evaluator:
             self.result_per_class_ap = torch.zeros(self.num_classes)
             self.result_per_class_ap_union = torch.zeros(self.num_classes)
             self.num_conn_target_per_class_ap = torch.zeros(self.num_classes)
+        # commonsense filter (run modes train_cs / eval_cs; reference evaluator.py:76-81 loads the two triplet dicts)
+        self._cs = None
+        self._cs_keys = None
+        if self.run_mode in ("train_cs", "eval_cs"):
+            suffix = "_gpt4v" if args["models"].get("llm_model") == "gpt4v" else ""
+            d = args["dataset"]
+            pa = d.get("commonsense_aligned_triplets", "triplets/commonsense_aligned_triplets%s.pt" % suffix)
+            pv = d.get("commonsense_violated_triplets", "triplets/commonsense_violated_triplets%s.pt" % suffix)
+            self._cs_keys = (list(torch.load(pa).keys()), list(torch.load(pv).keys()))
         self.annotation_paths = None
         self._equiv = _equiv_matrix()
         self.last_topk = {}
@@ -206,6 +215,7 @@ class Evaluator:
         conf = conf.clone()
         if iou_mask is not None:
             conf[~iou_mask.bool()[pair_of]] = -math.inf
+        conf = self._commonsense(subject_cat[pair_of], pred, object_cat[pair_of], conf)
         L = self._l
         L["which"].append(which_in_batch[pair_of]); L["conf"].append(conf); L["pred"].append(pred)
         L["conn"].append(connectivity[pair_of]); L["scat"].append(subject_cat[pair_of]); L["ocat"].append(object_cat[pair_of])
@@ -214,12 +224,22 @@ class Evaluator:
         L["scat_t"].append(subject_cat); L["ocat_t"].append(object_cat)
         L["sbox_t"].append(subject_bbox); L["obox_t"].append(object_bbox)
 
+    def _commonsense(self, scat, pred, ocat, conf):
+        if self._cs_keys is None:
+            return conf
+        if self._cs is None or self._cs.device != conf.device:
+            from .commonsense import TripletBitmaps
+            self._cs = TripletBitmaps(self._cs_keys[0], self._cs_keys[1], self.args["models"]["num_classes"], self.num_classes,
+                                      conf.device)
+        return self._cs.filter_(scat, pred, ocat, conf.contiguous().float())
+
     def _append(self, which, conf, pred, conn, scat, ocat, sbox, obox, iou_mask, rep, predcls, rel_t, scat_t, ocat_t,
                 sbox_t, obox_t, csub, cobj):
         if not predcls:
             conf = conf + (csub + cobj).repeat(rep)
         conf = conf.clone()
         conf[~iou_mask.repeat(rep)] = -math.inf
+        conf = self._commonsense(scat.repeat(rep), pred, ocat.repeat(rep), conf)
         L = self._l
         L["which"].append(which.repeat(rep)); L["conf"].append(conf); L["pred"].append(pred)
         L["conn"].append(conn.repeat(rep)); L["scat"].append(scat.repeat(rep)); L["ocat"].append(ocat.repeat(rep))

@@ -12,11 +12,12 @@ CASES = {
     "vg_flat": (dict(hierarchical=False), (4, 3), 2, 6.0, 0.5, False),
     "oiv6_full": (dict(dataset="oiv6", num_classes=601, num_super_classes=0, num_geometric=4, num_possessive=2,
                        num_semantic=24), (4, 3), 3, 6.0, 0.5, False),
+    "vg_full_hit": (dict(), (6, 5, 4), 6, 6.0, 0.0, False),
     "vg_small": (dict(hidden_dim=16, feature_size=8), (7, 6, 6, 2), 4, 6.0, 0.4, True),
     "vg_bert_small": (dict(hidden_dim=16, feature_size=8, num_geometric=12, num_possessive=25, num_semantic=13),
                       (5, 5), 5, 6.0, 0.4, False),
 }
-FULL = ("vg_full", "vg_flat", "oiv6_full")
+FULL = ("vg_full", "vg_flat", "oiv6_full", "vg_full_hit")
 SMALL = ("vg_small", "vg_bert_small")
 
 
@@ -26,6 +27,12 @@ def load_case(name):
     sd = make_state_dict(cfg, seed=seed, head_gain=gain)
     batch = make_scene_batch(cfg, nobj, seed=seed, connect_frac=cfrac, edge_boxes=edge)
     gold = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+    if name.endswith("_hit"):          # targets stored in the golden file (the reference's own predictions)
+        import torch
+        for b, n in enumerate(nobj):
+            for g in range(1, n):
+                batch.relationships[b][g - 1] = torch.from_numpy(gold["tgt_rel_%d_%d" % (b, g)])
+                batch.subj_or_obj[b][g - 1] = torch.from_numpy(gold["tgt_dir_%d_%d" % (b, g)])
     return cfg, sd, batch, gold
 
 

@@ -36,7 +36,7 @@ def _rel_err(a, ref):
     return np.abs(a - ref).max() / max(np.abs(ref).max(), 1e-12)
 
 
-@pytest.mark.parametrize("name", ["vg_full", "oiv6_full", "vg_flat"])
+@pytest.mark.parametrize("name", ["vg_full", "oiv6_full", "vg_flat", "vg_full_hit"])
 def test_forward_matches_reference_golden(name):
     cfg, sd, batch, gold = load_case(name)
     sc, out = _forward(cfg, sd, batch)

@@ -179,3 +179,18 @@ def test_data_parallel_gradient_allreduce_gloo_world2():
         assert g1 == [1.5 * i for i in range(5)]
         assert g2 == [5.0, 5.0, 5.0]
         assert cnt == [3, 14]
+
+
+def test_commonsense_bitmap_packing_host():
+    from scene_graph_commonsense_amd.commonsense import TripletBitmaps
+    keys = [(0, 0, 0), (1, 2, 3), (149, 49, 149), (5, 7, 31), (5, 7, 32)]
+    bm = TripletBitmaps(keys, [(1, 2, 3)], 150, 50, "cpu")
+    words = bm.aligned.numpy().view(np.uint32)
+    def bit(w, s, r, o):
+        b = (s * 50 + r) * 150 + o
+        return (int(w[b >> 5]) >> (b & 31)) & 1
+    for k in keys:
+        assert bit(words, *k) == 1
+    assert bit(words, 2, 2, 3) == 0 and bit(words, 5, 7, 33) == 0
+    assert int(sum(bin(int(x)).count("1") for x in words)) == len(keys)
+    assert bit(bm.violated.numpy().view(np.uint32), 1, 2, 3) == 1
