@@ -88,12 +88,19 @@ int sgc_pair_expand_train(const void* U, const void* V, const int* sub_idx, cons
 
 /* Loss + head backward per pair   (train_utils.py:64-94,116-157, utils.py:28-35 with the step weights of train_test.py:219-258 folded
  * into per-pair coefficients by the host): loss_i = -a*super[st] - b*rel[t] + c*BCE(conn, y).
- * W [64][512] f32 head rows; dl [n_pairs][64] dL/dlogits; loss [n_pairs]; dpre [n_pairs][512] bf16 = dL/d(fc2 pre-activation). */
+ * W [64][512] f32 head rows; dl [n_pairs][64] dL/dlogits; loss [n_pairs]; dpre [n_pairs][512] bf16 = dL/d(fc2 pre-activation);
+ * dp_extra (may be NULL) [n_pairs][512] f32 is added to dL/d(hidden) before the ReLU/dropout mask (contrastive term). */
 int sgc_head_loss_bwd(const float* rel, const float* sup, const float* conn, const float* p, const int* tgt, const float* coef_a,
                       const float* coef_b, const float* coef_c, const float* conn_y, const float* W, int n_pairs, int ng, int np, int ns,
-                      int hier, float T1, float T2, float T3, float drop_scale, float* dl, float* loss, void* dpre, void* stream);
+                      int hier, float T1, float T2, float T3, float drop_scale, float* dl, float* loss, void* dpre, const float* dp_extra,
+                      void* stream);
 /* part [ceil(n_pairs/chunk)][64][513] f32 partial head weight (cols 0..511) and bias (col 512) gradients */
 int sgc_head_wgrad(const float* dl, const float* p, float* part, int n_pairs, int chunk, void* stream);
+
+/* Supervised-contrastive loss of the training step (sup_contrast/losses.py:85-181 SupConLossHierar on the hidden vectors of
+ * the connected pairs and of their augmented view; train_test.py:260-273): loss_rows [2M], G [2M][2M] scratch, dF [2M][512]. */
+int sgc_supcon_hierar(const float* F, const int* labels, int M, float temperature, float grad_scale, float* G, float* loss_rows,
+                      float* dF, void* stream);
 
 int sgc_slab_sum(const float* in, float* out, long n, int slabs, int accumulate, void* stream);          /* out[n] (+)= sum_s in[s][n] */
 int sgc_colsum(int elem, const void* X, float* part, long rows, int cols, int row_blocks, void* stream);  /* bias gradients */

@@ -22,6 +22,8 @@ Reference map (all paths relative to the reference repo):
   relationship_loss        train_utils.py:116-157, utils.py:28-35
   direction_step_loss      train_utils.py:64-94
   run_pair_loop            train_test.py:174-258 (train) / :373-437 (test), train_utils.py:160-196
+  supcon_hierar_loss       sup_contrast/losses.py:85-181 (SupConLossHierar, contrast_mode 'all')
+  contrastive term         train_utils.py:28-29,96-99 (hidden/hidden_aug of connected pairs), train_test.py:260-273
   OracleEvaluator          evaluator.py:118-367, :568-583
   OracleEvaluatorTop3      evaluator.py:639-790
 """
@@ -161,11 +163,39 @@ def direction_step_loss(relation, super_relation, conn, rel_row, dir_row, first_
     return loss_rel, loss_conn, connected, not_connected
 
 
+def supcon_hierar_loss(features: Tensor, labels: Tensor, temperature: float = 0.07, base_temperature: float = 0.07) -> Tensor:
+    """features [M, 2, D] (original and augmented view), labels [M].  Positives: same label (other view included);
+    denominator: every other sample under the same parent super-category (hard-coded 15 / 26 boundaries)."""
+    M = features.shape[0]
+    lab = labels.contiguous().view(-1, 1)
+    parent = lab.clone()
+    parent[lab < 15] = 0
+    parent[(lab >= 15) & (lab < 26)] = 1
+    parent[lab >= 26] = 2
+    mask_same_parent = torch.eq(parent, parent.T).float()
+    mask = torch.eq(lab, lab.T).float()
+    contrast = torch.cat(torch.unbind(features, dim=1), dim=0)            # [2M, D]: view 0 rows, then view 1 rows
+    a = torch.div(torch.matmul(contrast, contrast.T), temperature)
+    logits = a - torch.max(a, dim=1, keepdim=True)[0].detach()
+    mask = mask.repeat(2, 2)
+    mask_same_parent = mask_same_parent.repeat(2, 2)
+    logits_mask = torch.ones_like(mask)
+    logits_mask.fill_diagonal_(0)
+    mask = mask * logits_mask
+    logits_mask = logits_mask * mask_same_parent
+    exp_logits = torch.exp(logits) * logits_mask
+    log_prob = logits - torch.log(exp_logits.sum(1, keepdim=True) + 1e-7)
+    mean_log_prob_pos = (mask * log_prob).sum(1) / (mask.sum(1) + 1e-7)
+    loss = -(temperature / base_temperature) * mean_log_prob_pos
+    return loss.view(2, M).mean()
+
+
 # --------------------------------------------------------------------------- pair loop
 def run_pair_loop(sd: Dict[str, Tensor], batch, cfg, mode: str = "eval", evaluator=None, evaluator_top3=None,
                   weights: Optional[Tensor] = None, lambda_connectivity: float = 0.1,
                   lambda_not_connected: float = 1.0, overlap_filtering: Optional[bool] = None,
-                  max_steps: Optional[int] = None, step_filter=None):
+                  max_steps: Optional[int] = None, step_filter=None, image_feature_aug: Optional[Tensor] = None,
+                  lambda_contrast: float = 1.0):
     """The reference's nested (graph_iter, edge_iter) x 2-direction loop.
 
     mode 'eval' mirrors ``testing()`` (overlap filter on, steps with no overlapping image skipped),
@@ -191,10 +221,14 @@ def run_pair_loop(sd: Dict[str, Tensor], batch, cfg, mode: str = "eval", evaluat
     losses = 0.0
     run_rel, run_conn = 0.0, 0.0
     nsteps = 0
+    contrast = image_feature_aug is not None and mode == "train"
+    hid_acc = [[] for _ in range(B)]       # per image: [2,512] stacks of (hidden, hidden_aug) of connected pairs
+    lab_acc = [[] for _ in range(B)]
     for g in range(int(n_obj.max())):
         keep = torch.nonzero(n_obj > g).view(-1)
         gm = torch.stack([masks[i][g].unsqueeze(0) for i in keep])
         h_graph = torch.cat((batch.image_feature[keep] * gm, batch.image_depth[keep] * gm), dim=1)
+        h_graph_aug = torch.cat((image_feature_aug[keep] * gm, batch.image_depth[keep] * gm), dim=1) if contrast else None
         cat_g = torch.tensor([int(batch.categories[i][g]) for i in keep])
         sp_g = [batch.super_categories[i][g] for i in keep] if batch.super_categories is not None else None
         bb_g = torch.stack([batch.bbox[i][g] for i in keep])
@@ -205,6 +239,7 @@ def run_pair_loop(sd: Dict[str, Tensor], batch, cfg, mode: str = "eval", evaluat
                 continue
             em = torch.stack([masks[i][e].unsqueeze(0) for i in keep])
             h_edge = torch.cat((batch.image_feature[keep] * em, batch.image_depth[keep] * em), dim=1)
+            h_edge_aug = torch.cat((image_feature_aug[keep] * em, batch.image_depth[keep] * em), dim=1) if contrast else None
             cat_e = torch.tensor([int(batch.categories[i][e]) for i in keep])
             sp_e = [batch.super_categories[i][e] for i in keep] if batch.super_categories is not None else None
             bb_e = torch.stack([batch.bbox[i][e] for i in keep])
@@ -234,11 +269,20 @@ def run_pair_loop(sd: Dict[str, Tensor], batch, cfg, mode: str = "eval", evaluat
                 directed = rel_row.clone()
                 directed[not_connected] = -1
                 if mode == "train":
-                    lr_, lc_, _, _ = direction_step_loss(relation, sup, conn, rel_row, dir_row, first, weights, ng,
-                                                         npos, hier, lambda_not_connected)
+                    lr_, lc_, connected, _ = direction_step_loss(relation, sup, conn, rel_row, dir_row, first, weights, ng,
+                                                                 npos, hier, lambda_not_connected)
                     run_rel = run_rel + lr_
                     run_conn = run_conn + lc_
                     losses = losses + run_rel + lambda_connectivity * run_conn
+                    if contrast and len(connected) > 0:
+                        hsa, hoa = (h_graph_aug, h_edge_aug) if first else (h_edge_aug, h_graph_aug)
+                        h_aug = conv_trunk(sd, hsa, hoa)
+                        hca = concat_labels(h_aug, cs, co, ss, so, cfg.num_classes, cfg.num_super_classes)
+                        hidden_aug = F.relu(F.linear(hca, sd["fc2.weight"], sd["fc2.bias"]))
+                        for idx in connected:
+                            bi = int(keep[idx])
+                            hid_acc[bi].append(torch.stack((hidden[idx], hidden_aug[idx])))
+                            lab_acc[bi].append(rel_row[idx])
                 logsig = torch.log(torch.sigmoid(conn[:, 0]))
                 if evaluator is not None:
                     evaluator.accumulate(keep, relation.detach(), directed, None if sup is None else sup.detach(),
@@ -250,7 +294,14 @@ def run_pair_loop(sd: Dict[str, Tensor], batch, cfg, mode: str = "eval", evaluat
                                     super_relation=None if sup is None else sup.detach(),
                                     connectivity=conn.detach()[:, 0], hidden=hidden.detach(),
                                     iou_mask=iou_mask.clone(), target=directed))
-    return dict(records=records, losses=losses if mode == "train" else None)
+    loss_contrast = None
+    if contrast and any(len(x) > 0 for x in hid_acc):
+        feats = torch.cat([torch.stack(x) for x in hid_acc if len(x) > 0], dim=0)
+        labs = torch.cat([torch.stack(x) for x in lab_acc if len(x) > 0], dim=0)
+        temp = supcon_hierar_loss(feats, labs)
+        loss_contrast = 0.0 if torch.isnan(temp) else lambda_contrast * temp
+        losses = losses + lambda_contrast * loss_contrast          # lambda applied twice, as in train_test.py:270-273
+    return dict(records=records, losses=losses if mode == "train" else None, loss_contrast=loss_contrast)
 
 
 # --------------------------------------------------------------------------- evaluator

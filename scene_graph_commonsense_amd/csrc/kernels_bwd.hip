@@ -18,6 +18,7 @@ struct HeadBwdParams {
     const float* W;            // [64][512] rows as in the forward head
     int n_pairs, ng, np, ns, hier; float invT1, invT2, invT3; float drop_scale;
     float* dl; float* loss; u16* dpre;
+    const float* dp_extra;     // optional [n_pairs][512]: extra dL/d(hidden) (supervised-contrastive term)
 };
 
 __device__ __forceinline__ float wave_max_f(float x) {
@@ -94,7 +95,8 @@ __global__ __launch_bounds__(256) void head_loss_bwd_kernel(const HeadBwdParams 
         for (int j = 0; j < 8; ++j) {
             const int k = lane + 64 * j;
             const float pv = hp.p[(long)pr * 512 + k];
-            hp.dpre[(long)pr * 512 + k] = f32_to_bf16_bits(pv > 0.f ? acc[j] * hp.drop_scale : 0.f);
+            const float g = acc[j] + (hp.dp_extra ? hp.dp_extra[(long)pr * 512 + k] : 0.f);
+            hp.dpre[(long)pr * 512 + k] = f32_to_bf16_bits(pv > 0.f ? g * hp.drop_scale : 0.f);
         }
     }
 }
@@ -127,6 +129,89 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict
 #pragma unroll
     for (int r = 0; r < 64; ++r) { out[r * 513 + k0] = a0[r]; out[r * 513 + k1] = a1[r]; }
     if (threadIdx.x < 64) out[threadIdx.x * 513 + 512] = ab;
+}
+
+// ------------------------------------------------------------------------------------------------ supervised contrastive
+// SupConLossHierar (reference sup_contrast/losses.py:85-181, contrast_mode 'all') on F [2M][512] f32: rows 0..M-1 are the
+// hidden vectors of the connected pairs, rows M..2M-1 those of the augmented view; label of row i is labels[i mod M].
+// Positives: same label, i != j.  Denominator: every j != i whose parent super-category (label < 15 / < 26 / else, the
+// reference's hard-coded boundaries) equals that of i.  One workgroup per anchor row: dots against all rows, row max,
+// masked exp-sum, loss_i = -mean_pos(log_prob), and the row of G = dL/d(logits/temperature... before the max shift).
+__global__ __launch_bounds__(256) void supcon_rows_kernel(const float* __restrict__ Fm, const int* __restrict__ labels, int M,
+                                                          float inv_temp, float* __restrict__ G, float* __restrict__ loss_rows) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* fi = reinterpret_cast<float*>(smem);          // [512]
+    float* row = fi + 512;                               // [2M]
+    __shared__ float red[256];
+    const int n = 2 * M, i = blockIdx.x, tid = threadIdx.x;
+    for (int k = tid; k < 512; k += 256) fi[k] = Fm[(long)i * 512 + k];
+    __syncthreads();
+    const int li = labels[i % M];
+    const int pi = (li >= 15) + (li >= 26);
+    float lmax = -INFINITY;
+    for (int j = tid; j < n; j += 256) {
+        const float* fj = Fm + (long)j * 512;
+        float d = 0.f;
+        for (int k = 0; k < 512; k += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(fj + k);
+            d = fmaf(fi[k], v.x, d); d = fmaf(fi[k + 1], v.y, d); d = fmaf(fi[k + 2], v.z, d); d = fmaf(fi[k + 3], v.w, d);
+        }
+        d *= inv_temp;
+        row[j] = d;
+        lmax = fmaxf(lmax, d);
+    }
+    red[tid] = lmax;
+    __syncthreads();
+    for (int sft = 128; sft > 0; sft >>= 1) { if (tid < sft) red[tid] = fmaxf(red[tid], red[tid + sft]); __syncthreads(); }
+    const float m = red[0];
+    __syncthreads();
+    float s_exp = 0.f, s_mask = 0.f, s_pos = 0.f;
+    for (int j = tid; j < n; j += 256) {
+        if (j == i) continue;
+        const int lj = labels[j % M];
+        const int pj = (lj >= 15) + (lj >= 26);
+        const float l = row[j] - m;
+        if (pj == pi) s_exp += expf(l);
+        if (lj == li) { s_mask += 1.f; s_pos += l; }
+    }
+    __shared__ float r2[3][256];
+    r2[0][tid] = s_exp; r2[1][tid] = s_mask; r2[2][tid] = s_pos;
+    __syncthreads();
+    for (int sft = 128; sft > 0; sft >>= 1) {
+        if (tid < sft) { r2[0][tid] += r2[0][tid + sft]; r2[1][tid] += r2[1][tid + sft]; r2[2][tid] += r2[2][tid + sft]; }
+        __syncthreads();
+    }
+    const float S = r2[0][0] + 1e-7f, nm = r2[1][0], npos = r2[1][0] + 1e-7f, sp = r2[2][0];
+    if (tid == 0) loss_rows[i] = -(sp - nm * logf(S)) / npos;
+    const float wsum = nm / npos, invn = 1.f / (float)n;
+    for (int j = tid; j < n; j += 256) {
+        float g = 0.f;
+        if (j != i) {
+            const int lj = labels[j % M];
+            const int pj = (lj >= 15) + (lj >= 26);
+            const float e = (pj == pi) ? expf(row[j] - m) / S : 0.f;
+            g = -invn * ((lj == li ? 1.f / npos : 0.f) - wsum * e);
+        }
+        G[(long)i * n + j] = g;
+    }
+}
+
+// dF[i][:] = scale * sum_j (G[i][j] + G[j][i]) * F[j][:]   (logits = F F^T / temperature is symmetric in its two factors)
+__global__ __launch_bounds__(256) void supcon_dfeat_kernel(const float* __restrict__ Fm, const float* __restrict__ G, int n, float scale,
+                                                           float* __restrict__ dF) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* c = reinterpret_cast<float*>(smem);           // [n]
+    const int i = blockIdx.x, tid = threadIdx.x;
+    for (int j = tid; j < n; j += 256) c[j] = G[(long)i * n + j] + G[(long)j * n + i];
+    __syncthreads();
+    float a0 = 0.f, a1 = 0.f;
+    for (int j = 0; j < n; ++j) {
+        const float cj = c[j];
+        a0 = fmaf(cj, Fm[(long)j * 512 + tid], a0);
+        a1 = fmaf(cj, Fm[(long)j * 512 + 256 + tid], a1);
+    }
+    dF[(long)i * 512 + tid] = a0 * scale;
+    dF[(long)i * 512 + 256 + tid] = a1 * scale;
 }
 
 // ------------------------------------------------------------------------------------------------ small reductions
@@ -430,10 +515,10 @@ extern "C" {
 int sgc_head_loss_bwd(const float* rel, const float* sup, const float* conn, const float* p, const int* tgt,
                       const float* coef_a, const float* coef_b, const float* coef_c, const float* conn_y,
                       const float* W, int n_pairs, int ng, int np, int ns, int hier, float T1, float T2, float T3,
-                      float drop_scale, float* dl, float* loss, void* dpre, void* stream) {
+                      float drop_scale, float* dl, float* loss, void* dpre, const float* dp_extra, void* stream) {
     if (n_pairs <= 0) return SGC_OK;
     HeadBwdParams hp{rel, sup, conn, p, tgt, coef_a, coef_b, coef_c, conn_y, W, n_pairs, ng, np, ns, hier,
-                     1.f / T1, 1.f / T2, 1.f / T3, drop_scale, dl, loss, (u16*)dpre};
+                     1.f / T1, 1.f / T2, 1.f / T3, drop_scale, dl, loss, (u16*)dpre, dp_extra};
     const int lds = (64 * 512 + 4 * 64) * 4;
     static bool attr_set = false;
     if (!attr_set) {
@@ -451,6 +536,28 @@ int sgc_head_wgrad(const float* dl, const float* p, float* part, int n_pairs, in
     if (n_pairs <= 0) return SGC_OK;
     const int nb = (n_pairs + chunk - 1) / chunk;
     SGC_LAUNCH(head_wgrad_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, dl, p, part, n_pairs, chunk);
+    SGC_CHECK_LAUNCH();
+    return SGC_OK;
+}
+
+// SupConLossHierar forward + gradient.  F [2M][512] f32, labels [M]; G [2M][2M] and loss_rows [2M] are outputs/scratch;
+// dF [2M][512] = grad_scale * dL/dF with L = mean(loss_rows).  2M <= 16384.
+int sgc_supcon_hierar(const float* F, const int* labels, int M, float temperature, float grad_scale, float* G, float* loss_rows,
+                      float* dF, void* stream) {
+    if (M <= 0) return SGC_OK;
+    const int n = 2 * M;
+    if (n > 16384) return SGC_ERR_ARG;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(supcon_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (512 + 16384) * 4);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(supcon_dfeat_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  16384 * 4);
+        attr_set = true;
+    }
+    SGC_LAUNCH(supcon_rows_kernel, dim3(n), dim3(256), (512 + n) * 4, (hipStream_t)stream, F, labels, M, 1.f / temperature, G, loss_rows);
+    SGC_CHECK_LAUNCH();
+    SGC_LAUNCH(supcon_dfeat_kernel, dim3(n), dim3(256), n * 4, (hipStream_t)stream, F, G, n, grad_scale / temperature, dF);
     SGC_CHECK_LAUNCH();
     return SGC_OK;
 }

@@ -387,7 +387,7 @@ def train_forward(self, image_feature, image_depth, obj_img, bbox, cats, super_m
     return ctx
 
 
-def train_backward(self, ctx: "TrainContext", coefs, sub_csr, obj_csr, img_ptr, splits=8, grad_hook=None):
+def train_backward(self, ctx: "TrainContext", coefs, sub_csr, obj_csr, img_ptr, splits=8, grad_hook=None, dp_extra=None):
     """Backward of the whole path.  Returns (loss scalar tensor, {reference parameter name: f32 gradient})."""
     lib, ws, cfg, dev, w = self.lib, self.ws, self.cfg, self.device, self.w
     P, Ppad, n_obj, n_img = ctx.P, ctx.Ppad, ctx.n_obj, ctx.n_img
@@ -411,7 +411,8 @@ def train_backward(self, ctx: "TrainContext", coefs, sub_csr, obj_csr, img_ptr, 
                                      _lib.ptr(ctx.p), _lib.ptr(tgt), _lib.ptr(ca), _lib.ptr(cb), _lib.ptr(cc), _lib.ptr(cy),
                                      _lib.ptr(w["head_w"]), P, cfg.num_geometric if hier else R,
                                      cfg.num_possessive if hier else 0, cfg.num_semantic if hier else 0, int(hier),
-                                     f(T[0]), f(T[1]), f(T[2]), f(scale), _lib.ptr(dl), _lib.ptr(loss_i), _lib.ptr(dpre), st()),
+                                     f(T[0]), f(T[1]), f(T[2]), f(scale), _lib.ptr(dl), _lib.ptr(loss_i), _lib.ptr(dpre),
+                                     _lib.ptr(dp_extra), st()),
                "sgc_head_loss_bwd")
     loss = _slab_sum(self, loss_i, 1, P)[0] if P > 0 else torch.zeros((), device=dev)
     chunk = max(16, (P + 255) // 256)
@@ -524,3 +525,19 @@ def train_backward(self, ctx: "TrainContext", coefs, sub_csr, obj_csr, img_ptr, 
 RelHeadEngine.prep_bwd_weights = _prep_bwd_weights
 RelHeadEngine.train_forward = train_forward
 RelHeadEngine.train_backward = train_backward
+
+
+def supcon_loss(self, feats: torch.Tensor, labels: torch.Tensor, grad_scale: float = 1.0, temperature: float = 0.07):
+    """SupConLossHierar on feats [2M,512] f32 (view 0 rows then view 1 rows), labels [M] int32.
+    Returns (loss scalar tensor, dF [2M,512] = grad_scale * dloss/dfeats)."""
+    M = int(labels.shape[0])
+    n = 2 * M
+    G = self.ws.get("supcon_G", n * n, torch.float32)
+    rows = torch.empty(n, dtype=torch.float32, device=self.device)
+    dF = torch.empty(n, 512, dtype=torch.float32, device=self.device)
+    _lib.check(self.lib.sgc_supcon_hierar(_lib.ptr(feats), _lib.ptr(labels), M, ctypes.c_float(temperature), ctypes.c_float(grad_scale),
+                                          _lib.ptr(G), _lib.ptr(rows), _lib.ptr(dF), self._st()), "sgc_supcon_hierar")
+    return _slab_sum(self, rows, 1, n)[0] / n, dF
+
+
+RelHeadEngine.supcon_loss = supcon_loss

@@ -110,10 +110,13 @@ class _RelationBase(nn.Module):
 
     def training_step(self, scene: DeviceScene, relationships=None, subj_or_obj=None, directed: Optional[np.ndarray] = None,
                       lambda_connectivity: float = 0.1, lambda_not_connected: float = 1.0, class_weight=None,
-                      grad_hook=None):
+                      grad_hook=None, image_feature_aug: Optional[torch.Tensor] = None, lambda_contrast: float = 1.0):
         """Forward + loss + backward over all ordered pairs; gradients land in ``param.grad`` (accumulating like
         autograd).  Loss follows ``train_test.py:189-258`` / ``train_utils.py:64-157`` (hierarchical NLL, BCE on
-        connectivity, running-sum step weights); the contrastive and commonsense terms are out of scope."""
+        connectivity, running-sum step weights).  With ``image_feature_aug`` (DETR features of the colour-jittered view,
+        ``train_test.py:154``) the supervised-contrastive term of ``train_test.py:260-273`` is added: the augmented trunk
+        is run ONLY for the connected pairs (the only ones the loss reads; the reference runs it for every pair).
+        The commonsense term (train_cs) is out of scope."""
         cfg = self.head_config()
         eng = self.refresh_weights(backward=True)
         pidx = scene.pidx
@@ -137,7 +140,26 @@ class _RelationBase(nn.Module):
                                     scene.super_mh, scene.sub_idx, scene.obj_idx,
                                     seeds=self._next_seeds() if self.training else (0, 0), dropout=self.training,
                                     dense=_dense(scene))
-            loss, grads = eng.train_backward(ctx, coefs_d, sub_csr, obj_csr, img_ptr, grad_hook=grad_hook)
+            dp_main = None
+            extra = None
+            loss_c = None
+            conn_idx = np.nonzero(directed >= 0)[0]
+            if image_feature_aug is not None and len(conn_idx) > 0:
+                extra = self._contrast_forward(eng, scene, image_feature_aug, conn_idx, directed, ctx, lambda_contrast)
+                loss_c, dp_main = extra["loss"], extra["dp_main"]
+            loss, grads = eng.train_backward(ctx, coefs_d, sub_csr, obj_csr, img_ptr,
+                                             grad_hook=grad_hook if extra is None else None, dp_extra=dp_main)
+            if extra is not None:
+                eng_a = extra["engine"]
+                _, grads_a = eng_a.train_backward(extra["ctx"], extra["coefs"], extra["sub_csr"], extra["obj_csr"], img_ptr,
+                                                  dp_extra=extra["dp_aug"])
+                for k in grads:
+                    grads[k] = grads[k] + grads_a[k].view_as(grads[k])
+                if grad_hook is not None:
+                    grad_hook("fc1.weight", grads["fc1.weight"])
+                if not bool(torch.isnan(loss_c)):
+                    loss = loss + lambda_contrast * lambda_contrast * loss_c      # lambda applied twice (train_test.py:270-273)
+                self.last_contrast_loss = loss_c
             for name, p in self.named_parameters():
                 g = grads[name].view_as(p)
                 if p.grad is None:
@@ -146,6 +168,37 @@ class _RelationBase(nn.Module):
                     p.grad.add_(g)
         self.last_outputs = ctx.out
         return loss
+
+    def _contrast_forward(self, eng, scene, image_feature_aug, conn_idx, directed, ctx, lambda_contrast):
+        """Augmented-view trunk for the connected pairs + SupConLossHierar; returns what the two backward passes need."""
+        from .engine import RelHeadEngine
+        dev = eng.device
+        if getattr(self, "_engine_aug", None) is None or self._engine_aug.device != dev:
+            self._engine_aug = RelHeadEngine(self.head_config(), dev)
+        eng_a = self._engine_aug
+        eng_a.w, eng_a.T, eng_a.head_rows = eng.w, eng.T, eng.head_rows          # shared weights, own workspace
+        M = len(conn_idx)
+        cidx = torch.from_numpy(conn_idx).to(dev)
+        sub_a = scene.sub_idx[cidx].contiguous()
+        obj_a = scene.obj_idx[cidx].contiguous()
+        ctx_a = eng_a.train_forward(image_feature_aug.to(dev, torch.float32).contiguous(), scene.image_depth, scene.obj_img,
+                                    scene.bbox, scene.cats, scene.super_mh, sub_a, obj_a,
+                                    seeds=self._next_seeds() if self.training else (0, 0), dropout=self.training)
+        P = scene.pidx.n_pairs
+        feats = torch.cat((ctx.p[:P * 512].view(P, 512)[cidx], ctx_a.p[:M * 512].view(M, 512)), dim=0).contiguous()
+        labels = torch.from_numpy(directed[conn_idx].astype(np.int32)).to(dev)
+        lam2 = float(lambda_contrast) * float(lambda_contrast)
+        loss_c, dF = eng.supcon_loss(feats, labels, grad_scale=lam2)
+        dp_main = torch.zeros(P, 512, dtype=torch.float32, device=dev)
+        dp_main[cidx] = dF[:M]
+        n_obj = int(scene.obj_img.shape[0])
+        pidx = scene.pidx
+        zeros = torch.zeros(M, dtype=torch.float32, device=dev)
+        coefs = (torch.full((M,), -1, dtype=torch.int32, device=dev), zeros, zeros, zeros, zeros)
+        sub_csr = tuple(torch.from_numpy(a).to(dev) for a in csr_by(pidx.sub[conn_idx], n_obj))
+        obj_csr = tuple(torch.from_numpy(a).to(dev) for a in csr_by(pidx.obj[conn_idx], n_obj))
+        return dict(engine=eng_a, ctx=ctx_a, loss=loss_c, dp_main=dp_main, dp_aug=dF[M:].contiguous(), coefs=coefs,
+                    sub_csr=sub_csr, obj_csr=obj_csr)
 
     # ------------------------------------------------------------------ reference per-step call
     def _compat_forward(self, h_sub, h_obj, c1, c2, s1, s2):

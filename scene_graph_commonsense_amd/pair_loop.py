@@ -3,7 +3,7 @@
 ``evaluate_minibatch`` is what ``train_test.py:373-437`` + ``train_utils.py:160-196`` do for one minibatch: score
 every ordered pair, apply the overlap filter (a step in which no image's two boxes overlap is skipped entirely -
 no candidates and no targets), and feed the Recall@K evaluators in the reference's candidate order.
-``train_minibatch`` is ``train_test.py:174-277`` without the contrastive/commonsense terms.
+``train_minibatch`` is ``train_test.py:174-277`` (pass ``image_feature_aug`` for the contrastive term; no commonsense term).
 """
 from __future__ import annotations
 

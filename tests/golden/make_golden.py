@@ -304,6 +304,97 @@ def run_case(name, ref_model, ref_train, ref_eval):
     print(name, "steps", len(steps), "calls", len(spy.calls), "loss", float(losses), "recall", out["ev_recall"])
 
 
+def aug_features(batch, seed):
+    """Deterministic stand-in for the colour-jittered view's DETR features (train_test.py:154)."""
+    from scene_graph_commonsense_amd.synthetic import hash_normal
+    f = batch.image_feature
+    noise = torch.from_numpy(hash_normal(seed * 31 + 99, f.numel()).reshape(f.shape))
+    return 0.9 * f + 0.3 * noise
+
+
+def run_contrast_case(name, ref_model, ref_train, ref_eval):
+    """Training loss INCLUDING the supervised-contrastive term (train_test.py:189-273 with a distinct augmented view)
+    -> <name>_contrast.npz: total loss, contrastive loss, gradient fingerprints."""
+    sys.path.insert(0, os.path.join(REF))
+    from sup_contrast.losses import SupConLossHierar
+    kw, nobj, seed, gain, cfrac, edge = CASES[name]
+    cfg = HeadConfig(**kw)
+    targs = ref_args(cfg)
+    targs["training"]["run_mode"] = "train"
+    targs["training"]["eval_freq"] = 10 ** 9
+    sd = make_state_dict(cfg, seed=seed, head_gain=gain)
+    batch = make_scene_batch(cfg, nobj, seed=seed, connect_frac=cfrac, edge_boxes=edge)
+    if name.endswith("_hit"):
+        gold = dict(np.load(os.path.join(HERE, name + ".npz")))
+        for b, n in enumerate(nobj):
+            for g in range(1, n):
+                batch.relationships[b][g - 1] = torch.from_numpy(gold["tgt_rel_%d_%d" % (b, g)])
+                batch.subj_or_obj[b][g - 1] = torch.from_numpy(gold["tgt_dir_%d_%d" % (b, g)])
+    feat_aug = aug_features(batch, seed)
+    model = build_ref_model(ref_model, cfg, targs, sd)
+    masks = ref_masks(batch.bbox, cfg.feature_size)
+    relations_target, direction_target = targets(batch, masks)
+    counts = predicate_counts(cfg)
+    class_weight = 1 - counts / torch.sum(counts)
+    ng, npos = cfg.num_geometric, cfg.num_possessive
+    crit = [torch.nn.NLLLoss(weight=class_weight[:ng]), torch.nn.NLLLoss(weight=class_weight[ng:ng + npos]),
+            torch.nn.NLLLoss(weight=class_weight[ng + npos:]), torch.nn.NLLLoss()]
+    crit_conn = torch.nn.BCEWithLogitsLoss()
+    crit_contrast = SupConLossHierar()
+    model.zero_grad()
+    B = len(nobj)
+    hid_acc = [[] for _ in range(B)]
+    hid_lab = [[] for _ in range(B)]
+    losses, loss_connectivity, loss_relationship, loss_contrast = 0.0, 0.0, 0.0, 0.0
+    num_graph_iter = torch.as_tensor([len(m) for m in masks])
+    for g in range(max(num_graph_iter)):
+        keep = torch.nonzero(num_graph_iter > g).view(-1)
+        gm = torch.stack([torch.unsqueeze(masks[i][g], dim=0) for i in keep])
+        h_graph = torch.cat((batch.image_feature[keep] * gm, batch.image_depth[keep] * gm), dim=1)
+        h_graph_aug = torch.cat((feat_aug[keep] * gm, batch.image_depth[keep] * gm), dim=1)
+        cat_graph = torch.tensor([torch.unsqueeze(batch.categories[i][g], dim=0) for i in keep])
+        sp_graph = [batch.super_categories[i][g] for i in keep]
+        bb_graph = torch.stack([batch.bbox[i][g] for i in keep])
+        for e in range(g):
+            em = torch.stack([torch.unsqueeze(masks[i][e], dim=0) for i in keep])
+            h_edge = torch.cat((batch.image_feature[keep] * em, batch.image_depth[keep] * em), dim=1)
+            h_edge_aug = torch.cat((feat_aug[keep] * em, batch.image_depth[keep] * em), dim=1)
+            cat_edge = torch.tensor([torch.unsqueeze(batch.categories[i][e], dim=0) for i in keep])
+            sp_edge = [batch.super_categories[i][e] for i in keep]
+            bb_edge = torch.stack([batch.bbox[i][e] for i in keep])
+            iou_mask = torch.ones(len(keep), dtype=torch.bool)
+            for first in (True, False):
+                hs, ho = (h_graph, h_edge) if first else (h_edge, h_graph)
+                hsa, hoa = (h_graph_aug, h_edge_aug) if first else (h_edge_aug, h_graph_aug)
+                cs, co = (cat_graph, cat_edge) if first else (cat_edge, cat_graph)
+                ss, so = (sp_graph, sp_edge) if first else (sp_edge, sp_graph)
+                bs, bo = (bb_graph, bb_edge) if first else (bb_edge, bb_graph)
+                r = ref_train.train_one_direction(model, targs, hs, ho, cs, co, ss, so, bs, bo, hsa, hoa, iou_mask, "cpu", g, e,
+                                                  keep, None, None, crit, crit_conn, relations_target, direction_target, 1,
+                                                  hid_acc, hid_lab, None, None, 10 ** 6, first_direction=first)
+                hid_acc, hid_lab = r[8], r[9]
+                loss_relationship += r[0]
+                loss_connectivity += r[1]
+                losses += loss_relationship + targs["training"]["lambda_connectivity"] * loss_connectivity
+    if not all(len(sub) == 0 for sub in hid_acc):
+        ha = [torch.stack(sub) for sub in hid_acc if len(sub) > 0]
+        hl = [torch.stack(sub) for sub in hid_lab if len(sub) > 0]
+        temp = crit_contrast("cpu", torch.cat(ha, dim=0), torch.cat(hl, dim=0))
+        loss_contrast += 0.0 if torch.isnan(temp) else targs["training"]["lambda_contrast"] * temp
+    losses += targs["training"]["lambda_contrast"] * loss_contrast
+    out = {"trainc_loss": np.array([float(losses)]), "trainc_contrast": np.array([float(loss_contrast)]),
+           "trainc_num_connected": np.array([sum(len(x) for x in hid_lab)])}
+    losses.backward()
+    for pname, p in model.named_parameters():
+        gflat = p.grad.detach().flatten()
+        stride = max(1, gflat.numel() // 509)
+        key = pname.replace(".", "__")
+        out["gradc_l2__" + key] = np.array([float(gflat.double().norm())])
+        out["gradc_sample__" + key] = gflat[::stride][:509].numpy().copy()
+    np.savez_compressed(os.path.join(HERE, name + "_contrast.npz"), **out)
+    print(name, "contrast: loss", float(losses), "contrastive", float(loss_contrast), "connected", out["trainc_num_connected"])
+
+
 def run_cs_case(name, ref_model, ref_train, ref_eval):
     """Commonsense-filtered evaluation (run_mode eval_cs, reference evaluator.py:189-194,261-266) -> <name>_cs.npz."""
     kw, nobj, seed, gain, cfrac, edge = CASES[name]
@@ -352,6 +443,9 @@ if __name__ == "__main__":
     if argv and argv[0] == "--cs":
         for nm in argv[1:]:
             run_cs_case(nm, *mods)
+    elif argv and argv[0] == "--contrast":
+        for nm in argv[1:]:
+            run_contrast_case(nm, *mods)
     else:
         which = argv or list(CASES)
         for nm in which:
