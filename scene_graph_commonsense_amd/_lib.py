@@ -21,6 +21,9 @@ def load(build_if_missing: bool = True) -> ctypes.CDLL:
     global _LIB
     if _LIB is not None:
         return _LIB
+    # torch must be loaded first: it brings the HIP runtime (libamdhip64) this library's kernels have to register
+    # with.  Loading the library before torch leaves two runtimes in the process and every launch fails.
+    import torch  # noqa: F401
     path = lib_path()
     if not os.path.exists(path):
         if not build_if_missing:

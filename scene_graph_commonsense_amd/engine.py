@@ -66,8 +66,60 @@ class Workspace:
         return sum(t.numel() * t.element_size() for t in self.bufs.values())
 
 
+# ---------------------------------------------------------------------------------- host-side training helpers
+def csr_by(index: np.ndarray, n: int):
+    """ptr/list of pair ids grouped by object id (stable, so sums run in pair order)."""
+    order = np.argsort(index, kind="stable").astype(np.int32)
+    ptr = np.searchsorted(index[order], np.arange(n + 1)).astype(np.int32)
+    return ptr, order
+
+
+def loss_coefficients(cfg: HeadConfig, step: np.ndarray, n_steps: int, directed: np.ndarray, class_weight: np.ndarray,
+                      lambda_connectivity: float = 0.1, lambda_not_connected: float = 1.0):
+    """Fold the reference's per-step loss bookkeeping into per-pair coefficients.
+
+    Reference: each direction-step t adds  loss_rel_t + lambda_c * loss_conn_t  to running sums that are
+    themselves added to ``losses`` after every step (``train_test.py:219-233``), so step t carries the weight
+    (T - t).  Inside a step (``train_utils.py:64-94,116-157``): BCE(conn, 1) averaged over the connected pairs
+    REPLACES lambda_nc * BCE(conn, 0) averaged over the others whenever a connected pair exists; the relation
+    term is mean NLL on the super-category plus, per super-category, a class-weighted mean NLL.
+    Returns float32/int32 arrays (tgt, a, b, c, y): loss_i = -a*super[st] - b*rel[t] + c*BCE(conn, y).
+    """
+    P = step.shape[0]
+    w = (n_steps - step).astype(np.float64)
+    conn = directed >= 0
+    n_conn = np.bincount(step[conn], minlength=n_steps).astype(np.float64)
+    n_all = np.bincount(step, minlength=n_steps).astype(np.float64)
+    n_nc = n_all - n_conn
+    has = n_conn[step] > 0
+    c = np.zeros(P)
+    c[conn] = w[conn] * lambda_connectivity / n_conn[step[conn]]
+    sel = (~conn) & (~has)
+    c[sel] = w[sel] * lambda_connectivity * lambda_not_connected / np.maximum(n_nc[step[sel]], 1)
+    a = np.zeros(P)
+    b = np.zeros(P)
+    t = np.where(conn, directed, 0)
+    cw = class_weight.astype(np.float64)[t]
+    if cfg.hierarchical:
+        ng, npos = cfg.num_geometric, cfg.num_possessive
+        seg = np.where(t < ng, 0, np.where(t < ng + npos, 1, 2))
+        a[conn] = w[conn] / n_conn[step[conn]]
+        key = step * 3 + seg
+        wsum = np.bincount(key[conn], weights=cw[conn], minlength=3 * n_steps)
+        b[conn] = w[conn] * cw[conn] / wsum[key[conn]]
+    else:
+        wsum = np.bincount(step[conn], weights=cw[conn], minlength=n_steps)
+        b[conn] = w[conn] * cw[conn] / wsum[step[conn]]
+    return (directed.astype(np.int32), a.astype(np.float32), b.astype(np.float32), c.astype(np.float32),
+            conn.astype(np.float32))
+
+
+class TrainContext:
+    pass
+
+
 class RelHeadEngine:
-    """Forward (and, in ``engine_bwd``, backward) of the relation head over explicit pair lists."""
+    """Forward and backward of the relation head over explicit pair lists (one instance = one GPU, one workspace)."""
 
     def __init__(self, cfg: HeadConfig, device="cuda:0"):
         if cfg.hidden_dim != 128 or cfg.feature_size != 32:
@@ -258,286 +310,226 @@ class RelHeadEngine:
         self._lsub, self._lobj = lsub, lobj
         return self.pair_trunk(uv[0], uv[1], sub_idx, obj_idx, lsub, lobj, train, seeds, keep_argmax, iou_mask, dense)
 
-
-# ====================================================================================== training (fwd + bwd)
-def csr_by(index: np.ndarray, n: int):
-    """ptr/list of pair ids grouped by object id (stable, so sums run in pair order)."""
-    order = np.argsort(index, kind="stable").astype(np.int32)
-    ptr = np.searchsorted(index[order], np.arange(n + 1)).astype(np.int32)
-    return ptr, order
-
-
-def loss_coefficients(cfg: HeadConfig, step: np.ndarray, n_steps: int, directed: np.ndarray, class_weight: np.ndarray,
-                      lambda_connectivity: float = 0.1, lambda_not_connected: float = 1.0):
-    """Fold the reference's per-step loss bookkeeping into per-pair coefficients.
-
-    Reference: each direction-step t adds  loss_rel_t + lambda_c * loss_conn_t  to running sums that are
-    themselves added to ``losses`` after every step (``train_test.py:219-233``), so step t carries the weight
-    (T - t).  Inside a step (``train_utils.py:64-94,116-157``): BCE(conn, 1) averaged over the connected pairs
-    REPLACES lambda_nc * BCE(conn, 0) averaged over the others whenever a connected pair exists; the relation
-    term is mean NLL on the super-category plus, per super-category, a class-weighted mean NLL.
-    Returns float32/int32 arrays (tgt, a, b, c, y): loss_i = -a*super[st] - b*rel[t] + c*BCE(conn, y).
-    """
-    P = step.shape[0]
-    w = (n_steps - step).astype(np.float64)
-    conn = directed >= 0
-    n_conn = np.bincount(step[conn], minlength=n_steps).astype(np.float64)
-    n_all = np.bincount(step, minlength=n_steps).astype(np.float64)
-    n_nc = n_all - n_conn
-    has = n_conn[step] > 0
-    c = np.zeros(P)
-    c[conn] = w[conn] * lambda_connectivity / n_conn[step[conn]]
-    sel = (~conn) & (~has)
-    c[sel] = w[sel] * lambda_connectivity * lambda_not_connected / np.maximum(n_nc[step[sel]], 1)
-    a = np.zeros(P)
-    b = np.zeros(P)
-    t = np.where(conn, directed, 0)
-    cw = class_weight.astype(np.float64)[t]
-    if cfg.hierarchical:
-        ng, npos = cfg.num_geometric, cfg.num_possessive
-        seg = np.where(t < ng, 0, np.where(t < ng + npos, 1, 2))
-        a[conn] = w[conn] / n_conn[step[conn]]
-        key = step * 3 + seg
-        wsum = np.bincount(key[conn], weights=cw[conn], minlength=3 * n_steps)
-        b[conn] = w[conn] * cw[conn] / wsum[key[conn]]
-    else:
-        wsum = np.bincount(step[conn], weights=cw[conn], minlength=n_steps)
-        b[conn] = w[conn] * cw[conn] / wsum[step[conn]]
-    return (directed.astype(np.int32), a.astype(np.float32), b.astype(np.float32), c.astype(np.float32),
-            conn.astype(np.float32))
+    # ====================================================================== training (forward + backward)
+    def prep_bwd_weights(self, sd):
+        """bf16 transposed / flipped weight copies for the data-gradient GEMMs."""
+        dev = self.device
+        g = lambda k: sd[k].detach().to(dev, torch.float32)
+        w = self.w
+        w["w2mT"] = w["fc2_full"][:, :4096].t().contiguous().to(torch.bfloat16)
+        w["w1pT"] = self._transpose_cast(g("fc1.weight").contiguous(), "w1pT", torch.bfloat16, 1, 64, 1024, 64 * 65536, 64, 65536,
+                                         64, 4096, 1024 * 4096)
+        w["wd3"] = conv_k_layout(g("conv3_1.weight").flip(2, 3).permute(1, 0, 2, 3)).to(torch.bfloat16).contiguous()
+        c2 = g("conv2_1.weight")
+        w["wd2"] = torch.stack([conv_k_layout(c2[:, r * 128:(r + 1) * 128].flip(2, 3).permute(1, 0, 2, 3))
+                                for r in (0, 1)]).to(torch.bfloat16).contiguous()
+        rows = self.head_rows
+        Wc = torch.zeros(64, 512, device=dev)
+        Wc[:rows] = w["head_wt"].t()[:rows]
+        w["head_w"] = Wc.contiguous()
 
 
-class TrainContext:
-    pass
+    def _slab_sum(self, slabs, n, count):
+        out = torch.empty(n, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.sgc_slab_sum(_lib.ptr(slabs), _lib.ptr(out), _c_long(n), int(count), 0, self._st()), "sgc_slab_sum")
+        return out
 
 
-def _prep_bwd_weights(self, sd):
-    """bf16 transposed / flipped weight copies for the data-gradient GEMMs."""
-    dev = self.device
-    g = lambda k: sd[k].detach().to(dev, torch.float32)
-    w = self.w
-    w["w2mT"] = w["fc2_full"][:, :4096].t().contiguous().to(torch.bfloat16)
-    w["w1pT"] = self._transpose_cast(g("fc1.weight").contiguous(), "w1pT", torch.bfloat16, 1, 64, 1024, 64 * 65536, 64, 65536,
-                                     64, 4096, 1024 * 4096)
-    w["wd3"] = conv_k_layout(g("conv3_1.weight").flip(2, 3).permute(1, 0, 2, 3)).to(torch.bfloat16).contiguous()
-    c2 = g("conv2_1.weight")
-    w["wd2"] = torch.stack([conv_k_layout(c2[:, r * 128:(r + 1) * 128].flip(2, 3).permute(1, 0, 2, 3))
-                            for r in (0, 1)]).to(torch.bfloat16).contiguous()
-    rows = self.head_rows
-    Wc = torch.zeros(64, 512, device=dev)
-    Wc[:rows] = w["head_wt"].t()[:rows]
-    w["head_w"] = Wc.contiguous()
+    def _colsum(self, X, rows, cols, elem=ELEM_BF16, blocks=None):
+        if blocks is None:
+            blocks = max(1, min(512, rows // 64))
+        blocks = int(max(1, min(blocks, rows)))
+        part = self.ws.get("colsum_part", blocks * cols, torch.float32)
+        _lib.check(self.lib.sgc_colsum(elem, _lib.ptr(X), _lib.ptr(part), _c_long(rows), cols, blocks, self._st()), "sgc_colsum")
+        return self._slab_sum(part, cols, blocks)
 
 
-def _slab_sum(self, slabs, n, count):
-    out = torch.empty(n, dtype=torch.float32, device=self.device)
-    _lib.check(self.lib.sgc_slab_sum(_lib.ptr(slabs), _lib.ptr(out), _c_long(n), int(count), 0, self._st()), "sgc_slab_sum")
-    return out
+    def _to_bf16(self, name, src, n):
+        dst = self.ws.get(name, n, torch.bfloat16)
+        self._timed("convert", lambda: _lib.check(self.lib.sgc_convert_f16_bf16(_lib.ptr(src), _lib.ptr(dst), _c_long(n), self._st()),
+                                                  "sgc_convert_f16_bf16"))
+        return dst
 
 
-def _colsum(self, X, rows, cols, elem=ELEM_BF16, blocks=None):
-    if blocks is None:
-        blocks = max(1, min(512, rows // 64))
-    blocks = int(max(1, min(blocks, rows)))
-    part = self.ws.get("colsum_part", blocks * cols, torch.float32)
-    _lib.check(self.lib.sgc_colsum(elem, _lib.ptr(X), _lib.ptr(part), _c_long(rows), cols, blocks, self._st()), "sgc_colsum")
-    return _slab_sum(self, part, cols, blocks)
+    def train_forward(self, image_feature, image_depth, obj_img, bbox, cats, super_mh, sub_idx, obj_idx, seeds=(0, 0),
+                      dropout=True, dense=None) -> "TrainContext":
+        """Forward that keeps what the backward needs (pool argmaxes, expansion routing mask)."""
+        lib, ws = self.lib, self.ws
+        ctx = TrainContext()
+        ctx.n_img = int(image_feature.shape[0])
+        ctx.n_obj = int(obj_img.shape[0])
+        ctx.P = P = int(sub_idx.shape[0])
+        ctx.Ppad = Ppad = (P + 63) // 64 * 64
+        ctx.obj_img, ctx.bbox, ctx.cats, ctx.super_mh, ctx.sub_idx, ctx.obj_idx = obj_img, bbox, cats, super_mh, sub_idx, obj_idx
+        ctx.dropout, ctx.seeds = dropout, seeds
+        ctx.a_img = self.image_maps(image_feature, image_depth)
+        ctx.x = self._x
+        ctx.uv = self.object_halves(ctx.a_img, obj_img, bbox)
+        ctx.lsub, ctx.lobj = self.label_vectors(cats, super_mh)
+        z = ws.get("z_pad", P * 18 * 18 * 512, torch.float16)
+        z_bf = ws.get("z_pad_bf", P * 18 * 18 * 512, torch.bfloat16)
+        amz = ws.get("amz", P * 256 * 512, torch.uint8)
+        self.expand(ctx.uv[0], ctx.uv[1], sub_idx, obj_idx, P, z, z_bf, amz, dense=dense)
+        ctx.z_bf = z_bf
+        y = ws.get("y", Ppad * 65536, torch.float16)
+        am = ws.get("argmax", P * 65536, torch.uint8)
+        self._timed("conv3_fwd", lambda: _lib.check(lib.sgc_conv3_relu_pool(_lib.ptr(z), _lib.ptr(self.w["w3r"]), _lib.ptr(self.w["b3"]), _lib.ptr(y), _lib.ptr(am),
+                                           P, self._st()), "sgc_conv3_relu_pool"))
+        h1 = ws.get("h1", Ppad * 4096, torch.float16)
+        self._timed("fc1_fwd", lambda: _lib.check(lib.sgc_fc1_relu(_lib.ptr(y), _lib.ptr(self.w["w1p"]), _lib.ptr(self.w["bf1"]), _lib.ptr(h1), P, 65536,
+                                    int(dropout), ctypes.c_uint(seeds[0]), self._st()), "sgc_fc1_relu"))
+        p = ws.get("p", Ppad * 512, torch.float32)
+        self._timed("fc2_fwd", lambda: _lib.check(lib.sgc_fc2_labels_relu(_lib.ptr(h1), _lib.ptr(self.w["w2m"]), _lib.ptr(self.w["bf2"]), _lib.ptr(ctx.lsub),
+                                           _lib.ptr(ctx.lobj), _lib.ptr(sub_idx), _lib.ptr(obj_idx), _lib.ptr(p), P, int(dropout),
+                                           ctypes.c_uint(seeds[1]), self._st()), "sgc_fc2_labels_relu"))
+        ctx.z, ctx.amz, ctx.y, ctx.am, ctx.h1, ctx.p = z, amz, y, am, h1, p
+        ctx.out = self.head(p, P)
+        return ctx
 
 
-def _to_bf16(self, name, src, n):
-    dst = self.ws.get(name, n, torch.bfloat16)
-    self._timed("convert", lambda: _lib.check(self.lib.sgc_convert_f16_bf16(_lib.ptr(src), _lib.ptr(dst), _c_long(n), self._st()),
-                                              "sgc_convert_f16_bf16"))
-    return dst
+    def train_backward(self, ctx: "TrainContext", coefs, sub_csr, obj_csr, img_ptr, splits=8, grad_hook=None, dp_extra=None):
+        """Backward of the whole path.  Returns (loss scalar tensor, {reference parameter name: f32 gradient})."""
+        lib, ws, cfg, dev, w = self.lib, self.ws, self.cfg, self.device, self.w
+        P, Ppad, n_obj, n_img = ctx.P, ctx.Ppad, ctx.n_obj, ctx.n_img
+        st = self._st
+        hier = cfg.hierarchical
+        R = cfg.num_relations
+        scale = 2.0 if ctx.dropout else 1.0
+        f = ctypes.c_float
+        tgt, ca, cb, cc, cy = coefs
+        grads: Dict[str, torch.Tensor] = {}
+        slabs_n = ctypes.c_int(0)
+
+        # ---- head: loss, dlogits, d(fc2 pre-activation)
+        dl = ws.get("dl", P * 64, torch.float32)
+        loss_i = ws.get("loss_i", P, torch.float32)
+        dpre = ws.get("dpre", Ppad * 512, torch.bfloat16)
+        if Ppad > P:
+            dpre[P * 512:].zero_()
+        T = self.T
+        _lib.check(lib.sgc_head_loss_bwd(_lib.ptr(ctx.out.relation), _lib.ptr(ctx.out.super_relation), _lib.ptr(ctx.out.connectivity),
+                                         _lib.ptr(ctx.p), _lib.ptr(tgt), _lib.ptr(ca), _lib.ptr(cb), _lib.ptr(cc), _lib.ptr(cy),
+                                         _lib.ptr(w["head_w"]), P, cfg.num_geometric if hier else R,
+                                         cfg.num_possessive if hier else 0, cfg.num_semantic if hier else 0, int(hier),
+                                         f(T[0]), f(T[1]), f(T[2]), f(scale), _lib.ptr(dl), _lib.ptr(loss_i), _lib.ptr(dpre),
+                                         _lib.ptr(dp_extra), st()),
+                   "sgc_head_loss_bwd")
+        loss = loss_i.sum() if P > 0 else torch.zeros((), device=dev)      # P scalars: host-side glue
+        chunk = max(16, (P + 255) // 256)
+        nb = (P + chunk - 1) // chunk
+        part = ws.get("head_part", nb * 64 * 513, torch.float32)
+        _lib.check(lib.sgc_head_wgrad(_lib.ptr(dl), _lib.ptr(ctx.p), _lib.ptr(part), P, chunk, st()), "sgc_head_wgrad")
+        hw = self._slab_sum(part, 64 * 513, nb).view(64, 513)
+        names = (["fc3_1", "fc3_2", "fc3_3", "fc5", "fc4"] if hier else ["fc3", "fc4"])
+        sizes = ([cfg.num_geometric, cfg.num_possessive, cfg.num_semantic, 3, 1] if hier else [R, 1])
+        r0 = 0
+        for nm, sz in zip(names, sizes):
+            grads[nm + ".weight"] = hw[r0:r0 + sz, :512].contiguous()
+            grads[nm + ".bias"] = hw[r0:r0 + sz, 512].contiguous()
+            r0 += sz
+
+        # ---- fc2
+        h1_bf = self._to_bf16("h1_bf", ctx.h1, Ppad * 4096)
+        sl = ws.get("slabs", 32 * 1024 * 4608, torch.float32)      # split-K slabs (largest user: conv3 wgrad)
+        self._timed("fc2_wgrad", lambda: _lib.check(lib.sgc_fc2_wgrad(_lib.ptr(dpre), _lib.ptr(h1_bf), _lib.ptr(sl), Ppad, 32, ctypes.byref(slabs_n), st()),
+                   "sgc_fc2_wgrad"))
+        dW2m = self._slab_sum(sl, 512 * 4096, slabs_n.value).view(512, 4096)
+        gfc2 = torch.zeros_like(w["fc2_full"])
+        gfc2[:, :4096] = dW2m
+        dls = torch.empty(n_obj, 512, dtype=torch.float32, device=dev)
+        dlo = torch.empty(n_obj, 512, dtype=torch.float32, device=dev)
+        _lib.check(lib.sgc_segment_sum_rows(_lib.ptr(dpre), _lib.ptr(sub_csr[0]), _lib.ptr(sub_csr[1]), _lib.ptr(dls), n_obj, 512, st()),
+                   "sgc_segment_sum_rows")
+        _lib.check(lib.sgc_segment_sum_rows(_lib.ptr(dpre), _lib.ptr(obj_csr[0]), _lib.ptr(obj_csr[1]), _lib.ptr(dlo), n_obj, 512, st()),
+                   "sgc_segment_sum_rows")
+        C = cfg.num_classes
+        gfc2[:, 4096:4096 + C].index_add_(1, ctx.cats, dls.t())            # one-hot label columns (tiny, host glue)
+        gfc2[:, 4096 + C:4096 + 2 * C].index_add_(1, ctx.cats, dlo.t())
+        if ctx.super_mh is not None and cfg.dataset == "vg":
+            S = cfg.num_super_classes
+            gfc2[:, 4096 + 2 * C:4096 + 2 * C + S] = dls.t() @ ctx.super_mh
+            gfc2[:, 4096 + 2 * C + S:4096 + 2 * C + 2 * S] = dlo.t() @ ctx.super_mh
+        grads["fc2.weight"] = gfc2
+        grads["fc2.bias"] = self._colsum(dpre, Ppad, 512)
+        dh1 = ws.get("dh1", Ppad * 4096, torch.bfloat16)
+        if Ppad > P:
+            dh1[P * 4096:].zero_()
+        self._timed("fc2_dgrad", lambda: _lib.check(lib.sgc_fc2_dgrad(_lib.ptr(dpre), _lib.ptr(w["w2mT"]), _lib.ptr(ctx.h1), _lib.ptr(dh1), P, f(scale), st()),
+                   "sgc_fc2_dgrad"))
+
+        # ---- fc1
+        y_bf = self._to_bf16("y_bf", ctx.y, Ppad * 65536)
+        dW1p = ws.get("dW1p", 4096 * 65536, torch.float32)
+        self._timed("fc1_wgrad", lambda: _lib.check(lib.sgc_fc1_wgrad(_lib.ptr(dh1), _lib.ptr(y_bf), _lib.ptr(dW1p), Ppad, 65536, st()), "sgc_fc1_wgrad"))
+        # back to the reference column order (c*64 + window): 64x64 tile transposes, f32 -> f32
+        gfc1 = torch.empty(4096, 65536, dtype=torch.float32, device=dev)
+        _lib.check(lib.sgc_transpose_cast(_lib.ptr(dW1p), _lib.ptr(gfc1), 2, 4096, 16, _c_long(65536), _c_long(64), _c_long(1024),
+                                          _c_long(65536), _c_long(4096), _c_long(64), st()), "sgc_transpose_cast")
+        grads["fc1.weight"] = gfc1
+        if grad_hook is not None:          # largest gradient (97 % of the bytes) is ready first: overlap its all-reduce
+            grad_hook("fc1.weight", grads["fc1.weight"])
+        grads["fc1.bias"] = self._colsum(dh1, Ppad, 4096)
+        dy = ws.get("dy", Ppad * 65536, torch.bfloat16)
+        self._timed("fc1_dgrad", lambda: _lib.check(lib.sgc_fc1_dgrad(_lib.ptr(dh1), _lib.ptr(w["w1pT"]), _lib.ptr(dy), P, 65536, st()), "sgc_fc1_dgrad"))
+
+        # ---- conv3
+        dy3 = ws.get("dy3_pad", P * 18 * 18 * 1024, torch.bfloat16)
+        bpart = ws.get("b3_part", 2048 * 1024, torch.float32)
+        nparts = ctypes.c_int(0)
+        self._timed("unpool", lambda: _lib.check(lib.sgc_unpool_relu_bwd(_lib.ptr(dy), _lib.ptr(ctx.am), _lib.ptr(dy3), _lib.ptr(bpart), ctypes.byref(nparts), P, st()),
+                   "sgc_unpool_relu_bwd"))
+        grads["conv3_1.bias"] = self._slab_sum(bpart, 1024, nparts.value)
+        z_bf = ctx.z_bf
+        self._timed("conv3_wgrad", lambda: _lib.check(lib.sgc_conv3_wgrad(_lib.ptr(dy3), _lib.ptr(z_bf), _lib.ptr(sl), P, 32, ctypes.byref(slabs_n), st()),
+                   "sgc_conv3_wgrad"))
+        dW3r = self._slab_sum(sl, 1024 * 4608, slabs_n.value)
+        grads["conv3_1.weight"] = dW3r.view(1024, 3, 3, 512).permute(0, 3, 1, 2).contiguous()
+        dz = ws.get("dz", P * 256 * 512, torch.bfloat16)
+        self._timed("conv3_dgrad", lambda: _lib.check(lib.sgc_conv3_dgrad(_lib.ptr(dy3), _lib.ptr(w["wd3"]), _lib.ptr(dz), P, st()), "sgc_conv3_dgrad"))
+
+        # ---- pair contraction + conv2 + masks + conv1
+        gc2 = torch.empty(512, 256, 3, 3, dtype=torch.float32, device=dev)
+        x_bf = self._to_bf16("x_bf", ctx.x, n_img * 1024 * XC)
+        for r, csr in ((0, sub_csr), (1, obj_csr)):
+            dU = ws.get("dU_pad_%d" % r, n_obj * 34 * 34 * 512, torch.bfloat16)
+            self._timed("contract", lambda: _lib.check(lib.sgc_pair_contract(_lib.ptr(dz), _lib.ptr(ctx.amz), _lib.ptr(csr[0]), _lib.ptr(csr[1]), _lib.ptr(dU), n_obj, st()),
+                       "sgc_pair_contract"))
+            a_pad = ws.get("a_pad_%d" % r, n_obj * 34 * 34 * 128, torch.float16)
+            a_bf = self._to_bf16("a_pad_bf", a_pad, n_obj * 34 * 34 * 128)
+            self._timed("conv2_wgrad", lambda: _lib.check(lib.sgc_conv2_wgrad(_lib.ptr(dU), _lib.ptr(a_bf), _lib.ptr(sl), n_obj, 16, ctypes.byref(slabs_n), st()),
+                       "sgc_conv2_wgrad"))
+            dW2r = self._slab_sum(sl, 512 * 1152, slabs_n.value)
+            gc2[:, r * 128:(r + 1) * 128] = dW2r.view(512, 3, 3, 128).permute(0, 3, 1, 2)
+            if r == 1:
+                grads["conv2_1.bias"] = self._colsum(dU, n_obj * 34 * 34, 512)
+            da = ws.get("da", n_obj * 1024 * 128, torch.bfloat16)
+            self._timed("conv2_dgrad", lambda: _lib.check(lib.sgc_conv2_dgrad(_lib.ptr(dU), _lib.ptr(w["wd2"][r]), _lib.ptr(da), n_obj, st()), "sgc_conv2_dgrad"))
+            dA = ws.get("dA", n_img * 1024 * 128, torch.float32)
+            dcst = torch.zeros(128, dtype=torch.float32, device=dev)
+            _lib.check(lib.sgc_object_masked_maps_bwd(_lib.ptr(da), _lib.ptr(img_ptr), _lib.ptr(ctx.bbox), _lib.ptr(dA), _lib.ptr(dcst),
+                                                      n_img, 32, 128, st()), "sgc_object_masked_maps_bwd")
+            dp1 = ws.get("dpre1", n_img * 1024 * 128, torch.bfloat16)
+            _lib.check(lib.sgc_tanh_bwd(_lib.ptr(dA), _lib.ptr(ctx.a_img[r]), _lib.ptr(dp1), _c_long(n_img * 1024 * 128), st()),
+                       "sgc_tanh_bwd")
+            _lib.check(lib.sgc_conv1_wgrad(_lib.ptr(dp1), _lib.ptr(x_bf), _lib.ptr(sl), n_img * 1024, XC, 16, ctypes.byref(slabs_n), st()),
+                       "sgc_conv1_wgrad")
+            dW1 = self._slab_sum(sl, 128 * XC, slabs_n.value).view(128, XC)
+            nm = "conv1_%d" % (r + 1)
+            grads[nm + ".weight"] = dW1[:, :257].reshape(128, 257, 1, 1).contiguous()
+            tb = torch.tanh(w["b1"][r])
+            grads[nm + ".bias"] = self._colsum(dp1, n_img * 1024, 128) + dcst * (1 - tb * tb)
+        grads["conv2_1.weight"] = gc2
+        return loss, grads
 
 
-def train_forward(self, image_feature, image_depth, obj_img, bbox, cats, super_mh, sub_idx, obj_idx, seeds=(0, 0),
-                  dropout=True, dense=None) -> "TrainContext":
-    """Forward that keeps what the backward needs (pool argmaxes, expansion routing mask)."""
-    lib, ws = self.lib, self.ws
-    ctx = TrainContext()
-    ctx.n_img = int(image_feature.shape[0])
-    ctx.n_obj = int(obj_img.shape[0])
-    ctx.P = P = int(sub_idx.shape[0])
-    ctx.Ppad = Ppad = (P + 63) // 64 * 64
-    ctx.obj_img, ctx.bbox, ctx.cats, ctx.super_mh, ctx.sub_idx, ctx.obj_idx = obj_img, bbox, cats, super_mh, sub_idx, obj_idx
-    ctx.dropout, ctx.seeds = dropout, seeds
-    ctx.a_img = self.image_maps(image_feature, image_depth)
-    ctx.x = self._x
-    ctx.uv = self.object_halves(ctx.a_img, obj_img, bbox)
-    ctx.lsub, ctx.lobj = self.label_vectors(cats, super_mh)
-    z = ws.get("z_pad", P * 18 * 18 * 512, torch.float16)
-    z_bf = ws.get("z_pad_bf", P * 18 * 18 * 512, torch.bfloat16)
-    amz = ws.get("amz", P * 256 * 512, torch.uint8)
-    self.expand(ctx.uv[0], ctx.uv[1], sub_idx, obj_idx, P, z, z_bf, amz, dense=dense)
-    ctx.z_bf = z_bf
-    y = ws.get("y", Ppad * 65536, torch.float16)
-    am = ws.get("argmax", P * 65536, torch.uint8)
-    self._timed("conv3_fwd", lambda: _lib.check(lib.sgc_conv3_relu_pool(_lib.ptr(z), _lib.ptr(self.w["w3r"]), _lib.ptr(self.w["b3"]), _lib.ptr(y), _lib.ptr(am),
-                                       P, self._st()), "sgc_conv3_relu_pool"))
-    h1 = ws.get("h1", Ppad * 4096, torch.float16)
-    self._timed("fc1_fwd", lambda: _lib.check(lib.sgc_fc1_relu(_lib.ptr(y), _lib.ptr(self.w["w1p"]), _lib.ptr(self.w["bf1"]), _lib.ptr(h1), P, 65536,
-                                int(dropout), ctypes.c_uint(seeds[0]), self._st()), "sgc_fc1_relu"))
-    p = ws.get("p", Ppad * 512, torch.float32)
-    self._timed("fc2_fwd", lambda: _lib.check(lib.sgc_fc2_labels_relu(_lib.ptr(h1), _lib.ptr(self.w["w2m"]), _lib.ptr(self.w["bf2"]), _lib.ptr(ctx.lsub),
-                                       _lib.ptr(ctx.lobj), _lib.ptr(sub_idx), _lib.ptr(obj_idx), _lib.ptr(p), P, int(dropout),
-                                       ctypes.c_uint(seeds[1]), self._st()), "sgc_fc2_labels_relu"))
-    ctx.z, ctx.amz, ctx.y, ctx.am, ctx.h1, ctx.p = z, amz, y, am, h1, p
-    ctx.out = self.head(p, P)
-    return ctx
-
-
-def train_backward(self, ctx: "TrainContext", coefs, sub_csr, obj_csr, img_ptr, splits=8, grad_hook=None, dp_extra=None):
-    """Backward of the whole path.  Returns (loss scalar tensor, {reference parameter name: f32 gradient})."""
-    lib, ws, cfg, dev, w = self.lib, self.ws, self.cfg, self.device, self.w
-    P, Ppad, n_obj, n_img = ctx.P, ctx.Ppad, ctx.n_obj, ctx.n_img
-    st = self._st
-    hier = cfg.hierarchical
-    R = cfg.num_relations
-    scale = 2.0 if ctx.dropout else 1.0
-    f = ctypes.c_float
-    tgt, ca, cb, cc, cy = coefs
-    grads: Dict[str, torch.Tensor] = {}
-    slabs_n = ctypes.c_int(0)
-
-    # ---- head: loss, dlogits, d(fc2 pre-activation)
-    dl = ws.get("dl", P * 64, torch.float32)
-    loss_i = ws.get("loss_i", P, torch.float32)
-    dpre = ws.get("dpre", Ppad * 512, torch.bfloat16)
-    if Ppad > P:
-        dpre[P * 512:].zero_()
-    T = self.T
-    _lib.check(lib.sgc_head_loss_bwd(_lib.ptr(ctx.out.relation), _lib.ptr(ctx.out.super_relation), _lib.ptr(ctx.out.connectivity),
-                                     _lib.ptr(ctx.p), _lib.ptr(tgt), _lib.ptr(ca), _lib.ptr(cb), _lib.ptr(cc), _lib.ptr(cy),
-                                     _lib.ptr(w["head_w"]), P, cfg.num_geometric if hier else R,
-                                     cfg.num_possessive if hier else 0, cfg.num_semantic if hier else 0, int(hier),
-                                     f(T[0]), f(T[1]), f(T[2]), f(scale), _lib.ptr(dl), _lib.ptr(loss_i), _lib.ptr(dpre),
-                                     _lib.ptr(dp_extra), st()),
-               "sgc_head_loss_bwd")
-    loss = _slab_sum(self, loss_i, 1, P)[0] if P > 0 else torch.zeros((), device=dev)
-    chunk = max(16, (P + 255) // 256)
-    nb = (P + chunk - 1) // chunk
-    part = ws.get("head_part", nb * 64 * 513, torch.float32)
-    _lib.check(lib.sgc_head_wgrad(_lib.ptr(dl), _lib.ptr(ctx.p), _lib.ptr(part), P, chunk, st()), "sgc_head_wgrad")
-    hw = _slab_sum(self, part, 64 * 513, nb).view(64, 513)
-    names = (["fc3_1", "fc3_2", "fc3_3", "fc5", "fc4"] if hier else ["fc3", "fc4"])
-    sizes = ([cfg.num_geometric, cfg.num_possessive, cfg.num_semantic, 3, 1] if hier else [R, 1])
-    r0 = 0
-    for nm, sz in zip(names, sizes):
-        grads[nm + ".weight"] = hw[r0:r0 + sz, :512].contiguous()
-        grads[nm + ".bias"] = hw[r0:r0 + sz, 512].contiguous()
-        r0 += sz
-
-    # ---- fc2
-    h1_bf = _to_bf16(self, "h1_bf", ctx.h1, Ppad * 4096)
-    sl = ws.get("slabs", 32 * 1024 * 4608, torch.float32)      # split-K slabs (largest user: conv3 wgrad)
-    self._timed("fc2_wgrad", lambda: _lib.check(lib.sgc_fc2_wgrad(_lib.ptr(dpre), _lib.ptr(h1_bf), _lib.ptr(sl), Ppad, 32, ctypes.byref(slabs_n), st()),
-               "sgc_fc2_wgrad"))
-    dW2m = _slab_sum(self, sl, 512 * 4096, slabs_n.value).view(512, 4096)
-    gfc2 = torch.zeros_like(w["fc2_full"])
-    gfc2[:, :4096] = dW2m
-    dls = torch.empty(n_obj, 512, dtype=torch.float32, device=dev)
-    dlo = torch.empty(n_obj, 512, dtype=torch.float32, device=dev)
-    _lib.check(lib.sgc_segment_sum_rows(_lib.ptr(dpre), _lib.ptr(sub_csr[0]), _lib.ptr(sub_csr[1]), _lib.ptr(dls), n_obj, 512, st()),
-               "sgc_segment_sum_rows")
-    _lib.check(lib.sgc_segment_sum_rows(_lib.ptr(dpre), _lib.ptr(obj_csr[0]), _lib.ptr(obj_csr[1]), _lib.ptr(dlo), n_obj, 512, st()),
-               "sgc_segment_sum_rows")
-    C = cfg.num_classes
-    gfc2[:, 4096:4096 + C].index_add_(1, ctx.cats, dls.t())            # one-hot label columns (tiny, host glue)
-    gfc2[:, 4096 + C:4096 + 2 * C].index_add_(1, ctx.cats, dlo.t())
-    if ctx.super_mh is not None and cfg.dataset == "vg":
-        S = cfg.num_super_classes
-        gfc2[:, 4096 + 2 * C:4096 + 2 * C + S] = dls.t() @ ctx.super_mh
-        gfc2[:, 4096 + 2 * C + S:4096 + 2 * C + 2 * S] = dlo.t() @ ctx.super_mh
-    grads["fc2.weight"] = gfc2
-    grads["fc2.bias"] = _colsum(self, dpre, Ppad, 512)
-    dh1 = ws.get("dh1", Ppad * 4096, torch.bfloat16)
-    if Ppad > P:
-        dh1[P * 4096:].zero_()
-    self._timed("fc2_dgrad", lambda: _lib.check(lib.sgc_fc2_dgrad(_lib.ptr(dpre), _lib.ptr(w["w2mT"]), _lib.ptr(ctx.h1), _lib.ptr(dh1), P, f(scale), st()),
-               "sgc_fc2_dgrad"))
-
-    # ---- fc1
-    y_bf = _to_bf16(self, "y_bf", ctx.y, Ppad * 65536)
-    dW1p = ws.get("dW1p", 4096 * 65536, torch.float32)
-    self._timed("fc1_wgrad", lambda: _lib.check(lib.sgc_fc1_wgrad(_lib.ptr(dh1), _lib.ptr(y_bf), _lib.ptr(dW1p), Ppad, 65536, st()), "sgc_fc1_wgrad"))
-    # back to the reference column order (c*64 + window): 64x64 tile transposes, f32 -> f32
-    gfc1 = torch.empty(4096, 65536, dtype=torch.float32, device=dev)
-    _lib.check(lib.sgc_transpose_cast(_lib.ptr(dW1p), _lib.ptr(gfc1), 2, 4096, 16, _c_long(65536), _c_long(64), _c_long(1024),
-                                      _c_long(65536), _c_long(4096), _c_long(64), st()), "sgc_transpose_cast")
-    grads["fc1.weight"] = gfc1
-    if grad_hook is not None:          # largest gradient (97 % of the bytes) is ready first: overlap its all-reduce
-        grad_hook("fc1.weight", grads["fc1.weight"])
-    grads["fc1.bias"] = _colsum(self, dh1, Ppad, 4096)
-    dy = ws.get("dy", Ppad * 65536, torch.bfloat16)
-    self._timed("fc1_dgrad", lambda: _lib.check(lib.sgc_fc1_dgrad(_lib.ptr(dh1), _lib.ptr(w["w1pT"]), _lib.ptr(dy), P, 65536, st()), "sgc_fc1_dgrad"))
-
-    # ---- conv3
-    dy3 = ws.get("dy3_pad", P * 18 * 18 * 1024, torch.bfloat16)
-    bpart = ws.get("b3_part", 2048 * 1024, torch.float32)
-    nparts = ctypes.c_int(0)
-    self._timed("unpool", lambda: _lib.check(lib.sgc_unpool_relu_bwd(_lib.ptr(dy), _lib.ptr(ctx.am), _lib.ptr(dy3), _lib.ptr(bpart), ctypes.byref(nparts), P, st()),
-               "sgc_unpool_relu_bwd"))
-    grads["conv3_1.bias"] = _slab_sum(self, bpart, 1024, nparts.value)
-    z_bf = ctx.z_bf
-    self._timed("conv3_wgrad", lambda: _lib.check(lib.sgc_conv3_wgrad(_lib.ptr(dy3), _lib.ptr(z_bf), _lib.ptr(sl), P, 32, ctypes.byref(slabs_n), st()),
-               "sgc_conv3_wgrad"))
-    dW3r = _slab_sum(self, sl, 1024 * 4608, slabs_n.value)
-    grads["conv3_1.weight"] = dW3r.view(1024, 3, 3, 512).permute(0, 3, 1, 2).contiguous()
-    dz = ws.get("dz", P * 256 * 512, torch.bfloat16)
-    self._timed("conv3_dgrad", lambda: _lib.check(lib.sgc_conv3_dgrad(_lib.ptr(dy3), _lib.ptr(w["wd3"]), _lib.ptr(dz), P, st()), "sgc_conv3_dgrad"))
-
-    # ---- pair contraction + conv2 + masks + conv1
-    gc2 = torch.empty(512, 256, 3, 3, dtype=torch.float32, device=dev)
-    x_bf = _to_bf16(self, "x_bf", ctx.x, n_img * 1024 * XC)
-    for r, csr in ((0, sub_csr), (1, obj_csr)):
-        dU = ws.get("dU_pad_%d" % r, n_obj * 34 * 34 * 512, torch.bfloat16)
-        self._timed("contract", lambda: _lib.check(lib.sgc_pair_contract(_lib.ptr(dz), _lib.ptr(ctx.amz), _lib.ptr(csr[0]), _lib.ptr(csr[1]), _lib.ptr(dU), n_obj, st()),
-                   "sgc_pair_contract"))
-        a_pad = ws.get("a_pad_%d" % r, n_obj * 34 * 34 * 128, torch.float16)
-        a_bf = _to_bf16(self, "a_pad_bf", a_pad, n_obj * 34 * 34 * 128)
-        self._timed("conv2_wgrad", lambda: _lib.check(lib.sgc_conv2_wgrad(_lib.ptr(dU), _lib.ptr(a_bf), _lib.ptr(sl), n_obj, 16, ctypes.byref(slabs_n), st()),
-                   "sgc_conv2_wgrad"))
-        dW2r = _slab_sum(self, sl, 512 * 1152, slabs_n.value)
-        gc2[:, r * 128:(r + 1) * 128] = dW2r.view(512, 3, 3, 128).permute(0, 3, 1, 2)
-        if r == 1:
-            grads["conv2_1.bias"] = _colsum(self, dU, n_obj * 34 * 34, 512)
-        da = ws.get("da", n_obj * 1024 * 128, torch.bfloat16)
-        self._timed("conv2_dgrad", lambda: _lib.check(lib.sgc_conv2_dgrad(_lib.ptr(dU), _lib.ptr(w["wd2"][r]), _lib.ptr(da), n_obj, st()), "sgc_conv2_dgrad"))
-        dA = ws.get("dA", n_img * 1024 * 128, torch.float32)
-        dcst = torch.zeros(128, dtype=torch.float32, device=dev)
-        _lib.check(lib.sgc_object_masked_maps_bwd(_lib.ptr(da), _lib.ptr(img_ptr), _lib.ptr(ctx.bbox), _lib.ptr(dA), _lib.ptr(dcst),
-                                                  n_img, 32, 128, st()), "sgc_object_masked_maps_bwd")
-        dp1 = ws.get("dpre1", n_img * 1024 * 128, torch.bfloat16)
-        _lib.check(lib.sgc_tanh_bwd(_lib.ptr(dA), _lib.ptr(ctx.a_img[r]), _lib.ptr(dp1), _c_long(n_img * 1024 * 128), st()),
-                   "sgc_tanh_bwd")
-        _lib.check(lib.sgc_conv1_wgrad(_lib.ptr(dp1), _lib.ptr(x_bf), _lib.ptr(sl), n_img * 1024, XC, 16, ctypes.byref(slabs_n), st()),
-                   "sgc_conv1_wgrad")
-        dW1 = _slab_sum(self, sl, 128 * XC, slabs_n.value).view(128, XC)
-        nm = "conv1_%d" % (r + 1)
-        grads[nm + ".weight"] = dW1[:, :257].reshape(128, 257, 1, 1).contiguous()
-        tb = torch.tanh(w["b1"][r])
-        grads[nm + ".bias"] = _colsum(self, dp1, n_img * 1024, 128) + dcst * (1 - tb * tb)
-    grads["conv2_1.weight"] = gc2
-    return loss, grads
-
-
-RelHeadEngine.prep_bwd_weights = _prep_bwd_weights
-RelHeadEngine.train_forward = train_forward
-RelHeadEngine.train_backward = train_backward
-
-
-def supcon_loss(self, feats: torch.Tensor, labels: torch.Tensor, grad_scale: float = 1.0, temperature: float = 0.07):
-    """SupConLossHierar on feats [2M,512] f32 (view 0 rows then view 1 rows), labels [M] int32.
-    Returns (loss scalar tensor, dF [2M,512] = grad_scale * dloss/dfeats)."""
-    M = int(labels.shape[0])
-    n = 2 * M
-    G = self.ws.get("supcon_G", n * n, torch.float32)
-    rows = torch.empty(n, dtype=torch.float32, device=self.device)
-    dF = torch.empty(n, 512, dtype=torch.float32, device=self.device)
-    _lib.check(self.lib.sgc_supcon_hierar(_lib.ptr(feats), _lib.ptr(labels), M, ctypes.c_float(temperature), ctypes.c_float(grad_scale),
-                                          _lib.ptr(G), _lib.ptr(rows), _lib.ptr(dF), self._st()), "sgc_supcon_hierar")
-    return _slab_sum(self, rows, 1, n)[0] / n, dF
-
-
-RelHeadEngine.supcon_loss = supcon_loss
+    def supcon_loss(self, feats: torch.Tensor, labels: torch.Tensor, grad_scale: float = 1.0, temperature: float = 0.07):
+        """SupConLossHierar on feats [2M,512] f32 (view 0 rows then view 1 rows), labels [M] int32.
+        Returns (loss scalar tensor, dF [2M,512] = grad_scale * dloss/dfeats)."""
+        M = int(labels.shape[0])
+        n = 2 * M
+        G = self.ws.get("supcon_G", n * n, torch.float32)
+        rows = torch.empty(n, dtype=torch.float32, device=self.device)
+        dF = torch.empty(n, 512, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.sgc_supcon_hierar(_lib.ptr(feats), _lib.ptr(labels), M, ctypes.c_float(temperature), ctypes.c_float(grad_scale),
+                                              _lib.ptr(G), _lib.ptr(rows), _lib.ptr(dF), self._st()), "sgc_supcon_hierar")
+        return rows.sum() / n, dF
