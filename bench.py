@@ -78,6 +78,7 @@ def main():
     ap.add_argument("--images", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--forward-only", action="store_true")
+    ap.add_argument("--dataset", default="vg", choices=["vg", "oiv6"], help="oiv6 = 601 classes, (4,2,24) head, no super-classes")
     args = ap.parse_args()
 
     rank, world, local = sgd_dist.init_from_env()
@@ -88,9 +89,12 @@ def main():
 
     from scene_graph_commonsense_amd.model import BayesianRelationClassifier
     from scene_graph_commonsense_amd.pairs import flatten_scene, pair_targets_fast
-    cfg = HeadConfig()
+    cfg = HeadConfig() if args.dataset == "vg" else HeadConfig(dataset="oiv6", num_classes=601, num_super_classes=0,
+                                                               num_geometric=4, num_possessive=2, num_semantic=24)
     sd = make_state_dict(cfg, seed=0)
-    model = BayesianRelationClassifier(cfg.args(run_mode="train")).to(dev)
+    model = BayesianRelationClassifier(cfg.args(run_mode="train"), num_classes=cfg.num_classes,
+                                       num_super_classes=cfg.num_super_classes, num_geometric=cfg.num_geometric,
+                                       num_possessive=cfg.num_possessive, num_semantic=cfg.num_semantic).to(dev)
     model.load_state_dict(sd)
     model.train()
     batch = make_scene_batch(cfg, [args.objects] * args.images, seed=1000 + rank, connect_frac=0.02)
@@ -165,8 +169,8 @@ def main():
             "value": round(value, 1), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16 fwd / bf16 bwd (f32 accumulate, f32 master weights)", "data": "synthetic",
-            "config": {"workload": "VG PredCLS synthetic, %d images x %d objects per GPU = %d ordered pairs per GPU per step"
-                                   % (args.images, args.objects, P), "parallelism": "dp%d" % world},
+            "config": {"workload": "%s PredCLS synthetic, %d images x %d objects per GPU = %d ordered pairs per GPU per step"
+                                   % (args.dataset.upper(), args.images, args.objects, P), "parallelism": "dp%d" % world},
             "loss": None if loss is None else float(loss), "loss_first_step": first_loss,
             "roofline": roof,
             "kernels_ms": {k: round(v, 3) for k, v in sorted(kern.items())},

@@ -31,6 +31,7 @@ struct NtParams {
     float scale;                // EPI_RELUMASK / dropout scale
     unsigned drop_seed; int drop_enable;
     int tiles_m, tiles_n;
+    int epi_lds;                // 1: LDS-staged 16-byte stores for EPI_STORE in the 8-wave kernels (set by the launcher)
 };
 
 template <int ELEM>
@@ -109,6 +110,49 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x16 (&acc)[TM]
                 }
             }
         }
+    }
+}
+
+// LDS-staged epilogue for 16-bit EPI_STORE outputs of the 8-wave 256x256 block (conv3 / fc1 / conv2 data gradients write
+// 4-9 GB per launch): the MFMA C layout gives each lane ONE column of 16 rows per tile, i.e. 2-byte global stores.  Here
+// each wave transposes its 128x64 sub-tile through its own 18 KiB LDS region (row pitch 144 B): neighbouring lanes swap a
+// value (DPP) so that every lane writes one packed dword (two adjacent columns), then the wave reads rows back as 16-byte
+// pieces and issues 16 full-line 16-byte stores per lane instead of 128 2-byte ones.  Needs 8 x 18432 B of LDS.
+constexpr int EPI_LDS_BYTES = 8 * 128 * 144;
+template <int ELEM>
+__device__ __forceinline__ void nt_epilogue_store16(const NtParams& p, f32x16 (&acc)[4][2], int m0, int n0, int wr, int wc, int lane,
+                                                    int wid, char* smem) {
+    __syncthreads();                                   // every wave is done reading operand tiles
+    char* reg = smem + wid * (128 * 144);
+    const int h = lane >> 5, cl = lane & 31;
+    const bool odd = cl & 1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wc * 64 + j * 32 + cl;
+            const float bias = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+            for (int rp = 0; rp < 8; ++rp) {
+                const float v0 = acc[i][j][2 * rp] + bias, v1 = acc[i][j][2 * rp + 1] + bias;
+                const float recv = __shfl_xor(odd ? v0 : v1, 1);
+                const int r0 = ((2 * rp) & 3) + 8 * ((2 * rp) >> 2) + 4 * h;       // row of register 2rp; register 2rp+1 is r0+1
+                const unsigned lo = odd ? to_elem<ELEM>(recv) : to_elem<ELEM>(v0);
+                const unsigned hi = odd ? to_elem<ELEM>(v1) : to_elem<ELEM>(recv);
+                const int row = i * 32 + r0 + (odd ? 1 : 0);
+                *reinterpret_cast<unsigned*>(reg + row * 144 + (j * 32 + (cl & ~1)) * 2) = lo | (hi << 16);
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    u16* out = reinterpret_cast<u16*>(p.C);
+    const int c8 = lane & 7, rsub = lane >> 3;
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        const int rowl = it * 8 + rsub;
+        const uint4 v = *reinterpret_cast<const uint4*>(reg + rowl * 144 + c8 * 16);
+        const int row = m0 + wr * 128 + rowl;
+        if (row < p.M) *reinterpret_cast<uint4*>(out + (long)row * p.ldc + n0 + wc * 64 + c8 * 8) = v;
     }
 }
 
@@ -221,6 +265,9 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void gemm_nt_kernel(const NtParams
         }
     }
 
+    if constexpr (EPI == EPI_STORE && TM == 4 && TN == 2 && WR * WC == 8) {
+        if (p.epi_lds) { nt_epilogue_store16<ELEM>(p, acc, m0, n0, wr, wc, lane, wid, smem); return; }
+    }
     nt_epilogue<ELEM, EPI, TM, TN>(p, acc, m0, n0, wr, wc, lane);
 }
 
@@ -239,7 +286,8 @@ inline int sgc_gemm_cfg() {       // test hook: SGC_GEMM_CFG=1 forces the 128x12
 template <int ELEM, int AMODE, int EPI, int WR, int WC, int TM, int TN, int ABL = 0>
 static int launch_gemm_nt_cfg(NtParams p, hipStream_t stream) {
     constexpr int BM = WR * TM * 32, BN = WC * TN * 32;
-    constexpr int LDS = 2 * (BM + BN) * 128;
+    constexpr int LDS0 = 2 * (BM + BN) * 128;
+    constexpr int LDS = (EPI == EPI_STORE && TM == 4 && TN == 2 && WR * WC == 8 && LDS0 < EPI_LDS_BYTES) ? EPI_LDS_BYTES : LDS0;
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = p.N / BN;
     static bool attr_set = false;
@@ -496,6 +544,9 @@ __global__ __launch_bounds__(512, 2) void conv16_halo_kernel(const NtParams p) {
             }
         }
     }
+    if constexpr (EPI == EPI_STORE) {
+        if (p.epi_lds) { nt_epilogue_store16<ELEM>(p, acc, m0, n0, wr, wc, lane, wid, smem); return; }
+    }
     nt_epilogue<ELEM, EPI, TM, TN>(p, acc, m0, n0, wr, wc, lane);
 }
 
@@ -527,6 +578,11 @@ static int launch_gemm_nt(NtParams p, hipStream_t stream) {
     if ((p.K & 63) || (p.N & 127) || p.K <= 0) return SGC_ERR_ARG;
     if (AMODE == AMODE_CONV && ((p.Cin & 63) || p.K != 9 * p.Cin)) return SGC_ERR_ARG;
     const int cfg = sgc_gemm_cfg();
+    {
+        static int epi = -1;        // SGC_EPI_LDS=0 keeps the direct 2-byte stores (A/B hook)
+        if (epi < 0) { const char* e = getenv("SGC_EPI_LDS"); epi = e ? atoi(e) : 1; }
+        p.epi_lds = epi;
+    }
     const bool big_ok = (p.N % 256) == 0;
     if constexpr (AMODE == AMODE_CONV && (EPI == EPI_POOL || EPI == EPI_STORE)) {
         if (p.lgS == 4 && big_ok && (p.M % 256) == 0 && (cfg == 4 || (cfg == 0 && sgc_conv_halo() && (long)p.M * p.N >= 256L * 256 * 256)))
