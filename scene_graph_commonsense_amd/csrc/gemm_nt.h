@@ -113,6 +113,23 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x16 (&acc)[TM]
     }
 }
 
+// Tile walk order: the tiles_m x tiles_n grid is traversed in 16 x 16 super-tiles (N fastest inside a super-tile), so
+// the ~256 blocks in flight cover a square patch of the output: each A row-panel is shared by 16 blocks and each B
+// row-panel by 16 blocks through L2 / Infinity Cache.  With the plain "N fastest" order a GEMM with many N tiles
+// (fc1 data gradient: 126 x 256 tiles) re-streams the whole B operand from HBM for every M tile (63 GB per launch).
+__device__ __forceinline__ void supertile_map(int id, int tiles_m, int tiles_n, int& tm, int& tn) {
+    constexpr int GS = 16;
+    const int a = id / (GS * tiles_n);
+    const int hm = min(GS, tiles_m - a * GS);
+    const int id2 = id - a * GS * tiles_n;
+    const int sn = (tiles_n + GS - 1) / GS;
+    const int b = min(id2 / (hm * GS), sn - 1);
+    const int id3 = id2 - b * hm * GS;
+    const int wn = min(GS, tiles_n - b * GS);
+    tm = a * GS + id3 / wn;
+    tn = b * GS + id3 % wn;
+}
+
 // LDS-staged epilogue for 16-bit EPI_STORE outputs of the 8-wave 256x256 block (conv3 / fc1 / conv2 data gradients write
 // 4-9 GB per launch): the MFMA C layout gives each lane ONE column of 16 rows per tile, i.e. 2-byte global stores.  Here
 // each wave transposes its 128x64 sub-tile through its own 18 KiB LDS region (row pitch 144 B): neighbouring lanes swap a
@@ -170,7 +187,8 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void gemm_nt_kernel(const NtParams
     constexpr int AI = BM / (8 * NW), BI = BN / (8 * NW);      // global_load_lds instructions per wave per K tile
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tn = blockIdx.x % p.tiles_n, tm = blockIdx.x / p.tiles_n;
+    int tm, tn;
+    supertile_map(blockIdx.x, p.tiles_m, p.tiles_n, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
 
     // ---- loader addresses: wave w stages rows w*AI*8 .. of A and w*BI*8 .. of B, 8 rows (1 KiB) per instruction

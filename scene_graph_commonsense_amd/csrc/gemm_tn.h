@@ -36,13 +36,14 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void gemm_tn_kernel(const TnParams
     constexpr int APK = MB16 / 8, BPK = NB16 / 8;             // instructions per k block row
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // Work mapping: N tile fastest, then M tile, then K split.  Blocks that run concurrently sit at the same K
-    // position of neighbouring tiles, so their A/B rows are shared through L2.  (An XCD-grouped mapping - all N
-    // tiles of one (M tile, split) on one XCD - was measured 9 % slower on the conv3 weight gradient: the tail of
-    // each group starts out of phase with its head and re-fetches the slices.)
-    const int tn = blockIdx.x % p.tiles_n;
-    const int tm = (blockIdx.x / p.tiles_n) % p.tiles_m;
-    const int split = blockIdx.x / (p.tiles_n * p.tiles_m);
+    // Work mapping: K split slowest; inside a split the tile grid is walked in 16 x 16 super-tiles (supertile_map), so the
+    // blocks in flight sit at the same K position of a square patch of tiles and share their A/B rows through L2 / MALL.
+    // (An XCD-grouped mapping - all N tiles of one (M tile, split) on one XCD - was measured 9 % slower on the conv3
+    // weight gradient: the tail of each group starts out of phase with its head and re-fetches the slices.)
+    const int tiles = p.tiles_n * p.tiles_m;
+    const int split = blockIdx.x / tiles;
+    int tm, tn;
+    supertile_map(blockIdx.x - split * tiles, p.tiles_m, p.tiles_n, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
     const int kt_begin = split * p.ktiles_per_split;
     int kt_end = kt_begin + p.ktiles_per_split;
