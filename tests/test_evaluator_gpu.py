@@ -154,3 +154,65 @@ def test_evaluator_eval_cs_matches_reference(name):
     # tied -inf entries, and which of them land in it depends on the reference's unstable argsort (ties are resolved
     # by append order here).
     assert all(0.0 <= r <= 1.0 for r in ev.compute()[0])
+
+
+def test_reference_style_loop_on_dropin_modules():
+    """INTEGRATION.md mode A: the reference's own nested loops (restated here exactly as tests/golden/make_golden.py drives
+    the real reference) running on the drop-in classifier (per-step forward on pre-masked inputs), the drop-in
+    evaluate_one_direction and the drop-in evaluators; compared with the real reference's Evaluator outputs."""
+    from scene_graph_commonsense_amd.evaluator import Evaluator, Evaluator_Top3
+    from scene_graph_commonsense_amd.model import BayesianRelationClassifier
+    from scene_graph_commonsense_amd.train_utils import evaluate_one_direction
+    cfg, sd, batch, gold = load_case("vg_full_hit")
+    args = cfg.args(fixtures=FX)
+    model = BayesianRelationClassifier(args).cuda()
+    model.load_state_dict(sd)
+    model.eval()
+    Recall = Evaluator(args, cfg.num_relations, 0.5, [20, 50, 100])
+    Top3 = Evaluator_Top3(args, cfg.num_relations, 0.5, [20, 50, 100])
+    dev = "cuda:0"
+    feat, depth = batch.image_feature.to(dev), batch.image_depth.to(dev)
+    masks = []
+    for b in batch.bbox:
+        m = torch.zeros(b.shape[0], 32, 32, dtype=torch.bool, device=dev)
+        for j in range(b.shape[0]):
+            m[j, int(b[j][2]):int(b[j][3]), int(b[j][0]):int(b[j][1])] = 1
+        masks.append(m)
+    n_it = torch.as_tensor([len(m) for m in masks])
+    relations_target, direction_target = [], []
+    for g in range(int(n_it.max()) - 1):
+        keep = torch.nonzero(n_it - 1 > g).view(-1)
+        relations_target.append(torch.vstack([batch.relationships[i][g] for i in keep]).T.to(dev))
+        direction_target.append(torch.vstack([batch.subj_or_obj[i][g] for i in keep]).T.to(dev))
+    steps = []
+    for g in range(int(n_it.max())):
+        keep = torch.nonzero(n_it > g).view(-1).to(dev)
+        gm = torch.stack([masks[i][g].unsqueeze(0) for i in keep])
+        h_graph = torch.cat((feat[keep] * gm, depth[keep] * gm), dim=1)
+        cat_graph = torch.tensor([int(batch.categories[i][g]) for i in keep]).to(dev)
+        sp_graph = [batch.super_categories[i][g] for i in keep]
+        bb_graph = torch.stack([batch.bbox[i][g] for i in keep]).to(dev)
+        for e in range(g):
+            em = torch.stack([masks[i][e].unsqueeze(0) for i in keep])
+            h_edge = torch.cat((feat[keep] * em, depth[keep] * em), dim=1)
+            cat_edge = torch.tensor([int(batch.categories[i][e]) for i in keep]).to(dev)
+            sp_edge = [batch.super_categories[i][e] for i in keep]
+            bb_edge = torch.stack([batch.bbox[i][e] for i in keep]).to(dev)
+            j_or, j_and = torch.logical_or(gm, em), torch.logical_and(gm, em)
+            ratio = (j_or.sum(-1).sum(-1) / j_and.sum(-1).sum(-1)).flatten()
+            ratio[torch.isinf(ratio)] = 0
+            iou_mask = ratio > 0
+            if torch.sum(iou_mask) == 0:
+                continue
+            steps.append((g, e))
+            for first in (True, False):
+                a = (h_graph, h_edge, cat_graph, cat_edge, sp_graph, sp_edge, bb_graph, bb_edge) if first else \
+                    (h_edge, h_graph, cat_edge, cat_graph, sp_edge, sp_graph, bb_edge, bb_graph)
+                evaluate_one_direction(model, args, *a, iou_mask, 0, g, e, keep, Recall, Top3, relations_target,
+                                       direction_target, 0, 1, first_direction=first)
+    assert steps == [tuple(x) for x in gold["eval_steps"].tolist()]
+    np.testing.assert_array_equal(Recall.which_in_batch.cpu().numpy(), gold["ev_which_in_batch"])
+    np.testing.assert_array_equal(Recall.relation_target.cpu().numpy(), gold["ev_relation_target"])
+    res = Recall.compute(per_class=True)
+    np.testing.assert_allclose(np.array(res[0]), gold["ev_recall"], atol=0.1)
+    np.testing.assert_allclose(np.array(Top3.compute()[0]), gold["top3_recall"], atol=0.1)
