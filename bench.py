@@ -81,9 +81,9 @@ def main():
     ap.add_argument("--dataset", default="vg", choices=["vg", "oiv6"], help="oiv6 = 601 classes, (4,2,24) head, no super-classes")
     args = ap.parse_args()
 
-    rank, world, local = sgd_dist.init_from_env()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    rank, world, local = sgd_dist.init_from_env()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
