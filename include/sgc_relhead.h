@@ -79,6 +79,10 @@ int sgc_overlap_filter(const int* bbox, const int* sub_idx, const int* obj_idx, 
 int sgc_commonsense_filter(const long* scat, const long* pred, const long* ocat, float* conf, int n, const unsigned* aligned,
                            const unsigned* violated, int C, int R, void* stream);
 
+/* train_cs flags per candidate (train_utils.py:49-50): weak = triplet not in the aligned set, strong = in the violated set (f32 0/1). */
+int sgc_commonsense_flags(const long* scat, const long* ocat, const int* cand_pred, int n_pairs, int n_cand, const unsigned* aligned,
+                          const unsigned* violated, int C, int R, float* weak, float* strong, void* stream);
+
 /* ----------------------------------------------------------------------------------------------- backward */
 
 /* Forward expansion for training: writes z in f16 (conv3 forward operand) and bf16 (conv3 weight-gradient operand) and records
@@ -89,11 +93,13 @@ int sgc_pair_expand_train(const void* U, const void* V, const int* sub_idx, cons
 /* Loss + head backward per pair   (train_utils.py:64-94,116-157, utils.py:28-35 with the step weights of train_test.py:219-258 folded
  * into per-pair coefficients by the host): loss_i = -a*super[st] - b*rel[t] + c*BCE(conn, y).
  * W [64][512] f32 head rows; dl [n_pairs][64] dL/dlogits; loss [n_pairs]; dpre [n_pairs][512] bf16 = dL/d(fc2 pre-activation);
- * dp_extra (may be NULL) [n_pairs][512] f32 is added to dL/d(hidden) before the ReLU/dropout mask (contrastive term). */
+ * dp_extra (may be NULL) [n_pairs][512] f32 is added to dL/d(hidden) before the ReLU/dropout mask (contrastive term);
+ * cs_coef (may be NULL) [n_pairs][3|1] adds the train_cs penalty cs_coef * max softmax per candidate (train_utils.py:36-62),
+ * using the forward candidates cand_conf / cand_pred. */
 int sgc_head_loss_bwd(const float* rel, const float* sup, const float* conn, const float* p, const int* tgt, const float* coef_a,
                       const float* coef_b, const float* coef_c, const float* conn_y, const float* W, int n_pairs, int ng, int np, int ns,
                       int hier, float T1, float T2, float T3, float drop_scale, float* dl, float* loss, void* dpre, const float* dp_extra,
-                      void* stream);
+                      const float* cs_coef, const float* cand_conf, const int* cand_pred, void* stream);
 /* part [ceil(n_pairs/chunk)][64][513] f32 partial head weight (cols 0..511) and bias (col 512) gradients */
 int sgc_head_wgrad(const float* dl, const float* p, float* part, int n_pairs, int chunk, void* stream);
 

@@ -22,6 +22,7 @@ Reference map (all paths relative to the reference repo):
   relationship_loss        train_utils.py:116-157, utils.py:28-35
   direction_step_loss      train_utils.py:64-94
   run_pair_loop            train_test.py:174-258 (train) / :373-437 (test), train_utils.py:160-196
+  commonsense_step_loss    train_utils.py:36-62 (run_mode train_cs)
   supcon_hierar_loss       sup_contrast/losses.py:85-181 (SupConLossHierar, contrast_mode 'all')
   contrastive term         train_utils.py:28-29,96-99 (hidden/hidden_aug of connected pairs), train_test.py:260-273
   OracleEvaluator          evaluator.py:118-367, :568-583
@@ -163,6 +164,30 @@ def direction_step_loss(relation, super_relation, conn, rel_row, dir_row, first_
     return loss_rel, loss_conn, connected, not_connected
 
 
+def commonsense_step_loss(relation: Tensor, cat_sub: Tensor, cat_obj: Tensor, aligned, violated, ng: int, npos: int,
+                          hierarchical: bool = True, lambda_weak: float = 0.1, lambda_strong: float = 10.0):
+    """Penalty on the most confident prediction of every super-category when its (subject, predicate, object) triplet is
+    not in the aligned set (weak) / is in the violated set (strong); means over the flagged candidates of the step."""
+    if hierarchical:
+        segs = [(0, ng), (ng, ng + npos), (ng + npos, relation.shape[1])]
+        probs = torch.hstack([torch.max(F.softmax(relation[:, lo:hi], dim=1), dim=1)[0] for lo, hi in segs])
+        pred = torch.hstack([torch.argmax(relation[:, lo:hi], dim=1) + lo for lo, hi in segs])
+        trip = torch.hstack((cat_sub.repeat(3).unsqueeze(1), pred.unsqueeze(1), cat_obj.repeat(3).unsqueeze(1)))
+    else:
+        probs = torch.max(F.softmax(relation, dim=1), dim=1)[0]
+        pred = torch.argmax(relation, dim=1)
+        trip = torch.hstack((cat_sub.unsqueeze(1), pred.unsqueeze(1), cat_obj.unsqueeze(1)))
+    keys = [tuple(t.tolist()) for t in trip]
+    not_yes = torch.tensor([k not in aligned for k in keys], dtype=torch.bool)
+    in_no = torch.tensor([k in violated for k in keys], dtype=torch.bool)
+    loss = 0.0
+    if probs[not_yes].numel() > 0:
+        loss = loss + lambda_weak * probs[not_yes].mean()
+    if probs[in_no].numel() > 0:
+        loss = loss + lambda_strong * probs[in_no].mean()
+    return loss
+
+
 def supcon_hierar_loss(features: Tensor, labels: Tensor, temperature: float = 0.07, base_temperature: float = 0.07) -> Tensor:
     """features [M, 2, D] (original and augmented view), labels [M].  Positives: same label (other view included);
     denominator: every other sample under the same parent super-category (hard-coded 15 / 26 boundaries)."""
@@ -195,7 +220,7 @@ def run_pair_loop(sd: Dict[str, Tensor], batch, cfg, mode: str = "eval", evaluat
                   weights: Optional[Tensor] = None, lambda_connectivity: float = 0.1,
                   lambda_not_connected: float = 1.0, overlap_filtering: Optional[bool] = None,
                   max_steps: Optional[int] = None, step_filter=None, image_feature_aug: Optional[Tensor] = None,
-                  lambda_contrast: float = 1.0):
+                  lambda_contrast: float = 1.0, commonsense=None, lambda_commonsense: float = 1.0):
     """The reference's nested (graph_iter, edge_iter) x 2-direction loop.
 
     mode 'eval' mirrors ``testing()`` (overlap filter on, steps with no overlapping image skipped),
@@ -219,7 +244,7 @@ def run_pair_loop(sd: Dict[str, Tensor], batch, cfg, mode: str = "eval", evaluat
 
     records = []
     losses = 0.0
-    run_rel, run_conn = 0.0, 0.0
+    run_rel, run_conn, run_cs = 0.0, 0.0, 0.0      # commonsense = (aligned dict/set, violated dict/set) for run_mode train_cs
     nsteps = 0
     contrast = image_feature_aug is not None and mode == "train"
     hid_acc = [[] for _ in range(B)]       # per image: [2,512] stacks of (hidden, hidden_aug) of connected pairs
@@ -273,7 +298,9 @@ def run_pair_loop(sd: Dict[str, Tensor], batch, cfg, mode: str = "eval", evaluat
                                                                  npos, hier, lambda_not_connected)
                     run_rel = run_rel + lr_
                     run_conn = run_conn + lc_
-                    losses = losses + run_rel + lambda_connectivity * run_conn
+                    if commonsense is not None:
+                        run_cs = run_cs + commonsense_step_loss(relation, cs, co, commonsense[0], commonsense[1], ng, npos, hier)
+                    losses = losses + run_rel + lambda_connectivity * run_conn + lambda_commonsense * run_cs
                     if contrast and len(connected) > 0:
                         hsa, hoa = (h_graph_aug, h_edge_aug) if first else (h_edge_aug, h_graph_aug)
                         h_aug = conv_trunk(sd, hsa, hoa)

@@ -19,6 +19,8 @@ struct HeadBwdParams {
     int n_pairs, ng, np, ns, hier; float invT1, invT2, invT3; float drop_scale;
     float* dl; float* loss; u16* dpre;
     const float* dp_extra;     // optional [n_pairs][512]: extra dL/d(hidden) (supervised-contrastive term)
+    const float* cs_coef;      // optional [n_pairs][3 or 1]: commonsense penalty coefficient per candidate (train_cs)
+    const float* cand_conf; const int* cand_pred;   // forward candidates (max log-prob / logit and argmax per segment)
 };
 
 __device__ __forceinline__ float wave_max_f(float x) {
@@ -63,6 +65,20 @@ __global__ __launch_bounds__(256) void head_loss_bwd_kernel(const HeadBwdParams 
                 }
                 lossv += -a * sst - b * hp.rel[(long)pr * R + t];
             }
+            if (hp.cs_coef) {        // penalty kappa_s * max_r softmax(x_s / T_s): d/dx_r = kappa * pmax * ([r == argmax] - p_r) / T
+                const int seg = lane < hp.ng ? 0 : (lane < hp.ng + hp.np ? 1 : 2);
+#pragma unroll
+                for (int s2 = 0; s2 < 3; ++s2) {
+                    const float kap = hp.cs_coef[(long)pr * 3 + s2];
+                    if (kap == 0.f) continue;
+                    const float ss = hp.sup[(long)pr * 3 + s2];
+                    const float pmax = expf(hp.cand_conf[(long)pr * 3 + s2] - ss);
+                    const float invT = s2 == 0 ? hp.invT1 : (s2 == 1 ? hp.invT2 : hp.invT3);
+                    if (lane < R && seg == s2)
+                        dl += kap * invT * pmax * ((lane == hp.cand_pred[(long)pr * 3 + s2] ? 1.f : 0.f) - expf(hp.rel[(long)pr * R + lane] - ss));
+                    lossv += kap * pmax;
+                }
+            }
         } else {
             if (lane == R) dl = cc * (sig - y);
             if (t >= 0) {                                   // weighted cross-entropy on raw logits
@@ -73,6 +89,16 @@ __global__ __launch_bounds__(256) void head_loss_bwd_kernel(const HeadBwdParams 
                 if (lane < R) dl = b * (e / s - (lane == t ? 1.f : 0.f));
                 const float xt = hp.rel[(long)pr * R + t];
                 lossv += -b * (xt - m - logf(s));
+            }
+            if (hp.cs_coef && hp.cs_coef[pr] != 0.f) {
+                const float kap = hp.cs_coef[pr];
+                const float x = lane < R ? hp.rel[(long)pr * R + lane] : -INFINITY;
+                const float m = wave_max_f(x);
+                const float e = lane < R ? expf(x - m) : 0.f;
+                const float s = wave_sum_f(e);
+                const float pmax = 1.f / s;                       // exp(max - m) / s with max == m
+                if (lane < R) dl += kap * pmax * ((lane == hp.cand_pred[pr] ? 1.f : 0.f) - e / s);
+                lossv += kap * pmax;
             }
         }
         hp.dl[(long)pr * 64 + lane] = dl;
@@ -515,10 +541,11 @@ extern "C" {
 int sgc_head_loss_bwd(const float* rel, const float* sup, const float* conn, const float* p, const int* tgt,
                       const float* coef_a, const float* coef_b, const float* coef_c, const float* conn_y,
                       const float* W, int n_pairs, int ng, int np, int ns, int hier, float T1, float T2, float T3,
-                      float drop_scale, float* dl, float* loss, void* dpre, const float* dp_extra, void* stream) {
+                      float drop_scale, float* dl, float* loss, void* dpre, const float* dp_extra, const float* cs_coef,
+                      const float* cand_conf, const int* cand_pred, void* stream) {
     if (n_pairs <= 0) return SGC_OK;
     HeadBwdParams hp{rel, sup, conn, p, tgt, coef_a, coef_b, coef_c, conn_y, W, n_pairs, ng, np, ns, hier,
-                     1.f / T1, 1.f / T2, 1.f / T3, drop_scale, dl, loss, (u16*)dpre, dp_extra};
+                     1.f / T1, 1.f / T2, 1.f / T3, drop_scale, dl, loss, (u16*)dpre, dp_extra, cs_coef, cand_conf, cand_pred};
     const int lds = (64 * 512 + 4 * 64) * 4;
     static bool attr_set = false;
     if (!attr_set) {

@@ -126,7 +126,36 @@ __global__ void commonsense_filter_kernel(const long* __restrict__ scat, const l
     if (!keep) conf[i] = -INFINITY;
 }
 
+// train_cs (reference train_utils.py:36-50): per candidate (pair, super-category) flags "triplet not in the aligned set"
+// (weak penalty) and "triplet in the violated set" (strong penalty).  cand_pred [n_pairs][n_cand] int32.
+__global__ void commonsense_flags_kernel(const long* __restrict__ scat, const long* __restrict__ ocat, const int* __restrict__ cand_pred,
+                                         int n_pairs, int n_cand, const unsigned* __restrict__ aligned,
+                                         const unsigned* __restrict__ violated, int C, int R, float* __restrict__ weak,
+                                         float* __restrict__ strong) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_pairs * n_cand) return;
+    const int pr = i / n_cand;
+    const long s = scat[pr], o = ocat[pr], r = cand_pred[i];
+    bool in_yes = false, in_no = false;
+    if (s >= 0 && s < C && o >= 0 && o < C && r >= 0 && r < R) {
+        const long bit = (s * R + r) * C + o;
+        in_yes = (aligned[bit >> 5] >> (bit & 31)) & 1u;
+        in_no = (violated[bit >> 5] >> (bit & 31)) & 1u;
+    }
+    weak[i] = in_yes ? 0.f : 1.f;
+    strong[i] = in_no ? 1.f : 0.f;
+}
+
 extern "C" {
+
+int sgc_commonsense_flags(const long* scat, const long* ocat, const int* cand_pred, int n_pairs, int n_cand, const unsigned* aligned,
+                          const unsigned* violated, int C, int R, float* weak, float* strong, void* stream) {
+    if (n_pairs <= 0) return SGC_OK;
+    SGC_LAUNCH(commonsense_flags_kernel, dim3((n_pairs * n_cand + 255) / 256), dim3(256), 0, (hipStream_t)stream, scat, ocat, cand_pred,
+               n_pairs, n_cand, aligned, violated, C, R, weak, strong);
+    SGC_CHECK_LAUNCH();
+    return SGC_OK;
+}
 
 int sgc_commonsense_filter(const long* scat, const long* pred, const long* ocat, float* conf, int n, const unsigned* aligned,
                            const unsigned* violated, int C, int R, void* stream) {

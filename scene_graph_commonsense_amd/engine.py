@@ -387,7 +387,8 @@ class RelHeadEngine:
         return ctx
 
 
-    def train_backward(self, ctx: "TrainContext", coefs, sub_csr, obj_csr, img_ptr, splits=8, grad_hook=None, dp_extra=None):
+    def train_backward(self, ctx: "TrainContext", coefs, sub_csr, obj_csr, img_ptr, splits=8, grad_hook=None, dp_extra=None,
+                       cs_coef=None):
         """Backward of the whole path.  Returns (loss scalar tensor, {reference parameter name: f32 gradient})."""
         lib, ws, cfg, dev, w = self.lib, self.ws, self.cfg, self.device, self.w
         P, Ppad, n_obj, n_img = ctx.P, ctx.Ppad, ctx.n_obj, ctx.n_img
@@ -412,7 +413,8 @@ class RelHeadEngine:
                                          _lib.ptr(w["head_w"]), P, cfg.num_geometric if hier else R,
                                          cfg.num_possessive if hier else 0, cfg.num_semantic if hier else 0, int(hier),
                                          f(T[0]), f(T[1]), f(T[2]), f(scale), _lib.ptr(dl), _lib.ptr(loss_i), _lib.ptr(dpre),
-                                         _lib.ptr(dp_extra), st()),
+                                         _lib.ptr(dp_extra), _lib.ptr(cs_coef), _lib.ptr(ctx.out.cand_conf),
+                                         _lib.ptr(ctx.out.cand_pred), st()),
                    "sgc_head_loss_bwd")
         loss = loss_i.sum() if P > 0 else torch.zeros((), device=dev)      # P scalars: host-side glue
         chunk = max(16, (P + 255) // 256)
@@ -521,6 +523,23 @@ class RelHeadEngine:
         grads["conv2_1.weight"] = gc2
         return loss, grads
 
+
+    def commonsense_coefficients(self, ctx: "TrainContext", bitmaps, step: torch.Tensor, n_steps: int, scat: torch.Tensor,
+                                 ocat: torch.Tensor, lambda_commonsense=1.0, lambda_weak=0.1, lambda_strong=10.0):
+        """Per-candidate coefficients of the train_cs penalty (train_utils.py:36-62 + the running-sum step weights of
+        train_test.py:219-233): kappa = (T - t) * lambda_cs * (lambda_weak * weak / #weak_t + lambda_strong * strong / #strong_t)."""
+        P = ctx.P
+        nc = int(ctx.out.cand_pred.shape[1])
+        weak = torch.empty(P, nc, dtype=torch.float32, device=self.device)
+        strong = torch.empty(P, nc, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.sgc_commonsense_flags(_lib.ptr(scat), _lib.ptr(ocat), _lib.ptr(ctx.out.cand_pred), P, nc,
+                                                  _lib.ptr(bitmaps.aligned), _lib.ptr(bitmaps.violated), bitmaps.C, bitmaps.R,
+                                                  _lib.ptr(weak), _lib.ptr(strong), self._st()), "sgc_commonsense_flags")
+        cw = torch.zeros(n_steps, device=self.device).index_add_(0, step, weak.sum(1))        # tiny host-side glue
+        cs = torch.zeros(n_steps, device=self.device).index_add_(0, step, strong.sum(1))
+        wt = (n_steps - step).float()[:, None] * lambda_commonsense
+        kap = wt * (lambda_weak * weak / cw.clamp(min=1)[step][:, None] + lambda_strong * strong / cs.clamp(min=1)[step][:, None])
+        return kap.contiguous()
 
     def supcon_loss(self, feats: torch.Tensor, labels: torch.Tensor, grad_scale: float = 1.0, temperature: float = 0.07):
         """SupConLossHierar on feats [2M,512] f32 (view 0 rows then view 1 rows), labels [M] int32.

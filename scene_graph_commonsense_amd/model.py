@@ -110,13 +110,15 @@ class _RelationBase(nn.Module):
 
     def training_step(self, scene: DeviceScene, relationships=None, subj_or_obj=None, directed: Optional[np.ndarray] = None,
                       lambda_connectivity: float = 0.1, lambda_not_connected: float = 1.0, class_weight=None,
-                      grad_hook=None, image_feature_aug: Optional[torch.Tensor] = None, lambda_contrast: float = 1.0):
+                      grad_hook=None, image_feature_aug: Optional[torch.Tensor] = None, lambda_contrast: float = 1.0,
+                      commonsense=None, lambda_commonsense: float = 1.0, lambda_cs_weak: float = 0.1,
+                      lambda_cs_strong: float = 10.0):
         """Forward + loss + backward over all ordered pairs; gradients land in ``param.grad`` (accumulating like
         autograd).  Loss follows ``train_test.py:189-258`` / ``train_utils.py:64-157`` (hierarchical NLL, BCE on
         connectivity, running-sum step weights).  With ``image_feature_aug`` (DETR features of the colour-jittered view,
         ``train_test.py:154``) the supervised-contrastive term of ``train_test.py:260-273`` is added: the augmented trunk
         is run ONLY for the connected pairs (the only ones the loss reads; the reference runs it for every pair).
-        The commonsense term (train_cs) is out of scope."""
+        ``commonsense=(aligned_keys, violated_keys)`` adds the train_cs penalty of ``train_utils.py:36-62``."""
         cfg = self.head_config()
         eng = self.refresh_weights(backward=True)
         pidx = scene.pidx
@@ -140,6 +142,16 @@ class _RelationBase(nn.Module):
                                     scene.super_mh, scene.sub_idx, scene.obj_idx,
                                     seeds=self._next_seeds() if self.training else (0, 0), dropout=self.training,
                                     dense=_dense(scene))
+            cs_coef = None
+            if commonsense is not None:
+                from .commonsense import TripletBitmaps
+                if getattr(self, "_cs_bitmaps", None) is None or self._cs_bitmaps[0] is not commonsense:
+                    self._cs_bitmaps = (commonsense, TripletBitmaps(commonsense[0], commonsense[1], cfg.num_classes,
+                                                                    cfg.num_relations, dev))
+                step_d = torch.from_numpy(pidx.step).to(dev)
+                cs_coef = eng.commonsense_coefficients(ctx, self._cs_bitmaps[1], step_d, len(pidx.call_sizes),
+                                                       scene.cats[scene.sub_idx.long()], scene.cats[scene.obj_idx.long()],
+                                                       lambda_commonsense, lambda_cs_weak, lambda_cs_strong)
             dp_main = None
             extra = None
             loss_c = None
@@ -148,7 +160,8 @@ class _RelationBase(nn.Module):
                 extra = self._contrast_forward(eng, scene, image_feature_aug, conn_idx, directed, ctx, lambda_contrast)
                 loss_c, dp_main = extra["loss"], extra["dp_main"]
             loss, grads = eng.train_backward(ctx, coefs_d, sub_csr, obj_csr, img_ptr,
-                                             grad_hook=grad_hook if extra is None else None, dp_extra=dp_main)
+                                             grad_hook=grad_hook if extra is None else None, dp_extra=dp_main,
+                                             cs_coef=cs_coef)
             if extra is not None:
                 eng_a = extra["engine"]
                 _, grads_a = eng_a.train_backward(extra["ctx"], extra["coefs"], extra["sub_csr"], extra["obj_csr"], img_ptr,

@@ -312,6 +312,78 @@ def aug_features(batch, seed):
     return 0.9 * f + 0.3 * noise
 
 
+def run_traincs_case(name, ref_model, ref_train, ref_eval):
+    """Training loss with the commonsense penalty (run_mode train_cs, train_utils.py:36-62) -> <name>_traincs.npz."""
+    kw, nobj, seed, gain, cfrac, edge = CASES[name]
+    cfg = HeadConfig(**kw)
+    targs = ref_args(cfg)
+    targs["training"]["run_mode"] = "train_cs"
+    targs["training"]["eval_freq"] = 10 ** 9
+    sd = make_state_dict(cfg, seed=seed, head_gain=gain)
+    batch = make_scene_batch(cfg, nobj, seed=seed, connect_frac=cfrac, edge_boxes=edge)
+    if name.endswith("_hit"):
+        gold = dict(np.load(os.path.join(HERE, name + ".npz")))
+        for b, n in enumerate(nobj):
+            for g in range(1, n):
+                batch.relationships[b][g - 1] = torch.from_numpy(gold["tgt_rel_%d_%d" % (b, g)])
+                batch.subj_or_obj[b][g - 1] = torch.from_numpy(gold["tgt_dir_%d_%d" % (b, g)])
+    aligned = torch.load(os.path.join(REF, "triplets/commonsense_aligned_triplets.pt"))
+    violated = torch.load(os.path.join(REF, "triplets/commonsense_violated_triplets.pt"))
+    model = build_ref_model(ref_model, cfg, targs, sd)
+    masks = ref_masks(batch.bbox, cfg.feature_size)
+    relations_target, direction_target = targets(batch, masks)
+    counts = predicate_counts(cfg)
+    class_weight = 1 - counts / torch.sum(counts)
+    ng, npos = cfg.num_geometric, cfg.num_possessive
+    crit = [torch.nn.NLLLoss(weight=class_weight[:ng]), torch.nn.NLLLoss(weight=class_weight[ng:ng + npos]),
+            torch.nn.NLLLoss(weight=class_weight[ng + npos:]), torch.nn.NLLLoss()]
+    crit_conn = torch.nn.BCEWithLogitsLoss()
+    model.zero_grad()
+    B = len(nobj)
+    hid_acc = [[] for _ in range(B)]
+    hid_lab = [[] for _ in range(B)]
+    losses, loss_connectivity, loss_relationship, loss_commonsense = 0.0, 0.0, 0.0, 0.0
+    num_graph_iter = torch.as_tensor([len(m) for m in masks])
+    for g in range(max(num_graph_iter)):
+        keep = torch.nonzero(num_graph_iter > g).view(-1)
+        gm = torch.stack([torch.unsqueeze(masks[i][g], dim=0) for i in keep])
+        h_graph = torch.cat((batch.image_feature[keep] * gm, batch.image_depth[keep] * gm), dim=1)
+        cat_graph = torch.tensor([torch.unsqueeze(batch.categories[i][g], dim=0) for i in keep])
+        sp_graph = [batch.super_categories[i][g] for i in keep]
+        bb_graph = torch.stack([batch.bbox[i][g] for i in keep])
+        for e in range(g):
+            em = torch.stack([torch.unsqueeze(masks[i][e], dim=0) for i in keep])
+            h_edge = torch.cat((batch.image_feature[keep] * em, batch.image_depth[keep] * em), dim=1)
+            cat_edge = torch.tensor([torch.unsqueeze(batch.categories[i][e], dim=0) for i in keep])
+            sp_edge = [batch.super_categories[i][e] for i in keep]
+            bb_edge = torch.stack([batch.bbox[i][e] for i in keep])
+            iou_mask = torch.ones(len(keep), dtype=torch.bool)
+            for first in (True, False):
+                hs, ho = (h_graph, h_edge) if first else (h_edge, h_graph)
+                cs, co = (cat_graph, cat_edge) if first else (cat_edge, cat_graph)
+                ss, so = (sp_graph, sp_edge) if first else (sp_edge, sp_graph)
+                bs, bo = (bb_graph, bb_edge) if first else (bb_edge, bb_graph)
+                r = ref_train.train_one_direction(model, targs, hs, ho, cs, co, ss, so, bs, bo, hs, ho, iou_mask, "cpu", g, e,
+                                                  keep, None, None, crit, crit_conn, relations_target, direction_target, 1,
+                                                  hid_acc, hid_lab, aligned, violated, 10 ** 6, first_direction=first)
+                hid_acc, hid_lab = r[8], r[9]
+                loss_relationship += r[0]
+                loss_connectivity += r[1]
+                loss_commonsense += r[2]
+                losses += loss_relationship + targs["training"]["lambda_connectivity"] * loss_connectivity \
+                    + targs["training"]["lambda_commonsense"] * loss_commonsense
+    out = {"traincs_loss": np.array([float(losses)]), "traincs_commonsense_sum": np.array([float(loss_commonsense)])}
+    losses.backward()
+    for pname, p in model.named_parameters():
+        gflat = p.grad.detach().flatten()
+        stride = max(1, gflat.numel() // 509)
+        key = pname.replace(".", "__")
+        out["gradcs_l2__" + key] = np.array([float(gflat.double().norm())])
+        out["gradcs_sample__" + key] = gflat[::stride][:509].numpy().copy()
+    np.savez_compressed(os.path.join(HERE, name + "_traincs.npz"), **out)
+    print(name, "train_cs: loss", float(losses), "commonsense running sum", float(loss_commonsense))
+
+
 def run_contrast_case(name, ref_model, ref_train, ref_eval):
     """Training loss INCLUDING the supervised-contrastive term (train_test.py:189-273 with a distinct augmented view)
     -> <name>_contrast.npz: total loss, contrastive loss, gradient fingerprints."""
@@ -443,6 +515,9 @@ if __name__ == "__main__":
     if argv and argv[0] == "--cs":
         for nm in argv[1:]:
             run_cs_case(nm, *mods)
+    elif argv and argv[0] == "--traincs":
+        for nm in argv[1:]:
+            run_traincs_case(nm, *mods)
     elif argv and argv[0] == "--contrast":
         for nm in argv[1:]:
             run_contrast_case(nm, *mods)

@@ -154,3 +154,85 @@ def test_contrastive_training_step_matches_reference(name):
         samp, ref = flat[::stride][:509].double().numpy(), gold["gradc_sample__" + key].astype(np.float64)
         err = np.linalg.norm(samp - ref) / max(np.linalg.norm(ref), 1e-30)
         assert err <= 2 * _tol(n), (n, err)
+
+
+def test_train_cs_step_matches_reference():
+    """Training step with the commonsense penalty (run_mode train_cs) against the reference's loss / gradient fingerprints."""
+    import os
+    from scene_graph_commonsense_amd.model import BayesianRelationClassifier
+    from scene_graph_commonsense_amd.pairs import flatten_scene
+    from tests.golden_cases import GOLDEN
+    name = "vg_full_hit"
+    gold = dict(np.load(os.path.join(GOLDEN, name + "_traincs.npz")))
+    fx = os.path.join(GOLDEN, "ref_fixtures") + os.sep
+    aligned = torch.load(fx + "commonsense_aligned_triplets.pt")
+    violated = torch.load(fx + "commonsense_violated_triplets.pt")
+    cfg, sd, batch, _ = load_case(name)
+    model = BayesianRelationClassifier(cfg.args()).cuda()
+    model.load_state_dict(sd)
+    model.eval()
+    sc = flatten_scene(cfg, batch, "cuda:0")
+    loss = model.training_step(sc, batch.relationships, batch.subj_or_obj, commonsense=(list(aligned.keys()), list(violated.keys())))
+    torch.cuda.synchronize()
+    print("train_cs loss", float(loss), gold["traincs_loss"][0])
+    assert abs(float(loss) - gold["traincs_loss"][0]) <= 2e-3 * abs(gold["traincs_loss"][0])
+    for n, p in model.named_parameters():
+        key = n.replace(".", "__")
+        flat = p.grad.flatten().float().cpu()
+        stride = max(1, flat.numel() // 509)
+        ref_l2 = gold["gradcs_l2__" + key][0]
+        assert abs(float(flat.double().norm()) - ref_l2) <= _tol(n) * ref_l2, (n, float(flat.norm()), ref_l2)
+        samp, ref = flat[::stride][:509].double().numpy(), gold["gradcs_sample__" + key].astype(np.float64)
+        err = np.linalg.norm(samp - ref) / max(np.linalg.norm(ref), 1e-30)
+        assert err <= 2 * _tol(n), (n, err)
+
+
+def test_commonsense_penalty_alone_matches_oracle():
+    """Only the train_cs penalty is active (no connected pair, lambda_connectivity = 0): loss and head gradients must match
+    the oracle tightly - this isolates the max-softmax gradient and the per-step mean / running-sum coefficients."""
+    import os
+    from oracle import relhead_oracle as O
+    from scene_graph_commonsense_amd.model import BayesianRelationClassifier
+    from scene_graph_commonsense_amd.pairs import flatten_scene
+    from scene_graph_commonsense_amd.synthetic import HeadConfig, make_scene_batch, make_state_dict, predicate_counts
+    from tests.golden_cases import GOLDEN
+    fx = os.path.join(GOLDEN, "ref_fixtures") + os.sep
+    aligned = torch.load(fx + "commonsense_aligned_triplets.pt")
+    violated = torch.load(fx + "commonsense_violated_triplets.pt")
+    for hier in (True, False):
+        cfg = HeadConfig(hierarchical=hier)
+        sd = make_state_dict(cfg, seed=31, head_gain=5.0)
+        batch = make_scene_batch(cfg, (4, 3), seed=31, connect_frac=0.0)
+        # make a few triplets aligned / violated so that both penalties and the "aligned -> no penalty" case occur
+        al = dict(aligned); vi = dict(violated)
+        if hier:
+            from scene_graph_commonsense_amd.model import BayesianRelationClassifier as M
+        else:
+            from scene_graph_commonsense_amd.model import FlatRelationClassifier as M
+        model = (M(cfg.args()) if hier else M(cfg.args(), output_dim=cfg.num_relations)).cuda()
+        model.load_state_dict(sd)
+        model.eval()
+        sc = flatten_scene(cfg, batch, "cuda:0")
+        out0 = model.forward_pairs(sc)
+        pred = out0.cand_pred.cpu().numpy()
+        cats = sc.cats.cpu().numpy()
+        for k in range(0, sc.pidx.n_pairs, 3):                       # every third pair: first candidate aligned
+            al[(int(cats[sc.pidx.sub[k]]), int(pred[k, 0]), int(cats[sc.pidx.obj[k]]))] = 1
+        for k in range(1, sc.pidx.n_pairs, 4):                       # every fourth: last candidate violated
+            vi[(int(cats[sc.pidx.sub[k]]), int(pred[k, -1]), int(cats[sc.pidx.obj[k]]))] = 1
+        loss = model.training_step(sc, batch.relationships, batch.subj_or_obj, lambda_connectivity=0.0,
+                                   commonsense=(list(al.keys()), list(vi.keys())))
+        torch.cuda.synchronize()
+        sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        ref = O.run_pair_loop(sdr, batch, cfg, mode="train", weights=O.class_weights(predicate_counts(cfg)),
+                              lambda_connectivity=0.0, commonsense=(al, vi))
+        ref["losses"].backward()
+        print("cs-only loss", float(loss), float(ref["losses"]))
+        assert abs(float(loss) - float(ref["losses"])) <= 1e-3 * abs(float(ref["losses"]))
+        for n, p in model.named_parameters():
+            if n.split(".")[0] in ("fc3", "fc3_1", "fc3_2", "fc3_3"):
+                e = _fro(p.grad.float().cpu(), sdr[n].grad)
+                assert e <= HEAD_TOL, (n, e)
+            if n == "fc5.weight":      # softmax is shift invariant: the super-category head gets no gradient (autograd: round-off)
+                assert float(p.grad.abs().max()) == 0.0
+                assert float(sdr[n].grad.norm()) <= 1e-4 * float(sdr["fc3_1.weight"].grad.norm())

@@ -152,3 +152,27 @@ def _check_contrast(name):
 def test_oracle_contrastive_small(name):
     """Supervised-contrastive branch (second augmented view + SupConLossHierar) against the reference."""
     _check_contrast(name)
+
+
+@pytest.mark.parametrize("name", SMALL)
+def test_oracle_train_cs_small(name):
+    """Training loss with the commonsense penalty (run_mode train_cs) against the reference."""
+    import os
+    from tests.golden_cases import GOLDEN
+    cfg, sd, batch, _ = load_case(name)
+    gold = dict(np.load(os.path.join(GOLDEN, name + "_traincs.npz")))
+    fx = os.path.join(GOLDEN, "ref_fixtures") + os.sep
+    aligned = torch.load(fx + "commonsense_aligned_triplets.pt")
+    violated = torch.load(fx + "commonsense_violated_triplets.pt")
+    sd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    out = O.run_pair_loop(sd, batch, cfg, mode="train", weights=O.class_weights(predicate_counts(cfg)),
+                          commonsense=(aligned, violated))
+    np.testing.assert_allclose(float(out["losses"]), gold["traincs_loss"][0], rtol=1e-5)
+    out["losses"].backward()
+    for pname, p in sd.items():
+        g = p.grad.flatten()
+        key = pname.replace(".", "__")
+        stride = max(1, g.numel() // 509)
+        ref_l2 = gold["gradcs_l2__" + key][0]
+        np.testing.assert_allclose(float(g.double().norm()), ref_l2, rtol=1e-4)
+        np.testing.assert_allclose(g[::stride][:509].numpy(), gold["gradcs_sample__" + key], rtol=1e-3, atol=1e-5 * max(ref_l2, 1e-12))
