@@ -27,6 +27,7 @@ __device__ __forceinline__ u16 f32_to_bf16_bits(float f) {
 }
 __device__ __forceinline__ float bf16_bits_to_f32(u16 h) { return __uint_as_float(((uint32_t)h) << 16); }
 __device__ __forceinline__ u16 f32_to_f16_bits(float f) {
+    f = fminf(fmaxf(f, -65504.f), 65504.f);        // saturate instead of overflowing to inf (NaN passes through)
     f16 h = (f16)f;
     return *reinterpret_cast<u16*>(&h);
 }

@@ -98,6 +98,12 @@ class _RelationBase(nn.Module):
         """All ordered pairs of a minibatch in one pass (eval numerics unless ``self.training``)."""
         eng = self.refresh_weights()
         seeds = self._next_seeds() if self.training else (0, 0)
+        if scene.pidx.n_pairs == 0:
+            cfg, dev = self.head_config(), eng.device
+            nc = 3 if cfg.hierarchical else 1
+            z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device=dev)
+            return PairOutputs(z(0, cfg.num_relations), z(0, 3) if cfg.hierarchical else None, z(0), z(0, 512), z(0, nc),
+                               z(0, nc, dt=torch.int32))
         with torch.no_grad():
             return eng.forward_pairs(scene.image_feature, scene.image_depth, scene.obj_img, scene.bbox, scene.cats,
                                      scene.super_mh, scene.sub_idx, scene.obj_idx, train=self.training, seeds=seeds,
@@ -123,6 +129,12 @@ class _RelationBase(nn.Module):
         eng = self.refresh_weights(backward=True)
         pidx = scene.pidx
         dev = eng.device
+        if pidx.n_pairs == 0:                      # no image with two objects: nothing to score, zero loss and gradients
+            for p in self.parameters():
+                if p.grad is None:
+                    p.grad = torch.zeros_like(p)
+            self.last_outputs = None
+            return torch.zeros((), device=dev)
         if directed is None:
             directed = pair_targets_fast(relationships, subj_or_obj, pidx)
         if class_weight is None:

@@ -159,3 +159,24 @@ def test_backward_is_linear_in_the_loss_coefficients_and_configs_run():
         # connectivity-only parameters scale exactly with lambda (fc4 sees only the BCE term)
         r = grads[1]["fc4.weight"].norm() / grads[0]["fc4.weight"].norm()
         assert abs(float(r) - 2.0) < 1e-3
+
+
+def test_degenerate_batches():
+    """Images with a single object contribute no pair; a batch without any pair is a no-op; ragged batches work."""
+    from scene_graph_commonsense_amd.pair_loop import evaluate_minibatch
+    from scene_graph_commonsense_amd.pairs import flatten_scene
+    from scene_graph_commonsense_amd.synthetic import HeadConfig, make_scene_batch
+    cfg = HeadConfig()
+    model = _model(cfg)
+    for nobj, expect in (((1, 3, 1), 6), ((2,), 2), ((1, 1), 0)):
+        batch = make_scene_batch(cfg, nobj, seed=3, connect_frac=0.5)
+        sc = flatten_scene(cfg, batch, "cuda:0")
+        assert sc.pidx.n_pairs == expect
+        out = model.forward_pairs(sc)
+        assert out.relation.shape[0] == expect and torch.isfinite(out.relation).all()
+        model.zero_grad(set_to_none=True)
+        loss = model.training_step(sc, batch.relationships, batch.subj_or_obj)
+        assert torch.isfinite(loss)
+        assert all(torch.isfinite(p.grad).all() for p in model.parameters())
+        if expect:
+            evaluate_minibatch(model, batch, overlap_filtering=True, scene=sc)
