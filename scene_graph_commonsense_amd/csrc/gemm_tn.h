@@ -133,7 +133,9 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void gemm_tn_kernel(const TnParams
         const char* bb = ab + A_BYTES;
         // The compiler groups the 12 transpose reads of a k-step ahead of its 8 MFMAs.  Forcing a finer
         // read/MFMA interleave with sched_group_barrier was measured 8 % SLOWER on the conv3 weight gradient
-        // (84.3 vs 77.8 ms), so the schedule is left to hipcc.
+        // (84.3 vs 77.8 ms); a register double buffer that pins the reads of k-step ks+1 ahead of the MFMAs of k-step ks
+        // was neutral (74.4 vs 74.3 ms): the kernel is bound by the L2->LDS stream, not by LDS-read latency.  The schedule
+        // is left to hipcc.
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int kb = ks * 4 + kh * 2;          // first of two 4-row k blocks
