@@ -1,0 +1,52 @@
+"""Two data-parallel ranks sharing the one GPU of the test box (gloo transport, CUDA tensors): the gradients that
+``train_minibatch`` + ``GradReducer`` leave in ``param.grad`` must equal the mean of the ranks' local gradients,
+including the early (asynchronous) fc1.weight reduction.  RCCL itself needs one GPU per rank and is exercised by the
+driver's multi-GPU bench; this test pins the integration logic."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    from scene_graph_commonsense_amd import distributed as D
+    from scene_graph_commonsense_amd.model import BayesianRelationClassifier
+    from scene_graph_commonsense_amd.pair_loop import train_minibatch
+    from scene_graph_commonsense_amd.synthetic import HeadConfig, make_scene_batch, make_state_dict
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg = HeadConfig()
+    model = BayesianRelationClassifier(cfg.args()).cuda()
+    model.load_state_dict(make_state_dict(cfg, seed=5, head_gain=4.0))
+    model.eval()
+    batch = make_scene_batch(cfg, (3, 2), seed=100 + rank, connect_frac=0.6)      # every rank its own images
+    train_minibatch(model, batch)                                                 # local gradients
+    local = {n: p.grad.clone() for n, p in model.named_parameters()}
+    model.zero_grad(set_to_none=True)
+    train_minibatch(model, batch, reducer=D.GradReducer(world))                   # reduced gradients
+    worst = 0.0
+    for n, p in model.named_parameters():
+        gathered = [torch.empty_like(local[n]) for _ in range(world)]
+        dist.all_gather(gathered, local[n].contiguous())
+        mean = torch.stack(gathered).mean(0)
+        err = float((p.grad - mean).abs().max() / mean.abs().max().clamp(min=1e-30))
+        worst = max(worst, err)
+    q.put((rank, worst))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_mean_gradients_on_one_gpu():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + (os.getpid() % 1000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = sorted(q.get(timeout=600) for _ in range(2))
+    [p.join(120) for p in procs]
+    for rank, worst in res:
+        assert worst <= 1e-5, (rank, worst)
