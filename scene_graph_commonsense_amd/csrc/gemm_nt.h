@@ -15,6 +15,7 @@
 //    max-pool + argmax, one-hot label columns of fc2 as a per-object row gather, ReLU-mask for dgrad).
 #pragma once
 #include "common.h"
+#include <type_traits>
 
 enum { AMODE_PLAIN = 0, AMODE_CONV = 1 };
 enum { EPI_STORE = 0, EPI_BIAS_TANH = 1, EPI_BIAS_RELU = 2, EPI_POOL = 3, EPI_FC2 = 4, EPI_RELUMASK = 5 };
@@ -128,6 +129,18 @@ __device__ __forceinline__ void supertile_map(int id, int tiles_m, int tiles_n, 
     const int wn = min(GS, tiles_n - b * GS);
     tm = a * GS + id3 / wn;
     tn = b * GS + id3 % wn;
+}
+
+__device__ __forceinline__ void supertile_map_g(int id, int tiles_m, int tiles_n, int GM, int GN, int& tm, int& tn) {
+    const int a = id / (GM * tiles_n);
+    const int hm = min(GM, tiles_m - a * GM);
+    const int id2 = id - a * GM * tiles_n;
+    const int sn = (tiles_n + GN - 1) / GN;
+    const int b = min(id2 / (hm * GN), sn - 1);
+    const int id3 = id2 - b * hm * GN;
+    const int wn = min(GN, tiles_n - b * GN);
+    tm = a * GM + id3 / wn;
+    tn = b * GN + id3 % wn;
 }
 
 // LDS-staged epilogue for 16-bit EPI_STORE outputs of the 8-wave 256x256 block (conv3 / fc1 / conv2 data gradients write
@@ -295,7 +308,7 @@ inline int sgc_gemm_ring() {      // SGC_GEMM_RING=1 selects the 4-stage ring ke
     return v;
 }
 
-inline int sgc_gemm_cfg() {       // test hook: SGC_GEMM_CFG=1 forces the 128x128 block, =2 the 2-stage 256x256 block, =3 the 4-stage ring, =4 the halo-staged conv
+inline int sgc_gemm_cfg() {       // test hook: SGC_GEMM_CFG=1 forces the 128x128 block, =2 the 2-stage 256x256 block, =3 the 4-stage ring, =4 the halo-staged conv (2-stage), =5 the ping-pong plain block, =7 the ping-pong halo conv
     static int cfg = -1;
     if (cfg < 0) { const char* e = getenv("SGC_GEMM_CFG"); cfg = e ? atoi(e) : 0; }
     return cfg;
@@ -584,6 +597,14 @@ static int launch_conv16_halo(NtParams p, hipStream_t stream) {
     return SGC_OK;
 }
 
+#include "gemm_nt_pp.h"
+
+inline int sgc_gemm_pp() {        // SGC_GEMM_PP=0 falls back to the 2-stage 256x256 loops (A/B hook)
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("SGC_GEMM_PP"); v = e ? atoi(e) : 1; }
+    return v;
+}
+
 inline int sgc_conv_halo() {      // SGC_CONV_HALO=0 falls back to the plain implicit GEMM (A/B hook)
     static int v = -1;
     if (v < 0) { const char* e = getenv("SGC_CONV_HALO"); v = e ? atoi(e) : 1; }
@@ -603,11 +624,16 @@ static int launch_gemm_nt(NtParams p, hipStream_t stream) {
     }
     const bool big_ok = (p.N % 256) == 0;
     if constexpr (AMODE == AMODE_CONV && (EPI == EPI_POOL || EPI == EPI_STORE)) {
-        if (p.lgS == 4 && big_ok && (p.M % 256) == 0 && (cfg == 4 || (cfg == 0 && sgc_conv_halo() && (long)p.M * p.N >= 256L * 256 * 256)))
+        if (p.lgS == 4 && big_ok && (p.M % 256) == 0 && (cfg == 4 || cfg == 7 || (cfg == 0 && sgc_conv_halo() && (long)p.M * p.N >= 256L * 256 * 256))) {
+            if (cfg == 7 || (cfg == 0 && sgc_gemm_pp())) return launch_conv16_halo_pp<ELEM, EPI>(p, stream);
             return launch_conv16_halo<ELEM, EPI>(p, stream);
+        }
     }
     const bool big = big_ok && (cfg == 2 || cfg == 3 || (cfg == 0 && (long)p.M * p.N >= 256L * 256 * 256));
     if (big && (cfg == 3 || (cfg == 0 && sgc_gemm_ring()))) return launch_gemm_nt_ring<ELEM, AMODE, EPI>(p, stream);
+    if constexpr (AMODE == AMODE_PLAIN) {
+        if (big_ok && (cfg == 5 || (big && cfg == 0 && sgc_gemm_pp()))) return launch_gemm_nt_pp<ELEM, EPI>(p, stream);
+    }
     if (big) return launch_gemm_nt_cfg<ELEM, AMODE, EPI, 2, 4, 4, 2>(p, stream);
     return launch_gemm_nt_cfg<ELEM, AMODE, EPI, 2, 2, 2, 2>(p, stream);
 }

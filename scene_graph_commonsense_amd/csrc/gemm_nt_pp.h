@@ -1,0 +1,360 @@
+// Ping-pong scheduled 256x256x64 NT GEMM blocks for gfx950 (included by gemm_nt.h): plain GEMM and the halo-staged 3x3
+// convolution on 16x16 maps.  Same tile geometry as the 8-wave block of gemm_nt_kernel (2x4 waves, 128x64 per wave) but a
+// different schedule:
+//  * The two waves that share a SIMD (w and w+4, i.e. the two wave ROWS wr = 0/1) run half a phase apart: while one
+//    issues its LDS fragment reads and its share of the global->LDS prefetch, the other issues MFMAs, and they swap at
+//    every s_barrier.  The 2-stage loop of gemm_nt_kernel leaves both waves of a SIMD reading LDS at the same time after
+//    each barrier (LDS-read + MFMA alone: 1450 TFLOP/s-equivalent there, 1555 here; tools/gemm_microbench.py).
+//  * A K tile is consumed in two phases = the two 64x64 halves of the wave's 128x64 output, 16 MFMAs per barrier slot:
+//    phase X (rows a0) reads the A0 half and both B halves (16 ds_read_b128), phase Y (rows a1) reads A1 (8).
+//  * Operands are staged in HALF tiles (128 rows x 64 k = 16 KiB = 2 global_load_lds per wave): A0/A1 = rows
+//    {0-63,128-191}/{64-127,192-255} of the block (the a-half of both wave rows), B0/B1 = the b-half of the four wave
+//    columns.  Eight 16 KiB slots (two K tiles) form a ring; a half tile's successor (two K tiles ahead) is issued in
+//    the phase after its last read, and every phase ends with a COUNTED s_waitcnt vmcnt(8): up to 64 KiB per CU stay
+//    in flight across the barriers, every half tile has two phases (~1.2 us) to land; vmcnt(0) only in the last two tiles.
+//  Hazards (phase p of wave row 0 occupies barrier slots 2p [loads] and 2p+1 [MFMA]; wave row 1 is one slot later):
+//   RAW  a half tile read in phase p+1 is waited for (vmcnt) in the load section of phase p by BOTH wave rows, i.e.
+//        before the barriers ending slots 2p and 2p+1; the first read is in slot 2p+2.
+//   WAR  the reads of phase p are retired (lgkmcnt(0)) before the barrier that ends their slot (2p or 2p+1); the slot's
+//        overwrite is issued in phase p+1 (slot >= 2p+2).
+//  Measured on 32768x4096x8192 bf16, random operands, one box: 2-stage loop 1.91 ms (1150 TFLOP/s), this schedule
+//  1.77 ms (1243), with the XCD-aware tile walk 1.74 ms (1264).  Variants measured and dropped: four phases per K tile
+//  (8 MFMAs per slot, vmcnt(12)) 2.0 ms - the ~85-cycle barrier slot overhead is paid twice as often; s_setprio(1)
+//  around the MFMA section -1 %.
+#pragma once
+
+#define SGC_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define SGC_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define SGC_PP_BARRIER()                                       \
+    do {                                                       \
+        __builtin_amdgcn_sched_barrier(0);                     \
+        __builtin_amdgcn_s_barrier();                          \
+        __builtin_amdgcn_sched_barrier(0);                     \
+    } while (0)
+
+// XCD-aware tile walk: block id -> XCD id%8 (hardware round-robin); each XCD walks a contiguous range of the tile
+// sequence in 4(M) x 8(N) patches, so the 32 blocks resident on one XCD share 4 A panels and 8 B panels through its L2.
+__device__ __forceinline__ void xcd_patch_map(int id, int tiles_m, int tiles_n, int& tm, int& tn) {
+    const int nb = tiles_m * tiles_n, q = nb >> 3, r = nb & 7, x = id & 7;
+    const int lin = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (id >> 3);
+    supertile_map_g(lin, tiles_m, tiles_n, 4, 8, tm, tn);
+}
+
+// ABL (tools/gemm_microbench.py only): 0 normal, 1 no global loads inside the K loop.
+template <int ELEM, int EPI, int ABL = 0>
+__global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(const NtParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int HT = 16384;                        // half-tile bytes; slot = parity*4 + kind, kind 0 A0, 1 B0, 2 B1, 3 A1
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 2, wc = wid & 3;
+    int tm, tn;
+    xcd_patch_map(blockIdx.x, p.tiles_m, p.tiles_n, tm, tn);
+    const int m0 = tm * 256, n0 = tn * 256;
+
+    // ---- staging sources: wave w writes LDS rows (2w+q)*8 .. +7 of every half tile (q = 0,1), 8 lanes per 128-B row
+    const int lrow = lane >> 3, cpos = lane & 7;
+    const u16* src[4][2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int r = (wid * 2 + q) * 8 + lrow;
+        const int chunk = (cpos ^ ((r >> 1) & 7)) << 3;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            int m = m0 + (r >> 6) * 128 + h * 64 + (r & 63);
+            if (m > p.M - 1) m = p.M - 1;
+            src[h ? 3 : 0][q] = p.A + (long)m * p.lda + chunk;
+            const int n = n0 + (r >> 5) * 64 + h * 32 + (r & 31);
+            src[1 + h][q] = p.B + (long)n * p.ldb + chunk;
+        }
+    }
+    auto stage = [&](int kind, int t) __attribute__((always_inline)) {
+        if (ABL == 1 && t > 1) return;
+        char* base = smem + (((t & 1) << 2) + kind) * HT + wid * 2048;
+        const long koff = (long)t << 6;
+        __builtin_amdgcn_global_load_lds(GLB_PTR(src[kind][0] + koff), LDS_PTR(base), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(GLB_PTR(src[kind][1] + koff), LDS_PTR(base + 1024), 16, 0, 0);
+    };
+
+    // ---- fragment reads (row swizzle (row>>1)&7 only depends on lane&31: half tiles start at multiples of 32 rows)
+    const int l31 = lane & 31, kh = lane >> 5, sw = (l31 >> 1) & 7;
+    int ko[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) ko[ks] = ((ks * 2 + kh) ^ sw) << 4;
+    const int a_rd = (wr * 64 + l31) * 128, b_rd = (wc * 32 + l31) * 128;
+    s16x8 af[2][4], bf[2][4];
+    auto read_a = [&](int h, int par) __attribute__((always_inline)) {
+        const char* base = smem + ((par << 2) + (h ? 3 : 0)) * HT + a_rd;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) af[i][ks] = *reinterpret_cast<const s16x8*>(base + i * 4096 + ko[ks]);
+    };
+    auto read_b = [&](int par) __attribute__((always_inline)) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const char* base = smem + ((par << 2) + 1 + h) * HT + b_rd;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) bf[h][ks] = *reinterpret_cast<const s16x8*>(base + ko[ks]);
+        }
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    auto half = [&](int a) __attribute__((always_inline)) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[2 * a + i][j] = mfma32<ELEM>(af[i][ks], bf[j][ks], acc[2 * a + i][j]);
+        SGC_PP_BARRIER();
+    };
+    // end of a load section: counted wait for the half tiles the NEXT phase reads, retire this phase's reads, barrier
+#define SGC_PP_CLOSE(STEADY)                                   \
+    do {                                                       \
+        if (STEADY) SGC_WAIT_VM(8); else SGC_WAIT_VM(0);       \
+        SGC_WAIT_LGKM0();                                      \
+        SGC_PP_BARRIER();                                      \
+    } while (0)
+
+    const int nk = p.K >> 6;
+    // ---- prologue: ring order is [A0 B0 B1](t) in phase Y(t-2), A1(t) in phase X(t-1)
+    stage(0, 0); stage(1, 0); stage(2, 0); stage(3, 0);
+    if (nk > 1) { stage(0, 1); stage(1, 1); stage(2, 1); SGC_WAIT_VM(8); } else SGC_WAIT_VM(0);
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();        // wave row 1 runs one barrier slot behind wave row 0
+
+    auto tile = [&](int t, int par, auto steady_c) __attribute__((always_inline)) {
+        constexpr bool STEADY = decltype(steady_c)::value;       // tile t+2 exists
+        read_a(0, par); read_b(par);                             // phase X
+        if (t + 1 < nk) stage(3, t + 1);                         // A1(t+1) replaces A1(t-1), read in phase Y(t-1)
+        SGC_PP_CLOSE(STEADY);
+        half(0);
+        read_a(1, par);                                          // phase Y
+        if (STEADY) { stage(0, t + 2); stage(1, t + 2); stage(2, t + 2); }     // replace what phase X(t) read
+        SGC_PP_CLOSE(STEADY);
+        half(1);
+    };
+    int t = 0;
+#pragma unroll 1
+    for (; t + 2 < nk; ++t) tile(t, t & 1, std::true_type{});
+#pragma unroll 1
+    for (; t < nk; ++t) tile(t, t & 1, std::false_type{});
+    if (wr == 0) __builtin_amdgcn_s_barrier();        // re-align the two wave rows
+
+    if constexpr (EPI == EPI_STORE) {
+        if (p.epi_lds) { nt_epilogue_store16<ELEM>(p, acc, m0, n0, wr, wc, lane, wid, smem); return; }
+    }
+    nt_epilogue<ELEM, EPI, 4, 2>(p, acc, m0, n0, wr, wc, lane);
+}
+
+template <int ELEM, int EPI, int ABL = 0>
+static int launch_gemm_nt_pp(NtParams p, hipStream_t stream) {
+    constexpr int LDS = (EPI == EPI_STORE) ? EPI_LDS_BYTES : 8 * 16384;
+    p.tiles_m = (p.M + 255) / 256;
+    p.tiles_n = p.N / 256;
+    static bool attr_set = false;
+    auto kern = gemm_nt_pp_kernel<ELEM, EPI, ABL>;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set = true;
+    }
+    SGC_LAUNCH(kern, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(512), LDS, stream, p);
+    SGC_CHECK_LAUNCH();
+    return SGC_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// Halo-staged implicit 3x3 convolution on 16x16 maps with the ping-pong schedule (conv3 forward / data gradient).
+// One workgroup = one image (256 pixels, window-major rows) x 256 output channels; K step = (64-channel chunk, tap).
+// The zero-padded 18x18x64 patch of a chunk is staged ONCE (41 KiB, double buffered) and the nine taps read their A
+// fragments from it at shifted pixel rows (see conv16_halo_kernel in gemm_nt.h for the swizzle); the weight tile is
+// staged per step as two half tiles B0/B1 in a four-slot ring (two steps).  LDS: 2 x 41 KiB + 4 x 16 KiB = 146 KiB.
+// Per wave and step: phase Y issues the four weight loads of step s+2 (replacing what phase X(s) read) and, in the first
+// taps of a chunk, one piece of the NEXT chunk's patch; it ends with vmcnt(4 or 5): only its own loads may still be in
+// flight, so the weights of step s+1 and every older patch piece have landed.  Phase X issues nothing and has no vmcnt wait.
+template <int ELEM, int EPI>
+__global__ __launch_bounds__(512, 2) void conv16_halo_pp_kernel(const NtParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int A_BYTES = 328 * 128;            // 324 patch rows, padded to 41 x 8 rows
+    constexpr int HT = 16384;
+    char* const abuf0 = smem;
+    char* const bbuf0 = smem + 2 * A_BYTES;       // slot = (step & 1) * 2 + b-half
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 2, wc = wid & 3;
+    // XCD-aware walk: the tiles_n blocks of one image are consecutive in the XCD's own sequence
+    int img, tn;
+    {
+        const int nb = p.tiles_m * p.tiles_n, q = nb >> 3, r = nb & 7, x = blockIdx.x & 7;
+        const int lin = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (blockIdx.x >> 3);
+        img = lin / p.tiles_n; tn = lin - img * p.tiles_n;
+    }
+    const int m0 = img * 256, n0 = tn * 256;
+    const int Cin = p.Cin;
+
+    // ---- A patch loader: 41 pieces of 8 rows; wave w issues pieces w, w+8, ... (<= 6), one per phase Y
+    const int lrow = lane >> 3, cpos = lane & 7;
+    int a_off[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        int r = (wid + 8 * i) * 8 + lrow;
+        if (r > 323) r = 323;
+        const int py = r / 18, px = r - py * 18;
+        const int f = ((px >> 1) + 4 * (py & 1)) & 7;
+        a_off[i] = r * Cin + ((cpos ^ f) << 3);
+    }
+    const u16* const a_img = p.A + (long)img * (324L * Cin);
+    const int npiece = (wid == 0) ? 6 : 5;
+    auto stage_a_piece = [&](int i, int cc) __attribute__((always_inline)) {
+        __builtin_amdgcn_global_load_lds(GLB_PTR(a_img + a_off[i] + (cc << 6)), LDS_PTR(abuf0 + (cc & 1) * A_BYTES + (wid + 8 * i) * 1024), 16, 0, 0);
+    };
+    // ---- B (weight) half tiles: LDS row r of half h <-> output channel n0 + (r>>5)*64 + h*32 + (r&31)
+    const u16* b_src[2][2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int r = (wid * 2 + q) * 8 + lrow;
+        const int chunk = (cpos ^ ((r >> 1) & 7)) << 3;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) b_src[h][q] = p.B + (long)(n0 + (r >> 5) * 64 + h * 32 + (r & 31)) * p.ldb + chunk;
+    }
+    auto stage_b = [&](int step) __attribute__((always_inline)) {
+        char* base = bbuf0 + ((step & 1) * 2) * HT + wid * 2048;
+        const long koff = (long)step << 6;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            __builtin_amdgcn_global_load_lds(GLB_PTR(b_src[h][0] + koff), LDS_PTR(base + h * HT), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GLB_PTR(b_src[h][1] + koff), LDS_PTR(base + h * HT + 1024), 16, 0, 0);
+        }
+    };
+
+    // ---- fragment addressing
+    const int l31 = lane & 31, kh = lane >> 5;
+    int a_row[4], a_px[4], a_py[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = wr * 128 + i * 32 + l31;
+        const int W = m >> 2, q = m & 3;
+        a_py[i] = 2 * (W >> 3) + (q >> 1);
+        a_px[i] = 2 * (W & 7) + (q & 1);
+        a_row[i] = a_py[i] * 18 + a_px[i];
+    }
+    const int bsw = (l31 >> 1) & 7;
+    int bko[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) bko[ks] = ((ks * 2 + kh) ^ bsw) << 4;
+    const int b_rd = (wc * 32 + l31) * 128;
+    s16x8 af[2][4], bf[2][4];
+    auto read_a = [&](int h, int cc, int ky, int kx) __attribute__((always_inline)) {
+        const char* ab = abuf0 + (cc & 1) * A_BYTES;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int ii = 2 * h + i;
+            const char* rowp = ab + (a_row[ii] + ky * 18 + kx) * 128;
+            const int f = (((a_px[ii] + kx) >> 1) + 4 * ((a_py[ii] + ky) & 1)) & 7;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) af[i][ks] = *reinterpret_cast<const s16x8*>(rowp + (((ks * 2 + kh) ^ f) << 4));
+        }
+    };
+    auto read_b = [&](int step) __attribute__((always_inline)) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const char* base = bbuf0 + ((step & 1) * 2 + h) * HT + b_rd;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) bf[h][ks] = *reinterpret_cast<const s16x8*>(base + bko[ks]);
+        }
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    auto half = [&](int a) __attribute__((always_inline)) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[2 * a + i][j] = mfma32<ELEM>(af[i][ks], bf[j][ks], acc[2 * a + i][j]);
+        SGC_PP_BARRIER();
+    };
+
+    const int ncc = Cin >> 6;
+    const int nsteps = ncc * 9;
+    // ---- prologue: patch of chunk 0, weights of steps 0 and 1
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+        if (i < npiece) stage_a_piece(i, 0);
+    stage_b(0);
+    if (nsteps > 1) { stage_b(1); SGC_WAIT_VM(4); } else SGC_WAIT_VM(0);
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();
+
+    int step = 0;
+    for (int cc = 0; cc < ncc; ++cc) {
+        const bool more_cc = cc + 1 < ncc;
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap, ++step) {
+            const int ky = tap / 3, kx = tap - 3 * ky;
+            // phase X: rows a0 x both weight halves
+            read_a(0, cc, ky, kx); read_b(step);
+            SGC_WAIT_LGKM0();
+            SGC_PP_BARRIER();
+            half(0);
+            // phase Y: rows a1
+            read_a(1, cc, ky, kx);
+            if (step + 2 < nsteps) {
+                stage_b(step + 2);
+                if (more_cc && tap < npiece) {
+                    switch (tap) {          // a_off[] must be indexed by a constant to stay in registers
+                        case 0: stage_a_piece(0, cc + 1); break;
+                        case 1: stage_a_piece(1, cc + 1); break;
+                        case 2: stage_a_piece(2, cc + 1); break;
+                        case 3: stage_a_piece(3, cc + 1); break;
+                        case 4: stage_a_piece(4, cc + 1); break;
+                        default: stage_a_piece(5, cc + 1); break;
+                    }
+                    SGC_WAIT_VM(5);
+                } else SGC_WAIT_VM(4);
+            } else SGC_WAIT_VM(0);
+            SGC_WAIT_LGKM0();
+            SGC_PP_BARRIER();
+            half(1);
+        }
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();
+
+    if constexpr (EPI == EPI_STORE) {
+        if (p.epi_lds) { nt_epilogue_store16<ELEM>(p, acc, m0, n0, wr, wc, lane, wid, smem); return; }
+    }
+    nt_epilogue<ELEM, EPI, 4, 2>(p, acc, m0, n0, wr, wc, lane);
+}
+
+template <int ELEM, int EPI>
+static int launch_conv16_halo_pp(NtParams p, hipStream_t stream) {
+    constexpr int LDS0 = 2 * 328 * 128 + 4 * 16384;
+    constexpr int LDS = (EPI == EPI_STORE && LDS0 < EPI_LDS_BYTES) ? EPI_LDS_BYTES : LDS0;
+    p.tiles_m = p.M / 256;
+    p.tiles_n = p.N / 256;
+    static bool attr_set = false;
+    auto kern = conv16_halo_pp_kernel<ELEM, EPI>;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set = true;
+    }
+    SGC_LAUNCH(kern, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(512), LDS, stream, p);
+    SGC_CHECK_LAUNCH();
+    return SGC_OK;
+}

@@ -28,7 +28,8 @@ def _window_major_index(S):
 
 
 @pytest.mark.parametrize("dtype,elem", [(torch.float16, 0), (torch.bfloat16, 1)])
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 256, 192), (1000, 512, 4096)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 256, 192), (1000, 512, 4096), (256, 256, 64), (300, 256, 128),
+                                   (520, 512, 256), (700, 256, 320), (512, 768, 1088)])
 def test_gemm_nt_plain(dtype, elem, M, N, K):
     lib, L = _lib()
     A, B = _rand((M, K), dtype, 1), _rand((N, K), dtype, 2)
@@ -55,7 +56,7 @@ def _conv_inputs(n_img, S, Cin, N, dtype):
 
 @pytest.mark.parametrize("dtype,elem", [(torch.float16, 0), (torch.bfloat16, 1)])
 @pytest.mark.parametrize("n_img,lgS,Cin,N", [(3, 4, 128, 128), (2, 5, 128, 256), (5, 4, 512, 128), (3, 4, 128, 256),
-                                             (2, 4, 512, 512), (2, 4, 1024, 256)])
+                                             (2, 4, 512, 512), (2, 4, 1024, 256), (9, 4, 64, 256), (11, 4, 192, 512)])
 def test_conv_nt(dtype, elem, n_img, lgS, Cin, N):
     lib, L = _lib()
     S = 1 << lgS

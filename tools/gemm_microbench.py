@@ -12,13 +12,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from scene_graph_commonsense_amd import _lib
 
 lib = _lib.load()
-M, N, K = 32768, 4096, 8192
+M, N, K = 32768, 4096, int(os.environ.get("MB_K", "8192"))
 A = (torch.rand(M, K, device="cuda") * 2 - 1).bfloat16()
 B = (torch.rand(N, K, device="cuda") * 2 - 1).bfloat16()
 C = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
-names = {0: "normal", 1: "no global loads", 2: "no loads, no barriers", 3: "loads + barriers only", 4: "4-stage ring BK=32", 5: "A staged 1 tile in 9"}
+names = {0: "normal", 1: "no global loads", 2: "no loads, no barriers", 3: "loads + barriers only", 4: "4-stage ring BK=32", 5: "A staged 1 tile in 9", 6: "ping-pong", 7: "ping-pong, no global loads"}
 for rep in range(2):
-    for abl in (0, 1, 2, 3, 4, 5):
+    for abl in [int(x) for x in os.environ.get("MB_ABL", "0,1,2,3,4,5,6,7").split(",")]:
         for _ in range(2):
             lib.sgc_dbg_gemm_nt_abl(abl, _lib.ptr(A), _lib.ptr(B), _lib.ptr(C), M, N, K, _lib.stream_ptr())
         torch.cuda.synchronize()
