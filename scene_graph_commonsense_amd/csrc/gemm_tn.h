@@ -207,6 +207,187 @@ static int launch_gemm_tn_cfg(TnParams p, int splits, int* slabs_out, hipStream_
     return SGC_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Ping-pong scheduled variant of the 256x256 block (schedule, ring and hazard rules: see gemm_nt_pp.h).  Half tiles are
+// 16(k blocks of 4 rows) x 8(sub-blocks of 16 columns) x 128 B = 16 KiB; A0/A1 hold the column halves {0-63,128-191} /
+// {64-127,192-255} of the M tile (the a-half of both wave rows), B0/B1 the 32-column halves of the four wave columns.
+// Phase X reads A0 and both B halves (32 ds_read_b64_tr_b16), phase Y reads A1 (16).
+template <int ELEM, int BMODE, int ACONV>
+__global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(const TnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int HT = 16384, BM = 256, BN = 256;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 2, wc = wid & 3;
+    const int tiles = p.tiles_n * p.tiles_m;
+    int split, tm, tn;
+    if (p.xcd_map) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        split = j / 9;
+        tm = xcd & 3;
+        tn = (j - split * 9) * 2 + (xcd >> 2);
+    } else {
+        split = blockIdx.x / tiles;
+        supertile_map(blockIdx.x - split * tiles, p.tiles_m, p.tiles_n, tm, tn);
+    }
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int kt_begin = split * p.ktiles_per_split;
+    int kt_end = kt_begin + p.ktiles_per_split;
+    const int nk_total = p.K >> 6;
+    if (kt_end > nk_total) kt_end = nk_total;
+    const int nk = kt_end - kt_begin;
+
+    // ---- staging: one instruction = one k block (4 rows) x 8 sub-blocks of a half tile; wave w owns k blocks 2w, 2w+1
+    const int kr = (lane >> 1) & 3, sb = lane >> 3, c8 = (lane & 1) * 8;
+    long boff_tap = 0;
+    int bcol0 = n0;
+    if constexpr (BMODE == BMODE_CONV) {
+        const int tap = n0 / p.Cin;
+        bcol0 = n0 - tap * p.Cin;
+        const int ky = tap / 3, kx = tap - 3 * ky;
+        boff_tap = (long)(ky * ((1 << p.lgS) + 2) + kx) * p.Cin;
+    }
+    long src[4][2];                                  // kind 0 A0, 1 B0, 2 B1, 3 A1
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int kl = (wid * 2 + q) * 4 + kr;
+        long arow, brow;
+        if constexpr (ACONV) arow = conv_row_base(kl, p.lgS, p.CinA) + (long)((1 << p.lgS) + 3) * p.CinA;
+        else arow = (long)kl * p.lda;
+        if constexpr (BMODE == BMODE_CONV) brow = conv_row_base(kl, p.lgS, p.Cin) + boff_tap;
+        else brow = (long)kl * p.ldb;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            src[h ? 3 : 0][q] = arow + m0 + ((sb >> 2) * 8 + h * 4 + (sb & 3)) * 16 + c8;
+            src[1 + h][q] = brow + bcol0 + ((sb >> 1) * 4 + h * 2 + (sb & 1)) * 16 + c8;
+        }
+    }
+    auto stage = [&](int kind, int it) __attribute__((always_inline)) {      // it = K tile index inside this split
+        char* base = smem + (((it & 1) << 2) + kind) * HT + wid * 2048;
+        const int kt = kt_begin + it;
+        long toff;
+        if (kind == 0 || kind == 3) {
+            if constexpr (ACONV) toff = conv_row_base(kt * 64, p.lgS, p.CinA); else toff = (long)kt * 64 * p.lda;
+            __builtin_amdgcn_global_load_lds(GLB_PTR(p.A + toff + src[kind][0]), LDS_PTR(base), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GLB_PTR(p.A + toff + src[kind][1]), LDS_PTR(base + 1024), 16, 0, 0);
+        } else {
+            if constexpr (BMODE == BMODE_CONV) toff = conv_row_base(kt * 64, p.lgS, p.Cin); else toff = (long)kt * 64 * p.ldb;
+            __builtin_amdgcn_global_load_lds(GLB_PTR(p.B + toff + src[kind][0]), LDS_PTR(base), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GLB_PTR(p.B + toff + src[kind][1]), LDS_PTR(base + 1024), 16, 0, 0);
+        }
+    };
+
+    // ---- fragment reads: sub-block (wr*4 + i*2 + g) of an A half, (wc*2 + g) of a B half; k blocks ks*4 + kh*2 (+1)
+    const int g = (lane >> 4) & 1, kh = lane >> 5, t16 = lane & 15;
+    const int lane_off = (t16 >> 2) * 32 + (t16 & 3) * 8 + kh * 2048;
+    const int a_rd = (wr * 4 + g) * 128 + lane_off, b_rd = (wc * 2 + g) * 128 + lane_off;
+    s16x8 af[2][4], bf[2][4];
+    auto tr2 = [&](const char* ptr) __attribute__((always_inline)) {
+        const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ptr));
+        const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ptr + 1024));
+        return __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+    auto read_a = [&](int h, int par) __attribute__((always_inline)) {
+        const char* base = smem + ((par << 2) + (h ? 3 : 0)) * HT + a_rd;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) af[i][ks] = tr2(base + i * 256 + ks * 4096);
+    };
+    auto read_b = [&](int par) __attribute__((always_inline)) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const char* base = smem + ((par << 2) + 1 + h) * HT + b_rd;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) bf[h][ks] = tr2(base + ks * 4096);
+        }
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    auto half = [&](int a) __attribute__((always_inline)) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[2 * a + i][j] = mfma32<ELEM>(af[i][ks], bf[j][ks], acc[2 * a + i][j]);
+        SGC_PP_BARRIER();
+    };
+
+    if (nk > 0) {
+        stage(0, 0); stage(1, 0); stage(2, 0); stage(3, 0);
+        if (nk > 1) { stage(0, 1); stage(1, 1); stage(2, 1); SGC_WAIT_VM(8); } else SGC_WAIT_VM(0);
+    }
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();
+    auto tile = [&](int it, int par, auto steady_c) __attribute__((always_inline)) {
+        constexpr bool STEADY = decltype(steady_c)::value;
+        read_a(0, par); read_b(par);
+        if (it + 1 < nk) stage(3, it + 1);
+        SGC_PP_CLOSE(STEADY);
+        half(0);
+        read_a(1, par);
+        if (STEADY) { stage(0, it + 2); stage(1, it + 2); stage(2, it + 2); }
+        SGC_PP_CLOSE(STEADY);
+        half(1);
+    };
+    int it = 0;
+#pragma unroll 1
+    for (; it + 2 < nk; ++it) tile(it, it & 1, std::true_type{});
+#pragma unroll 1
+    for (; it < nk; ++it) tile(it, it & 1, std::false_type{});
+    if (wr == 0) __builtin_amdgcn_s_barrier();
+
+    float* C = p.C + (long)split * p.slab_stride;
+    const int hh = lane >> 5, cl = lane & 31;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wc * 64 + j * 32 + cl;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wr * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                C[(long)row * p.ldc + col] = acc[i][j][r];
+            }
+        }
+}
+
+template <int ELEM, int BMODE, int ACONV>
+static int launch_gemm_tn_pp(TnParams p, int splits, int* slabs_out, hipStream_t stream) {
+    constexpr int LDS = 8 * 16384;
+    p.tiles_m = p.M / 256;
+    p.tiles_n = p.N / 256;
+    const int nk = p.K >> 6;
+    if (splits < 1) splits = 1;
+    if (splits > nk) splits = nk;
+    p.ktiles_per_split = (nk + splits - 1) / splits;
+    splits = (nk + p.ktiles_per_split - 1) / p.ktiles_per_split;
+    static bool attr_set = false;
+    auto kern = gemm_tn_pp_kernel<ELEM, BMODE, ACONV>;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set = true;
+    }
+    p.splits = splits;
+    {
+        static int xm = -1;
+        if (xm < 0) { const char* e = getenv("SGC_TN_XCD"); xm = e ? atoi(e) : 1; }
+        p.xcd_map = (xm && BMODE == BMODE_CONV && p.tiles_m == 4 && p.tiles_n == 18) ? 1 : 0;
+    }
+    SGC_LAUNCH(kern, dim3((unsigned)(p.tiles_m * p.tiles_n * splits)), dim3(512), LDS, stream, p);
+    SGC_CHECK_LAUNCH();
+    if (slabs_out) *slabs_out = splits;
+    return SGC_OK;
+}
+
 template <int ELEM, int BMODE, int ACONV = 0>
 static int launch_gemm_tn(TnParams p, int splits, int* slabs_out, hipStream_t stream) {
     if ((p.K & 63) || (p.N & 127) || (p.M & 127) || p.K <= 0) return SGC_ERR_ARG;
@@ -214,6 +395,7 @@ static int launch_gemm_tn(TnParams p, int splits, int* slabs_out, hipStream_t st
     const int cfg = sgc_gemm_cfg();
     const bool big_ok = (p.N % 256) == 0 && (p.M % 256) == 0 && (BMODE != BMODE_CONV || (p.Cin % 256) == 0);
     const bool big = big_ok && (cfg == 2 || (cfg == 0 && (long)p.M * p.N >= 512L * 512));
+    if (big_ok && (cfg == 5 || cfg == 7 || (big && cfg == 0 && sgc_gemm_pp()))) return launch_gemm_tn_pp<ELEM, BMODE, ACONV>(p, splits, slabs_out, stream);
     if (big) return launch_gemm_tn_cfg<ELEM, BMODE, ACONV, 2, 4, 4, 2>(p, splits, slabs_out, stream);
     return launch_gemm_tn_cfg<ELEM, BMODE, ACONV, 2, 2, 2, 2>(p, splits, slabs_out, stream);
 }

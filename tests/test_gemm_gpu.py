@@ -92,7 +92,7 @@ def test_tr_probe_layout():
 
 @pytest.mark.parametrize("dtype,elem", [(torch.float16, 0), (torch.bfloat16, 1)])
 @pytest.mark.parametrize("M,N,K,splits", [(128, 128, 64, 1), (256, 384, 640, 3), (512, 128, 4096, 8), (512, 512, 4096, 8),
-                                          (1024, 768, 2048, 16)])
+                                          (1024, 768, 2048, 16), (256, 256, 64, 1), (256, 512, 192, 1), (512, 256, 1088, 3)])
 def test_gemm_tn_plain(dtype, elem, M, N, K, splits):
     lib, L = _lib()
     A, B = _rand((K, M), dtype, 11), _rand((K, N), dtype, 12)
@@ -109,7 +109,8 @@ def test_gemm_tn_plain(dtype, elem, M, N, K, splits):
 
 
 @pytest.mark.parametrize("n_img,lgS,Cin,M,splits", [(2, 4, 128, 128, 2), (3, 5, 128, 256, 4), (2, 4, 512, 128, 1),
-                                                    (8, 4, 512, 1024, 8), (16, 4, 256, 512, 16)])
+                                                    (8, 4, 512, 1024, 8), (16, 4, 256, 512, 16), (3, 4, 256, 256, 1),
+                                                    (5, 4, 512, 256, 3)])
 def test_conv_tn(n_img, lgS, Cin, M, splits):
     lib, L = _lib()
     dtype, elem = torch.bfloat16, 1
