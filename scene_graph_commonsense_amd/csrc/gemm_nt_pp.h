@@ -32,6 +32,15 @@
         __builtin_amdgcn_sched_barrier(0);                     \
     } while (0)
 
+// global -> LDS copy of 16 B per lane through a buffer resource: wave-uniform base (SGPR descriptor) + 32-bit per-lane byte
+// offset (+ SGPR byte offset).  With global_load_lds every lane sends a 64-bit address; the buffer form was measured
+// +10 % on the whole GEMM (1272 -> 1400 TFLOP/s, 32768x4096x8192 bf16): the VMEM issue cost was the larger part of the
+// interference between the load stream and the MFMA loop.  Offsets stay far below the 2 GiB record limit set here.
+__device__ __forceinline__ void buf_load_lds16(const void* base, int voff, int soff, void* lds) {
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, LDS_PTR(lds), 16, voff, soff, 0, 0);
+}
+
 // XCD-aware tile walk: block id -> XCD id%8 (hardware round-robin); each XCD walks a contiguous range of the tile
 // sequence in 4(M) x 8(N) patches, so the 32 blocks resident on one XCD share 4 A panels and 8 B panels through its L2.
 __device__ __forceinline__ void xcd_patch_map(int id, int tiles_m, int tiles_n, int& tm, int& tn) {
@@ -54,26 +63,28 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(const NtParams p) {
 
     // ---- staging sources: wave w writes LDS rows (2w+q)*8 .. +7 of every half tile (q = 0,1), 8 lanes per 128-B row
     const int lrow = lane >> 3, cpos = lane & 7;
-    const u16* src[4][2];
+    const u16* const a_blk = p.A + (long)m0 * p.lda;
+    const u16* const b_blk = p.B + (long)n0 * p.ldb;
+    int voff[4][2];                                  // byte offsets from a_blk / b_blk
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int r = (wid * 2 + q) * 8 + lrow;
         const int chunk = (cpos ^ ((r >> 1) & 7)) << 3;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            int m = m0 + (r >> 6) * 128 + h * 64 + (r & 63);
-            if (m > p.M - 1) m = p.M - 1;
-            src[h ? 3 : 0][q] = p.A + (long)m * p.lda + chunk;
-            const int n = n0 + (r >> 5) * 64 + h * 32 + (r & 31);
-            src[1 + h][q] = p.B + (long)n * p.ldb + chunk;
+            int m = (r >> 6) * 128 + h * 64 + (r & 63);
+            if (m0 + m > p.M - 1) m = p.M - 1 - m0;
+            voff[h ? 3 : 0][q] = (int)((m * p.lda + chunk) * 2);
+            const int n = (r >> 5) * 64 + h * 32 + (r & 31);
+            voff[1 + h][q] = (int)((n * p.ldb + chunk) * 2);
         }
     }
     auto stage = [&](int kind, int t) __attribute__((always_inline)) {
         if (ABL == 1 && t > 1) return;
         char* base = smem + (((t & 1) << 2) + kind) * HT + wid * 2048;
-        const long koff = (long)t << 6;
-        __builtin_amdgcn_global_load_lds(GLB_PTR(src[kind][0] + koff), LDS_PTR(base), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds(GLB_PTR(src[kind][1] + koff), LDS_PTR(base + 1024), 16, 0, 0);
+        const u16* g = (kind == 0 || kind == 3) ? a_blk : b_blk;
+        buf_load_lds16(g, voff[kind][0], t << 7, base);
+        buf_load_lds16(g, voff[kind][1], t << 7, base + 1024);
     };
 
     // ---- fragment reads (row swizzle (row>>1)&7 only depends on lane&31: half tiles start at multiples of 32 rows)
@@ -215,24 +226,24 @@ __global__ __launch_bounds__(512, 2) void conv16_halo_pp_kernel(const NtParams p
     const u16* const a_img = p.A + (long)img * (324L * Cin);
     const int npiece = (wid == 0) ? 6 : 5;
     auto stage_a_piece = [&](int i, int cc) __attribute__((always_inline)) {
-        __builtin_amdgcn_global_load_lds(GLB_PTR(a_img + a_off[i] + (cc << 6)), LDS_PTR(abuf0 + (cc & 1) * A_BYTES + (wid + 8 * i) * 1024), 16, 0, 0);
+        buf_load_lds16(a_img, a_off[i] * 2, cc << 7, abuf0 + (cc & 1) * A_BYTES + (wid + 8 * i) * 1024);
     };
     // ---- B (weight) half tiles: LDS row r of half h <-> output channel n0 + (r>>5)*64 + h*32 + (r&31)
-    const u16* b_src[2][2];
+    const u16* const b_blk = p.B + (long)n0 * p.ldb;
+    int b_voff[2][2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int r = (wid * 2 + q) * 8 + lrow;
         const int chunk = (cpos ^ ((r >> 1) & 7)) << 3;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) b_src[h][q] = p.B + (long)(n0 + (r >> 5) * 64 + h * 32 + (r & 31)) * p.ldb + chunk;
+        for (int h = 0; h < 2; ++h) b_voff[h][q] = (int)((((r >> 5) * 64 + h * 32 + (r & 31)) * p.ldb + chunk) * 2);
     }
     auto stage_b = [&](int step) __attribute__((always_inline)) {
         char* base = bbuf0 + ((step & 1) * 2) * HT + wid * 2048;
-        const long koff = (long)step << 6;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            __builtin_amdgcn_global_load_lds(GLB_PTR(b_src[h][0] + koff), LDS_PTR(base + h * HT), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(GLB_PTR(b_src[h][1] + koff), LDS_PTR(base + h * HT + 1024), 16, 0, 0);
+            buf_load_lds16(b_blk, b_voff[h][0], step << 7, base + h * HT);
+            buf_load_lds16(b_blk, b_voff[h][1], step << 7, base + h * HT + 1024);
         }
     };
 

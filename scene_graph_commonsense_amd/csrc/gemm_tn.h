@@ -247,7 +247,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(const TnParams p) {
         const int ky = tap / 3, kx = tap - 3 * ky;
         boff_tap = (long)(ky * ((1 << p.lgS) + 2) + kx) * p.Cin;
     }
-    long src[4][2];                                  // kind 0 A0, 1 B0, 2 B1, 3 A1
+    int voff[4][2];                                  // kind 0 A0, 1 B0, 2 B1, 3 A1: byte offsets inside a K tile
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int kl = (wid * 2 + q) * 4 + kr;
@@ -258,23 +258,24 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(const TnParams p) {
         else brow = (long)kl * p.ldb;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            src[h ? 3 : 0][q] = arow + m0 + ((sb >> 2) * 8 + h * 4 + (sb & 3)) * 16 + c8;
-            src[1 + h][q] = brow + bcol0 + ((sb >> 1) * 4 + h * 2 + (sb & 1)) * 16 + c8;
+            voff[h ? 3 : 0][q] = (int)((arow + m0 + ((sb >> 2) * 8 + h * 4 + (sb & 3)) * 16 + c8) * 2);
+            voff[1 + h][q] = (int)((brow + bcol0 + ((sb >> 1) * 4 + h * 2 + (sb & 1)) * 16 + c8) * 2);
         }
     }
     auto stage = [&](int kind, int it) __attribute__((always_inline)) {      // it = K tile index inside this split
         char* base = smem + (((it & 1) << 2) + kind) * HT + wid * 2048;
         const int kt = kt_begin + it;
         long toff;
+        const u16* g;
         if (kind == 0 || kind == 3) {
             if constexpr (ACONV) toff = conv_row_base(kt * 64, p.lgS, p.CinA); else toff = (long)kt * 64 * p.lda;
-            __builtin_amdgcn_global_load_lds(GLB_PTR(p.A + toff + src[kind][0]), LDS_PTR(base), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(GLB_PTR(p.A + toff + src[kind][1]), LDS_PTR(base + 1024), 16, 0, 0);
+            g = p.A + toff;                          // wave-uniform: goes into the buffer descriptor
         } else {
             if constexpr (BMODE == BMODE_CONV) toff = conv_row_base(kt * 64, p.lgS, p.Cin); else toff = (long)kt * 64 * p.ldb;
-            __builtin_amdgcn_global_load_lds(GLB_PTR(p.B + toff + src[kind][0]), LDS_PTR(base), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(GLB_PTR(p.B + toff + src[kind][1]), LDS_PTR(base + 1024), 16, 0, 0);
+            g = p.B + toff;
         }
+        buf_load_lds16(g, voff[kind][0], 0, base);
+        buf_load_lds16(g, voff[kind][1], 0, base + 1024);
     };
 
     // ---- fragment reads: sub-block (wr*4 + i*2 + g) of an A half, (wc*2 + g) of a B half; k blocks ks*4 + kh*2 (+1)
