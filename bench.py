@@ -26,7 +26,7 @@ from scene_graph_commonsense_amd.synthetic import HeadConfig, make_scene_batch, 
 
 MFMA_PEAK_TFLOPS = 2500.0      # dense bf16/f16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
-DOMINANT_KERNEL = "conv16_halo_kernel<0, 3>"      # conv3 forward: f16, halo-staged implicit 3x3 conv, ReLU + max-pool epilogue
+DOMINANT_KERNEL = "conv16_halo_pp_kernel<0, 3>"      # conv3 forward: f16, halo-staged implicit 3x3 conv, ReLU + max-pool epilogue
 
 
 def pmc_traffic():
@@ -157,7 +157,7 @@ def main():
         roof = None
         if dom in kern and kern[dom] > 0:
             ach = flops[dom] / (kern[dom] * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": "conv16_halo_kernel<f16,relu+pool> (sgc_conv3_relu_pool)",
+            roof = {"bound": "mfma", "kernel": "conv16_halo_pp_kernel<f16,relu+pool> (sgc_conv3_relu_pool)",
                     "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic() if P == 32256 else None,
                     "traffic_note": "bytes/launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from profiles/r01_final_pmc_{f,w}.csv "

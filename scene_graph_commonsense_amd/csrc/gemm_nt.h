@@ -33,6 +33,7 @@ struct NtParams {
     unsigned drop_seed; int drop_enable;
     int tiles_m, tiles_n;
     int epi_lds;                // 1: LDS-staged 16-byte stores for EPI_STORE in the 8-wave kernels (set by the launcher)
+    int halo_walk;              // conv16_halo_pp_kernel: 0 = block id -> (image, N tile) directly, 1 = XCD-contiguous image ranges
 };
 
 template <int ELEM>
