@@ -361,9 +361,10 @@ static int launch_conv16_halo_pp(NtParams p, hipStream_t stream) {
     p.tiles_m = p.M / 256;
     p.tiles_n = p.N / 256;
     {
-        // One weight tile (256 x K) per XCD stays L2-resident when it is < ~3 MiB (conv3 forward: 2.4 MiB; FETCH_SIZE 27e6
-        // vs 52e6 KiB with the other walk); a larger tile thrashes either way and the XCD-contiguous walk at least fetches
-        // every image patch once (conv3 data gradient: 19.7e6 vs 31.5e6 KiB).  Time is the same to 0.3 %.  SGC_HALO_WALK=0/1 forces.
+        // One weight tile (256 x K) per XCD stays L2-resident when it is < ~3 MiB (conv3 forward: 2.4 MiB; FETCH_SIZE 26-27e6
+        // KiB against 38-52e6 with the XCD-contiguous walk, reproducibly).  A larger tile (conv3 data gradient: 4.7 MiB)
+        // thrashes either way; there the XCD-contiguous walk fetches every image patch once (20-28e6 vs 30-31e6 KiB, with a
+        // run-to-run spread nearly as large as the difference).  Kernel time is the same to 0.5 %.  SGC_HALO_WALK=0/1 forces.
         static int hw = -2;
         if (hw == -2) { const char* e = getenv("SGC_HALO_WALK"); hw = e ? atoi(e) : -1; }
         p.halo_walk = hw >= 0 ? hw : ((long)p.K * 512 > (3L << 20) ? 1 : 0);
