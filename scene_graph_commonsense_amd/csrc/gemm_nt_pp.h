@@ -20,7 +20,8 @@
 //  Measured on 32768x4096x8192 bf16, random operands, one box: 2-stage loop 1.91 ms (1150 TFLOP/s), this schedule
 //  1.77 ms (1243), with the XCD-aware tile walk 1.74 ms (1264).  Variants measured and dropped: four phases per K tile
 //  (8 MFMAs per slot, vmcnt(12)) 2.0 ms - the ~85-cycle barrier slot overhead is paid twice as often; s_setprio(1)
-//  around the MFMA section -1 %.
+//  around the MFMA section -1 %; issuing the last 1/2/4 MFMAs of a slot AFTER its closing barrier (to keep the pipe fed
+//  across the barrier) -7/-9/-11 %.
 #pragma once
 
 #define SGC_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")

@@ -24,6 +24,7 @@ struct TnParams {
     int CinA;                    // ACONV: A rows are the centre pixels of a zero-padded image with CinA channels
     int tiles_m, tiles_n, ktiles_per_split, splits;
     int xcd_map;                 // conv3 wgrad only: XCD-aware tile assignment (see kernel)
+    int xcd_patch;               // ping-pong block: per-XCD 4x8 tile patches (tile count per split divisible by 8)
 };
 
 template <int ELEM, int BMODE, int ACONV, int WR, int WC, int TM, int TN>
@@ -228,7 +229,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(const TnParams p) {
         tn = (j - split * 9) * 2 + (xcd >> 2);
     } else {
         split = blockIdx.x / tiles;
-        supertile_map(blockIdx.x - split * tiles, p.tiles_m, p.tiles_n, tm, tn);
+        if (p.xcd_patch) xcd_patch_map(blockIdx.x - split * tiles, p.tiles_m, p.tiles_n, tm, tn);
+        else supertile_map(blockIdx.x - split * tiles, p.tiles_m, p.tiles_n, tm, tn);
     }
     const int m0 = tm * BM, n0 = tn * BN;
     const int kt_begin = split * p.ktiles_per_split;
@@ -382,6 +384,9 @@ static int launch_gemm_tn_pp(TnParams p, int splits, int* slabs_out, hipStream_t
         static int xm = -1;
         if (xm < 0) { const char* e = getenv("SGC_TN_XCD"); xm = e ? atoi(e) : 1; }
         p.xcd_map = (xm && BMODE == BMODE_CONV && p.tiles_m == 4 && p.tiles_n == 18) ? 1 : 0;
+        static int xp = -1;          // SGC_TN_PATCH=0: 16x16 super-tiles instead of per-XCD 4x8 patches (A/B hook)
+        if (xp < 0) { const char* e = getenv("SGC_TN_PATCH"); xp = e ? atoi(e) : 1; }
+        p.xcd_patch = (xp && !p.xcd_map && ((p.tiles_m * p.tiles_n) & 7) == 0) ? 1 : 0;
     }
     SGC_LAUNCH(kern, dim3((unsigned)(p.tiles_m * p.tiles_n * splits)), dim3(512), LDS, stream, p);
     SGC_CHECK_LAUNCH();

@@ -92,7 +92,8 @@ def test_tr_probe_layout():
 
 @pytest.mark.parametrize("dtype,elem", [(torch.float16, 0), (torch.bfloat16, 1)])
 @pytest.mark.parametrize("M,N,K,splits", [(128, 128, 64, 1), (256, 384, 640, 3), (512, 128, 4096, 8), (512, 512, 4096, 8),
-                                          (1024, 768, 2048, 16), (256, 256, 64, 1), (256, 512, 192, 1), (512, 256, 1088, 3)])
+                                          (1024, 768, 2048, 16), (256, 256, 64, 1), (256, 512, 192, 1), (512, 256, 1088, 3), (512, 1024, 1088, 3),
+                                          (1024, 2048, 640, 2)])
 def test_gemm_tn_plain(dtype, elem, M, N, K, splits):
     lib, L = _lib()
     A, B = _rand((K, M), dtype, 11), _rand((K, N), dtype, 12)
