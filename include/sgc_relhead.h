@@ -40,9 +40,10 @@ int sgc_conv2_object(const void* a_pad, const void* w2r, const float* bias, void
  * out_elem: 0 = f16, 1 = bf16. */
 int sgc_pair_expand(const void* U, const void* V, const int* sub_idx, const int* obj_idx, void* z_pad, int n_pairs, int out_elem, void* stream);
 
-/* Dense form of the same expansion for ALL ordered pairs of every image (the fused path): U/V rows of an image are staged in LDS
- * once per (window, 64-channel chunk) and every U/V element is read from HBM once per minibatch.  pid [n_obj][pid_ld] maps
- * (subject object, object index inside the image) -> pair index (-1 = skip); img_ptr [n_img+1]; any output may be NULL. */
+/* Dense form of the same expansion for ALL ordered pairs of every image (the fused path): one workgroup per (image, window,
+ * tile of 16 objects) stages the V quads in LDS, every wavefront keeps one subject's U quad in registers and writes complete 1 KiB
+ * channel rows.  pid [n_obj][pid_ld] maps (subject object, object index inside the image) -> pair index (-1 = skip);
+ * img_ptr [n_img+1]; any output may be NULL. */
 int sgc_pair_expand_dense(const void* U, const void* V, const int* img_ptr, const int* pid, int pid_ld, int n_img, int max_n,
                           void* z_pad_f16, void* z_pad_bf16, unsigned char* amz, void* stream);
 

@@ -96,48 +96,49 @@ __global__ __launch_bounds__(256) void pair_expand_kernel(const u16* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------ dense expansion
-// All ordered pairs of one image at once.  One workgroup owns (image, window W, 64-channel chunk): it stages the
-// U and V rows of EVERY object of the image for that window/chunk in LDS once (2 x n x 512 B), then each 8-lane
-// group keeps one subject row U_i in registers and streams the object rows V_j from LDS, writing z_ij (and, for
-// training, the bf16 copy and the relu/maxpool routing byte).  HBM traffic is the algorithmic minimum: every U/V
-// element is read once per minibatch and every z element written once - the generic pair-list kernel above re-reads
-// 8 KiB of U/V per (pair, window) through L2 (66 GB per step at N=64, B=8).
-// Object stride in LDS is 528 B (512 + 16) so that the two 8-lane groups of a 16-lane ds_read_b128 group hit
-// different banks when their object indices differ.
-__global__ __launch_bounds__(256) void pair_expand_dense_kernel(const u16* __restrict__ U, const u16* __restrict__ V,
+// All ordered pairs of one image at once, written as FULL channel rows.  One workgroup owns (image, window W, tile of JT
+// object-role objects j): it stages the four source pixels x 512 channels of V_j for its JT objects in LDS (JT x 4 KiB);
+// every wavefront then takes subjects i = wave, wave + 8, ...: it keeps the four pixels of U_i in registers (lane l owns
+// channels 8l..8l+7) and streams the V_j from LDS, so that each store instruction of the wave writes one complete
+// 1 KiB row z[p][y][x][0..511] (and, for training, the bf16 copy and the 512 B of relu/maxpool routing bytes).
+// HBM traffic is the algorithmic minimum for z; U quads are re-read once per object tile through L2 (n x 4 KiB per block,
+// 2 GB per step at N=64, B=8).  The first version of this kernel owned (window, 64-channel chunk) and wrote 128-byte
+// pieces of 32 different pairs per store instruction: 3.0 TB/s; full rows reach the rate of the un-pool kernel.
+constexpr int EXPAND_JT = 16;
+__global__ __launch_bounds__(512) void pair_expand_dense_kernel(const u16* __restrict__ U, const u16* __restrict__ V,
                                                                 const int* __restrict__ img_ptr, const int* __restrict__ pid,
                                                                 int pid_ld, u16* __restrict__ z, u16* __restrict__ zb,
                                                                 unsigned char* __restrict__ amz) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int OS = 528;
-    const int W = blockIdx.x, cq = blockIdx.y, img = blockIdx.z;
+    __shared__ __attribute__((aligned(16))) char sv[EXPAND_JT * 4096];
+    const int W = blockIdx.x, jt = blockIdx.y, img = blockIdx.z;
     const int o0 = img_ptr[img], n = img_ptr[img + 1] - o0;
-    char* su = smem;
-    char* sv = smem + n * OS;
-    for (int it = threadIdx.x; it < n * 64; it += 256) {
-        const int role = it >= n * 32;
-        const int r = it - role * n * 32;
-        const int o = r >> 5, part = r & 31, q = part >> 3, l8 = part & 7;
-        const u16* src = (role ? V : U) + ((long)(o0 + o) * 1024 + 4 * W + q) * 512 + cq * 64 + l8 * 8;
-        *reinterpret_cast<uint4*>((role ? sv : su) + o * OS + q * 128 + l8 * 16) = *reinterpret_cast<const uint4*>(src);
+    const int j0 = jt * EXPAND_JT;
+    if (j0 >= n) return;
+    const int nj = min(EXPAND_JT, n - j0);
+    // stage V: object jj -> 4 pixels x 1 KiB, contiguous in global memory (window-major pixel order)
+    for (int it = threadIdx.x; it < nj * 256; it += 512) {
+        const int jj = it >> 8, part = it & 255;
+        const u16* src = V + ((long)(o0 + j0 + jj) * 1024 + 4 * W) * 512 + part * 8;
+        *reinterpret_cast<uint4*>(sv + jj * 4096 + part * 16) = *reinterpret_cast<const uint4*>(src);
     }
     __syncthreads();
-    const int grp = threadIdx.x >> 3, l8 = threadIdx.x & 7;
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int Y = W >> 4, X = W & 15;
-    const long zoff = ((long)(Y + 1) * 18 + X + 1) * 512 + cq * 64 + l8 * 8;
-    const long aoff = (long)W * 512 + cq * 64 + l8 * 8;
-    for (int i = grp; i < n; i += 32) {
+    const long zoff = ((long)(Y + 1) * 18 + X + 1) * 512 + lane * 8;
+    const long aoff = (long)W * 512 + lane * 8;
+    for (int i = wid; i < n; i += 8) {
         float uf[4][8];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const uint4 a = *reinterpret_cast<const uint4*>(su + i * OS + q * 128 + l8 * 16);
+            const uint4 a = *reinterpret_cast<const uint4*>(U + ((long)(o0 + i) * 1024 + 4 * W + q) * 512 + lane * 8);
             const u16* ah = reinterpret_cast<const u16*>(&a);
 #pragma unroll
             for (int k = 0; k < 8; ++k) uf[q][k] = f16_bits_to_f32(ah[k]);
         }
-        const int* prow = pid + (long)(o0 + i) * pid_ld;
-        for (int j = 0; j < n; ++j) {
-            const int p = prow[j];
+        const int* prow = pid + (long)(o0 + i) * pid_ld + j0;
+        for (int jj = 0; jj < nj; ++jj) {
+            const int p = __builtin_amdgcn_readfirstlane(prow[jj]);
             if (p < 0) continue;                       // diagonal (or a pair that is not requested)
             float best[8];
             unsigned char arg[8];
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(256) void pair_expand_dense_kernel(const u16* __res
             for (int k = 0; k < 8; ++k) { best[k] = 0.f; arg[k] = 4; }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const uint4 b = *reinterpret_cast<const uint4*>(sv + j * OS + q * 128 + l8 * 16);
+                const uint4 b = *reinterpret_cast<const uint4*>(sv + jj * 4096 + q * 1024 + lane * 16);
                 const u16* bh = reinterpret_cast<const u16*>(&b);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
@@ -335,15 +336,8 @@ int sgc_pair_expand_dense(const void* U, const void* V, const int* img_ptr, cons
                           void* z_pad_f16, void* z_pad_bf16, unsigned char* amz, void* stream) {
     if (max_n > 150 || max_n < 1) return SGC_ERR_ARG;
     if (n_img <= 0) return SGC_OK;
-    const int lds = 2 * max_n * 528;
-    static int attr_lds = 0;
-    if (lds > attr_lds) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pair_expand_dense_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 150 * 528);
-        attr_lds = 2 * 150 * 528;
-    }
-    SGC_LAUNCH(pair_expand_dense_kernel, dim3(256, 8, n_img), dim3(256), lds, (hipStream_t)stream, (const u16*)U, (const u16*)V,
-               img_ptr, pid, pid_ld, (u16*)z_pad_f16, (u16*)z_pad_bf16, amz);
+    SGC_LAUNCH(pair_expand_dense_kernel, dim3(256, (max_n + EXPAND_JT - 1) / EXPAND_JT, n_img), dim3(512), 0, (hipStream_t)stream,
+               (const u16*)U, (const u16*)V, img_ptr, pid, pid_ld, (u16*)z_pad_f16, (u16*)z_pad_bf16, amz);
     SGC_CHECK_LAUNCH();
     return SGC_OK;
 }
