@@ -130,3 +130,56 @@ def test_conv_tn(n_img, lgS, Cin, M, splits):
     ref = torch.nn.grad.conv2d_weight(x.float(), (M, Cin, 3, 3), dy.float(), padding=1)
     err = (got - ref).abs().max().item()
     assert err <= 1e-3 * ref.abs().max().item() + 1e-4, err
+
+
+def test_pingpong_blocks_repeatable():
+    """Race screen for the counted-vmcnt ping-pong blocks (csrc/gemm_nt_pp.h hazard rules): the same launch repeated under
+    memory load must give bit-identical results every time and match the f32 reference."""
+    lib, L = _lib()
+    dtype, elem = torch.bfloat16, 1
+    M, N, K = 2048, 1024, 4096
+    A, B = _rand((M, K), dtype, 31), _rand((N, K), dtype, 32)
+    ref = A.float() @ B.float().t()
+    noise = torch.empty(64 << 20, dtype=torch.float32, device="cuda")
+    first = None
+    for it in range(12):
+        C = torch.empty(M, N, dtype=dtype, device="cuda")
+        noise.normal_()                                            # evict L2 / perturb timing between launches
+        assert lib.sgc_dbg_gemm_nt(elem, L.ptr(A), L.ptr(B), L.ptr(C), M, N, K, ctypes.c_long(K), ctypes.c_long(K),
+                                   ctypes.c_long(N), None, L.stream_ptr()) == 0
+        torch.cuda.synchronize()
+        if first is None:
+            first = C.clone()
+            assert (C.float() - ref).abs().max().item() <= 1.6e-2 * ref.abs().max().item()
+        else:
+            assert torch.equal(C, first), "ping-pong NT block is not repeatable (iteration %d)" % it
+    # TN engine, 2 K splits
+    At, Bt = _rand((K, 512), dtype, 33), _rand((K, 1024), dtype, 34)
+    reft = At.float().t() @ Bt.float()
+    first = None
+    for it in range(12):
+        Cs = torch.zeros(2, 512, 1024, dtype=torch.float32, device="cuda")
+        slabs = ctypes.c_int(0)
+        noise.normal_()
+        assert lib.sgc_dbg_gemm_tn(elem, L.ptr(At), L.ptr(Bt), L.ptr(Cs), 512, 1024, K, ctypes.c_long(512), ctypes.c_long(1024), 2,
+                                   ctypes.byref(slabs), L.stream_ptr()) == 0
+        torch.cuda.synchronize()
+        got = Cs[:slabs.value].sum(0)
+        if first is None:
+            first = got.clone()
+            assert (got - reft).abs().max().item() <= 1e-3 * reft.abs().max().item() + 1e-4
+        else:
+            assert torch.equal(got, first), "ping-pong TN block is not repeatable (iteration %d)" % it
+    # halo conv
+    n_img, Cin, Nc = 64, 512, 512
+    x, w, xp, wr = _conv_inputs(n_img, 16, Cin, Nc, dtype)
+    first = None
+    for it in range(12):
+        C = torch.empty(n_img * 256, Nc, dtype=dtype, device="cuda")
+        noise.normal_()
+        assert lib.sgc_dbg_conv_nt(elem, L.ptr(xp), L.ptr(wr), L.ptr(C), n_img, 4, Cin, Nc, None, L.stream_ptr()) == 0
+        torch.cuda.synchronize()
+        if first is None:
+            first = C.clone()
+        else:
+            assert torch.equal(C, first), "ping-pong halo conv block is not repeatable (iteration %d)" % it
