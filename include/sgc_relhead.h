@@ -47,8 +47,10 @@ int sgc_pair_expand(const void* U, const void* V, const int* sub_idx, const int*
 int sgc_pair_expand_dense(const void* U, const void* V, const int* img_ptr, const int* pid, int pid_ld, int n_img, int max_n,
                           void* z_pad_f16, void* z_pad_bf16, unsigned char* amz, void* stream);
 
-/* y [n_pairs*64][1024] f16 (+ argmax u8, may be NULL) = maxpool2(relu(conv3x3(z_pad, w3r[1024][8][9][64]) + b3))   (model.py:145-146) */
-int sgc_conv3_relu_pool(const void* z_pad, const void* w3r, const float* b3, void* y, unsigned char* argmax, int n_pairs, void* stream);
+/* y [n_pairs*64][1024] f16 (+ argmax u8, may be NULL; + y_bf16, the same values rounded to bf16 for the fc1 weight gradient, may be
+ * NULL) = maxpool2(relu(conv3x3(z_pad, w3r[1024][8][9][64]) + b3))   (model.py:145-146) */
+int sgc_conv3_relu_pool(const void* z_pad, const void* w3r, const float* b3, void* y, unsigned char* argmax, void* y_bf16, int n_pairs,
+                        void* stream);
 
 /* h1 [n_pairs][4096] f16 = dropout(relu(y[n_pairs][K] * w1p[4096][K]^T + b))   (model.py:148-149; columns of w1p in (window, channel) order) */
 int sgc_fc1_relu(const void* y, const void* w1p, const float* b, void* h1, int n_pairs, int K, int drop_enable, unsigned drop_seed, void* stream);

@@ -29,6 +29,7 @@ struct NtParams {
     const u16* mask_src;        // EPI_RELUMASK: forward activation [M][ldc], gradient passes where it is > 0
     const float* lsub; const float* lobj; const int* sub_idx; const int* obj_idx;   // EPI_FC2
     unsigned char* argmax;      // EPI_POOL (optional)
+    u16* C2;                    // EPI_POOL (optional): bf16 copy of the pooled output (operand of the fc1 weight gradient)
     float scale;                // EPI_RELUMASK / dropout scale
     unsigned drop_seed; int drop_enable;
     int tiles_m, tiles_n;
@@ -82,6 +83,7 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x16 (&acc)[TM]
                     if (prow * 4 < p.M) {
                         if (!(v > 0.f)) { v = 0.f; am = 4; }        // ReLU killed: no gradient path
                         out[(long)prow * p.ldc + col] = to_elem<ELEM>(v);
+                        if (p.C2) p.C2[(long)prow * p.ldc + col] = f32_to_bf16_bits(v);
                         if (p.argmax) p.argmax[(long)prow * p.ldc + col] = (unsigned char)am;
                     }
                 }

@@ -184,6 +184,65 @@ static int launch_gemm_nt_pp(NtParams p, hipStream_t stream) {
 }
 
 
+// LDS-staged bias + ReLU + 2x2 max-pool epilogue of the 8-wave block (conv3 forward: 4.2 GB of f16 + 2.1 GB of routing bytes
+// per launch, + 4.2 GB when the bf16 copy is requested).  In the MFMA C layout a lane owns ONE column, so the direct form
+// issues 2-byte and 1-byte stores (measured 2.0 ms of the 59 ms launch).  Here every wave pools in registers (the four
+// accumulator registers of a window), writes its 32 windows x 64 channels into a private LDS tile (pitch 144 B / 80 B) and
+// streams complete 128-byte / 64-byte rows out with 16-byte stores.
+constexpr int POOL_EPI_WAVE_BYTES = 32 * 144 * 2 + 32 * 80;      // f16 tile + bf16 tile + argmax tile
+template <int ELEM>
+__device__ __forceinline__ void nt_epilogue_pool16(const NtParams& p, f32x16 (&acc)[4][2], int m0, int n0, int wr, int wc, int lane,
+                                                   int wid, char* smem) {
+    __syncthreads();                                   // every wave is done reading operand tiles
+    char* ty = smem + wid * POOL_EPI_WAVE_BYTES;
+    char* tb = ty + 32 * 144;
+    char* ta = tb + 32 * 144;
+    const int h = lane >> 5, cl = lane & 31;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int colw = j * 32 + cl;
+            const float bias = p.bias ? p.bias[n0 + wc * 64 + colw] : 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                float v = acc[i][j][4 * w];
+                int am = 0;
+#pragma unroll
+                for (int q = 1; q < 4; ++q) {
+                    const float t = acc[i][j][4 * w + q];
+                    if (t > v) { v = t; am = q; }
+                }
+                v += bias;
+                if (!(v > 0.f)) { v = 0.f; am = 4; }        // ReLU killed: no gradient path
+                const int row = i * 8 + 2 * w + h;          // window inside the wave's 32
+                *reinterpret_cast<u16*>(ty + row * 144 + colw * 2) = to_elem<ELEM>(v);
+                if (p.C2) *reinterpret_cast<u16*>(tb + row * 144 + colw * 2) = f32_to_bf16_bits(v);
+                if (p.argmax) *reinterpret_cast<unsigned char*>(ta + row * 80 + colw) = (unsigned char)am;
+            }
+        }
+    __builtin_amdgcn_wave_barrier();
+    const long prow0 = ((long)m0 >> 2) + wr * 32;
+    const int c8 = lane & 7, r8 = lane >> 3;
+    u16* out = reinterpret_cast<u16*>(p.C);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int row = it * 8 + r8;
+        const long o = (prow0 + row) * p.ldc + n0 + wc * 64 + c8 * 8;
+        *reinterpret_cast<uint4*>(out + o) = *reinterpret_cast<const uint4*>(ty + row * 144 + c8 * 16);
+        if (p.C2) *reinterpret_cast<uint4*>(p.C2 + o) = *reinterpret_cast<const uint4*>(tb + row * 144 + c8 * 16);
+    }
+    if (p.argmax) {
+        const int c4 = lane & 3, r16 = lane >> 2;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int row = it * 16 + r16;
+            *reinterpret_cast<uint4*>(p.argmax + (prow0 + row) * p.ldc + n0 + wc * 64 + c4 * 16) =
+                *reinterpret_cast<const uint4*>(ta + row * 80 + c4 * 16);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Halo-staged implicit 3x3 convolution on 16x16 maps with the ping-pong schedule (conv3 forward / data gradient).
 // One workgroup = one image (256 pixels, window-major rows) x 256 output channels; K step = (64-channel chunk, tap).
@@ -351,6 +410,9 @@ __global__ __launch_bounds__(512, 2) void conv16_halo_pp_kernel(const NtParams p
 
     if constexpr (EPI == EPI_STORE) {
         if (p.epi_lds) { nt_epilogue_store16<ELEM>(p, acc, m0, n0, wr, wc, lane, wid, smem); return; }
+    }
+    if constexpr (EPI == EPI_POOL) {
+        if (p.epi_lds) { nt_epilogue_pool16<ELEM>(p, acc, m0, n0, wr, wc, lane, wid, smem); return; }
     }
     nt_epilogue<ELEM, EPI, 4, 2>(p, acc, m0, n0, wr, wc, lane);
 }

@@ -343,11 +343,11 @@ int sgc_pair_expand_dense(const void* U, const void* V, const int* img_ptr, cons
 }
 
 // y [n_pairs*64][1024] (+argmax u8) = maxpool2(relu(conv3x3(z_pad, w3r[1024][8][9][64]) + b3))
-int sgc_conv3_relu_pool(const void* z_pad, const void* w3r, const float* b3, void* y, unsigned char* argmax, int n_pairs,
-                        void* stream) {
+int sgc_conv3_relu_pool(const void* z_pad, const void* w3r, const float* b3, void* y, unsigned char* argmax, void* y_bf16,
+                        int n_pairs, void* stream) {
     NtParams p{};
     p.A = (const u16*)z_pad; p.B = (const u16*)w3r; p.C = y; p.M = n_pairs * 256; p.N = 1024; p.K = 9 * 512;
-    p.ldb = 9 * 512; p.ldc = 1024; p.lgS = 4; p.Cin = 512; p.bias = b3; p.argmax = argmax;
+    p.ldb = 9 * 512; p.ldc = 1024; p.lgS = 4; p.Cin = 512; p.bias = b3; p.argmax = argmax; p.C2 = (u16*)y_bf16;
     return launch_gemm_nt<ELEM_F16, AMODE_CONV, EPI_POOL>(p, (hipStream_t)stream);
 }
 

@@ -271,7 +271,7 @@ class RelHeadEngine:
         y = ws.get("y", Ppad * 65536, torch.float16)
         am = ws.get("argmax", P * 65536, torch.uint8) if keep_argmax else None
         self._timed("conv3_fwd", lambda: _lib.check(lib.sgc_conv3_relu_pool(_lib.ptr(z), _lib.ptr(self.w["w3r"]), _lib.ptr(self.w["b3"]), _lib.ptr(y),
-                                           _lib.ptr(am), P, self._st()), "sgc_conv3_relu_pool"))
+                                           _lib.ptr(am), _lib.ptr(None), P, self._st()), "sgc_conv3_relu_pool"))
         h1 = ws.get("h1", Ppad * 4096, torch.float16)
         self._timed("fc1_fwd", lambda: _lib.check(lib.sgc_fc1_relu(_lib.ptr(y), _lib.ptr(self.w["w1p"]), _lib.ptr(self.w["bf1"]), _lib.ptr(h1), P, 65536,
                                     int(train), ctypes.c_uint(seeds[0]), self._st()), "sgc_fc1_relu"))
@@ -372,9 +372,13 @@ class RelHeadEngine:
         self.expand(ctx.uv[0], ctx.uv[1], sub_idx, obj_idx, P, z, z_bf, amz, dense=dense)
         ctx.z_bf = z_bf
         y = ws.get("y", Ppad * 65536, torch.float16)
+        y_bf = ws.get("y_bf", Ppad * 65536, torch.bfloat16)         # bf16 copy for the fc1 weight gradient, written by the same epilogue
+        if Ppad > P:
+            y_bf[P * 65536:].zero_()
         am = ws.get("argmax", P * 65536, torch.uint8)
         self._timed("conv3_fwd", lambda: _lib.check(lib.sgc_conv3_relu_pool(_lib.ptr(z), _lib.ptr(self.w["w3r"]), _lib.ptr(self.w["b3"]), _lib.ptr(y), _lib.ptr(am),
-                                           P, self._st()), "sgc_conv3_relu_pool"))
+                                           _lib.ptr(y_bf), P, self._st()), "sgc_conv3_relu_pool"))
+        ctx.y_bf = y_bf
         h1 = ws.get("h1", Ppad * 4096, torch.float16)
         self._timed("fc1_fwd", lambda: _lib.check(lib.sgc_fc1_relu(_lib.ptr(y), _lib.ptr(self.w["w1p"]), _lib.ptr(self.w["bf1"]), _lib.ptr(h1), P, 65536,
                                     int(dropout), ctypes.c_uint(seeds[0]), self._st()), "sgc_fc1_relu"))
@@ -460,7 +464,7 @@ class RelHeadEngine:
                    "sgc_fc2_dgrad"))
 
         # ---- fc1
-        y_bf = self._to_bf16("y_bf", ctx.y, Ppad * 65536)
+        y_bf = ctx.y_bf
         dW1p = ws.get("dW1p", 4096 * 65536, torch.float32)
         self._timed("fc1_wgrad", lambda: _lib.check(lib.sgc_fc1_wgrad(_lib.ptr(dh1), _lib.ptr(y_bf), _lib.ptr(dW1p), Ppad, 65536, st()), "sgc_fc1_wgrad"))
         # back to the reference column order (c*64 + window): 64x64 tile transposes, f32 -> f32
