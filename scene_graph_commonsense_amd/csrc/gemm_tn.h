@@ -241,27 +241,29 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(const TnParams p) {
 
     // ---- staging: one instruction = one k block (4 rows) x 8 sub-blocks of a half tile; wave w owns k blocks 2w, 2w+1
     const int kr = (lane >> 1) & 3, sb = lane >> 3, c8 = (lane & 1) * 8;
-    long boff_tap = 0;
-    int bcol0 = n0;
-    if constexpr (BMODE == BMODE_CONV) {
-        const int tap = n0 / p.Cin;
-        bcol0 = n0 - tap * p.Cin;
-        const int ky = tap / 3, kx = tap - 3 * ky;
-        boff_tap = (long)(ky * ((1 << p.lgS) + 2) + kx) * p.Cin;
-    }
     int voff[4][2];                                  // kind 0 A0, 1 B0, 2 B1, 3 A1: byte offsets inside a K tile
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int kl = (wid * 2 + q) * 4 + kr;
-        long arow, brow;
+        long arow;
         if constexpr (ACONV) arow = conv_row_base(kl, p.lgS, p.CinA) + (long)((1 << p.lgS) + 3) * p.CinA;
         else arow = (long)kl * p.lda;
-        if constexpr (BMODE == BMODE_CONV) brow = conv_row_base(kl, p.lgS, p.Cin) + boff_tap;
-        else brow = (long)kl * p.ldb;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             voff[h ? 3 : 0][q] = (int)((arow + m0 + ((sb >> 2) * 8 + h * 4 + (sb & 3)) * 16 + c8) * 2);
-            voff[1 + h][q] = (int)((brow + bcol0 + ((sb >> 1) * 4 + h * 2 + (sb & 1)) * 16 + c8) * 2);
+            const int col = n0 + ((sb >> 1) * 4 + h * 2 + (sb & 1)) * 16;      // first column of this lane's 16-column sub-block
+            long b;
+            if constexpr (BMODE == BMODE_CONV) {
+                // the tap is a per-lane quantity: with Cin = 128 a 256-column tile spans two taps, and the last tile of
+                // N = 9*Cin may reach past tap 8 (those columns read tap 8 again and are never stored)
+                const int tap_raw = col / p.Cin;
+                const int tap = tap_raw > 8 ? 8 : tap_raw;
+                const int ky = tap / 3, kx = tap - 3 * ky;
+                b = conv_row_base(kl, p.lgS, p.Cin) + (long)(ky * ((1 << p.lgS) + 2) + kx) * p.Cin + (col - tap_raw * p.Cin);
+            } else {
+                b = (long)kl * p.ldb + col;
+            }
+            voff[1 + h][q] = (int)((b + c8) * 2);
         }
     }
     auto stage = [&](int kind, int it) __attribute__((always_inline)) {      // it = K tile index inside this split
@@ -355,6 +357,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(const TnParams p) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int col = n0 + wc * 64 + j * 32 + cl;
+            if (col >= p.N) continue;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wr * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
@@ -367,7 +370,7 @@ template <int ELEM, int BMODE, int ACONV>
 static int launch_gemm_tn_pp(TnParams p, int splits, int* slabs_out, hipStream_t stream) {
     constexpr int LDS = 8 * 16384;
     p.tiles_m = p.M / 256;
-    p.tiles_n = p.N / 256;
+    p.tiles_n = (p.N + 255) / 256;
     const int nk = p.K >> 6;
     if (splits < 1) splits = 1;
     if (splits > nk) splits = nk;
@@ -401,7 +404,10 @@ static int launch_gemm_tn(TnParams p, int splits, int* slabs_out, hipStream_t st
     const int cfg = sgc_gemm_cfg();
     const bool big_ok = (p.N % 256) == 0 && (p.M % 256) == 0 && (BMODE != BMODE_CONV || (p.Cin % 256) == 0);
     const bool big = big_ok && (cfg == 2 || (cfg == 0 && (long)p.M * p.N >= 512L * 512));
-    if (big_ok && (cfg == 5 || cfg == 7 || (big && cfg == 0 && sgc_gemm_pp()))) return launch_gemm_tn_pp<ELEM, BMODE, ACONV>(p, splits, slabs_out, stream);
+    // the ping-pong block takes per-lane taps: conv weight gradients with Cin = 128 (N = 1152 -> 5 column tiles, the last half empty)
+    const bool pp_ok = (p.M % 256) == 0 && (BMODE == BMODE_CONV ? (p.Cin % 128) == 0 : (p.N % 256) == 0);
+    if (pp_ok && (cfg == 5 || cfg == 7 || (cfg == 0 && sgc_gemm_pp() && (long)p.M * p.N >= 256L * 1024)))
+        return launch_gemm_tn_pp<ELEM, BMODE, ACONV>(p, splits, slabs_out, stream);
     if (big) return launch_gemm_tn_cfg<ELEM, BMODE, ACONV, 2, 4, 4, 2>(p, splits, slabs_out, stream);
     return launch_gemm_tn_cfg<ELEM, BMODE, ACONV, 2, 2, 2, 2>(p, splits, slabs_out, stream);
 }

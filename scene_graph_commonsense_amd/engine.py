@@ -502,7 +502,7 @@ class RelHeadEngine:
                        "sgc_pair_contract"))
             a_pad = ws.get("a_pad_%d" % r, n_obj * 34 * 34 * 128, torch.float16)
             a_bf = self._to_bf16("a_pad_bf", a_pad, n_obj * 34 * 34 * 128)
-            self._timed("conv2_wgrad", lambda: _lib.check(lib.sgc_conv2_wgrad(_lib.ptr(dU), _lib.ptr(a_bf), _lib.ptr(sl), n_obj, 16, ctypes.byref(slabs_n), st()),
+            self._timed("conv2_wgrad", lambda: _lib.check(lib.sgc_conv2_wgrad(_lib.ptr(dU), _lib.ptr(a_bf), _lib.ptr(sl), n_obj, 25, ctypes.byref(slabs_n), st()),
                        "sgc_conv2_wgrad"))
             dW2r = self._slab_sum(sl, 512 * 1152, slabs_n.value)
             gc2[:, r * 128:(r + 1) * 128] = dW2r.view(512, 3, 3, 128).permute(0, 3, 1, 2)

@@ -111,7 +111,7 @@ def test_gemm_tn_plain(dtype, elem, M, N, K, splits):
 
 @pytest.mark.parametrize("n_img,lgS,Cin,M,splits", [(2, 4, 128, 128, 2), (3, 5, 128, 256, 4), (2, 4, 512, 128, 1),
                                                     (8, 4, 512, 1024, 8), (16, 4, 256, 512, 16), (3, 4, 256, 256, 1),
-                                                    (5, 4, 512, 256, 3)])
+                                                    (5, 4, 512, 256, 3), (4, 5, 128, 512, 5), (3, 4, 128, 256, 2), (2, 5, 384, 256, 3)])
 def test_conv_tn(n_img, lgS, Cin, M, splits):
     lib, L = _lib()
     dtype, elem = torch.bfloat16, 1
