@@ -121,6 +121,9 @@ int sgc_transpose_cast(const float* src, void* dst, int out_kind, int na, int nb
                        long sb_d, long ds_j, void* stream);
 
 int sgc_fc2_dgrad(const void* dpre, const void* w2mT, const void* h1, void* dh1, int n_pairs, float drop_scale, void* stream);
+/* Weight gradients with a `splits` argument write split-K partial sums: slabs [*n_slabs][M][N] f32, reduced by sgc_slab_sum.
+ * splits <= 0 lets the library choose (whole waves of blocks on the 256 CUs, >= 8 K tiles per block): at most 7 slabs for
+ * sgc_conv3_wgrad and 25 for sgc_conv2_wgrad. */
 int sgc_fc2_wgrad(const void* dpre, const void* h1_bf16, float* slabs, int n_rows, int splits, int* n_slabs, void* stream);
 int sgc_fc1_dgrad(const void* dh1, const void* w1pT, void* dy, int n_pairs, int K, void* stream);
 int sgc_fc1_wgrad(const void* dh1, const void* y_bf16, float* dw, int n_rows, int K, void* stream);

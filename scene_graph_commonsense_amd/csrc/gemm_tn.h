@@ -397,6 +397,21 @@ static int launch_gemm_tn_pp(TnParams p, int splits, int* slabs_out, hipStream_t
     return SGC_OK;
 }
 
+// Split-K count for a tile grid when the caller passes splits <= 0: the smallest count that fills the 256 CUs in whole
+// waves of blocks to >= 95 % while leaving >= 8 K tiles per block.  Few, long splits matter: every split writes a full f32
+// slab with 4-byte stores and adds a slab to the reduction (conv3 weight gradient: 32 splits 62.1 ms, 7 splits 57.5 ms).
+static inline int tn_auto_splits(int tiles, int nk) {
+    int best = 1;
+    for (int s = 1; s <= 64; ++s) {
+        if (s > 1 && nk / s < 8) break;
+        const long blocks = (long)tiles * s;
+        const long waves = (blocks + 255) / 256;
+        best = s;
+        if (blocks >= 256 && blocks * 100 >= waves * 256 * 95) break;
+    }
+    return best;
+}
+
 template <int ELEM, int BMODE, int ACONV = 0>
 static int launch_gemm_tn(TnParams p, int splits, int* slabs_out, hipStream_t stream) {
     if ((p.K & 63) || (p.N & 127) || (p.M & 127) || p.K <= 0) return SGC_ERR_ARG;
@@ -406,8 +421,11 @@ static int launch_gemm_tn(TnParams p, int splits, int* slabs_out, hipStream_t st
     const bool big = big_ok && (cfg == 2 || (cfg == 0 && (long)p.M * p.N >= 512L * 512));
     // the ping-pong block takes per-lane taps: conv weight gradients with Cin = 128 (N = 1152 -> 5 column tiles, the last half empty)
     const bool pp_ok = (p.M % 256) == 0 && (BMODE == BMODE_CONV ? (p.Cin % 128) == 0 : (p.N % 256) == 0);
-    if (pp_ok && (cfg == 5 || cfg == 7 || (cfg == 0 && sgc_gemm_pp() && (long)p.M * p.N >= 256L * 1024)))
+    if (pp_ok && (cfg == 5 || cfg == 7 || (cfg == 0 && sgc_gemm_pp() && (long)p.M * p.N >= 256L * 1024))) {
+        if (splits <= 0) splits = tn_auto_splits((p.M / 256) * ((p.N + 255) / 256), p.K >> 6);
         return launch_gemm_tn_pp<ELEM, BMODE, ACONV>(p, splits, slabs_out, stream);
+    }
+    if (splits <= 0) splits = tn_auto_splits(big ? (p.M / 256) * (p.N / 256) : (p.M / 128) * (p.N / 128), p.K >> 6);
     if (big) return launch_gemm_tn_cfg<ELEM, BMODE, ACONV, 2, 4, 4, 2>(p, splits, slabs_out, stream);
     return launch_gemm_tn_cfg<ELEM, BMODE, ACONV, 2, 2, 2, 2>(p, splits, slabs_out, stream);
 }

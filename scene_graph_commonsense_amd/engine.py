@@ -486,7 +486,7 @@ class RelHeadEngine:
                    "sgc_unpool_relu_bwd"))
         grads["conv3_1.bias"] = self._slab_sum(bpart, 1024, nparts.value)
         z_bf = ctx.z_bf
-        self._timed("conv3_wgrad", lambda: _lib.check(lib.sgc_conv3_wgrad(_lib.ptr(dy3), _lib.ptr(z_bf), _lib.ptr(sl), P, 32, ctypes.byref(slabs_n), st()),
+        self._timed("conv3_wgrad", lambda: _lib.check(lib.sgc_conv3_wgrad(_lib.ptr(dy3), _lib.ptr(z_bf), _lib.ptr(sl), P, 0, ctypes.byref(slabs_n), st()),
                    "sgc_conv3_wgrad"))
         dW3r = self._slab_sum(sl, 1024 * 4608, slabs_n.value)
         grads["conv3_1.weight"] = dW3r.view(1024, 3, 3, 512).permute(0, 3, 1, 2).contiguous()
@@ -502,7 +502,7 @@ class RelHeadEngine:
                        "sgc_pair_contract"))
             a_pad = ws.get("a_pad_%d" % r, n_obj * 34 * 34 * 128, torch.float16)
             a_bf = self._to_bf16("a_pad_bf", a_pad, n_obj * 34 * 34 * 128)
-            self._timed("conv2_wgrad", lambda: _lib.check(lib.sgc_conv2_wgrad(_lib.ptr(dU), _lib.ptr(a_bf), _lib.ptr(sl), n_obj, 25, ctypes.byref(slabs_n), st()),
+            self._timed("conv2_wgrad", lambda: _lib.check(lib.sgc_conv2_wgrad(_lib.ptr(dU), _lib.ptr(a_bf), _lib.ptr(sl), n_obj, 0, ctypes.byref(slabs_n), st()),
                        "sgc_conv2_wgrad"))
             dW2r = self._slab_sum(sl, 512 * 1152, slabs_n.value)
             gc2[:, r * 128:(r + 1) * 128] = dW2r.view(512, 3, 3, 128).permute(0, 3, 1, 2)
