@@ -19,11 +19,18 @@ typedef unsigned short u16;
 
 enum { ELEM_F16 = 0, ELEM_BF16 = 1 };
 
+// f32 -> bf16, round to nearest even: gfx950 has the conversion in hardware (v_cvt_pk_bf16_f32, one VALU op per PAIR); the
+// integer emulation (NaN test + add + shift, ~6 ops per value) made the bf16 epilogues of the GEMM blocks VALU-bound
+// (128 values per lane: fc1 data gradient 13.3 -> see profiles/README.md).
 __device__ __forceinline__ u16 f32_to_bf16_bits(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (u16)((u >> 16) | 0x40);   // NaN
-    u += 0x7fffu + ((u >> 16) & 1u);                                       // round to nearest even
-    return (u16)(u >> 16);
+    const __bf16 h = (__bf16)f;
+    return __builtin_bit_cast(u16, h);
+}
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t f32x2_to_bf16x2_bits(float lo, float hi) {      // lo in bits [15:0]
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 __device__ __forceinline__ float bf16_bits_to_f32(u16 h) { return __uint_as_float(((uint32_t)h) << 16); }
 __device__ __forceinline__ u16 f32_to_f16_bits(float f) {
