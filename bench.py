@@ -161,7 +161,7 @@ def main():
                     "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic() if P == 32256 else None,
                     "traffic_note": "bytes/launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from profiles/r01_final_pmc_{f,w}.csv "
-                                    "(separate rocprofv3 --pmc passes at this workload); algorithmic 17.0e9",
+                                    "(separate rocprofv3 --pmc passes at this workload); algorithmic 21.2e9 (padded z 10.7 + y f16 4.2 + y bf16 4.2 + routing 2.1)",
                     "ms_per_launch": round(kern[dom], 3)}
         out = {
             "metric": "ordered object-pairs/sec (relation head fwd+bwd), batch=%d, N=%d" % (args.images, args.objects)

@@ -170,10 +170,12 @@ __device__ __forceinline__ void nt_epilogue_store16(const NtParams& p, f32x16 (&
                 const float v0 = acc[i][j][2 * rp] + bias, v1 = acc[i][j][2 * rp + 1] + bias;
                 const float recv = __shfl_xor(odd ? v0 : v1, 1);
                 const int r0 = ((2 * rp) & 3) + 8 * ((2 * rp) >> 2) + 4 * h;       // row of register 2rp; register 2rp+1 is r0+1
-                const unsigned lo = odd ? to_elem<ELEM>(recv) : to_elem<ELEM>(v0);
-                const unsigned hi = odd ? to_elem<ELEM>(v1) : to_elem<ELEM>(recv);
+                const float flo = odd ? recv : v0, fhi = odd ? v1 : recv;
+                unsigned packed;
+                if constexpr (ELEM == ELEM_BF16) packed = f32x2_to_bf16x2_bits(flo, fhi);      // one v_cvt_pk_bf16_f32
+                else packed = (unsigned)to_elem<ELEM>(flo) | ((unsigned)to_elem<ELEM>(fhi) << 16);
                 const int row = i * 32 + r0 + (odd ? 1 : 0);
-                *reinterpret_cast<unsigned*>(reg + row * 144 + (j * 32 + (cl & ~1)) * 2) = lo | (hi << 16);
+                *reinterpret_cast<unsigned*>(reg + row * 144 + (j * 32 + (cl & ~1)) * 2) = packed;
             }
         }
     }
