@@ -138,6 +138,28 @@ int sgc_object_masked_maps_bwd(const void* da, const int* img_ptr, const int* bb
 int sgc_tanh_bwd(const float* dA, const void* a_img, void* dpre, long n, void* stream);
 int sgc_conv1_wgrad(const void* dpre, const void* x_bf16, float* slabs, int n_rows, int XC, int splits, int* n_slabs, void* stream);
 
+/* ----------------------------------------------------------------------------------------------- SGDET / SGCLS object front-end
+ * (evaluate.py:309-366 = :543-589, utils.py:58-74,377-425)
+ *
+ * sgc_detr_candidates: per (image, query) softmax over the C1 decoder logits, has-object test (arg-max < num_classes), top-k
+ * probabilities/classes, DETR (alphabetical) -> dataset (frequency) class index through alp2fre [C1], box cxcywh in [0,1] ->
+ * (x0,x1,y0,y1) * feature_size with clamp   (evaluate.py:311-332).  cand_cat [n_img][n_query][topk] holds the mapped class or -1
+ * when the query has no object or the mapped class equals num_classes (:323,340-344); cand_conf the probabilities;
+ * cand_box [n_img][n_query][4]. */
+int sgc_detr_candidates(const float* logits, const float* boxes, const int* alp2fre, int n_img, int n_query, int C1, int num_classes,
+                        int topk, float feature_size, int* cand_cat, float* cand_conf, float* cand_box, void* stream);
+/* Per-class greedy NMS of every image's n_query*topk candidate slots (evaluate.py:347-366; torchvision.ops.nms 0.15.2: stable
+ * descending score order, suppress when inter/(a_i + a_j - inter) > iou_threshold).  out_slot [n_img][n_query*topk]: kept slot
+ * indices (slot = query*topk + rank) in the reference's concatenation order (classes ascending, scores descending), -1 padded;
+ * out_count [n_img].  n_query*topk <= 256. */
+int sgc_nms_per_class(const int* cand_cat, const float* cand_conf, const float* cand_box, int n_img, int n_query, int topk,
+                      double iou_threshold, int* out_slot, int* out_count, void* stream);
+/* SGCLS label matching (utils.py:377-425): for every ground-truth box [tgt_ptr segments] the two predicted boxes
+ * [pred_ptr segments] of its image with the largest rasterised-grid IoU (utils.py:58-74); equal IoUs resolve to the lower
+ * prediction index.  top_idx / top_iou [n_tgt][2] (image-local prediction indices, -1 / -1.0 when the image has < 2 predictions). */
+int sgc_match_boxes_top2(const float* pred_box, const int* pred_ptr, const float* tgt_box, const int* tgt_ptr, int n_img, int max_tgt,
+                         int feature_size, int* top_idx, float* top_iou, void* stream);
+
 /* ----------------------------------------------------------------------------------------------- test hooks (raw GEMM engines) */
 int sgc_dbg_gemm_nt(int elem, const void* A, const void* B, void* C, int M, int N, int K, long lda, long ldb, long ldc, const float* bias, void* stream);
 int sgc_dbg_gemm_nt_abl(int abl, const void* A, const void* B, void* C, int M, int N, int K, void* stream);
