@@ -25,7 +25,10 @@ Reference map (all paths relative to the reference repo):
   commonsense_step_loss    train_utils.py:36-62 (run_mode train_cs)
   supcon_hierar_loss       sup_contrast/losses.py:85-181 (SupConLossHierar, contrast_mode 'all')
   contrastive term         train_utils.py:28-29,96-99 (hidden/hidden_aug of connected pairs), train_test.py:260-273
-  OracleEvaluator          evaluator.py:118-367, :568-583
+  OracleEvaluator          evaluator.py:118-367, :568-583 (incl. accumulate_target :270-275 and the predcls=False branch of compute)
+  compare_object_cat       utils.py:355-373
+  match_target_sgd         utils.py:294-350
+  run_sgdet_loop           evaluate.py:375-440 (SGDET: pair loop over PREDICTED objects, predcls=False evaluator feed)
   OracleEvaluatorTop3      evaluator.py:639-790
 """
 from __future__ import annotations
@@ -331,6 +334,97 @@ def run_pair_loop(sd: Dict[str, Tensor], batch, cfg, mode: str = "eval", evaluat
     return dict(records=records, losses=losses if mode == "train" else None, loss_contrast=loss_contrast)
 
 
+# --------------------------------------------------------------------------- SGDET (predicted objects)
+def compare_object_cat(pred_cat, target_cat) -> bool:
+    """utils.py:355-373: object classes that count as the same label when categories are predicted."""
+    equiv = [[1, 5, 11, 23, 38, 44, 121, 124, 148, 149], [0, 50], [92, 137]]
+    unsymm_equiv = {123: [14, 63, 95, 87, 123], 108: [89, 102, 67, 72, 71, 81, 96, 105, 90, 111, 108], 60: [145, 106, 142, 144, 77, 60]}
+    pred_cat, target_cat = int(pred_cat), int(target_cat)
+    if pred_cat == target_cat:
+        return True
+    for group in equiv:
+        if pred_cat in group and target_cat in group:
+            return True
+    for key in unsymm_equiv:
+        if pred_cat == key and target_cat in unsymm_equiv[key]:
+            return True
+        elif target_cat == key and pred_cat in unsymm_equiv[key]:
+            return True
+    return False
+
+
+def match_target_sgd(relationships, subj_or_obj, categories_target, bbox_target):
+    """utils.py:294-350: the ground-truth triplets of every image as flat per-image tensors (None when an image has none):
+    subject/object categories, subject/object boxes [t,4], predicate; direction flag 1 -> (graph, edge), 0 -> (edge, graph).
+    Quirk kept: graph_iter runs over range(len(relationships[b])) = 0..n-2, so relations whose graph object is the last object
+    of the image are never collected (the list has n-1 rows for g = 1..n-1)."""
+    cs_l, co_l, bs_l, bo_l, rt_l = [], [], [], [], []
+    for b in range(len(relationships)):
+        cs, co, bs, bo, rt = [], [], [], [], []
+        for g in range(len(relationships[b])):
+            for e in range(g):
+                flag = subj_or_obj[b][g - 1][e]
+                if flag == 1:
+                    s_i, o_i = g, e
+                elif flag == 0:
+                    s_i, o_i = e, g
+                else:
+                    continue
+                cs.append(categories_target[b][s_i]); co.append(categories_target[b][o_i])
+                bs.append(bbox_target[b][s_i]); bo.append(bbox_target[b][o_i]); rt.append(relationships[b][g - 1][e])
+        if rt:
+            cs_l.append(torch.stack([torch.as_tensor(x).reshape(()) for x in cs])); co_l.append(torch.stack([torch.as_tensor(x).reshape(()) for x in co]))
+            bs_l.append(torch.stack(bs).view(-1, 4)); bo_l.append(torch.stack(bo).view(-1, 4))
+            rt_l.append(torch.stack([torch.as_tensor(x).reshape(()) for x in rt]))
+        else:
+            cs_l.append(None); co_l.append(None); bs_l.append(None); bo_l.append(None); rt_l.append(None)
+    return cs_l, co_l, bs_l, bo_l, rt_l
+
+
+def run_sgdet_loop(sd: Dict[str, Tensor], image_feature: Tensor, image_depth: Tensor, categories_pred, cat_pred_confidence,
+                   bbox_pred, super_categories_pred, cfg, evaluator):
+    """evaluate.py:375-440: the (graph_iter, edge_iter) x 2-direction loop over the PREDICTED objects of every image (one entry
+    per image in the lists), overlap filter on, evaluator fed with predcls=False and the category confidences."""
+    Fs = cfg.feature_size
+    hier = cfg.hierarchical
+    masks = [build_masks(b, Fs) for b in bbox_pred]
+    n_obj = torch.as_tensor([len(m) for m in masks])
+    for g in range(int(n_obj.max())):
+        keep = torch.nonzero(n_obj > g).view(-1)
+        gm = torch.stack([masks[i][g].unsqueeze(0) for i in keep])
+        h_graph = torch.cat((image_feature[keep] * gm, image_depth[keep] * gm), dim=1)
+        cat_g = torch.tensor([int(categories_pred[i][g]) for i in keep])
+        bb_g = torch.stack([bbox_pred[i][g] for i in keep])
+        cf_g = torch.hstack([cat_pred_confidence[i][g] for i in keep])
+        for e in range(g):
+            em = torch.stack([masks[i][e].unsqueeze(0) for i in keep])
+            h_edge = torch.cat((image_feature[keep] * em, image_depth[keep] * em), dim=1)
+            cat_e = torch.tensor([int(categories_pred[i][e]) for i in keep])
+            bb_e = torch.stack([bbox_pred[i][e] for i in keep])
+            cf_e = torch.hstack([cat_pred_confidence[i][e] for i in keep])
+            iou_mask = overlap_filter(gm, em)
+            if torch.sum(iou_mask) == 0:
+                continue
+            sp_g = [super_categories_pred[i][g] for i in keep] if super_categories_pred is not None else None
+            sp_e = [super_categories_pred[i][e] for i in keep] if super_categories_pred is not None else None
+            for first in (True, False):
+                hs, ho = (h_graph, h_edge) if first else (h_edge, h_graph)
+                cs, co = (cat_g, cat_e) if first else (cat_e, cat_g)
+                ss, so = (sp_g, sp_e) if first else (sp_e, sp_g)
+                bs, bo = (bb_g, bb_e) if first else (bb_e, bb_g)
+                fs, fo_ = (cf_g, cf_e) if first else (cf_e, cf_g)
+                out = classifier_forward(sd, hs, ho, cs, co, ss, so, cfg.num_classes, cfg.num_super_classes, hier)
+                if hier:
+                    r1, r2, r3, sup, conn, _ = out
+                    relation = torch.cat((r1, r2, r3), dim=1)
+                else:
+                    relation, conn, _ = out
+                    sup = None
+                evaluator.accumulate(keep, relation.detach(), None, None if sup is None else sup.detach(),
+                                     torch.log(torch.sigmoid(conn[:, 0])).detach(), cs, co, None, None, bs, bo, None, None,
+                                     iou_mask, False, fs, fo_)
+
+
 # --------------------------------------------------------------------------- evaluator
 def grid_iou(bt, bp, feature_size: int) -> float:
     """Rectangles rasterised with int() truncation on the FxF grid; union==0 -> 0."""
@@ -374,6 +468,11 @@ class OracleEvaluator:
         self.scat, self.ocat, self.sbox, self.obox = [], [], [], []
         self.which_t, self.rel_t, self.scat_t, self.ocat_t, self.sbox_t, self.obox_t = [], [], [], [], [], []
         self.last_sorted = {}
+        self.targets_by_image = None
+
+    def accumulate_target(self, relation_target, subject_cat_target, object_cat_target, subject_bbox_target, object_bbox_target):
+        """evaluator.py:270-275: per-image lists (entries may be None)."""
+        self.targets_by_image = (relation_target, subject_cat_target, object_cat_target, subject_bbox_target, object_bbox_target)
 
     def accumulate(self, which_in_batch, relation_pred, relation_target, super_relation_pred, connectivity,
                    subject_cat_pred, object_cat_pred, subject_cat_target, object_cat_target,
@@ -404,13 +503,14 @@ class OracleEvaluator:
 
     def flat_state(self):
         cat = torch.hstack
-        return dict(which=cat(self.which), conf=cat(self.conf), conn=cat(self.conn), pred=cat(self.pred),
-                    scat=cat(self.scat), ocat=cat(self.ocat), sbox=torch.vstack(self.sbox),
-                    obox=torch.vstack(self.obox), which_t=cat(self.which_t), rel_t=cat(self.rel_t),
-                    scat_t=cat(self.scat_t), ocat_t=cat(self.ocat_t), sbox_t=torch.vstack(self.sbox_t),
-                    obox_t=torch.vstack(self.obox_t))
+        d = dict(which=cat(self.which), conf=cat(self.conf), conn=cat(self.conn), pred=cat(self.pred),
+                 scat=cat(self.scat), ocat=cat(self.ocat), sbox=torch.vstack(self.sbox), obox=torch.vstack(self.obox))
+        if self.targets_by_image is None:
+            d.update(which_t=cat(self.which_t), rel_t=cat(self.rel_t), scat_t=cat(self.scat_t), ocat_t=cat(self.ocat_t),
+                     sbox_t=torch.vstack(self.sbox_t), obox_t=torch.vstack(self.obox_t))
+        return d
 
-    def compute(self, per_class=False):
+    def compute(self, per_class=False, predcls=True):
         if len(self.which) == 0:
             return self._ratios()
         s = self.flat_state()
@@ -418,7 +518,8 @@ class OracleEvaluator:
         Fs = self.cfg.feature_size
         for image in torch.unique(s["which"]):
             cur = s["which"] == image
-            cur_t = s["which_t"] == image
+            if self.targets_by_image is not None and self.targets_by_image[0][int(image)] is None:
+                continue
             c = conf[cur]
             order = torch.sort(c, descending=True, stable=True)[1]
             this_k = min(self.top_k[-1], len(c))
@@ -426,15 +527,23 @@ class OracleEvaluator:
             self.last_sorted[int(image)] = keep.clone()
             pred, scat, ocat = s["pred"][cur][keep], s["scat"][cur][keep], s["ocat"][cur][keep]
             sbox, obox = s["sbox"][cur][keep], s["obox"][cur][keep]
-            rel_t, scat_t, ocat_t = s["rel_t"][cur_t], s["scat_t"][cur_t], s["ocat_t"][cur_t]
-            sbox_t, obox_t = s["sbox_t"][cur_t], s["obox_t"][cur_t]
+            if self.targets_by_image is None:
+                cur_t = s["which_t"] == image
+                rel_t, scat_t, ocat_t = s["rel_t"][cur_t], s["scat_t"][cur_t], s["ocat_t"][cur_t]
+                sbox_t, obox_t = s["sbox_t"][cur_t], s["obox_t"][cur_t]
+            else:
+                rel_t, scat_t, ocat_t, sbox_t, obox_t = (x[int(image)] for x in self.targets_by_image)
             for i in range(len(rel_t)):
                 if rel_t[i] == -1:
                     continue
                 trip = "%d_%d_%d" % (int(scat_t[i]), int(rel_t[i]), int(ocat_t[i]))
                 is_zs = self.zero_shot is not None and trip in self.zero_shot
                 for j in range(this_k):
-                    if scat_t[i] == scat[j] and ocat_t[i] == ocat[j]:
+                    if predcls:
+                        label_ok = scat_t[i] == scat[j] and ocat_t[i] == ocat[j]
+                    else:
+                        label_ok = compare_object_cat(scat_t[i], scat[j]) and compare_object_cat(ocat_t[i], ocat[j])
+                    if label_ok:
                         if grid_iou(sbox_t[i], sbox[j], Fs) >= self.iou_thresh and \
                                 grid_iou(obox_t[i], obox[j], Fs) >= self.iou_thresh:
                             if rel_t[i] == pred[j]:

@@ -165,6 +165,10 @@ class Evaluator:
     confidence = property(lambda s: s._cat("conf"))
     connectivity = property(lambda s: s._cat("conn"))
     relation_pred = property(lambda s: s._cat("pred"))
+    subject_cat_pred = property(lambda s: s._cat("scat"))
+    object_cat_pred = property(lambda s: s._cat("ocat"))
+    subject_bbox_pred = property(lambda s: s._cat("sbox"))
+    object_bbox_pred = property(lambda s: s._cat("obox"))
     relation_target = property(lambda s: s._cat("rel_t") if s._targets_by_image is None else s._targets_by_image[0])
     which_in_batch_target = property(lambda s: s._cat("which_t"))
 
@@ -190,10 +194,13 @@ class Evaluator:
                      subject_bbox_target, object_bbox_target, cat_subject_confidence, cat_object_confidence)
 
     def accumulate_candidates(self, which_in_batch, cand_conf, cand_pred, relation_target, connectivity, subject_cat,
-                              object_cat, subject_bbox, object_bbox, iou_mask=None, call_sizes=None):
+                              object_cat, subject_bbox, object_bbox, iou_mask=None, call_sizes=None, cat_confidence=None):
         """Fused feed: per-pair candidates straight from ``sgc_bayes_head`` ([P,3] / [P,1]) for a whole minibatch in
         reference order.  ``call_sizes`` (pairs per direction-step) reproduces the reference's blocked append order
-        [geo block | poss block | sem block] per step; without it the order is per-pair interleaved."""
+        [geo block | poss block | sem block] per step; without it the order is per-pair interleaved.
+        SGDET / SGCLS (``predcls=False``, evaluator.py:129-130,164-165): pass ``cat_confidence`` [P] = subject + object category
+        confidence (added to every candidate of the pair before the overlap mask) and ``relation_target=None`` (targets come
+        through ``accumulate_target``)."""
         rep = cand_conf.shape[1]
         P = cand_conf.shape[0]
         if call_sizes is not None and rep > 1:
@@ -213,6 +220,8 @@ class Evaluator:
             pair_of = torch.arange(P, device=cand_conf.device).repeat_interleave(rep)
             conf, pred = cand_conf.reshape(-1), cand_pred.reshape(-1).long()
         conf = conf.clone()
+        if cat_confidence is not None:
+            conf = conf + cat_confidence[pair_of]
         if iou_mask is not None:
             conf[~iou_mask.bool()[pair_of]] = -math.inf
         conf = self._commonsense(subject_cat[pair_of], pred, object_cat[pair_of], conf)
@@ -220,9 +229,10 @@ class Evaluator:
         L["which"].append(which_in_batch[pair_of]); L["conf"].append(conf); L["pred"].append(pred)
         L["conn"].append(connectivity[pair_of]); L["scat"].append(subject_cat[pair_of]); L["ocat"].append(object_cat[pair_of])
         L["sbox"].append(subject_bbox[pair_of]); L["obox"].append(object_bbox[pair_of])
-        L["which_t"].append(which_in_batch); L["rel_t"].append(relation_target)
-        L["scat_t"].append(subject_cat); L["ocat_t"].append(object_cat)
-        L["sbox_t"].append(subject_bbox); L["obox_t"].append(object_bbox)
+        if relation_target is not None:
+            L["which_t"].append(which_in_batch); L["rel_t"].append(relation_target)
+            L["scat_t"].append(subject_cat); L["ocat_t"].append(object_cat)
+            L["sbox_t"].append(subject_bbox); L["obox_t"].append(object_bbox)
 
     def _commonsense(self, scat, pred, ocat, conf):
         if self._cs_keys is None:

@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .pairs import DeviceScene, flatten_scene, pair_targets_fast
+from .pairs import DeviceScene, flatten_scene, match_target_sgd, pair_targets_fast
 
 
 def overlap_mask(scene: DeviceScene) -> torch.Tensor:
@@ -63,6 +63,51 @@ def evaluate_minibatch(model, batch, evaluator=None, evaluator_top3=None, overla
             evaluator_top3.accumulate_candidates(which, conf3, out.cand_pred[sel], tgt, logsig, scat, ocat, sbox, obox,
                                                  iou_mask=iou_sel)
     return scene, out, included, directed
+
+
+def evaluate_sgdet_minibatch(model, image_feature, image_depth, categories_pred, cat_pred_confidence, bbox_pred, evaluator,
+                             sub2super=None, targets=None, overlap_filtering: bool = True):
+    """SGDET evaluation of one minibatch (``evaluate.py:375-444``): every ordered pair of the PREDICTED objects of each image
+    (per-image lists as returned by ``object_frontend.DetrFrontEnd.sgdet``: categories, category confidences, boxes
+    (x0,x1,y0,y1) on the grid, one entry per image of ``image_feature``), overlap filter, evaluator fed in the reference's
+    candidate order with ``predcls=False`` semantics (category confidences added).  ``targets`` =
+    (relationships, subj_or_obj, categories_target, bbox_target) sets the ground truth through ``match_target_sgd`` +
+    ``Evaluator.accumulate_target``; call ``evaluator.compute(per_class, predcls=False)`` afterwards.
+    ``sub2super``: the ``sub2super_cat_dict`` (VG hierarchical label vectors)."""
+    from .synthetic import SceneBatch
+    cfg = model.head_config()
+    dev = next(model.parameters()).device
+    if len(categories_pred) != int(image_feature.shape[0]):
+        raise ValueError("one predicted-object list per image is required (the reference drops the whole minibatch otherwise)")
+    sp = None
+    if cfg.dataset == "vg":
+        if sub2super is None:
+            raise ValueError("sub2super_cat_dict is required for Visual Genome label vectors")
+        sp = [[torch.as_tensor(sub2super[int(c)]) for c in cats.tolist()] for cats in categories_pred]
+    batch = SceneBatch(image_feature, image_depth, [b.detach().float().cpu() for b in bbox_pred],
+                       [c.detach().cpu().long() for c in categories_pred], sp, None, None)
+    scene = flatten_scene(cfg, batch, dev)
+    pidx = scene.pidx
+    P = pidx.n_pairs
+    iou = overlap_mask(scene) if overlap_filtering else torch.ones(P, dtype=torch.uint8, device=dev)
+    out = model.forward_pairs(scene, iou_mask=iou)
+    iou_h = iou.cpu().numpy().astype(bool)
+    any_overlap = np.bincount(pidx.step[iou_h], minlength=len(pidx.call_sizes)) > 0
+    included = any_overlap[pidx.step]
+    sel = torch.from_numpy(np.nonzero(included)[0]).to(dev)
+    which = torch.from_numpy(pidx.image[included]).to(dev)
+    conf_obj = torch.cat([c.reshape(-1).to(dev, torch.float32) for c in cat_pred_confidence])
+    csum = (conf_obj[scene.sub_idx.long()] + conf_obj[scene.obj_idx.long()])[sel]
+    scat, ocat = scene.cats[scene.sub_idx.long()][sel], scene.cats[scene.obj_idx.long()][sel]
+    raw = torch.from_numpy(scene.bbox_raw).to(dev)
+    sbox, obox = raw[scene.sub_idx.long()][sel], raw[scene.obj_idx.long()][sel]
+    evaluator.accumulate_candidates(which, out.cand_conf[sel], out.cand_pred[sel], None, torch.log(torch.sigmoid(out.connectivity[sel])),
+                                    scat, ocat, sbox, obox, iou_mask=iou[sel].bool(), call_sizes=pidx.call_sizes[any_overlap],
+                                    cat_confidence=csum)
+    if targets is not None:
+        cs, co, bs, bo, rt = match_target_sgd(*targets)
+        evaluator.accumulate_target(rt, cs, co, bs, bo)
+    return scene, out, included
 
 
 def train_minibatch(model, batch, optimizer=None, reducer=None, scene: Optional[DeviceScene] = None, **loss_kw):

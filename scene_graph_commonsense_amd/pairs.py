@@ -164,3 +164,30 @@ def pair_targets_fast(relationships, subj_or_obj, pidx: PairIndex) -> np.ndarray
     idx = sq_off[pidx.image] + pidx.g * n[pidx.image] + pidx.e
     flag = np.where(pidx.first, 1.0, 0.0).astype(np.float32)
     return np.where(dirs[idx] == flag, rel[idx], -1).astype(np.int64)
+
+
+def match_target_sgd(relationships, subj_or_obj, categories_target, bbox_target):
+    """``utils.match_target_sgd`` (utils.py:294-350) without the per-element tensor appends: the ground-truth triplets of every
+    image as (cat_subject, cat_object, bbox_subject [t,4], bbox_object [t,4], relation) lists, ``None`` where an image has none.
+    The reference's loop bound is kept: ``graph_iter`` runs over ``range(len(relationships[i]))`` = 0..n-2, so relations whose
+    graph object is the last object of an image are not collected."""
+    out = ([], [], [], [], [])
+    for b in range(len(relationships)):
+        s_idx, o_idx, rel = [], [], []
+        for g in range(len(relationships[b])):
+            if g == 0:
+                continue
+            flag = np.asarray(subj_or_obj[b][g - 1])[:g]
+            r = np.asarray(relationships[b][g - 1])[:g]
+            for e in np.nonzero((flag == 1) | (flag == 0))[0]:
+                s_i, o_i = (g, int(e)) if flag[e] == 1 else (int(e), g)
+                s_idx.append(s_i); o_idx.append(o_i); rel.append(int(r[e]))
+        if rel:
+            cats, box = torch.as_tensor(categories_target[b]).reshape(-1), torch.as_tensor(bbox_target[b]).reshape(-1, 4)
+            si, oi = torch.as_tensor(s_idx), torch.as_tensor(o_idx)
+            vals = (cats[si], cats[oi], box[si], box[oi], torch.as_tensor(rel, dtype=torch.int64))
+        else:
+            vals = (None, None, None, None, None)
+        for lst, v in zip(out, vals):
+            lst.append(v)
+    return out

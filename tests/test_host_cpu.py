@@ -194,3 +194,22 @@ def test_commonsense_bitmap_packing_host():
     assert bit(words, 2, 2, 3) == 0 and bit(words, 5, 7, 33) == 0
     assert int(sum(bin(int(x)).count("1") for x in words)) == len(keys)
     assert bit(bm.violated.numpy().view(np.uint32), 1, 2, 3) == 1
+
+
+def test_match_target_sgd_host_matches_oracle():
+    """pairs.match_target_sgd (vectorised) against the literal oracle restatement of utils.py:294-350, incl. its loop-bound quirk."""
+    from oracle import relhead_oracle as ro
+    from scene_graph_commonsense_amd.pairs import match_target_sgd
+    from scene_graph_commonsense_amd.synthetic import HeadConfig, make_scene_batch
+    batch = make_scene_batch(HeadConfig(), (6, 5, 2, 1), seed=9, connect_frac=0.5)
+    got = match_target_sgd(batch.relationships, batch.subj_or_obj, batch.categories, batch.bbox)
+    want = ro.match_target_sgd(batch.relationships, batch.subj_or_obj, batch.categories, batch.bbox)
+    n_rel = 0
+    for g_l, w_l in zip(got, want):
+        assert len(g_l) == len(w_l) == 4
+        for g, w in zip(g_l, w_l):
+            assert (g is None) == (w is None)
+            if g is not None:
+                assert torch.equal(g.to(w.dtype), w)
+                n_rel += len(g)
+    assert n_rel > 0 and want[4][3] is None
