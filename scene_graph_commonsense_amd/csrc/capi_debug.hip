@@ -28,6 +28,8 @@ int sgc_dbg_gemm_nt_abl(int abl, const void* A, const void* B, void* C, int M, i
         case 4: return launch_gemm_nt_ring<ELEM_BF16, AMODE_PLAIN, EPI_STORE>(p, (hipStream_t)stream);
         case 6: p.epi_lds = 1; return launch_gemm_nt_pp<ELEM_BF16, EPI_STORE, 0>(p, (hipStream_t)stream);
         case 7: p.epi_lds = 1; return launch_gemm_nt_pp<ELEM_BF16, EPI_STORE, 1>(p, (hipStream_t)stream);
+        case 8: return launch_gemm_nt_w4<ELEM_BF16, EPI_STORE, 0>(p, (hipStream_t)stream);
+        case 9: return launch_gemm_nt_w4<ELEM_BF16, EPI_STORE, 1>(p, (hipStream_t)stream);
     }
     return SGC_ERR_ARG;
 }
