@@ -117,3 +117,40 @@ def test_edge_cases():
     # more than 256 candidate slots per image is refused loudly
     with pytest.raises(RuntimeError):
         fe.sgdet(torch.zeros(1, 129, 151).cuda(), torch.zeros(1, 129, 4).cuda())
+
+
+@pytest.mark.parametrize("seed", range(20, 28))
+def test_nms_and_matching_random_stress(seed):
+    """Randomised cases with many same-class overlaps, exact score ties (duplicated queries), degenerate (zero-area) boxes and
+    several thresholds: kept ORDER must equal the oracle's, and the matching kernel must equal the oracle's stable rule."""
+    g = torch.Generator().manual_seed(seed)
+    B, Q, C1 = 4, 100, 151
+    n_cls = 3 + seed % 5                                       # few classes -> long same-class segments
+    logits = torch.randn(B, Q, C1, generator=g)
+    logits[:, :, 150] -= 5.0
+    cls = torch.randint(0, n_cls, (B, Q), generator=g)
+    logits.scatter_add_(2, cls[:, :, None], torch.full((B, Q, 1), 8.0) + torch.rand(B, Q, 1, generator=g) * 4)
+    centres = torch.rand(B, 6, 2, generator=g) * 0.6 + 0.2     # six clusters per image -> heavy overlap
+    pick = torch.randint(0, 6, (B, Q), generator=g)
+    boxes = torch.cat([centres[torch.arange(B)[:, None], pick] + 0.05 * torch.randn(B, Q, 2, generator=g),
+                       torch.rand(B, Q, 2, generator=g) * 0.3 + 0.1], dim=2).clamp(0.01, 0.99)
+    for b in range(B):                                         # exact duplicates and zero-area boxes
+        logits[b, 1] = logits[b, 0]; boxes[b, 1] = boxes[b, 0]
+        logits[b, 3] = logits[b, 2]
+        boxes[b, 5, 2:] = 0.0
+        boxes[b, 6, 2] = 0.0
+    thr = [0.3, 0.5, 0.7][seed % 3]
+    fe = _fe(nms=thr)
+    cats, confs, bxs, kept = fe.sgdet(logits.cuda(), boxes.cuda())
+    # oracle NMS on the DEVICE's candidate lists (same f32 scores), so that a 1-ulp soft-max difference cannot reorder anything
+    cat, conf, box = fe.candidates(logits.cuda(), boxes.cuda())
+    pc, pf, pb, pk = _lists_from_candidates(cat, conf, box)
+    assert kept == pk
+    for i in range(len(pk)):
+        wc, wf, wb, _ = fo.per_class_nms(pc[i], pf[i], pb[i], thr)
+        assert torch.equal(cats[i].cpu(), wc) and torch.equal(confs[i].cpu(), wf) and torch.equal(bxs[i].cpu(), wb)
+    tgt = [torch.cat([torch.floor(b[:3].cpu()), torch.tensor([[0., 32, 0, 32], [5, 5, 7, 9], [31, 32, 31, 32]])]) for b in bxs]
+    m, mc, tm = fe.match_object_categories(cats, confs, bxs, [t.cuda() for t in tgt])
+    om, omc, otm = fo.match_object_categories([c.cpu() for c in cats], [c.cpu() for c in confs], [b.cpu() for b in bxs], tgt, stable_ties=True)
+    for i in range(len(kept)):
+        assert torch.equal(m[i].cpu(), torch.stack(om[i])) and torch.equal(mc[i].cpu(), torch.stack(omc[i])) and torch.equal(tm[i].cpu(), otm[i])
