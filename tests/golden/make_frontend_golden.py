@@ -8,7 +8,7 @@ be imported (tensorboard, process group, a live DETR): it is restated below line
 ``oracle.frontend_oracle.nms`` standing in for ``torchvision.ops.nms`` (torchvision 0.15.2 is not installed) - that one step
 is therefore not pinned by the reference.
 
-Only data is committed: tests/golden/frontend_vg.npz and tests/golden/ref_fixtures/object_class_alp2fre.npy.
+Only data is committed: tests/golden/frontend_vg.npz and tests/golden/ref_fixtures/{object_class_alp2fre,relation_class_freq2scat}.npy.
 
     PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_frontend_golden.py
 """
@@ -112,6 +112,9 @@ def main():
     table = np.array([alp[i] for i in range(len(alp))], dtype=np.int32)
     os.makedirs(os.path.join(HERE, "ref_fixtures"), exist_ok=True)
     np.save(os.path.join(HERE, "ref_fixtures", "object_class_alp2fre.npy"), table)
+    # predicate re-indexing table of the data loader (dataset_utils.py:647-650; index 50 = the "no relation" slot -> -1)
+    np.save(os.path.join(HERE, "ref_fixtures", "relation_class_freq2scat.npy"),
+            ref_du.relation_class_freq2scat().numpy().astype(np.int64))
     args = {'models': {'num_classes': 150, 'topk_cat': 2, 'feature_size': 32, 'nms': 0.5}}
     out = {}
     for seed in (1, 2):

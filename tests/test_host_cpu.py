@@ -213,3 +213,49 @@ def test_match_target_sgd_host_matches_oracle():
                 assert torch.equal(g.to(w.dtype), w)
                 n_rel += len(g)
     assert n_rel > 0 and want[4][3] is None
+
+
+def test_annotation_files_round_trip(tmp_path):
+    """annotations.py against a literal restatement of dataloader.py:111-147 on files written in the reference's on-disk format
+    (dataset_utils.py:186-196), incl. the drop rules and the predicate re-indexing table taken from the reference."""
+    import numpy as np
+    from scene_graph_commonsense_amd import annotations as AN
+    table = torch.from_numpy(np.load(os.path.join(GOLDEN, "ref_fixtures", "relation_class_freq2scat.npy")))
+    assert torch.equal(AN.RELATION_CLASS_FREQ2SCAT, table)
+    cfg = HeadConfig()
+    g = torch.Generator().manual_seed(3)
+    paths, want = [], []
+    for k, n in enumerate((5, 1, 21, 3)):
+        b = make_scene_batch(cfg, (n,), seed=40 + k, connect_frac=0.5)
+        rels = [torch.randint(0, 50, r.shape, generator=g) * (r >= 0) + r * (r < 0) for r in b.relationships[0]]   # frequency-order ids
+        if rels:
+            rels[0][0] = 12
+        annot = dict(image_depth=b.image_depth[0], curr_instance=list(range(n)), num_relations=0, categories=b.categories[0],
+                     super_categories=b.super_categories[0], masks=torch.zeros(n, 32, 32, dtype=torch.uint8),
+                     bbox=b.bbox[0].float() + 0.4, bbox_origin=b.bbox[0].float() * 10, relationships=rels, subj_or_obj=b.subj_or_obj[0])
+        p = str(tmp_path / ("img%d_annotations.pkl" % k))
+        torch.save(annot, p)
+        paths.append(p)
+        # literal restatement of the loader
+        if n <= 1 or n > 20:
+            want.append(None)
+        else:
+            rr = []
+            for rel in [r.clone() for r in rels]:
+                rel[rel == 12] = 4
+                rr.append(table[rel])
+            want.append(dict(bbox=(b.bbox[0].float() + 0.4).int(), relationships=rr))
+    got = [AN.load_annotation(p, image_hw=(480, 640)) for p in paths]
+    assert [x is None for x in got] == [False, True, True, False]
+    for gt, w in zip(got, want):
+        if w is not None:
+            assert torch.equal(gt["bbox"], w["bbox"]) and gt["bbox"].dtype == torch.int32
+            assert all(torch.equal(a, b_) for a, b_ in zip(gt["relationships"], w["relationships"]))
+    assert int(got[0]["relationships"][0][0]) == int(table[4])            # wears -> wearing -> super-category order
+    feat = torch.randn(4, 256, 32, 32)
+    batch, keep = AN.collate(feat, got)
+    assert keep == [0, 3] and batch.image_feature.shape[0] == 2 and batch.num_objects == [5, 3]
+    assert torch.equal(batch.image_feature[1], feat[3]) and len(batch.relationships[0]) == 4
+    # an object that is empty at image resolution drops the image (dataloader.py:123-128)
+    a = torch.load(paths[0]); a["bbox"][0] = torch.tensor([3.0, 3.0, 4.0, 9.0])
+    assert AN.prepare_annotation(a, image_hw=(480, 640)) is None and AN.prepare_annotation(a) is not None
