@@ -35,25 +35,30 @@ class PairIndex:
 
 
 def enumerate_pairs(num_objects: Sequence[int]) -> PairIndex:
+    """Reference call order: graph_iter g = 1.., edge_iter e < g, direction 1 then 2, and inside a direction-step the images
+    with more than g objects in batch order.  One numpy block per g (the per-step Python loop cost 28 ms at 8 x 64 objects)."""
     n = np.asarray(num_objects, dtype=np.int64)
     off = np.concatenate([[0], np.cumsum(n)])
     img, gg, ee, ff, ss, oo, st, sizes = [], [], [], [], [], [], [], []
     t = 0
     for g in range(1, int(n.max()) if len(n) else 0):
         keep = np.nonzero(n > g)[0]
-        if len(keep) == 0:
+        k = len(keep)
+        if k == 0:
             continue
-        for e in range(g):
-            for first in (True, False):
-                s = off[keep] + (g if first else e)
-                o = off[keep] + (e if first else g)
-                img.append(keep); gg.append(np.full(len(keep), g)); ee.append(np.full(len(keep), e))
-                ff.append(np.full(len(keep), first)); ss.append(s); oo.append(o)
-                st.append(np.full(len(keep), t)); sizes.append(len(keep))
-                t += 1
+        e_col = np.repeat(np.arange(g, dtype=np.int64), 2)[:, None]                  # [2g,1]: e of every direction-step
+        f_col = np.tile(np.array([True, False]), g)[:, None]
+        base = off[keep][None, :]
+        shape = (2 * g, k)
+        img.append(np.broadcast_to(keep[None, :], shape).reshape(-1)); gg.append(np.full(2 * g * k, g, dtype=np.int64))
+        ee.append(np.broadcast_to(e_col, shape).reshape(-1)); ff.append(np.broadcast_to(f_col, shape).reshape(-1))
+        ss.append((base + np.where(f_col, g, e_col)).reshape(-1)); oo.append((base + np.where(f_col, e_col, g)).reshape(-1))
+        st.append(np.broadcast_to((t + np.arange(2 * g, dtype=np.int64))[:, None], shape).reshape(-1))
+        sizes.append(np.full(2 * g, k, dtype=np.int64))
+        t += 2 * g
     cat = lambda xs, dt: (np.concatenate(xs).astype(dt) if xs else np.zeros(0, dtype=dt))
     return PairIndex(cat(img, np.int64), cat(gg, np.int64), cat(ee, np.int64), cat(ff, bool), cat(ss, np.int32),
-                     cat(oo, np.int32), cat(st, np.int64), np.asarray(sizes, dtype=np.int64), off)
+                     cat(oo, np.int32), cat(st, np.int64), cat(sizes, np.int64), off)
 
 
 def slice_norm(i: int, F: int) -> int:
