@@ -12,6 +12,7 @@ identities are SURVEY §7.1:
 from __future__ import annotations
 
 import ctypes
+import math
 from dataclasses import dataclass
 from typing import Dict, Optional
 
@@ -302,13 +303,44 @@ class RelHeadEngine:
 
     # ------------------------------------------------------------------ fused entry
     def forward_pairs(self, image_feature, image_depth, obj_img, bbox, cats, super_mh, sub_idx, obj_idx, train=False,
-                      seeds=(0, 0), keep_argmax=False, iou_mask=None, dense=None) -> PairOutputs:
-        """One call per minibatch: image maps -> per-object halves -> all pairs."""
+                      seeds=(0, 0), keep_argmax=False, iou_mask=None, dense=None, select=None) -> PairOutputs:
+        """One call per minibatch: image maps -> per-object halves -> all pairs.
+        ``select`` ([P] bool / uint8 device tensor): run the per-pair trunk (expansion, conv3, fc1, fc2, head) ONLY for the selected
+        pairs and scatter the results into full-size outputs; the other pairs get confidence -inf (exactly what the overlap filter
+        gives them in the evaluator, ``evaluator.py:131-134``), prediction 0, zero log-probs and hidden vectors."""
         a_img = self.image_maps(image_feature, image_depth)
         uv = self.object_halves(a_img, obj_img, bbox)
         lsub, lobj = self.label_vectors(cats, super_mh)
         self._lsub, self._lobj = lsub, lobj
-        return self.pair_trunk(uv[0], uv[1], sub_idx, obj_idx, lsub, lobj, train, seeds, keep_argmax, iou_mask, dense)
+        if select is None:
+            return self.pair_trunk(uv[0], uv[1], sub_idx, obj_idx, lsub, lobj, train, seeds, keep_argmax, iou_mask, dense)
+        sel = select.bool()
+        idx = torch.nonzero(sel).flatten()
+        P, Ps = int(sub_idx.shape[0]), int(idx.shape[0])
+        cfg, dev = self.cfg, self.device
+        nc = 3 if cfg.hierarchical else 1
+        full = PairOutputs(torch.zeros(P, cfg.num_relations, device=dev), torch.zeros(P, 3, device=dev) if cfg.hierarchical else None,
+                           torch.zeros(P, device=dev), torch.zeros(P, 512, device=dev),
+                           torch.full((P, nc), -math.inf, device=dev), torch.zeros(P, nc, dtype=torch.int32, device=dev))
+        if Ps == 0:
+            return full
+        dense_s = None
+        if dense is not None:
+            img_ptr, pid, max_n = dense
+            rank = (torch.cumsum(sel.int(), 0) - 1).int()
+            ok = pid >= 0
+            pc = pid.clamp(min=0).long()
+            dense_s = (img_ptr, torch.where(ok & sel[pc], rank[pc], torch.full_like(pid, -1)).contiguous(), max_n)
+        out = self.pair_trunk(uv[0], uv[1], sub_idx[idx].contiguous(), obj_idx[idx].contiguous(), lsub, lobj, train, seeds, keep_argmax,
+                              None if iou_mask is None else iou_mask[idx].contiguous(), dense_s)
+        full.relation[idx] = out.relation
+        if full.super_relation is not None:
+            full.super_relation[idx] = out.super_relation
+        full.connectivity[idx] = out.connectivity
+        full.hidden[idx] = out.hidden
+        full.cand_conf[idx] = out.cand_conf
+        full.cand_pred[idx] = out.cand_pred
+        return full
 
     # ====================================================================== training (forward + backward)
     def prep_bwd_weights(self, sd):

@@ -94,8 +94,9 @@ class _RelationBase(nn.Module):
         return eng
 
     # ------------------------------------------------------------------ fused path
-    def forward_pairs(self, scene: DeviceScene, iou_mask: Optional[torch.Tensor] = None) -> PairOutputs:
-        """All ordered pairs of a minibatch in one pass (eval numerics unless ``self.training``)."""
+    def forward_pairs(self, scene: DeviceScene, iou_mask: Optional[torch.Tensor] = None, select: Optional[torch.Tensor] = None) -> PairOutputs:
+        """All ordered pairs of a minibatch in one pass (eval numerics unless ``self.training``).  ``select`` [P]: compute only
+        these pairs (the others come back with confidence -inf), see ``RelHeadEngine.forward_pairs``."""
         eng = self.refresh_weights()
         seeds = self._next_seeds() if self.training else (0, 0)
         if scene.pidx.n_pairs == 0:
@@ -107,7 +108,7 @@ class _RelationBase(nn.Module):
         with torch.no_grad():
             return eng.forward_pairs(scene.image_feature, scene.image_depth, scene.obj_img, scene.bbox, scene.cats,
                                      scene.super_mh, scene.sub_idx, scene.obj_idx, train=self.training, seeds=seeds,
-                                     iou_mask=iou_mask, dense=_dense(scene))
+                                     iou_mask=iou_mask, dense=_dense(scene), select=select)
 
     def _next_seeds(self):
         self._step += 1

@@ -216,3 +216,37 @@ def test_reference_style_loop_on_dropin_modules():
     res = Recall.compute(per_class=True)
     np.testing.assert_allclose(np.array(res[0]), gold["ev_recall"], atol=0.1)
     np.testing.assert_allclose(np.array(Top3.compute()[0]), gold["top3_recall"], atol=0.1)
+
+
+def test_skipping_filtered_pairs_keeps_recall():
+    """evaluate_minibatch(skip_filtered=True): images with >= top-K unfiltered pairs only get those pairs computed; recall counters,
+    the ranked top-K indices and the confidences of all unfiltered candidates are identical to the full computation."""
+    from scene_graph_commonsense_amd.evaluator import Evaluator, Evaluator_Top3
+    from scene_graph_commonsense_amd.model import BayesianRelationClassifier
+    from scene_graph_commonsense_amd.pair_loop import evaluate_minibatch
+    from scene_graph_commonsense_amd.synthetic import HeadConfig, make_scene_batch, make_state_dict
+    cfg = HeadConfig()
+    args = cfg.args(fixtures=FX)
+    model = BayesianRelationClassifier(args).cuda()
+    model.load_state_dict(make_state_dict(cfg, seed=2, head_gain=6.0))
+    model.eval()
+    batch = make_scene_batch(cfg, (24, 5, 30, 9), seed=11, connect_frac=0.3)          # two big images, two below the top-K limit
+    res = []
+    for skip in (False, True):
+        ev = Evaluator(args, cfg.num_relations, 0.5, [20, 50, 100])
+        t3 = Evaluator_Top3(args, cfg.num_relations, 0.5, [20, 50, 100])
+        scene, out, included, _ = evaluate_minibatch(model, batch, ev, t3, skip_filtered=skip)
+        conf = ev.confidence.cpu().numpy().copy()
+        r = ev.compute(per_class=True)
+        r3 = t3.compute(per_class=True)
+        res.append((conf, [float(x) for x in r[0]], [float(x) for x in r3[0]], dict(ev.last_topk), float(ev.num_connected_target),
+                    [float(ev.result_dict[k]) for k in (20, 50, 100)], out))
+    a, b = res
+    np.testing.assert_array_equal(np.isinf(a[0]), np.isinf(b[0]))
+    fin = np.isfinite(a[0])
+    np.testing.assert_array_equal(a[0][fin], b[0][fin])                  # same kernels on the same rows: bit-identical
+    assert a[1] == b[1] and a[2] == b[2] and a[4] == b[4] and a[5] == b[5] and a[5][2] > 0
+    for k in a[3]:
+        np.testing.assert_array_equal(a[3][k], b[3][k])
+    # the skip really skipped something
+    assert float((b[6].relation.abs().sum(1) == 0).float().mean()) > 0.2
