@@ -27,6 +27,16 @@ def overlap_mask(scene: DeviceScene) -> torch.Tensor:
     return out
 
 
+def _unfiltered_selection(scene: DeviceScene, iou_h: np.ndarray, evaluators) -> torch.Tensor:
+    """[P] bool: the pairs whose trunk must be computed when the overlap filter is on.  A filtered candidate can only matter when
+    its image has fewer unfiltered pairs than the evaluator ranks (then -inf entries enter the top K and may still match a
+    ground-truth triple): such images are computed completely."""
+    pidx = scene.pidx
+    k_max = max([100] + [int(e.top_k[-1]) for e in evaluators if e is not None])
+    per_image = np.bincount(pidx.image[iou_h], minlength=int(scene.image_feature.shape[0]))
+    return torch.from_numpy(iou_h | (per_image < k_max)[pidx.image]).to(scene.bbox.device)
+
+
 def evaluate_minibatch(model, batch, evaluator=None, evaluator_top3=None, overlap_filtering: bool = True,
                        scene: Optional[DeviceScene] = None, skip_filtered: bool = False):
     """Returns (scene, outputs, included[P] bool numpy, directed targets numpy).
@@ -42,14 +52,7 @@ def evaluate_minibatch(model, batch, evaluator=None, evaluator_top3=None, overla
     P = pidx.n_pairs
     iou = overlap_mask(scene) if overlap_filtering else torch.ones(P, dtype=torch.uint8, device=dev)
     iou_h = iou.cpu().numpy().astype(bool)
-    select = None
-    if skip_filtered and overlap_filtering:
-        # A filtered candidate can only matter when its image has fewer unfiltered candidates than the evaluator ranks (then
-        # -inf entries enter the top K and may still match a ground-truth triple): such images are computed completely.
-        k_max = max([100] + [int(e.top_k[-1]) for e in (evaluator, evaluator_top3) if e is not None])
-        per_image = np.bincount(pidx.image[iou_h], minlength=int(scene.image_feature.shape[0]))
-        sel_h = iou_h | (per_image < k_max)[pidx.image]
-        select = torch.from_numpy(sel_h).to(dev)
+    select = _unfiltered_selection(scene, iou_h, (evaluator, evaluator_top3)) if (skip_filtered and overlap_filtering) else None
     out = model.forward_pairs(scene, iou_mask=iou, select=select)
     directed = pair_targets_fast(batch.relationships, batch.subj_or_obj, pidx)
     n_steps = len(pidx.call_sizes)
@@ -78,7 +81,7 @@ def evaluate_minibatch(model, batch, evaluator=None, evaluator_top3=None, overla
 
 
 def evaluate_sgdet_minibatch(model, image_feature, image_depth, categories_pred, cat_pred_confidence, bbox_pred, evaluator,
-                             sub2super=None, targets=None, overlap_filtering: bool = True):
+                             sub2super=None, targets=None, overlap_filtering: bool = True, skip_filtered: bool = False):
     """SGDET evaluation of one minibatch (``evaluate.py:375-444``): every ordered pair of the PREDICTED objects of each image
     (per-image lists as returned by ``object_frontend.DetrFrontEnd.sgdet``: categories, category confidences, boxes
     (x0,x1,y0,y1) on the grid, one entry per image of ``image_feature``), overlap filter, evaluator fed in the reference's
@@ -102,8 +105,9 @@ def evaluate_sgdet_minibatch(model, image_feature, image_depth, categories_pred,
     pidx = scene.pidx
     P = pidx.n_pairs
     iou = overlap_mask(scene) if overlap_filtering else torch.ones(P, dtype=torch.uint8, device=dev)
-    out = model.forward_pairs(scene, iou_mask=iou)
     iou_h = iou.cpu().numpy().astype(bool)
+    select = _unfiltered_selection(scene, iou_h, (evaluator,)) if (skip_filtered and overlap_filtering) else None
+    out = model.forward_pairs(scene, iou_mask=iou, select=select)
     any_overlap = np.bincount(pidx.step[iou_h], minlength=len(pidx.call_sizes)) > 0
     included = any_overlap[pidx.step]
     sel = torch.from_numpy(np.nonzero(included)[0]).to(dev)

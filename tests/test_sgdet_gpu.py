@@ -49,6 +49,12 @@ def test_sgdet_end_to_end_matches_reference():
     assert float(ev.num_connected_target) == float(GOLD["num_connected_target"])
     np.testing.assert_allclose(np.array([float(r) for r in res[0]]), GOLD["recall"], atol=0.1)
     assert [float(ev.result_dict[k]) for k in (20, 50, 100)] == GOLD["hits"].tolist()
+    # the skip of filtered pairs (images here are below the top-K limit, so everything is still computed) gives the same state
+    ev2 = Evaluator(args, cfg.num_relations, 0.5, [20, 50, 100])
+    evaluate_sgdet_minibatch(model, batch.image_feature.cuda(), batch.image_depth.cuda(), cats, confs, bxs, ev2,
+                             sub2super=default_sub2super(cfg.num_classes, cfg.num_super_classes),
+                             targets=(batch.relationships, batch.subj_or_obj, batch.categories, batch.bbox), skip_filtered=True)
+    np.testing.assert_array_equal(ev2.confidence.cpu().numpy(), conf)
 
 
 def test_sgcls_path_matches_oracle():
