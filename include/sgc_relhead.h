@@ -89,7 +89,8 @@ int sgc_commonsense_flags(const long* scat, const long* ocat, const int* cand_pr
 /* ----------------------------------------------------------------------------------------------- backward */
 
 /* Forward expansion for training: writes z in f16 (conv3 forward operand) and bf16 (conv3 weight-gradient operand) and records
- * the relu/maxpool routing (amz u8 [n_pairs*256][512]: winning position 0..3, 4 = none).  Any output may be NULL. */
+ * the relu/maxpool routing (amz [n_pairs*256][256] bytes: two 4-bit codes per byte - channel 2k in the low nibble, 2k+1 in the high one;
+ * code = winning position 0..3, 4 = none).  Any output may be NULL. */
 int sgc_pair_expand_train(const void* U, const void* V, const int* sub_idx, const int* obj_idx, void* z_pad_f16, void* z_pad_bf16,
                           unsigned char* amz, int n_pairs, void* stream);
 
@@ -130,7 +131,8 @@ int sgc_fc1_wgrad(const void* dh1, const void* y_bf16, float* dw, int n_rows, in
 int sgc_unpool_relu_bwd(const void* dy, const unsigned char* argmax, void* dy3_pad, float* dbias_part, int* n_parts, int n_pairs, void* stream);
 int sgc_conv3_dgrad(const void* dy3_pad, const void* wd3, void* dz, int n_pairs, void* stream);
 int sgc_conv3_wgrad(const void* dy3_pad, const void* z_pad_bf16, float* slabs, int n_pairs, int splits, int* n_slabs, void* stream);
-/* dU_pad [n_obj][34][34][512] bf16 = sum over the pairs listed for each object of the routed dz  (transpose of the expansion) */
+/* dU_pad [n_obj][34][34][512] bf16 = sum over the pairs listed for each object of the routed dz  (transpose of the expansion);
+ * amz: the nibble-packed routing codes written by the expansion. */
 int sgc_pair_contract(const void* dz, const unsigned char* amz, const int* ptr, const int* list, void* dU_pad, int n_obj, void* stream);
 int sgc_conv2_dgrad(const void* dU_pad, const void* wd2, void* da, int n_obj, void* stream);
 int sgc_conv2_wgrad(const void* dU_pad, const void* a_pad_bf16, float* slabs, int n_obj, int splits, int* n_slabs, void* stream);

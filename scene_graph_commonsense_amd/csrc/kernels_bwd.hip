@@ -428,18 +428,18 @@ __global__ __launch_bounds__(256) void pair_expand_train_kernel(const u16* __res
             for (int k = 0; k < 8; ++k) oh[k] = f32_to_bf16_bits(best[k]);
             *reinterpret_cast<uint4*>(zb + zo) = o;
         }
-        if (amz) {
-            uint2 ao;
-            unsigned char* ab = reinterpret_cast<unsigned char*>(&ao);
+        if (amz) {                                             // two 4-bit routing codes per byte: channel 2k low, 2k+1 high
+            unsigned ao = 0;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) ab[k] = arg[k];
-            *reinterpret_cast<uint2*>(amz + it * 512 + lane * 8) = ao;
+            for (int k = 0; k < 8; ++k) ao |= (unsigned)arg[k] << (4 * k);
+            *reinterpret_cast<unsigned*>(amz + it * 256 + lane * 4) = ao;
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------ pair contraction
-// dU_pad[o][2Y+dy+1][2X+dx+1][c] = sum over pairs p in list(o):  (amz[p][W][c] == dy*2+dx) ? dz[p][m3(W)][c] : 0
+// dU_pad[o][2Y+dy+1][2X+dx+1][c] = sum over pairs p in list(o):  (code(amz[p][W], c) == dy*2+dx) ? dz[p][m3(W)][c] : 0
+// amz [P][256][256]: two 4-bit codes per byte (channel 2k in the low nibble, 2k+1 in the high one)
 // (the transpose of the expansion: dU_i = sum_j g_ij, dV_j = sum_i g_ij; one wavefront owns one (object, window),
 //  so the segmented reduction needs no atomics.)
 __global__ __launch_bounds__(256) void pair_contract_kernel(const u16* __restrict__ dz, const unsigned char* __restrict__ amz,
@@ -459,14 +459,14 @@ __global__ __launch_bounds__(256) void pair_contract_kernel(const u16* __restric
         for (int i = i0; i < i1; ++i) {
             const long p = list[i];
             const uint4 g = *reinterpret_cast<const uint4*>(dz + (p * 256 + m3) * 512 + lane * 8);
-            const uint2 a = *reinterpret_cast<const uint2*>(amz + (p * 256 + W) * 512 + lane * 8);
+            const unsigned a = *reinterpret_cast<const unsigned*>(amz + (p * 256 + W) * 256 + lane * 4);
             const u16* gh = reinterpret_cast<const u16*>(&g);
-            const unsigned char* ab = reinterpret_cast<const unsigned char*>(&a);
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const float v = bf16_bits_to_f32(gh[k]);
+                const unsigned code = (a >> (4 * k)) & 15u;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) acc[q][k] += (ab[k] == q) ? v : 0.f;
+                for (int q = 0; q < 4; ++q) acc[q][k] += (code == (unsigned)q) ? v : 0.f;
             }
         }
 #pragma unroll

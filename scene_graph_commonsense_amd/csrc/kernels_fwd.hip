@@ -126,7 +126,7 @@ __global__ __launch_bounds__(512) void pair_expand_dense_kernel(const u16* __res
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int Y = W >> 4, X = W & 15;
     const long zoff = ((long)(Y + 1) * 18 + X + 1) * 512 + lane * 8;
-    const long aoff = (long)W * 512 + lane * 8;
+    const long aoff = (long)W * 256 + lane * 4;
     for (int i = wid; i < n; i += 8) {
         float uf[4][8];
 #pragma unroll
@@ -168,12 +168,11 @@ __global__ __launch_bounds__(512) void pair_expand_dense_kernel(const u16* __res
                 for (int k = 0; k < 8; ++k) oh[k] = f32_to_bf16_bits(best[k]);
                 *reinterpret_cast<uint4*>(zb + (long)p * (18 * 18 * 512) + zoff) = o;
             }
-            if (amz) {
-                uint2 ao;
-                unsigned char* ab = reinterpret_cast<unsigned char*>(&ao);
+            if (amz) {                                  // two 4-bit routing codes per byte: channel 2k low, 2k+1 high
+                unsigned ao = 0;
 #pragma unroll
-                for (int k = 0; k < 8; ++k) ab[k] = arg[k];
-                *reinterpret_cast<uint2*>(amz + (long)p * (256 * 512) + aoff) = ao;
+                for (int k = 0; k < 8; ++k) ao |= (unsigned)arg[k] << (4 * k);
+                *reinterpret_cast<unsigned*>(amz + (long)p * (256 * 256) + aoff) = ao;
             }
         }
     }

@@ -400,7 +400,7 @@ class RelHeadEngine:
         ctx.lsub, ctx.lobj = self.label_vectors(cats, super_mh)
         z = ws.get("z_pad", P * 18 * 18 * 512, torch.float16)
         z_bf = ws.get("z_pad_bf", P * 18 * 18 * 512, torch.bfloat16)
-        amz = ws.get("amz", P * 256 * 512, torch.uint8)
+        amz = ws.get("amz", P * 256 * 256, torch.uint8)              # two 4-bit routing codes per byte
         self.expand(ctx.uv[0], ctx.uv[1], sub_idx, obj_idx, P, z, z_bf, amz, dense=dense)
         ctx.z_bf = z_bf
         y = ws.get("y", Ppad * 65536, torch.float16)

@@ -111,7 +111,8 @@ def test_contraction_is_the_transpose_of_the_expansion_routing():
     sc = flatten_scene(cfg, batch, "cuda:0")
     n_obj, P = 10, sc.pidx.n_pairs
     g = torch.Generator().manual_seed(4)
-    amz = torch.randint(0, 5, (P, 256, 512), generator=g, dtype=torch.uint8).cuda()
+    codes = torch.randint(0, 5, (P, 256, 512), generator=g, dtype=torch.uint8)
+    amz = (codes[:, :, 0::2] | (codes[:, :, 1::2] << 4)).contiguous().cuda()        # two 4-bit routing codes per byte
     dz_std = torch.randint(-3, 4, (P, 16, 16, 512), generator=g).float()         # small integers: exact in bf16 / f32 sums
     m3 = torch.zeros(16, 16, dtype=torch.long)
     for Y in range(16):
@@ -126,7 +127,7 @@ def test_contraction_is_the_transpose_of_the_expansion_routing():
         assert lib.sgc_pair_contract(_lib.ptr(dz), _lib.ptr(amz), _lib.ptr(ptr), _lib.ptr(lst), _lib.ptr(dU), n_obj, _lib.stream_ptr()) == 0
         torch.cuda.synchronize()
         ref = torch.zeros(n_obj, 32, 32, 512)
-        a = amz.cpu().view(P, 16, 16, 512)
+        a = codes.view(P, 16, 16, 512)
         for p in range(P):
             for q in range(4):
                 ref[idx[p], (q >> 1)::2, (q & 1)::2] += torch.where(a[p] == q, dz_std[p], torch.zeros(()))
