@@ -30,6 +30,7 @@ int sgc_dbg_gemm_nt_abl(int abl, const void* A, const void* B, void* C, int M, i
         case 7: p.epi_lds = 1; return launch_gemm_nt_pp<ELEM_BF16, EPI_STORE, 1>(p, (hipStream_t)stream);
         case 8: return launch_gemm_nt_w4<ELEM_BF16, EPI_STORE, 0>(p, (hipStream_t)stream);
         case 9: return launch_gemm_nt_w4<ELEM_BF16, EPI_STORE, 1>(p, (hipStream_t)stream);
+        case 10: p.epi_lds = 1; return launch_gemm_nt_pp1<ELEM_BF16, EPI_STORE>(p, (hipStream_t)stream);
     }
     return SGC_ERR_ARG;
 }

@@ -604,6 +604,7 @@ static int launch_conv16_halo(NtParams p, hipStream_t stream) {
 
 #include "gemm_nt_pp.h"
 #include "gemm_nt_w4.h"
+#include "gemm_nt_pp1.h"
 
 inline int sgc_gemm_pp() {        // SGC_GEMM_PP=0 falls back to the 2-stage 256x256 loops (A/B hook)
     static int v = -1;

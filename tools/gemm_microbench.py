@@ -16,7 +16,7 @@ M, N, K = 32768, 4096, int(os.environ.get("MB_K", "8192"))
 A = (torch.rand(M, K, device="cuda") * 2 - 1).bfloat16()
 B = (torch.rand(N, K, device="cuda") * 2 - 1).bfloat16()
 C = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
-names = {0: "normal", 1: "no global loads", 2: "no loads, no barriers", 3: "loads + barriers only", 4: "4-stage ring BK=32", 5: "A staged 1 tile in 9", 6: "ping-pong", 7: "ping-pong, no global loads", 8: "4 waves x 128x128, compiler schedule", 9: "4 waves x 128x128, sched_group_barrier interleave"}
+names = {0: "normal", 1: "no global loads", 2: "no loads, no barriers", 3: "loads + barriers only", 4: "4-stage ring BK=32", 5: "A staged 1 tile in 9", 6: "ping-pong", 7: "ping-pong, no global loads", 8: "4 waves x 128x128, compiler schedule", 9: "4 waves x 128x128, sched_group_barrier interleave", 10: "ping-pong, one phase per K tile (32 MFMAs per slot)"}
 for rep in range(2):
     for abl in [int(x) for x in os.environ.get("MB_ABL", "0,1,2,3,4,5,6,7").split(",")]:
         for _ in range(2):
@@ -30,7 +30,7 @@ for rep in range(2):
         torch.cuda.synchronize()
         ms = a.elapsed_time(b) / 5
         note = ""
-        if abl in (0, 6, 8, 9) and rep == 0:          # the variants that compute the real product: spot-check 256 rows
+        if abl in (0, 6, 8, 9, 10) and rep == 0:          # the variants that compute the real product: spot-check 256 rows
             ref = A[:256].float() @ B.float().t()
             note = "  max rel err %.1e" % ((C[:256].float() - ref).abs().max() / ref.abs().max()).item()
         print("abl=%d %-24s %8.3f ms  %7.1f TFLOP/s-equivalent%s" % (abl, names[abl], ms, 2.0 * M * N * K / ms / 1e9, note))
