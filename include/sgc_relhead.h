@@ -153,7 +153,7 @@ int sgc_detr_candidates(const float* logits, const float* boxes, const int* alp2
 /* Per-class greedy NMS of every image's n_query*topk candidate slots (evaluate.py:347-366; torchvision.ops.nms 0.15.2: stable
  * descending score order, suppress when inter/(a_i + a_j - inter) > iou_threshold).  out_slot [n_img][n_query*topk]: kept slot
  * indices (slot = query*topk + rank) in the reference's concatenation order (classes ascending, scores descending), -1 padded;
- * out_count [n_img].  n_query*topk <= 256. */
+ * out_count [n_img].  n_query*topk <= 512. */
 int sgc_nms_per_class(const int* cand_cat, const float* cand_conf, const float* cand_box, int n_img, int n_query, int topk,
                       double iou_threshold, int* out_slot, int* out_count, void* stream);
 /* SGCLS label matching (utils.py:377-425): for every ground-truth box [tgt_ptr segments] the two predicted boxes

@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void detr_candidates_kernel(const float* __res
 // S = Q*k candidate slots are sorted by (class ascending [torch.unique order], score descending, slot ascending [stable
 // sort]) with a bitonic network on 64-bit keys, then suppressed greedily inside each class segment.  Output: the kept slot
 // indices in exactly the order the reference concatenates them.
-constexpr int NMS_MAX = 256;
+constexpr int NMS_MAX = 512;                 // candidate slots per image (100 queries x up to 5 categories)
 __global__ __launch_bounds__(NMS_MAX) void nms_per_class_kernel(const int* __restrict__ cand_cat, const float* __restrict__ cand_conf,
                                                                 const float* __restrict__ cand_box, int Q, int topk,
                                                                 double iou_threshold, int* __restrict__ out_slot,
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(NMS_MAX) void nms_per_class_kernel(const int* __res
         const int c = cand_cat[(long)b * S + t];
         if (c >= 0) {
             const unsigned sb = __float_as_uint(cand_conf[(long)b * S + t]);       // probabilities are >= 0: bit order = value order
-            k = ((unsigned long long)c << 40) | ((unsigned long long)(0xffffffffu - sb) << 8) | (unsigned long long)t;
+            k = ((unsigned long long)c << 42) | ((unsigned long long)(0xffffffffu - sb) << 10) | (unsigned long long)t;
         }
     }
     key[t] = k;
@@ -112,11 +112,11 @@ __global__ __launch_bounds__(NMS_MAX) void nms_per_class_kernel(const int* __res
             __syncthreads();
         }
     const unsigned long long mine = key[t];
-    const int slot = (int)(mine & 0xff);
+    const int slot = (int)(mine & 0x3ff);
     const bool valid = mine != ~0ull;
     if (valid) {
         atomicAdd(&n_valid, 1);
-        cls[t] = (int)(mine >> 40);
+        cls[t] = (int)(mine >> 42);
         const float* bp = cand_box + ((long)b * Q + slot / topk) * 4;       // (x0,x1,y0,y1); every category of a query shares its box
         bx[t][0] = bp[0]; bx[t][1] = bp[2]; bx[t][2] = bp[1]; bx[t][3] = bp[3];     // -> (x1,y1,x2,y2) as handed to nms (:349)
     }
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(NMS_MAX) void nms_per_class_kernel(const int* __res
     if (t == 0) {
         int c = 0;
         for (int i = 0; i < n; ++i)
-            if (!supp[i]) out_slot[(long)b * S + c++] = (int)(key[i] & 0xff);
+            if (!supp[i]) out_slot[(long)b * S + c++] = (int)(key[i] & 0x3ff);
         for (int i = c; i < S; ++i) out_slot[(long)b * S + i] = -1;
         out_count[b] = c;
     }

@@ -99,7 +99,7 @@ def test_edge_cases():
     cats, confs, bxs, kept = fe.sgdet(logits.cuda(), boxes.cuda())
     wc, wf, wb, wk = fo.frontend_sgdet(logits, boxes, list(range(C1)), num_classes=601, topk_cat=1)
     assert kept == wk and torch.equal(cats[0].cpu(), wc[0]) and _close(confs[0], wf[0]) and torch.equal(bxs[0].cpu(), wb[0])
-    # exact duplicates: equal scores and IoU 1 -> the lower slot survives (stable), 128 queries x 2 = the 256-slot limit
+    # exact duplicates: equal scores and IoU 1 -> the lower slot survives (stable); 128 queries x 2 slots
     fe = _fe()
     logits, boxes = make_detr_outputs(3, n_img=2, n_query=128)
     logits[0, 5] = logits[0, 4]; boxes[0, 5] = boxes[0, 4]
@@ -114,9 +114,14 @@ def test_edge_cases():
     # every query is background: nothing survives, no image is kept
     logits = torch.zeros(2, 100, 151); logits[:, :, 150] = 10.
     assert fe.sgdet(logits.cuda(), torch.rand(2, 100, 4).cuda())[3] == []
-    # more than 256 candidate slots per image is refused loudly
+    # three categories per query (300 slots) work; more than 512 candidate slots per image is refused loudly
+    fe3 = _fe(topk_cat=3)
+    logits, boxes = make_detr_outputs(4, n_img=2)
+    c3, f3, b3, k3 = fe3.sgdet(logits.cuda(), boxes.cuda())
+    w3 = fo.frontend_sgdet(logits, boxes, ALP.tolist(), topk_cat=3)
+    assert k3 == w3[3] and all(torch.equal(a.cpu(), b) for a, b in zip(c3, w3[0]))
     with pytest.raises(RuntimeError):
-        fe.sgdet(torch.zeros(1, 129, 151).cuda(), torch.zeros(1, 129, 4).cuda())
+        fe.sgdet(torch.zeros(1, 257, 151).cuda(), torch.zeros(1, 257, 4).cuda())
 
 
 @pytest.mark.parametrize("seed", range(20, 28))
