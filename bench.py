@@ -78,6 +78,7 @@ def main():
     ap.add_argument("--images", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--forward-only", action="store_true")
+    ap.add_argument("--torch-sgd", action="store_true", help="torch.optim.SGD instead of the one-pass optim.FusedSGD (same update)")
     ap.add_argument("--dataset", default="vg", choices=["vg", "oiv6"], help="oiv6 = 601 classes, (4,2,24) head, no super-classes")
     args = ap.parse_args()
 
@@ -104,7 +105,12 @@ def main():
     # the update as stable as the reference's at N=64 (T=4032): otherwise the weights diverge within three steps and
     # the timed kernels would run on inf/NaN data (data-dependent clocks, meaningless ReLU masks).
     T = len(scene.pidx.call_sizes)
-    opt = torch.optim.SGD(model.parameters(), lr=1e-5 * min(1.0, (380.0 / max(T, 1)) ** 2), momentum=0.9, weight_decay=1e-4)
+    lr = 1e-5 * min(1.0, (380.0 / max(T, 1)) ** 2)
+    if args.torch_sgd:
+        opt = torch.optim.SGD(model.parameters(), lr=lr, momentum=0.9, weight_decay=1e-4)
+    else:                                    # same update in one pass over (grad, weight, momentum buffer): optim.FusedSGD
+        from scene_graph_commonsense_amd.optim import FusedSGD
+        opt = FusedSGD(model.parameters(), lr=lr, momentum=0.9, weight_decay=1e-4)
     directed = pair_targets_fast(batch.relationships, batch.subj_or_obj, scene.pidx)
     P = scene.pidx.n_pairs
     reducer = sgd_dist.GradReducer(world)

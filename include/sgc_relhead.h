@@ -140,6 +140,12 @@ int sgc_object_masked_maps_bwd(const void* da, const int* img_ptr, const int* bb
 int sgc_tanh_bwd(const float* dA, const void* a_img, void* dpre, long n, void* stream);
 int sgc_conv1_wgrad(const void* dpre, const void* x_bf16, float* slabs, int n_rows, int XC, int splits, int* n_slabs, void* stream);
 
+/* One-pass SGD with momentum and weight decay on one f32 parameter tensor (torch.optim.SGD semantics with dampening 0, no Nesterov:
+ * the optimizer of train_test.py:99-100): g' = g + wd*w; buf = first_step ? g' : momentum*buf + g'; w -= lr*buf.
+ * 16-byte aligned pointers take the float4 path, anything else a scalar one. */
+int sgc_sgd_momentum_step(float* w, const float* g, float* momentum_buf, long n, float lr, float momentum, float weight_decay,
+                          int first_step, void* stream);
+
 /* ----------------------------------------------------------------------------------------------- SGDET / SGCLS object front-end
  * (evaluate.py:309-366 = :543-589, utils.py:58-74,377-425)
  *

@@ -250,6 +250,47 @@ __global__ void slab_sum_kernel(const float* __restrict__ in, float* __restrict_
     }
 }
 
+// SGD with momentum and weight decay in one pass (torch.optim.SGD semantics, dampening 0, no Nesterov; train_test.py:99-100):
+//   g' = g + wd * w;  buf = first ? g' : momentum * buf + g';  w -= lr * buf.      torch's foreach path makes three passes.
+__global__ __launch_bounds__(256) void sgd_momentum_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ buf,
+                                                           long n, float lr, float momentum, float wd, int first) {
+    const long n4 = n >> 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        float4 wv = reinterpret_cast<float4*>(w)[i];
+        const float4 gv = reinterpret_cast<const float4*>(g)[i];
+        float4 bv = first ? make_float4(0.f, 0.f, 0.f, 0.f) : reinterpret_cast<float4*>(buf)[i];
+        float* wp = reinterpret_cast<float*>(&wv);
+        const float* gp = reinterpret_cast<const float*>(&gv);
+        float* bp = reinterpret_cast<float*>(&bv);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float gg = gp[k] + wd * wp[k];
+            bp[k] = first ? gg : momentum * bp[k] + gg;
+            wp[k] = wp[k] - lr * bp[k];
+        }
+        reinterpret_cast<float4*>(buf)[i] = bv;
+        reinterpret_cast<float4*>(w)[i] = wv;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {                 // tail (n not a multiple of 4)
+        const long i = (n4 << 2) + threadIdx.x;
+        const float gg = g[i] + wd * w[i];
+        const float b = first ? gg : momentum * buf[i] + gg;
+        buf[i] = b;
+        w[i] = w[i] - lr * b;
+    }
+}
+
+__global__ __launch_bounds__(256) void sgd_momentum_scalar_kernel(float* __restrict__ w, const float* __restrict__ g,
+                                                                  float* __restrict__ buf, long n, float lr, float momentum, float wd,
+                                                                  int first) {       // views that are not 16-byte aligned (small tensors)
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float gg = g[i] + wd * w[i];
+        const float b = first ? gg : momentum * buf[i] + gg;
+        buf[i] = b;
+        w[i] = w[i] - lr * b;
+    }
+}
+
 // column sums of a 16-bit matrix: part[blockIdx.y][cols] = sum over this block's rows.
 // Block = 32 column chunks (8 columns, 16 B each) x 8 row lanes; row lanes are reduced through LDS.
 template <int ELEM>
@@ -593,6 +634,19 @@ int sgc_slab_sum(const float* in, float* out, long n, int slabs, int accumulate,
     if (n <= 0) return SGC_OK;
     SGC_LAUNCH(slab_sum_kernel, dim3(grid_for(n, 256, 65536)), dim3(256), 0, (hipStream_t)stream, in, out, n, slabs,
                        accumulate);
+    SGC_CHECK_LAUNCH();
+    return SGC_OK;
+}
+
+int sgc_sgd_momentum_step(float* w, const float* g, float* momentum_buf, long n, float lr, float momentum, float weight_decay,
+                          int first_step, void* stream) {
+    if (n <= 0) return SGC_OK;
+    if ((((uintptr_t)w | (uintptr_t)g | (uintptr_t)momentum_buf) & 15) != 0)       // a view that is not 16-byte aligned: scalar accesses
+        SGC_LAUNCH(sgd_momentum_scalar_kernel, dim3(grid_for(n, 256, 16384)), dim3(256), 0, (hipStream_t)stream, w, g, momentum_buf, n,
+                   lr, momentum, weight_decay, first_step);
+    else
+        SGC_LAUNCH(sgd_momentum_kernel, dim3(grid_for(n, 1024, 16384)), dim3(256), 0, (hipStream_t)stream, w, g, momentum_buf, n, lr,
+                   momentum, weight_decay, first_step);
     SGC_CHECK_LAUNCH();
     return SGC_OK;
 }
