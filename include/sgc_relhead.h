@@ -131,6 +131,11 @@ int sgc_fc1_wgrad(const void* dh1, const void* y_bf16, float* dw, int n_rows, in
 int sgc_unpool_relu_bwd(const void* dy, const unsigned char* argmax, void* dy3_pad, float* dbias_part, int* n_parts, int n_pairs, void* stream);
 int sgc_conv3_dgrad(const void* dy3_pad, const void* wd3, void* dz, int n_pairs, void* stream);
 int sgc_conv3_wgrad(const void* dy3_pad, const void* z_pad_bf16, float* slabs, int n_pairs, int splits, int* n_slabs, void* stream);
+/* The same weight gradient on the sparse matrix cores (2:4 structured sparsity: at most one non-zero per 2x2 pooling window):
+ * dy [n_pairs*64][1024] bf16 = the POOLED gradient (output of sgc_fc1_dgrad), argmax = the routing byte of sgc_conv3_relu_pool;
+ * pack_ac (n_pairs*4*1024*64 bytes) and pack_ic (n_pairs*4*1024*8 bytes) are scratch for the packed operand. */
+int sgc_conv3_wgrad_sparse(const void* dy, const unsigned char* argmax, const void* z_pad_bf16, void* pack_ac, void* pack_ic,
+                           float* slabs, int n_pairs, int splits, int* n_slabs, void* stream);
 /* dU_pad [n_obj][34][34][512] bf16 = sum over the pairs listed for each object of the routed dz  (transpose of the expansion);
  * amz: the nibble-packed routing codes written by the expansion. */
 int sgc_pair_contract(const void* dz, const unsigned char* amz, const int* ptr, const int* list, void* dU_pad, int n_obj, void* stream);
@@ -175,6 +180,8 @@ int sgc_dbg_conv_nt(int elem, const void* A, const void* B, void* C, int n_img, 
 int sgc_dbg_gemm_tn(int elem, const void* A, const void* B, float* C, int M, int N, int K, long lda, long ldb, int splits, int* slabs, void* stream);
 int sgc_dbg_conv_tn(int elem, const void* A, const void* B, float* C, int M, int n_img, int lgS, int Cin, int splits, int* slabs, void* stream);
 int sgc_dbg_tr_probe(const int* addr, short* out, void* stream);
+int sgc_dbg_mfma_rate(float* out, int blocks, int iters, int mode, void* stream);
+int sgc_dbg_smfmac_probe(const void* a, const void* b, const int* idx, float* c, int abid, void* stream);
 
 #ifdef __cplusplus
 }

@@ -82,4 +82,59 @@ int sgc_dbg_tr_probe(const int* addr, short* out, void* stream) {
     return SGC_OK;
 }
 
+// v_smfmac_f32_32x32x32_bf16 semantics probe: every lane supplies its 8 compressed A values, 16 B values and the index word
+__global__ void smfmac_probe_kernel(const u16* a, const u16* b, const int* idx, float* c, int abid) {
+    typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+    typedef __bf16 bf16x16_t __attribute__((ext_vector_type(16)));
+    const int l = threadIdx.x;
+    bf16x8_t av; bf16x16_t bv;
+    for (int i = 0; i < 8; ++i) { u16 t = a[l * 8 + i]; av[i] = __builtin_bit_cast(__bf16, t); }
+    for (int i = 0; i < 16; ++i) { u16 t = b[l * 16 + i]; bv[i] = __builtin_bit_cast(__bf16, t); }
+    f32x16 acc;
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    if (abid == 0) acc = __builtin_amdgcn_smfmac_f32_32x32x32_bf16(av, bv, acc, idx[l], 0, 0);
+    else if (abid == 1) acc = __builtin_amdgcn_smfmac_f32_32x32x32_bf16(av, bv, acc, idx[l], 0, 1);
+    else acc = __builtin_amdgcn_smfmac_f32_32x32x32_bf16(av, bv, acc, idx[l], 1, 0);
+    for (int r = 0; r < 16; ++r) c[l * 16 + r] = acc[r];
+}
+int sgc_dbg_smfmac_probe(const void* a, const void* b, const int* idx, float* c, int abid, void* stream) {
+    SGC_LAUNCH(smfmac_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const u16*)a, (const u16*)b, idx, c, abid);
+    SGC_CHECK_LAUNCH();
+    return SGC_OK;
+}
+
+}  // extern "C"
+// MFMA issue-rate probe: 8 independent accumulators, `iters` rounds of 8 instructions per wave; mode 0 dense 32x32x16, 1 sparse 32x32x32
+template <int mode>
+__global__ __launch_bounds__(512, 2) void mfma_rate_kernel(float* out, int iters) {
+    typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+    typedef __bf16 bf16x16_t __attribute__((ext_vector_type(16)));
+    f32x16 acc[8];
+    for (int i = 0; i < 8; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    bf16x8_t a; bf16x16_t b;
+    for (int i = 0; i < 8; ++i) a[i] = (__bf16)(float)(threadIdx.x * 0.001f + i);
+    for (int i = 0; i < 16; ++i) b[i] = (__bf16)(float)(threadIdx.x * 0.002f + i);
+    const bf16x8_t b8 = __builtin_shufflevector(b, b, 0, 1, 2, 3, 4, 5, 6, 7);
+    const int idx = 0x4444;
+    for (int it = 0; it < iters; ++it) {
+        if (mode == 0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b8, acc[i], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_smfmac_f32_32x32x32_bf16(a, b, acc[i], idx, 0, 0);
+        }
+    }
+    float s = 0.f;
+    for (int i = 0; i < 8; ++i) for (int r = 0; r < 16; ++r) s += acc[i][r];
+    if (s == 12345.678f) out[0] = s;
+}
+extern "C" {
+int sgc_dbg_mfma_rate(float* out, int blocks, int iters, int mode, void* stream) {
+    if (mode == 0) SGC_LAUNCH(mfma_rate_kernel<0>, dim3(blocks), dim3(512), 0, (hipStream_t)stream, out, iters);
+    else SGC_LAUNCH(mfma_rate_kernel<1>, dim3(blocks), dim3(512), 0, (hipStream_t)stream, out, iters);
+    SGC_CHECK_LAUNCH();
+    return SGC_OK;
+}
+
 }  // extern "C"

@@ -7,6 +7,7 @@
 #include "common.h"
 #include "gemm_nt.h"
 #include "gemm_tn.h"
+#include "gemm_tn_sp.h"
 
 // ------------------------------------------------------------------------------------------------ head + loss
 // Per pair: dL/dlogits of the hierarchical NLL / BCE loss (reference train_utils.py:64-94,116-157 with the
@@ -750,6 +751,19 @@ int sgc_conv3_wgrad(const void* dy3_pad, const void* z_pad_bf16, float* slabs, i
     p.A = (const u16*)dy3_pad; p.B = (const u16*)z_pad_bf16; p.C = slabs; p.M = 1024; p.N = 9 * 512; p.K = n_pairs * 256;
     p.ldc = 9 * 512; p.slab_stride = 1024L * 9 * 512; p.lgS = 4; p.Cin = 512; p.CinA = 1024;
     return launch_gemm_tn<ELEM_BF16, BMODE_CONV, 1>(p, splits, n_slabs, (hipStream_t)stream);
+}
+// The same gradient on the sparse matrix cores (gemm_tn_sp.h): dy [n_pairs*64][1024] bf16 is the POOLED gradient (fc1 data
+// gradient, not yet un-pooled), argmax the conv3 forward routing byte (0..3, 4 = ReLU killed); pack_ac (n_pairs*4*1024*64 B)
+// and pack_ic (n_pairs*4*1024*8 B) are scratch for the packed 2:4 operand.
+int sgc_conv3_wgrad_sparse(const void* dy, const unsigned char* argmax, const void* z_pad_bf16, void* pack_ac, void* pack_ic,
+                           float* slabs, int n_pairs, int splits, int* n_slabs, void* stream) {
+    if (n_pairs <= 0) { if (n_slabs) *n_slabs = 0; return SGC_OK; }
+    int rc = launch_sparse_pack((const u16*)dy, argmax, (u16*)pack_ac, (unsigned*)pack_ic, n_pairs, (hipStream_t)stream);
+    if (rc != SGC_OK) return rc;
+    TnParams p{};
+    p.A = nullptr; p.B = (const u16*)z_pad_bf16; p.C = slabs; p.M = 1024; p.N = 9 * 512; p.K = n_pairs * 256;
+    p.ldc = 9 * 512; p.slab_stride = 1024L * 9 * 512; p.lgS = 4; p.Cin = 512; p.CinA = 1024;
+    return launch_gemm_tn_sp(p, (const u16*)pack_ac, (const unsigned*)pack_ic, splits, n_slabs, (hipStream_t)stream);
 }
 // ---- expansion / contraction
 int sgc_pair_expand_train(const void* U, const void* V, const int* sub_idx, const int* obj_idx, void* z_pad_f16, void* z_pad_bf16,

@@ -13,6 +13,7 @@ from __future__ import annotations
 
 import ctypes
 import math
+import os
 from dataclasses import dataclass
 from typing import Dict, Optional
 
@@ -518,8 +519,16 @@ class RelHeadEngine:
                    "sgc_unpool_relu_bwd"))
         grads["conv3_1.bias"] = self._slab_sum(bpart, 1024, nparts.value)
         z_bf = ctx.z_bf
-        self._timed("conv3_wgrad", lambda: _lib.check(lib.sgc_conv3_wgrad(_lib.ptr(dy3), _lib.ptr(z_bf), _lib.ptr(sl), P, 0, ctypes.byref(slabs_n), st()),
-                   "sgc_conv3_wgrad"))
+        if os.environ.get("SGC_W3_SPARSE", "1") != "0":
+            # sparse matrix cores: the pooled gradient + the arg-max byte ARE the 2:4-compressed operand (csrc/gemm_tn_sp.h)
+            pack_a = ws.get("w3_pack_a", P * 4 * 1024 * 64, torch.uint8)
+            pack_i = ws.get("w3_pack_i", P * 4 * 1024 * 8, torch.uint8)
+            self._timed("conv3_wgrad", lambda: _lib.check(lib.sgc_conv3_wgrad_sparse(
+                _lib.ptr(dy), _lib.ptr(ctx.am), _lib.ptr(z_bf), _lib.ptr(pack_a), _lib.ptr(pack_i), _lib.ptr(sl), P, 0,
+                ctypes.byref(slabs_n), st()), "sgc_conv3_wgrad_sparse"))
+        else:
+            self._timed("conv3_wgrad", lambda: _lib.check(lib.sgc_conv3_wgrad(_lib.ptr(dy3), _lib.ptr(z_bf), _lib.ptr(sl), P, 0, ctypes.byref(slabs_n), st()),
+                       "sgc_conv3_wgrad"))
         dW3r = self._slab_sum(sl, 1024 * 4608, slabs_n.value)
         grads["conv3_1.weight"] = dW3r.view(1024, 3, 3, 512).permute(0, 3, 1, 2).contiguous()
         dz = ws.get("dz", P * 256 * 512, torch.bfloat16)

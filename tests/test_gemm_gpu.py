@@ -183,3 +183,37 @@ def test_pingpong_blocks_repeatable():
             first = C.clone()
         else:
             assert torch.equal(C, first), "ping-pong halo conv block is not repeatable (iteration %d)" % it
+
+
+@pytest.mark.parametrize("n_pairs,splits", [(8, 1), (40, 0), (37, 3)])
+def test_conv3_wgrad_sparse_matches_dense(n_pairs, splits):
+    """Sparse-MFMA conv3 weight gradient (pooled gradient + arg-max byte as the 2:4 operand) against the dense path
+    (un-pool, then the ping-pong TN block) on the same data: same products, different summation order."""
+    lib, L = _lib()
+    g = torch.Generator().manual_seed(n_pairs)
+    P = n_pairs
+    dy = (torch.randn(P * 64, 1024, generator=g) * 0.5).bfloat16().cuda()
+    am = torch.randint(0, 5, (P * 64, 1024), generator=g, dtype=torch.uint8).cuda()
+    z = torch.zeros(P, 18, 18, 512, dtype=torch.bfloat16)
+    z[:, 1:17, 1:17] = (torch.randn(P, 16, 16, 512, generator=g) * 0.5).bfloat16()
+    z = z.cuda()
+    # dense reference path: un-pool into dy3_pad, then the dense weight gradient
+    dy3 = torch.zeros(P, 18, 18, 1024, dtype=torch.bfloat16, device="cuda")
+    bpart = torch.zeros(2048, 1024, device="cuda")
+    nparts = ctypes.c_int(0)
+    assert lib.sgc_unpool_relu_bwd(L.ptr(dy), L.ptr(am), L.ptr(dy3), L.ptr(bpart), ctypes.byref(nparts), P, L.stream_ptr()) == 0
+    sl = torch.zeros(32, 1024, 4608, device="cuda")
+    ns = ctypes.c_int(0)
+    assert lib.sgc_conv3_wgrad(L.ptr(dy3), L.ptr(z), L.ptr(sl), P, 4, ctypes.byref(ns), L.stream_ptr()) == 0
+    torch.cuda.synchronize()
+    ref = sl[:ns.value].sum(0)
+    ac = torch.empty(P * 4 * 1024 * 64, dtype=torch.uint8, device="cuda")
+    ic = torch.empty(P * 4 * 1024 * 8, dtype=torch.uint8, device="cuda")
+    sl2 = torch.zeros(32, 1024, 4608, device="cuda")
+    ns2 = ctypes.c_int(0)
+    assert lib.sgc_conv3_wgrad_sparse(L.ptr(dy), L.ptr(am), L.ptr(z), L.ptr(ac), L.ptr(ic), L.ptr(sl2), P, splits, ctypes.byref(ns2),
+                                      L.stream_ptr()) == 0
+    torch.cuda.synchronize()
+    got = sl2[:ns2.value].sum(0)
+    err = (got - ref).abs().max().item()
+    assert err <= 2e-4 * ref.abs().max().item() + 1e-5, (err, ref.abs().max().item())
