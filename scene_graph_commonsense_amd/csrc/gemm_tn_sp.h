@@ -19,6 +19,12 @@
 // kernel gives lane half ha the windows 8ha + 4s .. 8ha + 4s + 3 of the tile for instruction s, so that the eight windows of a lane
 // half are contiguous in the packed operand: B half hb element i then is pixel 16s + 8hb + i (i < 8) / 32 + 16s + 8hb + i - 8.
 //
+// Measured (N=64, B=8): pack 2.7 ms + sparse block 47.2 ms against 55.5 ms for the dense ping-pong block.  The sparse MFMA issues
+// at the dense instruction rate (probe: 3.6-3.9 PFLOP/s dense-equivalent), but the operand stream does not shrink with it: 50 KiB
+// per K tile instead of 64 (the dense z tile is unchanged), and the block sits at the same ~10 TB/s of L2->LDS traffic as the dense
+// one; without the loads it runs at 28 ms.  A three-tile ring (twice the time for loads to land) changed nothing: it is the
+// byte rate, not the latency.
+//
 // Packed operands (sgc_sparse_pack): per K tile T (16 windows)
 //   Ac [T][1024 oc][16 windows][2] bf16   the two kept values of every window (value + one zero)      64 B per (tile, oc)
 //   Ic [T][1024 oc][2] u32                per lane half: index bits of s = 0 (low 16) and s = 1 (high 16)
