@@ -136,6 +136,10 @@ int sgc_conv3_wgrad(const void* dy3_pad, const void* z_pad_bf16, float* slabs, i
  * pack_ac (n_pairs*4*1024*64 bytes) and pack_ic (n_pairs*4*1024*8 bytes) are scratch for the packed operand. */
 int sgc_conv3_wgrad_sparse(const void* dy, const unsigned char* argmax, const void* z_pad_bf16, void* pack_ac, void* pack_ic,
                            float* slabs, int n_pairs, int splits, int* n_slabs, void* stream);
+/* sgc_unpool_relu_bwd that also writes the packed operand in the same pass (dbias_part: at most 768 partials);
+ * sgc_conv3_wgrad_sparse called afterwards with dy == NULL uses pack_ac / pack_ic as they are. */
+int sgc_unpool_relu_bwd_pack(const void* dy, const unsigned char* argmax, void* dy3_pad, float* dbias_part, int* n_parts,
+                             void* pack_ac, void* pack_ic, int n_pairs, void* stream);
 /* dU_pad [n_obj][34][34][512] bf16 = sum over the pairs listed for each object of the routed dz  (transpose of the expansion);
  * amz: the nibble-packed routing codes written by the expansion. */
 int sgc_pair_contract(const void* dz, const unsigned char* amz, const int* ptr, const int* list, void* dU_pad, int n_obj, void* stream);

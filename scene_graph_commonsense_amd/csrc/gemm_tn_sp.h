@@ -74,6 +74,89 @@ __global__ __launch_bounds__(256) void sparse_pack_kernel(const u16* __restrict_
     Ic[((long)T * 1024 + oc0 + oc) * 2 + ha] = idx;
 }
 
+// Fused pass over the pooled gradient: un-pooling for the input gradient (dy3_pad, what unpool_kernel writes), the conv3 bias
+// partial sums and the packed sparse operand, reading dy and the routing byte once.  A block walks whole 16-window x 1024-channel
+// tiles (bx, bx+gx, ...) so that every dy3 pixel row (2 KiB) is written by one block in one go; bias partials dbias[bx][1024].
+__global__ __launch_bounds__(512) void unpool_pack_kernel(const u16* __restrict__ dy, const unsigned char* __restrict__ am,
+                                                          u16* __restrict__ dy3, float* __restrict__ dbias, u16* __restrict__ Ac,
+                                                          unsigned* __restrict__ Ic, int n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int SVS = 1024 + 8, SPS = 1024 + 16;
+    u16* sv = reinterpret_cast<u16*>(smem);                                  // [16][SVS]
+    unsigned char* sp = reinterpret_cast<unsigned char*>(smem) + 16 * SVS * 2;   // [16][SPS]
+    const int ch = threadIdx.x & 127, wq = threadIdx.x >> 7;
+    float bs[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) bs[k] = 0.f;
+    for (int T = blockIdx.x; T < n_tiles; T += gridDim.x) {
+        uint4 gv[4];
+        uint2 av[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long g = ((long)T * 16 + wq + 4 * i) * 1024 + ch * 8;
+            gv[i] = *reinterpret_cast<const uint4*>(dy + g);
+            av[i] = *reinterpret_cast<const uint2*>(am + g);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int w = wq + 4 * i;
+            const long wdx = (long)T * 16 + w;
+            *reinterpret_cast<uint4*>(&sv[w * SVS + ch * 8]) = gv[i];
+            *reinterpret_cast<uint2*>(&sp[w * SPS + ch * 8]) = av[i];
+            const u16* gh = reinterpret_cast<const u16*>(&gv[i]);
+            const unsigned char* ab = reinterpret_cast<const unsigned char*>(&av[i]);
+            const long p = wdx >> 6;
+            const int W = (int)(wdx & 63), py = W >> 3, px = W & 7;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                uint4 o;
+                u16* oh = reinterpret_cast<u16*>(&o);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) oh[k] = (ab[k] == q) ? gh[k] : (u16)0;
+                const int Y = 2 * py + (q >> 1) + 1, X = 2 * px + (q & 1) + 1;
+                *reinterpret_cast<uint4*>(dy3 + ((p * 18 + Y) * 18 + X) * 1024 + ch * 8) = o;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) if (ab[k] < 4) bs[k] += bf16_bits_to_f32(gh[k]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int item = threadIdx.x + 512 * it;
+            const int oc = item >> 1, ha = item & 1;
+            unsigned pairs[8];
+            unsigned idx = 0;
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int ga = 0; ga < 4; ++ga) {
+                    const int ww = 8 * ha + 4 * s + ga;
+                    const unsigned v = sv[ww * SVS + oc];
+                    const int pm = sp[ww * SPS + oc];
+                    unsigned pr, nib;
+                    if (pm < 3) { pr = v; nib = (unsigned)pm | (3u << 2); }
+                    else if (pm == 3) { pr = v << 16; nib = 2u | (3u << 2); }
+                    else { pr = 0; nib = 0u | (1u << 2); }
+                    pairs[4 * s + ga] = pr;
+                    idx |= nib << (16 * s + 4 * ga);
+                }
+            unsigned* dst = reinterpret_cast<unsigned*>(Ac) + (((long)T * 1024 + oc) * 16 + 8 * ha);
+            *reinterpret_cast<uint4*>(dst) = make_uint4(pairs[0], pairs[1], pairs[2], pairs[3]);
+            *reinterpret_cast<uint4*>(dst + 4) = make_uint4(pairs[4], pairs[5], pairs[6], pairs[7]);
+            Ic[((long)T * 1024 + oc) * 2 + ha] = idx;
+        }
+        __syncthreads();
+    }
+    if (dbias) {
+        float* red = reinterpret_cast<float*>(smem);       // [4][1024]
+#pragma unroll
+        for (int k = 0; k < 8; ++k) red[wq * 1024 + ch * 8 + k] = bs[k];
+        __syncthreads();
+        for (int c = threadIdx.x; c < 1024; c += 512)
+            dbias[(long)blockIdx.x * 1024 + c] = (red[c] + red[1024 + c]) + (red[2048 + c] + red[3072 + c]);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------- sparse TN block
 // Ping-pong schedule and ring exactly as gemm_tn_pp_kernel (two loads per wave per half tile, vmcnt(8)); an A half tile is now
 // 128 rows x 64 B of packed pairs (one load per wave) + 128 x 8 B of index words (one load: wave 0 for A0, wave 1 for A1).
@@ -258,6 +341,17 @@ static int launch_sparse_pack(const u16* dy, const unsigned char* am, u16* Ac, u
     const int n_tiles = n_pairs * 4;                          // 64 windows per pair / 16 windows per K tile
     if (n_tiles <= 0) return SGC_OK;
     SGC_LAUNCH(sparse_pack_kernel, dim3((unsigned)n_tiles, 8), dim3(256), 0, stream, dy, am, Ac, Ic, n_tiles);
+    SGC_CHECK_LAUNCH();
+    return SGC_OK;
+}
+
+static int launch_unpool_pack(const u16* dy, const unsigned char* am, u16* dy3, float* dbias, int* n_parts, u16* Ac, unsigned* Ic,
+                              int n_pairs, hipStream_t stream) {
+    constexpr int LDS = 16 * (1024 + 8) * 2 + 16 * (1024 + 16);
+    const int n_tiles = n_pairs * 4;
+    const int gx = n_tiles < 768 ? n_tiles : 768;          // 3 blocks per CU (LDS)
+    if (n_parts) *n_parts = gx;
+    SGC_LAUNCH(unpool_pack_kernel, dim3((unsigned)gx), dim3(512), LDS, stream, dy, am, dy3, dbias, Ac, Ic, n_tiles);
     SGC_CHECK_LAUNCH();
     return SGC_OK;
 }

@@ -738,6 +738,13 @@ int sgc_unpool_relu_bwd(const void* dy, const unsigned char* argmax, void* dy3_p
     SGC_CHECK_LAUNCH();
     return SGC_OK;
 }
+// The same un-pooling, also emitting the packed 2:4 operand of sgc_conv3_wgrad_sparse in the one pass over dy / argmax
+int sgc_unpool_relu_bwd_pack(const void* dy, const unsigned char* argmax, void* dy3_pad, float* dbias_part, int* n_parts,
+                             void* pack_ac, void* pack_ic, int n_pairs, void* stream) {
+    if (n_pairs <= 0) { if (n_parts) *n_parts = 0; return SGC_OK; }
+    return launch_unpool_pack((const u16*)dy, argmax, (u16*)dy3_pad, dbias_part, n_parts, (u16*)pack_ac, (unsigned*)pack_ic,
+                              n_pairs, (hipStream_t)stream);
+}
 // dz [n_pairs*256][512] bf16 = conv3x3(dy3_pad, wd3[512][9][1024])
 int sgc_conv3_dgrad(const void* dy3_pad, const void* wd3, void* dz, int n_pairs, void* stream) {
     NtParams p{};
@@ -758,8 +765,10 @@ int sgc_conv3_wgrad(const void* dy3_pad, const void* z_pad_bf16, float* slabs, i
 int sgc_conv3_wgrad_sparse(const void* dy, const unsigned char* argmax, const void* z_pad_bf16, void* pack_ac, void* pack_ic,
                            float* slabs, int n_pairs, int splits, int* n_slabs, void* stream) {
     if (n_pairs <= 0) { if (n_slabs) *n_slabs = 0; return SGC_OK; }
-    int rc = launch_sparse_pack((const u16*)dy, argmax, (u16*)pack_ac, (unsigned*)pack_ic, n_pairs, (hipStream_t)stream);
-    if (rc != SGC_OK) return rc;
+    if (dy) {                                              // dy == NULL: pack_ac / pack_ic already hold the operand (sgc_unpool_relu_bwd_pack)
+        int rc = launch_sparse_pack((const u16*)dy, argmax, (u16*)pack_ac, (unsigned*)pack_ic, n_pairs, (hipStream_t)stream);
+        if (rc != SGC_OK) return rc;
+    }
     TnParams p{};
     p.A = nullptr; p.B = (const u16*)z_pad_bf16; p.C = slabs; p.M = 1024; p.N = 9 * 512; p.K = n_pairs * 256;
     p.ldc = 9 * 512; p.slab_stride = 1024L * 9 * 512; p.lgS = 4; p.Cin = 512; p.CinA = 1024;

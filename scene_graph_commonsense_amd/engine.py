@@ -515,16 +515,23 @@ class RelHeadEngine:
         dy3 = ws.get("dy3_pad", P * 18 * 18 * 1024, torch.bfloat16)
         bpart = ws.get("b3_part", 2048 * 1024, torch.float32)
         nparts = ctypes.c_int(0)
-        self._timed("unpool", lambda: _lib.check(lib.sgc_unpool_relu_bwd(_lib.ptr(dy), _lib.ptr(ctx.am), _lib.ptr(dy3), _lib.ptr(bpart), ctypes.byref(nparts), P, st()),
-                   "sgc_unpool_relu_bwd"))
-        grads["conv3_1.bias"] = self._slab_sum(bpart, 1024, nparts.value)
+        sparse_w3 = os.environ.get("SGC_W3_SPARSE", "1") != "0"
         z_bf = ctx.z_bf
-        if os.environ.get("SGC_W3_SPARSE", "1") != "0":
-            # sparse matrix cores: the pooled gradient + the arg-max byte ARE the 2:4-compressed operand (csrc/gemm_tn_sp.h)
+        if sparse_w3:
+            # sparse matrix cores: the pooled gradient + the arg-max byte ARE the 2:4-compressed operand (csrc/gemm_tn_sp.h);
+            # one pass over dy writes the un-pooled gradient for the input-gradient GEMM, the bias partials and that operand
             pack_a = ws.get("w3_pack_a", P * 4 * 1024 * 64, torch.uint8)
             pack_i = ws.get("w3_pack_i", P * 4 * 1024 * 8, torch.uint8)
+            self._timed("unpool", lambda: _lib.check(lib.sgc_unpool_relu_bwd_pack(
+                _lib.ptr(dy), _lib.ptr(ctx.am), _lib.ptr(dy3), _lib.ptr(bpart), ctypes.byref(nparts), _lib.ptr(pack_a),
+                _lib.ptr(pack_i), P, st()), "sgc_unpool_relu_bwd_pack"))
+        else:
+            self._timed("unpool", lambda: _lib.check(lib.sgc_unpool_relu_bwd(_lib.ptr(dy), _lib.ptr(ctx.am), _lib.ptr(dy3), _lib.ptr(bpart), ctypes.byref(nparts), P, st()),
+                       "sgc_unpool_relu_bwd"))
+        grads["conv3_1.bias"] = self._slab_sum(bpart, 1024, nparts.value)
+        if sparse_w3:
             self._timed("conv3_wgrad", lambda: _lib.check(lib.sgc_conv3_wgrad_sparse(
-                _lib.ptr(dy), _lib.ptr(ctx.am), _lib.ptr(z_bf), _lib.ptr(pack_a), _lib.ptr(pack_i), _lib.ptr(sl), P, 0,
+                None, None, _lib.ptr(z_bf), _lib.ptr(pack_a), _lib.ptr(pack_i), _lib.ptr(sl), P, 0,
                 ctypes.byref(slabs_n), st()), "sgc_conv3_wgrad_sparse"))
         else:
             self._timed("conv3_wgrad", lambda: _lib.check(lib.sgc_conv3_wgrad(_lib.ptr(dy3), _lib.ptr(z_bf), _lib.ptr(sl), P, 0, ctypes.byref(slabs_n), st()),

@@ -217,3 +217,23 @@ def test_conv3_wgrad_sparse_matches_dense(n_pairs, splits):
     got = sl2[:ns2.value].sum(0)
     err = (got - ref).abs().max().item()
     assert err <= 2e-4 * ref.abs().max().item() + 1e-5, (err, ref.abs().max().item())
+    # fused un-pool + pack pass: identical dy3_pad and packed operand (bit-exact), bias partial sums to f32 rounding
+    dy3b = torch.zeros(P, 18, 18, 1024, dtype=torch.bfloat16, device="cuda")
+    bpart2 = torch.zeros(2048, 1024, device="cuda")
+    nparts2 = ctypes.c_int(0)
+    ac2 = torch.empty_like(ac)
+    ic2 = torch.empty_like(ic)
+    assert lib.sgc_unpool_relu_bwd_pack(L.ptr(dy), L.ptr(am), L.ptr(dy3b), L.ptr(bpart2), ctypes.byref(nparts2), L.ptr(ac2),
+                                        L.ptr(ic2), P, L.stream_ptr()) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(dy3b.view(torch.int16), dy3.view(torch.int16))
+    assert torch.equal(ac2, ac) and torch.equal(ic2, ic)
+    b_ref = bpart[:nparts.value].sum(0)
+    b_got = bpart2[:nparts2.value].sum(0)
+    assert (b_got - b_ref).abs().max().item() <= 1e-4 * b_ref.abs().max().item() + 1e-5
+    sl3 = torch.zeros(32, 1024, 4608, device="cuda")
+    ns3 = ctypes.c_int(0)
+    assert lib.sgc_conv3_wgrad_sparse(None, None, L.ptr(z), L.ptr(ac2), L.ptr(ic2), L.ptr(sl3), P, splits, ctypes.byref(ns3),
+                                      L.stream_ptr()) == 0
+    torch.cuda.synchronize()
+    assert ns3.value == ns2.value and torch.equal(sl3[:ns3.value], sl2[:ns2.value])
