@@ -1,0 +1,23 @@
+#!/bin/bash
+# Collect the profile set kept under profiles/ (run on the GPU box from the repo root):
+#   bash tools/collect_profiles.sh <tag>     ->  gpurun_out/<tag>_{bench.json,bench_under_rocprof.json,kernel_stats.csv,pmc_f.csv,pmc_w.csv,pmc_s.csv}
+# Counters are collected in their own passes with --kernel-trace only (never together with API / system traces).
+set -u
+TAG=${1:-rXX}
+R=$(pwd)
+OUT=$R/gpurun_out
+mkdir -p "$OUT"
+python3 bench.py --steps 5 --warmup 2 2>/dev/null | tail -1 > "$OUT/${TAG}_bench.json"
+cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/prof_ks /tmp/prof_f /tmp/prof_w /tmp/prof_s
+rocprofv3 --kernel-trace --stats -d /tmp/prof_ks -o ks -- python3 "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > /tmp/ks.log 2>&1
+grep '^{"metric"' /tmp/ks.log | tail -1 > "$OUT/${TAG}_bench_under_rocprof.json"
+python3 "$R/tools/rocpd_summary.py" "$(find /tmp/prof_ks -name '*.db' | head -1)" "$OUT/${TAG}_kernel_stats.csv"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/prof_f -o f --output-format csv -- python3 "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline > /tmp/f.log 2>&1
+python3 "$R/tools/pmc_summary.py" "$(find /tmp/prof_f -name '*counter_collection.csv' | head -1)" "$OUT/${TAG}_pmc_f.csv"
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/prof_w -o w --output-format csv -- python3 "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline > /tmp/w.log 2>&1
+python3 "$R/tools/pmc_summary.py" "$(find /tmp/prof_w -name '*counter_collection.csv' | head -1)" "$OUT/${TAG}_pmc_w.csv"
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_VALU_MFMA_MOPS_BF16 \
+    -d /tmp/prof_s -o s --output-format csv -- python3 "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline > /tmp/s.log 2>&1
+python3 "$R/tools/pmc_summary.py" "$(find /tmp/prof_s -name '*counter_collection.csv' | head -1)" "$OUT/${TAG}_pmc_s.csv"
+ls -la "$OUT"/${TAG}_*
