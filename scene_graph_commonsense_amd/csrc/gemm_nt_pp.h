@@ -21,7 +21,10 @@
 //  1.77 ms (1243), with the XCD-aware tile walk 1.74 ms (1264).  Variants measured and dropped: four phases per K tile
 //  (8 MFMAs per slot, vmcnt(12)) 2.0 ms - the ~85-cycle barrier slot overhead is paid twice as often; s_setprio(1)
 //  around the MFMA section -1 %; issuing the last 1/2/4 MFMAs of a slot AFTER its closing barrier (to keep the pipe fed
-//  across the barrier) -7/-9/-11 %.
+//  across the barrier) -7/-9/-11 %.  Row strides: padding the 128 KiB rows of the fc1 operands (K = 65536) by 128 B ... 1152 B
+//  moved the launch by <= 1 % (13.71 -> 13.55 ms): the power-of-two stride is not what costs the L2 its hits.  Counters for
+//  that launch: 56 GB of L2 misses against 25 GB for perfectly shared 4x8 patches (blocks of a patch drift apart in K) and an
+//  effective clock of 1.40 GHz (conv3 data gradient: 1.90) - the chip's power budget, not the schedule, sets these rates.
 #pragma once
 
 #define SGC_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
