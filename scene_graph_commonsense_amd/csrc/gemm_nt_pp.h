@@ -53,6 +53,29 @@ __device__ __forceinline__ void xcd_patch_map(int id, int tiles_m, int tiles_n, 
     supertile_map_g(lin, tiles_m, tiles_n, 4, 8, tm, tn);
 }
 
+// Patch-aligned form used by the NT block: the tile grid is cut into GM x GN = 32-tile patches (4 x 8; narrower grids 8x4, 16x2,
+// 32x1), patch k goes to XCD k % 8 and the grid is padded to whole patches, so the 32 blocks resident on an XCD are always ONE
+// patch (with the unpadded walk above an XCD's range starts at a multiple of nb/8, not of 32: fc1 forward, 126 x 16 tiles, ran
+// 2.6 % slower than the 128 x 16 grid that does MORE work).  Edge patches come last on every XCD; blocks beyond the grid exit.
+__host__ __device__ __forceinline__ int xcd_patch_gn(int tiles_n) { return tiles_n >= 8 ? 8 : (tiles_n >= 4 ? 4 : (tiles_n >= 2 ? 2 : 1)); }
+static inline int xcd_patch_grid(int tiles_m, int tiles_n) {
+    const int gn = xcd_patch_gn(tiles_n), gm = 32 / gn;
+    const int npatch = ((tiles_m + gm - 1) / gm) * ((tiles_n + gn - 1) / gn);
+    return ((npatch + 7) / 8) * 8 * 32;
+}
+__device__ __forceinline__ bool xcd_patch_map_aligned(int id, int tiles_m, int tiles_n, int& tm, int& tn) {
+    const int gn = xcd_patch_gn(tiles_n), gm = 32 / gn;
+    const int sn = (tiles_n + gn - 1) / gn, npatch = ((tiles_m + gm - 1) / gm) * sn;
+    const int x = id & 7, j = id >> 3;
+    const int patch = (j >> 5) * 8 + x, w = j & 31;
+    if (patch >= npatch) return false;
+    const int a = patch / sn, b = patch - a * sn;
+    const int wn = min(gn, tiles_n - b * gn);
+    tm = a * gm + w / wn;
+    tn = b * gn + w % wn;
+    return tm < tiles_m && w < gm * wn;
+}
+
 // ABL (tools/gemm_microbench.py only): 0 normal, 1 no global loads inside the K loop.
 template <int ELEM, int EPI, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(const NtParams p) {
@@ -62,7 +85,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(const NtParams p) {
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wid >> 2, wc = wid & 3;
     int tm, tn;
-    xcd_patch_map(blockIdx.x, p.tiles_m, p.tiles_n, tm, tn);
+    if (!xcd_patch_map_aligned(blockIdx.x, p.tiles_m, p.tiles_n, tm, tn)) return;      // padding block (uniform exit)
     const int m0 = tm * 256, n0 = tn * 256;
 
     // ---- staging sources: wave w writes LDS rows (2w+q)*8 .. +7 of every half tile (q = 0,1), 8 lanes per 128-B row
@@ -181,7 +204,7 @@ static int launch_gemm_nt_pp(NtParams p, hipStream_t stream) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;
     }
-    SGC_LAUNCH(kern, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(512), LDS, stream, p);
+    SGC_LAUNCH(kern, dim3((unsigned)xcd_patch_grid(p.tiles_m, p.tiles_n)), dim3(512), LDS, stream, p);
     SGC_CHECK_LAUNCH();
     return SGC_OK;
 }
