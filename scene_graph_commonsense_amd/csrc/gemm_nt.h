@@ -35,6 +35,7 @@ struct NtParams {
     int tiles_m, tiles_n;
     int epi_lds;                // 1: LDS-staged 16-byte stores for EPI_STORE in the 8-wave kernels (set by the launcher)
     int halo_walk;              // conv16_halo_pp_kernel: 0 = block id -> (image, N tile) directly, 1 = XCD-contiguous image ranges
+    int patch_aligned;          // gemm_nt_pp_kernel: 1 = grid padded to whole 32-tile patches (set by the launcher for large grids)
 };
 
 template <int ELEM>

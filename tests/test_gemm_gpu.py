@@ -29,7 +29,8 @@ def _window_major_index(S):
 
 @pytest.mark.parametrize("dtype,elem", [(torch.float16, 0), (torch.bfloat16, 1)])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 256, 192), (1000, 512, 4096), (256, 256, 64), (300, 256, 128),
-                                   (520, 512, 256), (700, 256, 320), (512, 768, 1088)])
+                                   (520, 512, 256), (700, 256, 320), (512, 768, 1088),
+                                   (9700, 8192, 128)])      # 38 x 32 tiles: the patch-aligned XCD walk with a partial band
 def test_gemm_nt_plain(dtype, elem, M, N, K):
     lib, L = _lib()
     A, B = _rand((M, K), dtype, 1), _rand((N, K), dtype, 2)
