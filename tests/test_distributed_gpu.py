@@ -43,7 +43,10 @@ def test_two_ranks_mean_gradients_on_one_gpu():
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29600 + (os.getpid() % 1000)
+    import socket
+    with socket.socket() as sk:                       # a port the OS knows to be free right now
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     [p.start() for p in procs]
     res = sorted(q.get(timeout=600) for _ in range(2))

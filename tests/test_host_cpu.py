@@ -169,7 +169,10 @@ def test_data_parallel_gradient_allreduce_gloo_world2():
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000)
+    import socket
+    with socket.socket() as sk:                       # a port the OS knows to be free right now
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
     [p.start() for p in procs]
     res = sorted(q.get(timeout=120) for _ in range(2))
