@@ -3,53 +3,118 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the hot path over one minibatch of synthetic input already resident in HBM:
-8 images x 64 objects per GPU -> 32 256 ordered pairs: per-image conv1, per-object conv2 halves, pair
-expansion, conv3, fc1, fc2, Bayesian head, hierarchical loss, full backward, (N>1: RCCL gradient all-reduce),
-SGD-momentum update of the f32 master weights and re-derivation of the 16-bit compute copies.  Weak scaling:
-every rank owns 8 images.  Rank 0 prints ONE JSON line.
+One "step" = one pass of the hot path over one minibatch of synthetic input already resident in HBM, from the RAW
+minibatch (the reference's data contract: features, depth, ragged boxes / categories / relation targets): pair
+enumeration and targets (row a2), per-image conv1, per-object conv2 halves, pair expansion, conv3, fc1, fc2, Bayesian
+head, hierarchical loss, full backward, (N>1: RCCL gradient all-reduce), SGD-momentum update of the f32 master weights
+and re-derivation of the 16-bit compute copies.  8 images x 64 objects per GPU -> 32 256 ordered pairs per GPU and
+step.  Weak scaling: every rank owns 8 images.  Rank 0 prints ONE JSON line.
+
+Multi-GPU: one process per GPU.  Under ``python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`` the ranks
+come from the environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*; the reference spawns them with ``mp.spawn``,
+``main.py:103,112-123``).  Called directly with ``--gpus N`` (N > 1) this file is its own launcher: the parent starts N
+child ranks BEFORE it touches the GPU, waits for them and exits with the worst of their codes.  ``--gpus`` must equal
+the world size, otherwise the run is refused (no silent single-rank numbers).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-from scene_graph_commonsense_amd import distributed as sgd_dist  # noqa: E402
-from scene_graph_commonsense_amd.synthetic import HeadConfig, make_scene_batch, make_state_dict, predicate_counts  # noqa: E402
-
 MFMA_PEAK_TFLOPS = 2500.0      # dense bf16/f16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
 DOMINANT_KERNEL = "conv16_halo_pp_kernel<0, 3>"      # conv3 forward: f16, halo-staged implicit 3x3 conv, ReLU + max-pool epilogue
+PMC_TAGS = ("r02_final", "r01_final")                # newest committed counter passes first
 
 
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--objects", type=int, default=64)
+    ap.add_argument("--images", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--forward-only", action="store_true")
+    ap.add_argument("--cached-scene", action="store_true",
+                    help="flatten the minibatch and build the targets once, outside the timed loop (round-1 behaviour; A/B only)")
+    ap.add_argument("--torch-sgd", action="store_true", help="torch.optim.SGD instead of the one-pass optim.FusedSGD (same update)")
+    ap.add_argument("--dataset", default="vg", choices=["vg", "oiv6"], help="oiv6 = 601 classes, (4,2,24) head, no super-classes")
+    ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / rendezvous / reduction plumbing only, no GPU work (the CPU test of the N-rank launch uses it with gloo)")
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------------------ launcher
+def launch_ranks(args, argv):
+    """Start ``args.gpus`` child ranks of this script (one per GPU) and wait.  Runs before anything in this process has
+    initialised the GPU; children are fresh interpreters, never an exec of this one."""
+    if not args.dry_run:
+        import torch
+        have = torch.cuda.device_count()                     # counting devices does not initialise the runtime
+        if have < args.gpus:
+            raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible" % (args.gpus, have))
+    with socket.socket() as sk:                              # a rendezvous port the OS knows to be free right now
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    code = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                rc = p.poll()
+                if rc is None:
+                    continue
+                pending.remove(p)
+                if rc != 0:                                  # one rank died: the others would wait in a collective forever
+                    code = code or rc
+                    for q in pending:
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return code
+
+
+# ------------------------------------------------------------------------------------------------ measurement helpers
 def pmc_traffic():
     """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (separate FETCH_SIZE
-    and WRITE_SIZE runs, profiles/r01_final_pmc_{f,w}.csv).  FETCH_SIZE is doubled: gfx950 counts 128-B requests of
+    and WRITE_SIZE runs, profiles/rNN_final_pmc_{f,w}.csv).  FETCH_SIZE is doubled: gfx950 counts 128-B requests of
     wide coalesced reads as 64 B (MI355X_MICROARCH.md, HBM section); both counters are KiB."""
-    vals = {}
-    for tag, ctr in (("f", "FETCH_SIZE"), ("w", "WRITE_SIZE")):
-        path = os.path.join(REPO, "profiles", "r01_final_pmc_%s.csv" % tag)
-        if not os.path.exists(path):
-            return None
-        for line in open(path):
-            if DOMINANT_KERNEL in line and "," + ctr + "," in line:
-                vals[ctr] = float(line.rsplit(",", 1)[1])
-    if len(vals) != 2:
-        return None
-    return int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024)
+    for tag in PMC_TAGS:
+        vals = {}
+        for suffix, ctr in (("f", "FETCH_SIZE"), ("w", "WRITE_SIZE")):
+            path = os.path.join(REPO, "profiles", "%s_pmc_%s.csv" % (tag, suffix))
+            if not os.path.exists(path):
+                break
+            for line in open(path):
+                if DOMINANT_KERNEL in line and "," + ctr + "," in line:
+                    vals[ctr] = float(line.rsplit(",", 1)[1])
+        if len(vals) == 2:
+            return int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024), tag
+    return None, None
 
 
 def cpu_baseline(cfg, sd, budget_s=20.0):
     """The CPU oracle (literal reference restatement) timed on this host: fwd + loss + bwd of the reference's
     per-step calls (b = 8 images per call), bounded sample, all host cores."""
+    import torch
     from oracle import relhead_oracle as O
+    from scene_graph_commonsense_amd.synthetic import make_scene_batch, predicate_counts
     batch = make_scene_batch(cfg, [6] * 8, seed=123, connect_frac=0.3)
     w = O.class_weights(predicate_counts(cfg))
     sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
@@ -69,27 +134,52 @@ def cpu_baseline(cfg, sd, budget_s=20.0):
             "sample": "%d reference calls of b=8 pairs (fwd+loss+bwd, f32, %.1f s)" % (len(out["records"]), dt)}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--objects", type=int, default=64)
-    ap.add_argument("--images", type=int, default=8)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--forward-only", action="store_true")
-    ap.add_argument("--torch-sgd", action="store_true", help="torch.optim.SGD instead of the one-pass optim.FusedSGD (same update)")
-    ap.add_argument("--dataset", default="vg", choices=["vg", "oiv6"], help="oiv6 = 601 classes, (4,2,24) head, no super-classes")
-    args = ap.parse_args()
+def dry_run(args):
+    """Everything of a rank except the GPU work: rendezvous, barrier, MAX-reduced time, one JSON line from rank 0."""
+    import torch
+    import torch.distributed as dist
+    from scene_graph_commonsense_amd import distributed as sgd_dist
+    rank, world, _ = sgd_dist.init_from_env(backend=args.backend or "gloo")
+    if world != args.gpus:
+        raise SystemExit("bench.py --gpus %d but WORLD_SIZE=%d: refusing to report a number for the wrong rank count" % (args.gpus, world))
+    if world > 1:
+        dist.barrier()
+    t0 = time.time()
+    for _ in range(args.steps):
+        time.sleep(0.001 * (rank + 1))
+    if world > 1:
+        dist.barrier()
+    t = torch.tensor([time.time() - t0], dtype=torch.float64)
+    ranks = torch.tensor([1.0])
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(ranks, op=dist.ReduceOp.SUM)
+    if rank == 0:
+        print(json.dumps({"metric": "dry run (launcher plumbing only)", "value": 0.0, "unit": "pairs/s", "n_gpus": world,
+                          "ranks_seen": int(ranks.item()), "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(float(t.item()) / max(args.steps, 1) * 1e3, 3), "dry_run": True}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------------ one rank
+def run_rank(args):
+    import numpy as np
+    import torch
+    from scene_graph_commonsense_amd import distributed as sgd_dist
+    from scene_graph_commonsense_amd.synthetic import HeadConfig, make_scene_batch, make_state_dict
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
-    rank, world, local = sgd_dist.init_from_env()
+    rank, world, local = sgd_dist.init_from_env(backend=args.backend)
+    if world != args.gpus:
+        raise SystemExit("bench.py --gpus %d but WORLD_SIZE=%d: refusing to report a number for the wrong rank count" % (args.gpus, world))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
     from scene_graph_commonsense_amd.model import BayesianRelationClassifier
-    from scene_graph_commonsense_amd.pairs import flatten_scene, pair_targets_fast
+    from scene_graph_commonsense_amd.pair_loop import train_minibatch
+    from scene_graph_commonsense_amd.pairs import flatten_scene
     cfg = HeadConfig() if args.dataset == "vg" else HeadConfig(dataset="oiv6", num_classes=601, num_super_classes=0,
                                                                num_geometric=4, num_possessive=2, num_semantic=24)
     sd = make_state_dict(cfg, seed=0)
@@ -99,33 +189,32 @@ def main():
     model.load_state_dict(sd)
     model.train()
     batch = make_scene_batch(cfg, [args.objects] * args.images, seed=1000 + rank, connect_frac=0.02)
-    scene = flatten_scene(cfg, batch, dev)
+    # inputs resident in HBM when the timed region starts (the DETR features are produced on the GPU upstream); the ragged
+    # annotation lists stay host-side Python objects exactly as the reference's dataloader hands them over
+    batch.image_feature = batch.image_feature.to(dev)
+    batch.image_depth = batch.image_depth.to(dev)
+    scene0 = flatten_scene(cfg, batch, dev)
+    P = scene0.n_pairs
     # SGD as in the reference (momentum 0.9, wd 1e-4, lr 1e-5 at its largest case N=20, i.e. T=380 direction-steps).
     # The running-sum loss quirk scales the gradient with T^2, so the learning rate is scaled by (380/T)^2 to keep
     # the update as stable as the reference's at N=64 (T=4032): otherwise the weights diverge within three steps and
     # the timed kernels would run on inf/NaN data (data-dependent clocks, meaningless ReLU masks).
-    T = len(scene.pidx.call_sizes)
+    T = scene0.n_steps
     lr = 1e-5 * min(1.0, (380.0 / max(T, 1)) ** 2)
     if args.torch_sgd:
         opt = torch.optim.SGD(model.parameters(), lr=lr, momentum=0.9, weight_decay=1e-4)
     else:                                    # same update in one pass over (grad, weight, momentum buffer): optim.FusedSGD
         from scene_graph_commonsense_amd.optim import FusedSGD
         opt = FusedSGD(model.parameters(), lr=lr, momentum=0.9, weight_decay=1e-4)
-    directed = pair_targets_fast(batch.relationships, batch.subj_or_obj, scene.pidx)
-    P = scene.pidx.n_pairs
     reducer = sgd_dist.GradReducer(world)
     eng = model.engine()
     eng.timers = {}
 
     def step():
         if args.forward_only:
-            model.forward_pairs(scene)
+            model.forward_pairs(scene0 if args.cached_scene else flatten_scene(cfg, batch, dev))
             return None
-        opt.zero_grad(set_to_none=True)
-        loss = model.training_step(scene, directed=directed, grad_hook=reducer.hook)
-        reducer.finish(list(model.named_parameters()))
-        opt.step()
-        return loss
+        return train_minibatch(model, batch, opt, reducer=reducer, scene=scene0 if args.cached_scene else None)
 
     def barrier():
         if world > 1:
@@ -146,9 +235,12 @@ def main():
     barrier()
     dt = time.time() - t0
     t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    ranks = torch.ones(1, device=dev)
     if world > 1:
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        torch.distributed.all_reduce(ranks, op=torch.distributed.ReduceOp.SUM)
     dt = float(t.item())
+    assert int(ranks.item()) == args.gpus, "ranks that took part in the timed region != --gpus"
 
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -163,11 +255,12 @@ def main():
         roof = None
         if dom in kern and kern[dom] > 0:
             ach = flops[dom] / (kern[dom] * 1e-3) / 1e12
+            traffic, tag = pmc_traffic() if P == 32256 else (None, None)
             roof = {"bound": "mfma", "kernel": "conv16_halo_pp_kernel<f16,relu+pool> (sgc_conv3_relu_pool)",
                     "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic() if P == 32256 else None,
-                    "traffic_note": "bytes/launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from profiles/r01_final_pmc_{f,w}.csv "
-                                    "(separate rocprofv3 --pmc passes at this workload); algorithmic 21.2e9 (padded z 10.7 + y f16 4.2 + y bf16 4.2 + routing 2.1)",
+                    "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                    "traffic_note": "bytes/launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from profiles/%s_pmc_{f,w}.csv "
+                                    "(separate rocprofv3 --pmc passes at this workload); algorithmic 21.2e9 (padded z 10.7 + y f16 4.2 + y bf16 4.2 + routing 2.1)" % tag,
                     "ms_per_launch": round(kern[dom], 3)}
         out = {
             "metric": "ordered object-pairs/sec (relation head fwd+bwd), batch=%d, N=%d" % (args.images, args.objects)
@@ -175,8 +268,10 @@ def main():
             "value": round(value, 1), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16 fwd / bf16 bwd (f32 accumulate, f32 master weights)", "data": "synthetic",
-            "config": {"workload": "%s PredCLS synthetic, %d images x %d objects per GPU = %d ordered pairs per GPU per step"
-                                   % (args.dataset.upper(), args.images, args.objects, P), "parallelism": "dp%d" % world},
+            "config": {"workload": "%s PredCLS synthetic, %d images x %d objects per GPU = %d ordered pairs per GPU per step%s"
+                                   % (args.dataset.upper(), args.images, args.objects, P,
+                                      " (scene flattened once outside the loop)" if args.cached_scene else ", from the raw minibatch"),
+                       "parallelism": "dp%d" % world},
             "loss": None if loss is None else float(loss), "loss_first_step": first_loss,
             "roofline": roof,
             "kernels_ms": {k: round(v, 3) for k, v in sorted(kern.items())},
@@ -184,9 +279,21 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, sd)
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
+    args = parse_args(argv)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args, argv))
+    if args.dry_run:
+        return dry_run(args)
+    run_rank(args)
 
 
 if __name__ == "__main__":

@@ -74,14 +74,32 @@ def overlap_filter(mask_g: Tensor, mask_e: Tensor) -> Tensor:
 
 
 # --------------------------------------------------------------------------- model
-def conv_trunk(sd: Dict[str, Tensor], h_sub: Tensor, h_obj: Tensor, drop1: Optional[Tensor] = None) -> Tensor:
+def routed_relu_pool(c: Tensor, code: Tensor) -> Tensor:
+    """ReLU + 2x2 max-pool with the routing IMPOSED instead of computed: ``code`` [b,C,H/2,W/2] holds, per pooling window,
+    which of its four elements (dy*2+dx) carries the value, or 4 when the ReLU kills the window.  Used only by the
+    route-injected backward parity test: with the device's own routing decisions the oracle's autograd walks exactly the
+    paths the device's backward walks, so what is left of the gradient difference is arithmetic, not routing."""
+    b, C, H, W = c.shape
+    win = c.reshape(b, C, H // 2, 2, W // 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(b, C, H // 2, W // 2, 4)
+    code = code.long()
+    out = torch.gather(win, 4, code.clamp(max=3).unsqueeze(-1)).squeeze(-1)
+    return out * (code < 4).to(out.dtype)
+
+
+def conv_trunk(sd: Dict[str, Tensor], h_sub: Tensor, h_obj: Tensor, drop1: Optional[Tensor] = None,
+               routes: Optional[dict] = None) -> Tensor:
+    """``routes`` (test hook, see ``routed_relu_pool``): dict(pool2 [b,512,16,16], pool3 [b,1024,8,8] window codes,
+    relu1 [b,4096] 0/1 pass mask of fc1's ReLU)."""
     a = torch.tanh(F.conv2d(h_sub, sd["conv1_1.weight"], sd["conv1_1.bias"]))
     b = torch.tanh(F.conv2d(h_obj, sd["conv1_2.weight"], sd["conv1_2.bias"]))
     h = torch.cat((a, b), dim=1)
-    h = F.max_pool2d(F.relu(F.conv2d(h, sd["conv2_1.weight"], sd["conv2_1.bias"], padding=1)), 2, 2)
-    h = F.max_pool2d(F.relu(F.conv2d(h, sd["conv3_1.weight"], sd["conv3_1.bias"], padding=1)), 2, 2)
+    h = F.conv2d(h, sd["conv2_1.weight"], sd["conv2_1.bias"], padding=1)
+    h = F.max_pool2d(F.relu(h), 2, 2) if routes is None else routed_relu_pool(h, routes["pool2"])
+    h = F.conv2d(h, sd["conv3_1.weight"], sd["conv3_1.bias"], padding=1)
+    h = F.max_pool2d(F.relu(h), 2, 2) if routes is None else routed_relu_pool(h, routes["pool3"])
     h = h.reshape(h.shape[0], -1)
-    h = F.relu(F.linear(h, sd["fc1.weight"], sd["fc1.bias"]))
+    h = F.linear(h, sd["fc1.weight"], sd["fc1.bias"])
+    h = F.relu(h) if routes is None else h * routes["relu1"]
     if drop1 is not None:          # injected dropout mask already scaled by 1/(1-p)
         h = h * drop1
     return h
@@ -108,12 +126,15 @@ def bayes_head(sd: Dict[str, Tensor], p: Tensor, T=(1.0, 1.0, 1.0)):
 
 def classifier_forward(sd: Dict[str, Tensor], h_sub: Tensor, h_obj: Tensor, c1: Tensor, c2: Tensor, s1, s2,
                        num_classes: int = 150, num_super: int = 17, hierarchical: bool = True,
-                       drop1: Optional[Tensor] = None, drop2: Optional[Tensor] = None, T=(1.0, 1.0, 1.0)):
+                       drop1: Optional[Tensor] = None, drop2: Optional[Tensor] = None, T=(1.0, 1.0, 1.0),
+                       routes: Optional[dict] = None):
     """Hierarchical: (rel1, rel2, rel3, super, connectivity[b,1], hidden[b,512]).
-    Flat: (relation[b,R] raw logits, connectivity[b,1], hidden)."""
-    h = conv_trunk(sd, h_sub, h_obj, drop1)
+    Flat: (relation[b,R] raw logits, connectivity[b,1], hidden).
+    ``drop1``/``drop2``: injected dropout masks (already scaled); ``routes``: injected ReLU/max-pool routing (tests only)."""
+    h = conv_trunk(sd, h_sub, h_obj, drop1, routes)
     hc = concat_labels(h, c1, c2, s1, s2, num_classes, num_super)
-    p = F.relu(F.linear(hc, sd["fc2.weight"], sd["fc2.bias"]))
+    p = F.linear(hc, sd["fc2.weight"], sd["fc2.bias"])
+    p = F.relu(p) if routes is None else p * routes["relu2"]
     if drop2 is not None:
         p = p * drop2
     conn = F.linear(p, sd["fc4.weight"], sd["fc4.bias"])
@@ -223,12 +244,16 @@ def run_pair_loop(sd: Dict[str, Tensor], batch, cfg, mode: str = "eval", evaluat
                   weights: Optional[Tensor] = None, lambda_connectivity: float = 0.1,
                   lambda_not_connected: float = 1.0, overlap_filtering: Optional[bool] = None,
                   max_steps: Optional[int] = None, step_filter=None, image_feature_aug: Optional[Tensor] = None,
-                  lambda_contrast: float = 1.0, commonsense=None, lambda_commonsense: float = 1.0):
+                  lambda_contrast: float = 1.0, commonsense=None, lambda_commonsense: float = 1.0, call_hook=None):
     """The reference's nested (graph_iter, edge_iter) x 2-direction loop.
+
+    ``call_hook(t, b)`` (tests only): for the t-th classifier call (0-based, direction-steps in loop order, b rows) returns a
+    dict with any of ``drop1`` [b,4096] / ``drop2`` [b,512] (dropout masks of ``model.py:120-121,149,175`` injected instead
+    of drawn - how the training-mode device path is compared) and ``routes`` (see ``conv_trunk``).
 
     mode 'eval' mirrors ``testing()`` (overlap filter on, steps with no overlapping image skipped),
     mode 'train' mirrors ``training()`` (iou_mask all ones, loss with the running-sum quirk; dropout
-    is not applied - parity is checked in eval-mode numerics).
+    only through masks injected by ``call_hook``).
     Returns dict(records=[per direction-step dict], losses=scalar tensor or None).
     """
     Fs = cfg.feature_size
@@ -283,7 +308,9 @@ def run_pair_loop(sd: Dict[str, Tensor], batch, cfg, mode: str = "eval", evaluat
                 cs, co = (cat_g, cat_e) if first else (cat_e, cat_g)
                 ss, so = (sp_g, sp_e) if first else (sp_e, sp_g)
                 bs, bo = (bb_g, bb_e) if first else (bb_e, bb_g)
-                out = classifier_forward(sd, hs, ho, cs, co, ss, so, cfg.num_classes, cfg.num_super_classes, hier)
+                inj = call_hook(len(records), len(keep)) if call_hook is not None else {}
+                out = classifier_forward(sd, hs, ho, cs, co, ss, so, cfg.num_classes, cfg.num_super_classes, hier,
+                                         drop1=inj.get("drop1"), drop2=inj.get("drop2"), routes=inj.get("routes"))
                 if hier:
                     r1, r2, r3, sup, conn, hidden = out
                     relation = torch.cat((r1, r2, r3), dim=1)

@@ -32,38 +32,59 @@ def init_from_env(backend: str = None):
 
 
 class GradReducer:
-    """Mean-reduce gradients across ranks with early launch for the large tensors."""
+    """Mean-reduce one step's gradients across ranks, with an early asynchronous launch for the large tensors.
+
+    ``hook(name, grad)`` is called by the backward as soon as a large gradient has been enqueued (``fc1.weight``: 97 % of the
+    bytes): RCCL all-reduces it in place on its own stream while the rest of the backward runs.  ``finish_grads(grads)``
+    reduces every other tensor of the step in one flat bucket, waits for the early ones and divides by the world size.  The
+    step's gradients are reduced BEFORE they are accumulated into ``param.grad`` (``model.training_step``), so gradient
+    accumulation over several steps sums mean gradients exactly as DDP + autograd would and never reads a tensor RCCL is
+    still writing."""
 
     def __init__(self, world: int, early=("fc1.weight",)):
         self.world = world
         self.early = set(early)
-        self.pending: List = []
+        self.pending: List = []          # (work handle, tensor) of the early reductions in flight
         self.done = set()
 
     def hook(self, name: str, grad: torch.Tensor):
-        if self.world <= 1 or name not in self.early:
+        if self.world <= 1 or name not in self.early or name in self.done:
             return
         self.pending.append((dist.all_reduce(grad, op=dist.ReduceOp.SUM, async_op=True), grad))
         self.done.add(name)
 
-    def finish(self, named_params):
-        """All-reduce everything not reduced yet (one flat bucket), wait, and divide by world size."""
-        if self.world <= 1:
-            self.pending.clear(); self.done.clear()
-            return
-        rest = [p.grad for n, p in named_params if p.grad is not None and n not in self.done]
-        if rest:
-            flat = torch.cat([g.reshape(-1) for g in rest])
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-            flat.div_(self.world)
-            off = 0
-            for g in rest:
-                g.copy_(flat[off:off + g.numel()].view_as(g))
-                off += g.numel()
+    def _drain(self):
         for work, g in self.pending:
-            work.wait()
+            work.wait()                  # orders the compute stream after RCCL's: later kernels see the reduced tensor
             g.div_(self.world)
-        self.pending.clear(); self.done.clear()
+        self.pending.clear()
+        self.done.clear()
+
+    def _flat(self, tensors: List[torch.Tensor]):
+        if not tensors:
+            return
+        flat = torch.cat([g.reshape(-1) for g in tensors])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat.div_(self.world)
+        off = 0
+        for g in tensors:
+            g.copy_(flat[off:off + g.numel()].view_as(g))
+            off += g.numel()
+
+    def finish_grads(self, grads: Dict[str, torch.Tensor]):
+        """Reduce the step's gradient dict in place: everything not handed to ``hook`` goes in one flat bucket."""
+        if self.world > 1:
+            for k in grads:
+                if not grads[k].is_contiguous():
+                    grads[k] = grads[k].contiguous()
+            self._flat([g for n, g in grads.items() if n not in self.done])
+        self._drain()
+
+    def finish(self, named_params):
+        """Same on ``param.grad`` (for callers that wrote the step's gradients there themselves)."""
+        if self.world > 1:
+            self._flat([p.grad for n, p in named_params if p.grad is not None and n not in self.done])
+        self._drain()
 
 
 def allreduce_counters(values: torch.Tensor) -> torch.Tensor:

@@ -117,7 +117,7 @@ class _RelationBase(nn.Module):
 
     def training_step(self, scene: DeviceScene, relationships=None, subj_or_obj=None, directed: Optional[np.ndarray] = None,
                       lambda_connectivity: float = 0.1, lambda_not_connected: float = 1.0, class_weight=None,
-                      grad_hook=None, image_feature_aug: Optional[torch.Tensor] = None, lambda_contrast: float = 1.0,
+                      grad_hook=None, reducer=None, image_feature_aug: Optional[torch.Tensor] = None, lambda_contrast: float = 1.0,
                       commonsense=None, lambda_commonsense: float = 1.0, lambda_cs_weak: float = 0.1,
                       lambda_cs_strong: float = 10.0):
         """Forward + loss + backward over all ordered pairs; gradients land in ``param.grad`` (accumulating like
@@ -125,7 +125,11 @@ class _RelationBase(nn.Module):
         connectivity, running-sum step weights).  With ``image_feature_aug`` (DETR features of the colour-jittered view,
         ``train_test.py:154``) the supervised-contrastive term of ``train_test.py:260-273`` is added: the augmented trunk
         is run ONLY for the connected pairs (the only ones the loss reads; the reference runs it for every pair).
-        ``commonsense=(aligned_keys, violated_keys)`` adds the train_cs penalty of ``train_utils.py:36-62``."""
+        ``commonsense=(aligned_keys, violated_keys)`` adds the train_cs penalty of ``train_utils.py:36-62``.
+        ``reducer`` (``distributed.GradReducer``): the step's gradients are mean-reduced across ranks before they are
+        accumulated into ``param.grad`` (the fc1 weight gradient is handed to RCCL as soon as it is enqueued)."""
+        if reducer is not None:
+            grad_hook = reducer.hook
         cfg = self.head_config()
         eng = self.refresh_weights(backward=True)
         pidx = scene.pidx
@@ -186,6 +190,8 @@ class _RelationBase(nn.Module):
                 if not bool(torch.isnan(loss_c)):
                     loss = loss + lambda_contrast * lambda_contrast * loss_c      # lambda applied twice (train_test.py:270-273)
                 self.last_contrast_loss = loss_c
+            if reducer is not None:
+                reducer.finish_grads(grads)
             for name, p in self.named_parameters():
                 g = grads[name].view_as(p)
                 if p.grad is None:
@@ -278,11 +284,12 @@ class BayesianRelationClassifier(_RelationBase):
         out = self._compat_forward(h_sub, h_obj, c1, c2, s1, s2)
         ng, npos = self.num_geometric, self.num_possessive
         rel = out.relation
+        pred = out.hidden.clone()      # ``hidden`` is a view of the engine workspace: own it before the trunk runs again
         pred_aug = None
         if h_sub_aug is not None:      # second (augmented) view: same trunk, hidden only (model.py:172)
             pred_aug = self._compat_forward(h_sub_aug, h_obj_aug, c1, c2, s1, s2).hidden.clone()
         return (rel[:, :ng], rel[:, ng:ng + npos], rel[:, ng + npos:], out.super_relation,
-                out.connectivity.view(-1, 1), out.hidden.clone(), pred_aug)
+                out.connectivity.view(-1, 1), pred, pred_aug)
 
 
 class FlatRelationClassifier(_RelationBase):
@@ -303,10 +310,11 @@ class FlatRelationClassifier(_RelationBase):
 
     def forward(self, h_sub, h_obj, c1, c2, s1, s2, rank, h_sub_aug=None, h_obj_aug=None, one_hot=True):
         out = self._compat_forward(h_sub, h_obj, c1, c2, s1, s2)
+        pred = out.hidden.clone()      # workspace view: own it before the trunk runs again
         pred_aug = None
         if h_sub_aug is not None:
             pred_aug = self._compat_forward(h_sub_aug, h_obj_aug, c1, c2, s1, s2).hidden.clone()
-        return out.relation, out.connectivity.view(-1, 1), out.hidden.clone(), pred_aug
+        return out.relation, out.connectivity.view(-1, 1), pred, pred_aug
 
 
 class BayesianHead(nn.Module):

@@ -134,10 +134,7 @@ def train_minibatch(model, batch, optimizer=None, reducer=None, scene: Optional[
         scene = flatten_scene(cfg, batch, dev)
     if optimizer is not None:
         optimizer.zero_grad(set_to_none=True)
-    loss = model.training_step(scene, batch.relationships, batch.subj_or_obj,
-                               grad_hook=None if reducer is None else reducer.hook, **loss_kw)
-    if reducer is not None:
-        reducer.finish(list(model.named_parameters()))
+    loss = model.training_step(scene, batch.relationships, batch.subj_or_obj, reducer=reducer, **loss_kw)
     if optimizer is not None:
         optimizer.step()
     return loss

@@ -131,6 +131,14 @@ class DeviceScene:
     pid: Optional[torch.Tensor] = None       # [n_obj, max_n] int32: (subject, object-in-image) -> pair index or -1
     max_n: int = 0
 
+    @property
+    def n_pairs(self) -> int:
+        return self.pidx.n_pairs
+
+    @property
+    def n_steps(self) -> int:
+        return int(len(self.pidx.call_sizes))
+
 
 def flatten_scene(cfg, batch, device) -> DeviceScene:
     """SceneBatch (reference data contract) -> DeviceScene with all ordered pairs in reference order."""

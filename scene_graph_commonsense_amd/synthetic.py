@@ -61,6 +61,15 @@ def hash_randint(seed: int, n: int, lo: int, hi: int) -> np.ndarray:
     return np.minimum((u * (hi - lo)).astype(np.int64) + lo, hi - 1)
 
 
+def dropout_keep_mask(seed: int, rows: int, cols: int, row0: int = 0) -> np.ndarray:
+    """Host replica of the kernels' dropout keep-bit (``csrc/common.h:dropout_keep``, p = 0.5 as ``model.py:120-121``):
+    element (row, col) of a ``[*, cols]`` activation is kept iff bit 16 of ``lowbias32((row*cols+col) ^ salt(seed))`` is
+    set.  ``[rows, cols]`` bool for rows ``row0 .. row0+rows-1``; the parity tests hand ``2 * mask`` to the oracle."""
+    salt = np.uint32((seed * 0x9E3779B1 + 0x7F4A7C15) & 0xFFFFFFFF)
+    idx = (np.arange(row0 * cols, (row0 + rows) * cols, dtype=np.uint64) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    return (((_lowbias32(idx ^ salt) >> np.uint32(16)) & np.uint32(1)) == 1).reshape(rows, cols)
+
+
 @dataclass
 class HeadConfig:
     """Sizes the hot path reads from ``args`` (reference ``main.py:49-85``, ``config.yaml``)."""

@@ -1,0 +1,38 @@
+"""bench.py as the driver runs it: a subprocess, one JSON line, n_gpus equal to --gpus, roofline object present."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*flags):
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + list(flags), capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+def test_bench_single_rank_line():
+    out = _run("--gpus", "1", "--steps", "1", "--warmup", "1", "--no-cpu-baseline")
+    assert out["n_gpus"] == 1 and out["steps"] == 1 and out["unit"] == "pairs/s" and out["scaling"] == "weak"
+    assert out["value"] > 0 and out["ms_per_step"] > 0
+    assert "from the raw minibatch" in out["config"]["workload"] and "32256" in out["config"]["workload"]
+    roof = out["roofline"]
+    assert roof["bound"] == "mfma" and 0 < roof["frac"] < 1 and roof["ms_per_launch"] < out["ms_per_step"]
+    assert out["loss"] == out["loss"]          # finite, not NaN
+
+
+def test_bench_refuses_a_world_size_that_is_not_gpus():
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode != 0 and "refusing" in (r.stderr + r.stdout)

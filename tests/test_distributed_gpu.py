@@ -35,6 +35,14 @@ def _worker(rank, world, port, q):
         mean = torch.stack(gathered).mean(0)
         err = float((p.grad - mean).abs().max() / mean.abs().max().clamp(min=1e-30))
         worst = max(worst, err)
+    # gradient accumulation (param.grad already set): a second reduced step must ADD the mean gradient - the early
+    # asynchronous fc1.weight reduction may not be read before it has finished and been divided
+    train_minibatch(model, batch, reducer=D.GradReducer(world))
+    for n, p in model.named_parameters():
+        gathered = [torch.empty_like(local[n]) for _ in range(world)]
+        dist.all_gather(gathered, local[n].contiguous())
+        mean2 = 2 * torch.stack(gathered).mean(0)
+        worst = max(worst, float((p.grad - mean2).abs().max() / mean2.abs().max().clamp(min=1e-30)))
     q.put((rank, worst))
     dist.destroy_process_group()
 

@@ -12,6 +12,25 @@ pytestmark = pytest.mark.gpu
 FX = os.path.join(GOLDEN, "ref_fixtures") + os.sep
 
 
+RECALL_ATOL = 1e-3       # recalls are fractions in [0,1] (evaluator.py:358-367); +-0.1 percentage points
+
+
+def _resolvable_candidates(cfg, gold, tol=1e-3):
+    """[n_candidates] bool in the evaluator's append order (per step: geometric block, possessive block, semantic block,
+    ``evaluator.py:231-246``): the reference's own top-2 gap of that super-category exceeds 2 x tol x output scale."""
+    rel = np.concatenate([gold["eval_rel1"], gold["eval_rel2"], gold["eval_rel3"]], axis=1)
+    scale = np.abs(rel).max()
+    segs = [(0, cfg.num_geometric), (cfg.num_geometric, cfg.num_geometric + cfg.num_possessive),
+            (cfg.num_geometric + cfg.num_possessive, cfg.num_relations)]
+    out, r0 = [], 0
+    for b in gold["eval_call_sizes"].tolist():
+        for lo, hi in segs:
+            top2 = np.sort(rel[r0:r0 + b, lo:hi], axis=1)[:, -2:]
+            out.append((top2[:, 1] - top2[:, 0]) > 2 * tol * scale)
+        r0 += b
+    return np.concatenate(out)
+
+
 def test_topk_matches_stable_sort():
     from scene_graph_commonsense_amd.evaluator import rank_topk
     g = torch.Generator().manual_seed(0)
@@ -102,12 +121,20 @@ def test_fused_eval_matches_reference_golden(name):
     assert (np.isinf(conf) == np.isinf(ref)).all()
     fin = np.isfinite(ref)
     assert np.abs(conf[fin] - ref[fin]).max() <= 1e-3 * np.abs(ref[fin]).max()
-    agree = (ev.relation_pred.cpu().numpy() == gold["ev_relation_pred"]).mean()
-    assert agree >= 0.95, agree
+    # integer outputs: the candidate's predicate must be the reference's wherever the reference's top-2 gap inside that
+    # super-category is resolvable at the forward tolerance (1e-3 of the output scale); the unresolvable rest is reported
+    pred, ref_pred = ev.relation_pred.cpu().numpy(), gold["ev_relation_pred"]
+    resolvable = _resolvable_candidates(cfg, gold)
+    assert resolvable.shape == pred.shape
+    assert (pred[resolvable] == ref_pred[resolvable]).all()
+    print(name, "candidates %d, resolvable %d, predicate flips among the unresolvable %d"
+          % (pred.size, int(resolvable.sum()), int((pred != ref_pred).sum())))
+    assert (pred == ref_pred).mean() >= 0.95
     res = ev.compute(per_class=True)
-    np.testing.assert_allclose(np.array(res[0]), gold["ev_recall"], atol=0.1)      # R@K parity (north_star: +-0.1)
+    # north_star: R@K within +-0.1 on the percentage scale of BASELINE.md's tables = 1e-3 on these fractions
+    np.testing.assert_allclose(np.array(res[0]), gold["ev_recall"], atol=RECALL_ATOL)
     r3 = t3.compute(per_class=True)
-    np.testing.assert_allclose(np.array(r3[0]), gold["top3_recall"], atol=0.1)
+    np.testing.assert_allclose(np.array(r3[0]), gold["top3_recall"], atol=RECALL_ATOL)
 
 
 def test_commonsense_filter_kernel_matches_set_membership():
@@ -214,8 +241,8 @@ def test_reference_style_loop_on_dropin_modules():
     np.testing.assert_array_equal(Recall.which_in_batch.cpu().numpy(), gold["ev_which_in_batch"])
     np.testing.assert_array_equal(Recall.relation_target.cpu().numpy(), gold["ev_relation_target"])
     res = Recall.compute(per_class=True)
-    np.testing.assert_allclose(np.array(res[0]), gold["ev_recall"], atol=0.1)
-    np.testing.assert_allclose(np.array(Top3.compute()[0]), gold["top3_recall"], atol=0.1)
+    np.testing.assert_allclose(np.array(res[0]), gold["ev_recall"], atol=RECALL_ATOL)
+    np.testing.assert_allclose(np.array(Top3.compute()[0]), gold["top3_recall"], atol=RECALL_ATOL)
 
 
 def test_skipping_filtered_pairs_keeps_recall():

@@ -262,3 +262,50 @@ def test_annotation_files_round_trip(tmp_path):
     # an object that is empty at image resolution drops the image (dataloader.py:123-128)
     a = torch.load(paths[0]); a["bbox"][0] = torch.tensor([3.0, 3.0, 4.0, 9.0])
     assert AN.prepare_annotation(a, image_hw=(480, 640)) is None and AN.prepare_annotation(a) is not None
+
+
+def test_oracle_injection_hooks_are_neutral_and_exact():
+    """The test-only hooks of the oracle: injecting the true routes / all-ones masks reproduces the plain forward, and the
+    host replica of the dropout hash is deterministic with rate 1/2."""
+    import torch.nn.functional as F
+    from oracle import relhead_oracle as O
+    from scene_graph_commonsense_amd.synthetic import dropout_keep_mask
+    g = torch.Generator().manual_seed(3)
+    c = torch.randn(2, 5, 8, 6, generator=g)
+    ref, idx = F.max_pool2d(F.relu(c), 2, 2, return_indices=True)
+    yy, xx = idx // 6, idx % 6
+    code = (yy % 2) * 2 + (xx % 2)
+    code[ref <= 0] = 4
+    assert torch.equal(O.routed_relu_pool(c, code), ref)
+    m = dropout_keep_mask(77, 64, 4096)
+    assert abs(m.mean() - 0.5) < 0.01 and np.array_equal(m[10:20], dropout_keep_mask(77, 10, 4096, row0=10))
+    assert not np.array_equal(m, dropout_keep_mask(78, 64, 4096))
+    # independent evaluation of the hash for a few elements (csrc/common.h:dropout_keep)
+    def keep(seed, idx):
+        x = (idx ^ ((seed * 0x9E3779B1 + 0x7F4A7C15) & 0xFFFFFFFF)) & 0xFFFFFFFF
+        x ^= x >> 16; x = (x * 0x7FEB352D) & 0xFFFFFFFF; x ^= x >> 15; x = (x * 0x846CA68B) & 0xFFFFFFFF; x ^= x >> 16
+        return bool((x >> 16) & 1)
+    for r, cc in ((0, 0), (3, 17), (63, 4095)):
+        assert m[r, cc] == keep(77, r * 4096 + cc)
+
+
+def test_bench_launcher_starts_every_rank_gloo_world2():
+    """``bench.py --gpus 2`` without torchrun is its own launcher (the flag used to be dead): two child ranks
+    rendezvous over gloo on 127.0.0.1, rank 0 prints ONE JSON line with n_gpus == 2; a world size that disagrees with --gpus
+    is refused instead of silently running one rank."""
+    import json
+    import subprocess
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run",
+                        "--backend", "gloo"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["steps"] == 3
+    env.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--dry-run", "--backend", "gloo"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0 and "refusing" in (r.stderr + r.stdout)

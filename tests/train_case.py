@@ -1,0 +1,73 @@
+"""Shared driver of the training-path parity tests: one fused forward+backward on the device that also hands back the
+device's own routing decisions, and the matching oracle run with injected dropout masks / routes."""
+import numpy as np
+import torch
+
+
+def run_train_gpu(cfg, sd, batch, dropout=False, seeds=(0, 0), keep_ctx=False):
+    """(loss, grads {name: f32 cpu}, ctx, scene) of ``RelHeadEngine.train_forward`` + ``train_backward``."""
+    from scene_graph_commonsense_amd.engine import RelHeadEngine, csr_by, loss_coefficients
+    from scene_graph_commonsense_amd.pairs import flatten_scene, pair_targets
+    from scene_graph_commonsense_amd.synthetic import predicate_counts
+    dev = "cuda:0"
+    eng = RelHeadEngine(cfg, dev)
+    eng.load_weights(sd)
+    eng.prep_bwd_weights(sd)
+    sc = flatten_scene(cfg, batch, dev)
+    pidx = sc.pidx
+    directed, _ = pair_targets(batch.relationships, batch.subj_or_obj, pidx)
+    counts = predicate_counts(cfg).numpy()
+    cw = 1 - counts / counts.sum()
+    coefs = loss_coefficients(cfg, pidx.step, len(pidx.call_sizes), directed, cw)
+    coefs_d = tuple(torch.from_numpy(c).to(dev) for c in coefs)
+    n_obj = int(sc.obj_img.shape[0])
+    sub_csr = tuple(torch.from_numpy(a).to(dev) for a in csr_by(pidx.sub, n_obj))
+    obj_csr = tuple(torch.from_numpy(a).to(dev) for a in csr_by(pidx.obj, n_obj))
+    img_ptr = torch.from_numpy(pidx.obj_offset.astype(np.int32)).to(dev)
+    ctx = eng.train_forward(sc.image_feature, sc.image_depth, sc.obj_img, sc.bbox, sc.cats, sc.super_mh, sc.sub_idx, sc.obj_idx,
+                            dropout=dropout, seeds=seeds, dense=(sc.img_ptr, sc.pid, sc.max_n))
+    routes = device_routes(ctx) if keep_ctx else None
+    loss, grads = eng.train_backward(ctx, coefs_d, sub_csr, obj_csr, img_ptr)
+    torch.cuda.synchronize()
+    return float(loss), {k: v.float().cpu() for k, v in grads.items()}, routes, sc
+
+
+def device_routes(ctx):
+    """The routing decisions the device's backward follows, in the oracle's layouts (CPU tensors, one row per ordered pair):
+    pool2 [P,512,16,16] / pool3 [P,1024,8,8] window codes (dy*2+dx, 4 = killed by the ReLU), relu1 [P,4096] / relu2 [P,512]
+    pass masks (an element the dropout removed reads as "not passed": the injected dropout mask zeroes it anyway)."""
+    P = ctx.P
+    amz = ctx.amz[:P * 256 * 256].view(P, 256, 256).cpu()                       # [pair][window][channel pair]: two 4-bit codes
+    codes = torch.stack((amz & 15, amz >> 4), dim=3).reshape(P, 256, 512)       # channel 2k low nibble, 2k+1 high
+    pool2 = codes.permute(0, 2, 1).reshape(P, 512, 16, 16).contiguous()
+    pool3 = ctx.am[:P * 65536].view(P, 64, 1024).cpu().permute(0, 2, 1).reshape(P, 1024, 8, 8).contiguous()
+    relu1 = (ctx.h1[:P * 4096].view(P, 4096) != 0).float().cpu()
+    relu2 = (ctx.p[:P * 512].view(P, 512) != 0).float().cpu()
+    return dict(pool2=pool2, pool3=pool3, relu1=relu1, relu2=relu2)
+
+
+def oracle_train(cfg, sd, batch, scene, dropout_seeds=None, routes=None):
+    """Oracle loss + autograd gradients; ``dropout_seeds`` injects the kernels' keep masks (x2), ``routes`` the device routing."""
+    from oracle import relhead_oracle as O
+    from scene_graph_commonsense_amd.synthetic import dropout_keep_mask, predicate_counts
+    start = np.concatenate([[0], np.cumsum(scene.pidx.call_sizes)])
+
+    def hook(t, b):
+        r0 = int(start[t])
+        assert int(start[t + 1]) - r0 == b
+        inj = {}
+        if dropout_seeds is not None:
+            inj["drop1"] = torch.from_numpy(dropout_keep_mask(dropout_seeds[0], b, 4096, r0)).float() * 2
+            inj["drop2"] = torch.from_numpy(dropout_keep_mask(dropout_seeds[1], b, 512, r0)).float() * 2
+        if routes is not None:
+            inj["routes"] = {k: v[r0:r0 + b] for k, v in routes.items()}
+        return inj
+
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    out = O.run_pair_loop(sdr, batch, cfg, mode="train", weights=O.class_weights(predicate_counts(cfg)), call_hook=hook)
+    out["losses"].backward()
+    return float(out["losses"]), {k: p.grad for k, p in sdr.items()}, out
+
+
+def fro(a, b):
+    return float((a.double() - b.double()).norm() / max(b.double().norm(), 1e-30))
