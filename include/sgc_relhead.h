@@ -86,6 +86,45 @@ int sgc_commonsense_filter(const long* scat, const long* pred, const long* ocat,
 int sgc_commonsense_flags(const long* scat, const long* ocat, const int* cand_pred, int n_pairs, int n_cand, const unsigned* aligned,
                           const unsigned* violated, int C, int R, float* weak, float* strong, void* stream);
 
+/* ----------------------------------------------------------------------------------------------- pair tables (row a2) */
+
+/* All ordered pairs of a minibatch in the reference's call order, built ON THE DEVICE from O(images + max objects) integers
+ * (train_test.py:174-258 = :373-437, evaluate.py:132-183: `for graph_iter: keep_in_batch = nonzero(num > graph_iter); for edge_iter
+ * < graph_iter: direction 1, direction 2`).  n_per_img [n_img], img_ptr [n_img+1] object ranges, goff [max_n+1] first pair of
+ * every graph_iter block (goff[g+1] = goff[g] + 2*g*#{images with more than g objects}); n_pairs = goff[max_n].
+ * Outputs (all int32): sub_idx / obj_idx / step (direction-step ordinal) / image [n_pairs]; pid [n_obj][pid_ld] (subject object,
+ * object index inside the image) -> pair index or -1; obj_ptr [n_obj+1] + sub_list / obj_list [n_pairs]: the pairs of every
+ * object as subject / as object in ascending pair order (CSR of the pair contraction); obj_img [n_obj]; step_ptr [T+1] with
+ * T = max_n*(max_n-1).  rel_tri / dir_tri (may both be NULL): per image cat(relationships[b]) / cat(subj_or_obj[b])
+ * (n(n-1)/2 entries, images concatenated; train_test.py:174-180); then raw [n_pairs] = the pair's stored predicate and
+ * directed [n_pairs] = it where the stored direction equals the pair's direction, else -1 (train_utils.py:169-187). */
+int sgc_scene_tables(const int* n_per_img, const int* img_ptr, const int* goff, int n_img, int max_n, int n_pairs, int n_obj, int pid_ld,
+                     const int* rel_tri, const float* dir_tri, int* sub_idx, int* obj_idx, int* step, int* image, int* directed,
+                     int* raw, int* pid, int* obj_ptr, int* sub_list, int* obj_list, int* obj_img, int* step_ptr, void* stream);
+
+/* Per-pair loss coefficients (train_utils.py:64-94,116-157; the running sums of train_test.py:219-258 give step t the weight T-t):
+ * loss_i = -a*super[st] - b*rel[t] + c*BCE(conn, y); one thread per direction-step, double arithmetic in pair order.
+ * class_weight [R] f32 (train_test.py:104-105); hier = 0: one class-weighted cross entropy (model.py:37-102 variant). */
+int sgc_loss_coefficients(const int* step_ptr, int n_steps, const int* directed, const float* class_weight, int ng, int np, int hier,
+                          float lambda_connectivity, float lambda_not_connected, int* tgt, float* coef_a, float* coef_b, float* coef_c,
+                          float* conn_y, void* stream);
+
+/* Connectivity statistics of train_one_direction / evaluate_one_direction summed over the minibatch (train_utils.py:66-87,176-184):
+ * out5 = {not connected, connected, predicted connected (sigmoid >= 0.5), precision numerator (predicted connected and the stored
+ * predicate of the unordered pair != -1), recall numerator (connected and round(sigmoid) == 1)}.  included (u8, may be NULL):
+ * count only the pairs of the steps the overlap filter kept (testing()). */
+int sgc_connectivity_stats(const float* conn, const int* directed, const int* raw, const unsigned char* included, int n_pairs,
+                           unsigned long long* out5, void* stream);
+
+/* Per-object label vectors (model.py:152-168 one-hot / multi-hot concat as additive rows of fc2): lsub[o] = W[:, col0+cat] +
+ * sum_k mh[o][k] * W[:, col0+2C+k], lobj[o] = W[:, col0+C+cat] + sum_k mh[o][k] * W[:, col0+2C+S+k]; W = fc2.weight [512][ld] f32,
+ * super_multihot [n_obj][S] f32 or NULL (OIV6).  sgc_label_grads is its transpose: writes columns col0 .. col0+2C+2S-1 of
+ * grad_fc2_weight from dlsub / dlobj [n_obj][512] (deterministic object order). */
+int sgc_label_vectors(const float* fc2_weight, int ld, int col0, const long* cats, const float* super_multihot, int n_obj, int C, int S,
+                      float* lsub, float* lobj, void* stream);
+int sgc_label_grads(const float* dlsub, const float* dlobj, const long* cats, const float* super_multihot, int n_obj, int C, int S,
+                    float* grad_fc2_weight, int ld, int col0, void* stream);
+
 /* ----------------------------------------------------------------------------------------------- backward */
 
 /* Forward expansion for training: writes z in f16 (conv3 forward operand) and bf16 (conv3 weight-gradient operand) and records
@@ -113,6 +152,7 @@ int sgc_supcon_hierar(const float* F, const int* labels, int M, float temperatur
                       float* dF, void* stream);
 
 int sgc_slab_sum(const float* in, float* out, long n, int slabs, int accumulate, void* stream);          /* out[n] (+)= sum_s in[s][n] */
+int sgc_slab_sum_ld(const float* in, float* out, int rows, int cols, long ld_out, int slabs, void* stream);  /* out[r*ld_out+c] = sum_s in[s][r][c] */
 int sgc_colsum(int elem, const void* X, float* part, long rows, int cols, int row_blocks, void* stream);  /* bias gradients */
 int sgc_segment_sum_rows(const void* X, const int* ptr, const int* list, float* out, int n_seg, int cols, void* stream); /* label-column grads */
 int sgc_convert_f16_bf16(const void* in, void* out, long n, void* stream);
@@ -145,7 +185,10 @@ int sgc_unpool_relu_bwd_pack(const void* dy, const unsigned char* argmax, void* 
 int sgc_pair_contract(const void* dz, const unsigned char* amz, const int* ptr, const int* list, void* dU_pad, int n_obj, void* stream);
 int sgc_conv2_dgrad(const void* dU_pad, const void* wd2, void* da, int n_obj, void* stream);
 int sgc_conv2_wgrad(const void* dU_pad, const void* a_pad_bf16, float* slabs, int n_obj, int splits, int* n_slabs, void* stream);
-int sgc_object_masked_maps_bwd(const void* da, const int* img_ptr, const int* bbox, float* dA, float* dcst, int n_img, int F, int D, void* stream);
+/* dA [n_img*F*F][D] f32 = gradient of the per-image map (inside the boxes); dcst_part [*n_parts][D] f32 = partial sums of the gradient
+ * of the tanh(b1) constant (outside the boxes), *n_parts = n_img * F*F*D/2048 rows, reduced by sgc_slab_sum (fixed order, no atomics). */
+int sgc_object_masked_maps_bwd(const void* da, const int* img_ptr, const int* bbox, float* dA, float* dcst_part, int* n_parts, int n_img,
+                               int F, int D, void* stream);
 int sgc_tanh_bwd(const float* dA, const void* a_img, void* dpre, long n, void* stream);
 int sgc_conv1_wgrad(const void* dpre, const void* x_bf16, float* slabs, int n_rows, int XC, int splits, int* n_slabs, void* stream);
 

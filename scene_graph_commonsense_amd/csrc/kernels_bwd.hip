@@ -524,17 +524,17 @@ __global__ __launch_bounds__(256) void pair_contract_kernel(const u16* __restric
 }
 
 // ------------------------------------------------------------------------------------------------ mask backward
-// dA[img][pix][c] = sum_{o in img, pix in box_o} da[o][m(pix)][c];  dcst[c] += sum_{o, pix not in box_o} da[...]
+// dA[img][pix][c] = sum_{o in img, pix in box_o} da[o][m(pix)][c];  dcst_part[img][block][c] = sum over the block's 16 pixels of
+// sum_{o, pix not in box_o} da[...]: per-block partials in a fixed order (no float atomics: the conv1 bias gradient is
+// reproducible bit for bit), reduced afterwards by sgc_slab_sum.
 __global__ __launch_bounds__(256) void mask_objects_bwd_kernel(const u16* __restrict__ da, const int* __restrict__ img_ptr,
                                                                const int* __restrict__ bbox, float* __restrict__ dA,
-                                                               float* __restrict__ dcst, int F, int D) {
-    __shared__ float outs[256];
+                                                               float* __restrict__ dcst_part, int F, int D) {
+    __shared__ float outs[256][9];
     const int cpp = D / 8;                                 // 16 chunks
     const int img = blockIdx.y;
     const int item = blockIdx.x * 256 + threadIdx.x;       // (pixel, chunk)
     const int pix = item / cpp, ch = item - pix * cpp;
-    if (threadIdx.x < D) outs[threadIdx.x] = 0.f;
-    __syncthreads();
     const int y = pix / F, x = pix - y * F;
     const int m = 4 * ((y >> 1) * (F >> 1) + (x >> 1)) + (y & 1) * 2 + (x & 1);
     float in[8], out[8];
@@ -555,11 +555,16 @@ __global__ __launch_bounds__(256) void mask_objects_bwd_kernel(const u16* __rest
         float* dst = dA + ((long)img * F * F + pix) * D + ch * 8;
 #pragma unroll
         for (int k = 0; k < 8; ++k) dst[k] = in[k];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) atomicAdd(&outs[ch * 8 + k], out[k]);
     }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) outs[threadIdx.x][k] = out[k];
     __syncthreads();
-    if (threadIdx.x < D) atomicAdd(dcst + threadIdx.x, outs[threadIdx.x]);
+    if (threadIdx.x < D) {                                 // channel c = chunk*8 + k: the block's 256/cpp pixels in order
+        const int c8 = threadIdx.x >> 3, k = threadIdx.x & 7;
+        float acc = 0.f;
+        for (int pl = 0; pl < 256 / cpp; ++pl) acc += outs[pl * cpp + c8][k];
+        dcst_part[((long)img * gridDim.x + blockIdx.x) * D + threadIdx.x] = acc;
+    }
 }
 
 // dpre = dA * (1 - a^2)  (tanh backward), 16-bit out for the conv1 weight-gradient GEMM
@@ -810,13 +815,15 @@ int sgc_conv2_wgrad(const void* dU_pad, const void* a_pad_bf16, float* slabs, in
     return launch_gemm_tn<ELEM_BF16, BMODE_CONV, 1>(p, splits, n_slabs, (hipStream_t)stream);
 }
 // ---- masks / conv1
-int sgc_object_masked_maps_bwd(const void* da, const int* img_ptr, const int* bbox, float* dA, float* dcst, int n_img, int F,
-                               int D, void* stream) {
+int sgc_object_masked_maps_bwd(const void* da, const int* img_ptr, const int* bbox, float* dA, float* dcst_part, int* n_parts,
+                               int n_img, int F, int D, void* stream) {
     if (D != 128) return SGC_ERR_ARG;
-    if (n_img <= 0) return SGC_OK;
     const int items = F * F * (D / 8);
-    SGC_LAUNCH(mask_objects_bwd_kernel, dim3((items + 255) / 256, n_img), dim3(256), 0, (hipStream_t)stream,
-                       (const u16*)da, img_ptr, bbox, dA, dcst, F, D);
+    const int blocks = (items + 255) / 256;
+    if (n_parts) *n_parts = blocks * (n_img > 0 ? n_img : 0);
+    if (n_img <= 0) return SGC_OK;
+    SGC_LAUNCH(mask_objects_bwd_kernel, dim3(blocks, n_img), dim3(256), 0, (hipStream_t)stream,
+                       (const u16*)da, img_ptr, bbox, dA, dcst_part, F, D);
     SGC_CHECK_LAUNCH();
     return SGC_OK;
 }

@@ -1,0 +1,286 @@
+// Device-side construction of the pair tables of a minibatch (row a2 of the hot path: the reference's nested
+// graph_iter / edge_iter / direction loops, train_test.py:174-258) and of the per-pair loss coefficients
+// (train_utils.py:64-94,116-157 + the running-sum step weights of train_test.py:219-258), plus the label-column
+// gather / scatter of fc2 (model.py:152-168).  All of it is small integer work: the point is that nothing of size
+// O(pairs) is built on the host or crosses PCIe - the host uploads O(images + max objects) integers per minibatch.
+//
+// Pair order (SURVEY 8a'): for g = 1..max_n-1, for e = 0..g-1, direction 1 (subject g, object e) then direction 2
+// (subject e, object g); inside a direction-step the images with more than g objects, ascending.  With
+// k_g = #{images : n > g} the block of graph_iter g starts at goff[g] = sum_{g'<g} 2 g' k_g' and holds 2g rows of
+// k_g pairs; direction-step ordinal t = g(g-1) + row (every g < max_n has k_g >= 1, so no step is empty).
+#include "common.h"
+
+struct SceneParams {
+    const int* n;          // [B] objects per image
+    const int* img_ptr;    // [B+1]
+    const int* goff;       // [max_n+1]
+    int B, max_n, P, n_obj, pid_ld;
+    const int* rel_tri;    // per image cat(relationships[b]) = n(n-1)/2 predicate ids, images concatenated (may be NULL)
+    const float* dir_tri;  // same shape: subj_or_obj flags 1 / 0 / -1
+    int *sub_idx, *obj_idx, *step, *image, *directed, *raw, *pid, *sub_list, *obj_list;
+    int *obj_ptr, *obj_img, *step_ptr;
+};
+
+__device__ __forceinline__ int pairs_before_image(const int* __restrict__ n, int image) {
+    int s = 0;
+    for (int b = 0; b < image; ++b) s += n[b] * (n[b] - 1);
+    return s;
+}
+
+__global__ __launch_bounds__(256) void scene_pairs_kernel(SceneParams s) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= s.P) return;
+    int lo = 1, hi = s.max_n - 1;                       // largest g with goff[g] <= p
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (s.goff[mid] <= p) lo = mid; else hi = mid - 1;
+    }
+    const int g = lo;
+    const int k = (s.goff[g + 1] - s.goff[g]) / (2 * g);
+    const int local = p - s.goff[g];
+    const int row = local / k, col = local - row * k;
+    const int e = row >> 1;
+    const bool first = !(row & 1);
+    int image = 0, seen = 0;
+    for (int b = 0; b < s.B; ++b) {
+        if (s.n[b] > g) {
+            if (seen == col) { image = b; break; }
+            ++seen;
+        }
+    }
+    const int o0 = s.img_ptr[image], nb = s.n[image];
+    const int sl = first ? g : e, ol = first ? e : g;
+    const int sub = o0 + sl, obj = o0 + ol;
+    s.sub_idx[p] = sub;
+    s.obj_idx[p] = obj;
+    s.step[p] = g * (g - 1) + row;
+    s.image[p] = image;
+    s.pid[(long)sub * s.pid_ld + ol] = p;
+    const int base = pairs_before_image(s.n, image);
+    // pairs of a subject (resp. object) sorted by pair index are its partners in ascending object order: for partner j < a
+    // the step is (g = a, e = j), for j > a it is (g = j, e = a) - both increase with j, and every g = j > a block lies
+    // behind the g = a block.  The CSR lists of the pair contraction are therefore closed-form.
+    s.sub_list[base + sl * (nb - 1) + ol - (ol > sl)] = p;
+    s.obj_list[base + ol * (nb - 1) + sl - (sl > ol)] = p;
+    if (s.rel_tri) {
+        const int idx = (base >> 1) + g * (g - 1) / 2 + e;
+        const int r = s.rel_tri[idx];
+        const float d = s.dir_tri[idx];
+        s.raw[p] = r;
+        s.directed[p] = (d == (first ? 1.f : 0.f)) ? r : -1;      // train_utils.py:169-187
+    }
+}
+
+__global__ __launch_bounds__(256) void scene_objects_kernel(SceneParams s, int T) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < (long)s.n_obj * s.pid_ld) {
+        const int o = (int)(i / s.pid_ld), j = (int)(i - (long)o * s.pid_ld);
+        int image = 0;
+        while (image + 1 < s.B && s.img_ptr[image + 1] <= o) ++image;
+        const int local = o - s.img_ptr[image], nb = s.n[image];
+        if (j == local || j >= nb) s.pid[i] = -1;
+        if (j == 0) {
+            s.obj_ptr[o] = pairs_before_image(s.n, image) + local * (nb - 1);
+            s.obj_img[o] = image;
+            if (o == s.n_obj - 1) s.obj_ptr[s.n_obj] = s.P;
+        }
+    }
+    if (i <= T) {                                        // first pair of every direction-step
+        if (i == T) { s.step_ptr[T] = s.P; return; }
+        const int t = (int)i;
+        int g = (int)((1.0 + sqrt(1.0 + 4.0 * t)) * 0.5);
+        while (g * (g - 1) > t) --g;
+        while ((g + 1) * g <= t) ++g;
+        const int k = (s.goff[g + 1] - s.goff[g]) / (2 * g);
+        s.step_ptr[t] = s.goff[g] + (t - g * (g - 1)) * k;
+    }
+}
+
+// One thread per direction-step (its pairs are contiguous, at most one per image): counts, class-weight sums and the
+// per-pair coefficients  loss_i = -a*super[st] - b*rel[t] + c*BCE(conn, y)  in double, sequential pair order - the same
+// arithmetic as the host reference implementation engine.loss_coefficients, bit for bit after the cast to f32.
+__global__ __launch_bounds__(64) void loss_coefficients_kernel(const int* __restrict__ step_ptr, int T, const int* __restrict__ directed,
+                                                               const float* __restrict__ class_weight, int ng, int npos, int hier,
+                                                               double lambda_c, double lambda_nc, int* __restrict__ tgt,
+                                                               float* __restrict__ ca, float* __restrict__ cb, float* __restrict__ cc,
+                                                               float* __restrict__ cy) {
+    const int t = blockIdx.x * 64 + threadIdx.x;
+    if (t >= T) return;
+    const int p0 = step_ptr[t], p1 = step_ptr[t + 1];
+    const double w = (double)(T - t);
+    double n_conn = 0, wsum[3] = {0, 0, 0};
+    for (int p = p0; p < p1; ++p) {
+        const int d = directed[p];
+        if (d >= 0) {
+            n_conn += 1;
+            const int seg = hier ? (d < ng ? 0 : (d < ng + npos ? 1 : 2)) : 0;
+            wsum[seg] += (double)class_weight[d];
+        }
+    }
+    const double n_nc = (double)(p1 - p0) - n_conn;
+    for (int p = p0; p < p1; ++p) {
+        const int d = directed[p];
+        double a = 0, b = 0, c = 0;
+        if (d >= 0) {
+            const int seg = hier ? (d < ng ? 0 : (d < ng + npos ? 1 : 2)) : 0;
+            c = w * lambda_c / n_conn;
+            if (hier) a = w / n_conn;
+            b = w * (double)class_weight[d] / wsum[seg];
+        } else if (n_conn == 0) {
+            c = w * lambda_c * lambda_nc / (n_nc > 1 ? n_nc : 1);
+        }
+        tgt[p] = d;
+        ca[p] = (float)a; cb[p] = (float)b; cc[p] = (float)c; cy[p] = d >= 0 ? 1.f : 0.f;
+    }
+}
+
+// Connectivity statistics of train_one_direction / evaluate_one_direction (train_utils.py:66-87,176-184) over all pairs:
+// out[0] not connected, [1] connected, [2] predicted connected (sigmoid >= 0.5), [3] precision numerator (predicted
+// connected whose unordered pair has a relation in either direction), [4] recall numerator (connected and predicted).
+__global__ __launch_bounds__(256) void connectivity_stats_kernel(const float* __restrict__ conn, const int* __restrict__ directed,
+                                                                 const int* __restrict__ raw, const unsigned char* __restrict__ included,
+                                                                 int P, unsigned long long* __restrict__ out) {
+    __shared__ unsigned int sh[5];
+    if (threadIdx.x < 5) sh[threadIdx.x] = 0;
+    __syncthreads();
+    unsigned int c[5] = {0, 0, 0, 0, 0};
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < P; p += gridDim.x * 256) {
+        if (included && !included[p]) continue;
+        const bool connected = directed[p] >= 0;
+        // sigmoid(x) >= 0.5 in f32 exactly as torch evaluates it; round(sigmoid) == 1 needs sigmoid > 0.5 (round half to even)
+        const float sg = 1.f / (1.f + expf(-conn[p]));
+        const bool pred = sg >= 0.5f;
+        c[0] += !connected; c[1] += connected; c[2] += pred; c[3] += pred && raw[p] != -1; c[4] += connected && sg > 0.5f;
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) atomicAdd(&sh[i], c[i]);
+    __syncthreads();
+    if (threadIdx.x < 5) atomicAdd(&out[threadIdx.x], (unsigned long long)sh[threadIdx.x]);
+}
+
+// Per-object label vectors: the one-hot / multi-hot columns of fc2 that model.py:152-168 concatenates to the 4096
+// trunk features act as per-object additive rows.  One workgroup per object, one thread per fc2 output row.
+__global__ __launch_bounds__(512) void label_vectors_kernel(const float* __restrict__ W, int ld, int col0, const long* __restrict__ cats,
+                                                            const float* __restrict__ mh, int C, int S, float* __restrict__ lsub,
+                                                            float* __restrict__ lobj) {
+    const int o = blockIdx.x, r = threadIdx.x;
+    const float* w = W + (long)r * ld + col0;
+    const int c = (int)cats[o];
+    float a = w[c], b = w[C + c];
+    if (mh) {
+        for (int k = 0; k < S; ++k) {
+            const float m = mh[(long)o * S + k];
+            if (m != 0.f) { a += m * w[2 * C + k]; b += m * w[2 * C + S + k]; }
+        }
+    }
+    lsub[(long)o * 512 + r] = a;
+    lobj[(long)o * 512 + r] = b;
+}
+
+// Transpose of label_vectors: gradient of the label columns of fc2.weight.  One workgroup per label column, objects
+// visited in ascending order (deterministic), one thread per fc2 row.
+__global__ __launch_bounds__(512) void label_grads_kernel(const float* __restrict__ dls, const float* __restrict__ dlo,
+                                                          const long* __restrict__ cats, const float* __restrict__ mh, int n_obj, int C,
+                                                          int S, float* __restrict__ gW, int ld, int col0) {
+    const int c = blockIdx.x, r = threadIdx.x;
+    float acc = 0.f;
+    if (c < 2 * C) {
+        const float* src = c < C ? dls : dlo;
+        const int cls = c < C ? c : c - C;
+        for (int o = 0; o < n_obj; ++o)
+            if ((int)cats[o] == cls) acc += src[(long)o * 512 + r];
+    } else {
+        const float* src = c < 2 * C + S ? dls : dlo;
+        const int k = c < 2 * C + S ? c - 2 * C : c - 2 * C - S;
+        for (int o = 0; o < n_obj; ++o) {
+            const float m = mh[(long)o * S + k];
+            if (m != 0.f) acc += m * src[(long)o * 512 + r];
+        }
+    }
+    gW[(long)r * ld + col0 + c] = acc;
+}
+
+__global__ __launch_bounds__(256) void slab_sum_ld_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols,
+                                                          long ld_out, int slabs) {
+    const long n = (long)rows * cols;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        float s = 0.f;
+        for (int k = 0; k < slabs; ++k) s += in[(long)k * n + i];
+        const long r = i / cols;
+        out[r * ld_out + (i - r * cols)] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ C ABI
+extern "C" {
+
+int sgc_scene_tables(const int* n_per_img, const int* img_ptr, const int* goff, int n_img, int max_n, int n_pairs, int n_obj, int pid_ld,
+                     const int* rel_tri, const float* dir_tri, int* sub_idx, int* obj_idx, int* step, int* image, int* directed,
+                     int* raw, int* pid, int* obj_ptr, int* sub_list, int* obj_list, int* obj_img, int* step_ptr, void* stream) {
+    if (n_img <= 0 || n_obj <= 0 || pid_ld < (max_n > 1 ? max_n : 1)) return SGC_ERR_ARG;
+    if ((rel_tri == nullptr) != (dir_tri == nullptr)) return SGC_ERR_ARG;
+    if (rel_tri && (!directed || !raw)) return SGC_ERR_ARG;
+    SceneParams s{n_per_img, img_ptr, goff, n_img, max_n, n_pairs, n_obj, pid_ld, rel_tri, dir_tri, sub_idx, obj_idx, step, image,
+                  directed, raw, pid, sub_list, obj_list, obj_ptr, obj_img, step_ptr};
+    const int T = max_n > 1 ? max_n * (max_n - 1) : 0;
+    const long work = (long)n_obj * pid_ld > T + 1 ? (long)n_obj * pid_ld : T + 1;
+    SGC_LAUNCH(scene_objects_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, (hipStream_t)stream, s, T);
+    SGC_CHECK_LAUNCH();
+    if (n_pairs > 0) {
+        SGC_LAUNCH(scene_pairs_kernel, dim3((n_pairs + 255) / 256), dim3(256), 0, (hipStream_t)stream, s);
+        SGC_CHECK_LAUNCH();
+    }
+    return SGC_OK;
+}
+
+int sgc_loss_coefficients(const int* step_ptr, int n_steps, const int* directed, const float* class_weight, int ng, int np, int hier,
+                          float lambda_connectivity, float lambda_not_connected, int* tgt, float* coef_a, float* coef_b, float* coef_c,
+                          float* conn_y, void* stream) {
+    if (n_steps <= 0) return SGC_OK;
+    SGC_LAUNCH(loss_coefficients_kernel, dim3((n_steps + 63) / 64), dim3(64), 0, (hipStream_t)stream, step_ptr, n_steps, directed,
+               class_weight, ng, np, hier, (double)lambda_connectivity, (double)lambda_not_connected, tgt, coef_a, coef_b, coef_c, conn_y);
+    SGC_CHECK_LAUNCH();
+    return SGC_OK;
+}
+
+int sgc_connectivity_stats(const float* conn, const int* directed, const int* raw, const unsigned char* included, int n_pairs,
+                           unsigned long long* out5, void* stream) {
+    if (hipMemsetAsync(out5, 0, 5 * sizeof(unsigned long long), (hipStream_t)stream) != hipSuccess) return SGC_ERR_LAUNCH;
+    if (n_pairs <= 0) return SGC_OK;
+    const int blocks = (n_pairs + 255) / 256 < 256 ? (n_pairs + 255) / 256 : 256;
+    SGC_LAUNCH(connectivity_stats_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, conn, directed, raw, included, n_pairs, out5);
+    SGC_CHECK_LAUNCH();
+    return SGC_OK;
+}
+
+int sgc_label_vectors(const float* fc2_weight, int ld, int col0, const long* cats, const float* super_multihot, int n_obj, int C, int S,
+                      float* lsub, float* lobj, void* stream) {
+    if (n_obj <= 0) return SGC_OK;
+    if (super_multihot == nullptr) S = 0;
+    SGC_LAUNCH(label_vectors_kernel, dim3(n_obj), dim3(512), 0, (hipStream_t)stream, fc2_weight, ld, col0, cats, super_multihot, C, S, lsub,
+               lobj);
+    SGC_CHECK_LAUNCH();
+    return SGC_OK;
+}
+
+int sgc_label_grads(const float* dlsub, const float* dlobj, const long* cats, const float* super_multihot, int n_obj, int C, int S,
+                    float* grad_fc2_weight, int ld, int col0, void* stream) {
+    if (super_multihot == nullptr) S = 0;
+    const int cols = 2 * C + 2 * S;
+    if (cols <= 0) return SGC_OK;
+    SGC_LAUNCH(label_grads_kernel, dim3(cols), dim3(512), 0, (hipStream_t)stream, dlsub, dlobj, cats, super_multihot, n_obj, C, S,
+               grad_fc2_weight, ld, col0);
+    SGC_CHECK_LAUNCH();
+    return SGC_OK;
+}
+
+int sgc_slab_sum_ld(const float* in, float* out, int rows, int cols, long ld_out, int slabs, void* stream) {
+    if (rows <= 0 || cols <= 0) return SGC_OK;
+    const long n = (long)rows * cols;
+    const long blocks = (n + 255) / 256 < 65536 ? (n + 255) / 256 : 65536;
+    SGC_LAUNCH(slab_sum_ld_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, in, out, rows, cols, ld_out, slabs);
+    SGC_CHECK_LAUNCH();
+    return SGC_OK;
+}
+
+}  // extern "C"

@@ -199,16 +199,40 @@ class RelHeadEngine:
         return _lib.stream_ptr()
 
     def label_vectors(self, cats: torch.Tensor, super_mh: Optional[torch.Tensor]):
-        """Per-object 512-vectors replacing the one-hot/multi-hot concat of ``model.py:152-168``."""
+        """Per-object 512-vectors replacing the one-hot/multi-hot concat of ``model.py:152-168`` (``sgc_label_vectors``)."""
         cfg, fc2 = self.cfg, self.w["fc2_full"]
-        C = cfg.num_classes
-        lsub = fc2[:, 4096 + cats].t()
-        lobj = fc2[:, 4096 + C + cats].t()
-        if super_mh is not None and cfg.dataset == "vg":
-            S = cfg.num_super_classes
-            lsub = lsub + super_mh @ fc2[:, 4096 + 2 * C:4096 + 2 * C + S].t()
-            lobj = lobj + super_mh @ fc2[:, 4096 + 2 * C + S:4096 + 2 * C + 2 * S].t()
-        return lsub.contiguous(), lobj.contiguous()
+        n_obj = int(cats.shape[0])
+        mh = super_mh if (super_mh is not None and cfg.dataset == "vg") else None
+        lsub = torch.empty(n_obj, 512, dtype=torch.float32, device=self.device)
+        lobj = torch.empty(n_obj, 512, dtype=torch.float32, device=self.device)
+        cats = cats if cats.dtype == torch.int64 else cats.long()
+        _lib.check(self.lib.sgc_label_vectors(_lib.ptr(fc2), int(fc2.shape[1]), 4096, _lib.ptr(cats), _lib.ptr(mh), n_obj, cfg.num_classes,
+                                              cfg.num_super_classes if mh is not None else 0, _lib.ptr(lsub), _lib.ptr(lobj), self._st()),
+                   "sgc_label_vectors")
+        return lsub, lobj
+
+    def loss_coefficients_device(self, step_ptr: torch.Tensor, n_steps: int, directed: torch.Tensor, class_weight: torch.Tensor,
+                                 lambda_connectivity: float = 0.1, lambda_not_connected: float = 1.0):
+        """Device form of ``loss_coefficients`` (``sgc_loss_coefficients``: one thread per direction-step, same double arithmetic
+        in the same order).  ``directed`` [P] int32, ``class_weight`` [R] f32, both on the device."""
+        cfg = self.cfg
+        P = int(directed.shape[0])
+        tgt = torch.empty(P, dtype=torch.int32, device=self.device)
+        co = torch.empty(4, P, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.sgc_loss_coefficients(_lib.ptr(step_ptr), int(n_steps), _lib.ptr(directed), _lib.ptr(class_weight),
+                                                  cfg.num_geometric if cfg.hierarchical else cfg.num_relations, cfg.num_possessive,
+                                                  int(cfg.hierarchical), ctypes.c_float(lambda_connectivity),
+                                                  ctypes.c_float(lambda_not_connected), _lib.ptr(tgt), _lib.ptr(co[0]), _lib.ptr(co[1]),
+                                                  _lib.ptr(co[2]), _lib.ptr(co[3]), self._st()), "sgc_loss_coefficients")
+        return (tgt, co[0], co[1], co[2], co[3])
+
+    def connectivity_stats(self, conn: torch.Tensor, directed: torch.Tensor, raw: torch.Tensor, included: Optional[torch.Tensor] = None):
+        """[5] int64 device counters (not connected, connected, predicted connected, precision numerator, recall numerator) of
+        ``train_utils.py:66-87,176-184`` summed over the pairs (``included`` u8: only the steps the overlap filter kept)."""
+        out = torch.empty(5, dtype=torch.int64, device=self.device)
+        _lib.check(self.lib.sgc_connectivity_stats(_lib.ptr(conn), _lib.ptr(directed), _lib.ptr(raw), _lib.ptr(included),
+                                                   int(conn.shape[0]), _lib.ptr(out), self._st()), "sgc_connectivity_stats")
+        return out
 
     # ------------------------------------------------------------------ stages
     def image_maps(self, f0: torch.Tensor, f1: Optional[torch.Tensor], roles=(0, 1), tag="img"):
@@ -472,22 +496,20 @@ class RelHeadEngine:
         sl = ws.get("slabs", 32 * 1024 * 4608, torch.float32)      # split-K slabs (largest user: conv3 wgrad)
         self._timed("fc2_wgrad", lambda: _lib.check(lib.sgc_fc2_wgrad(_lib.ptr(dpre), _lib.ptr(h1_bf), _lib.ptr(sl), Ppad, 32, ctypes.byref(slabs_n), st()),
                    "sgc_fc2_wgrad"))
-        dW2m = self._slab_sum(sl, 512 * 4096, slabs_n.value).view(512, 4096)
-        gfc2 = torch.zeros_like(w["fc2_full"])
-        gfc2[:, :4096] = dW2m
+        gfc2 = torch.empty_like(w["fc2_full"])                       # every column is written: main block + label columns
+        ld2 = int(gfc2.shape[1])
+        _lib.check(lib.sgc_slab_sum_ld(_lib.ptr(sl), _lib.ptr(gfc2), 512, 4096, _c_long(ld2), slabs_n.value, st()), "sgc_slab_sum_ld")
         dls = torch.empty(n_obj, 512, dtype=torch.float32, device=dev)
         dlo = torch.empty(n_obj, 512, dtype=torch.float32, device=dev)
         _lib.check(lib.sgc_segment_sum_rows(_lib.ptr(dpre), _lib.ptr(sub_csr[0]), _lib.ptr(sub_csr[1]), _lib.ptr(dls), n_obj, 512, st()),
                    "sgc_segment_sum_rows")
         _lib.check(lib.sgc_segment_sum_rows(_lib.ptr(dpre), _lib.ptr(obj_csr[0]), _lib.ptr(obj_csr[1]), _lib.ptr(dlo), n_obj, 512, st()),
                    "sgc_segment_sum_rows")
-        C = cfg.num_classes
-        gfc2[:, 4096:4096 + C].index_add_(1, ctx.cats, dls.t())            # one-hot label columns (tiny, host glue)
-        gfc2[:, 4096 + C:4096 + 2 * C].index_add_(1, ctx.cats, dlo.t())
-        if ctx.super_mh is not None and cfg.dataset == "vg":
-            S = cfg.num_super_classes
-            gfc2[:, 4096 + 2 * C:4096 + 2 * C + S] = dls.t() @ ctx.super_mh
-            gfc2[:, 4096 + 2 * C + S:4096 + 2 * C + 2 * S] = dlo.t() @ ctx.super_mh
+        mh = ctx.super_mh if (ctx.super_mh is not None and cfg.dataset == "vg") else None
+        cats = ctx.cats if ctx.cats.dtype == torch.int64 else ctx.cats.long()
+        _lib.check(lib.sgc_label_grads(_lib.ptr(dls), _lib.ptr(dlo), _lib.ptr(cats), _lib.ptr(mh), n_obj, cfg.num_classes,
+                                       cfg.num_super_classes if mh is not None else 0, _lib.ptr(gfc2), ld2, 4096, st()),
+                   "sgc_label_grads")
         grads["fc2.weight"] = gfc2
         grads["fc2.bias"] = self._colsum(dpre, Ppad, 512)
         dh1 = ws.get("dh1", Ppad * 4096, torch.bfloat16)
@@ -559,9 +581,10 @@ class RelHeadEngine:
             da = ws.get("da", n_obj * 1024 * 128, torch.bfloat16)
             self._timed("conv2_dgrad", lambda: _lib.check(lib.sgc_conv2_dgrad(_lib.ptr(dU), _lib.ptr(w["wd2"][r]), _lib.ptr(da), n_obj, st()), "sgc_conv2_dgrad"))
             dA = ws.get("dA", n_img * 1024 * 128, torch.float32)
-            dcst = torch.zeros(128, dtype=torch.float32, device=dev)
-            _lib.check(lib.sgc_object_masked_maps_bwd(_lib.ptr(da), _lib.ptr(img_ptr), _lib.ptr(ctx.bbox), _lib.ptr(dA), _lib.ptr(dcst),
-                                                      n_img, 32, 128, st()), "sgc_object_masked_maps_bwd")
+            cpart = ws.get("dcst_part", n_img * 64 * 128, torch.float32)
+            _lib.check(lib.sgc_object_masked_maps_bwd(_lib.ptr(da), _lib.ptr(img_ptr), _lib.ptr(ctx.bbox), _lib.ptr(dA), _lib.ptr(cpart),
+                                                      ctypes.byref(nparts), n_img, 32, 128, st()), "sgc_object_masked_maps_bwd")
+            dcst = self._slab_sum(cpart, 128, nparts.value)
             dp1 = ws.get("dpre1", n_img * 1024 * 128, torch.bfloat16)
             _lib.check(lib.sgc_tanh_bwd(_lib.ptr(dA), _lib.ptr(ctx.a_img[r]), _lib.ptr(dp1), _c_long(n_img * 1024 * 128), st()),
                        "sgc_tanh_bwd")

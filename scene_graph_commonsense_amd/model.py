@@ -19,7 +19,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from .engine import PairOutputs, RelHeadEngine, csr_by, loss_coefficients
+from .engine import PairOutputs, RelHeadEngine, csr_by
 from .pairs import DeviceScene, pair_targets_fast, super_multihot
 from .synthetic import HeadConfig, predicate_counts
 
@@ -99,7 +99,7 @@ class _RelationBase(nn.Module):
         these pairs (the others come back with confidence -inf), see ``RelHeadEngine.forward_pairs``."""
         eng = self.refresh_weights()
         seeds = self._next_seeds() if self.training else (0, 0)
-        if scene.pidx.n_pairs == 0:
+        if scene.n_pairs == 0:
             cfg, dev = self.head_config(), eng.device
             nc = 3 if cfg.hierarchical else 1
             z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device=dev)
@@ -132,28 +132,36 @@ class _RelationBase(nn.Module):
             grad_hook = reducer.hook
         cfg = self.head_config()
         eng = self.refresh_weights(backward=True)
-        pidx = scene.pidx
         dev = eng.device
-        if pidx.n_pairs == 0:                      # no image with two objects: nothing to score, zero loss and gradients
+        P = scene.n_pairs
+        if P == 0:                                 # no image with two objects: nothing to score, zero loss and gradients
             for p in self.parameters():
                 if p.grad is None:
                     p.grad = torch.zeros_like(p)
             self.last_outputs = None
+            self.last_connectivity_stats = None
             return torch.zeros((), device=dev)
-        if directed is None:
-            directed = pair_targets_fast(relationships, subj_or_obj, pidx)
+        # directed target per pair on the device: an explicit array wins, else what flatten_scene derived from the batch's
+        # relationships / subj_or_obj lists (sgc_scene_tables), else derive it from the lists given here
+        if directed is not None:
+            directed_d = torch.from_numpy(np.ascontiguousarray(directed, dtype=np.int32)).to(dev)
+        elif scene.directed is not None and (relationships is None or relationships is scene._rel_src):
+            directed_d = scene.directed
+        elif relationships is not None:            # lists other than the ones the scene was flattened from
+            directed_d = torch.from_numpy(pair_targets_fast(relationships, subj_or_obj, scene.pidx).astype(np.int32)).to(dev)
+        else:
+            raise ValueError("training_step needs relation targets: build the scene from a batch with relationships / subj_or_obj, "
+                             "or pass them (or a directed array) here")
         if class_weight is None:
             counts = predicate_counts(cfg).numpy()
             class_weight = 1 - counts / counts.sum()
-        coefs = loss_coefficients(cfg, pidx.step, len(pidx.call_sizes), directed, np.asarray(class_weight),
-                                  lambda_connectivity, lambda_not_connected)
-        coefs_d = tuple(torch.from_numpy(c).to(dev, non_blocking=True) for c in coefs)
-        n_obj = int(scene.obj_img.shape[0])
-        if getattr(scene, "_csr", None) is None:
-            scene._csr = (tuple(torch.from_numpy(a).to(dev) for a in csr_by(pidx.sub, n_obj)),
-                          tuple(torch.from_numpy(a).to(dev) for a in csr_by(pidx.obj, n_obj)),
-                          torch.from_numpy(pidx.obj_offset.astype(np.int32)).to(dev))
-        sub_csr, obj_csr, img_ptr = scene._csr
+        cw = np.ascontiguousarray(class_weight, dtype=np.float32)
+        if getattr(self, "_cw_cache", None) is None or self._cw_cache[0].shape != cw.shape or not np.array_equal(self._cw_cache[0], cw) \
+                or self._cw_cache[1].device != dev:
+            self._cw_cache = (cw.copy(), torch.from_numpy(cw.copy()).to(dev))
+        coefs_d = eng.loss_coefficients_device(scene.step_ptr, scene.n_steps, directed_d, self._cw_cache[1], lambda_connectivity,
+                                               lambda_not_connected)
+        sub_csr, obj_csr, img_ptr = scene.sub_csr, scene.obj_csr, scene.img_ptr
         with torch.no_grad():
             ctx = eng.train_forward(scene.image_feature, scene.image_depth, scene.obj_img, scene.bbox, scene.cats,
                                     scene.super_mh, scene.sub_idx, scene.obj_idx,
@@ -165,16 +173,17 @@ class _RelationBase(nn.Module):
                 if getattr(self, "_cs_bitmaps", None) is None or self._cs_bitmaps[0] is not commonsense:
                     self._cs_bitmaps = (commonsense, TripletBitmaps(commonsense[0], commonsense[1], cfg.num_classes,
                                                                     cfg.num_relations, dev))
-                step_d = torch.from_numpy(pidx.step).to(dev)
-                cs_coef = eng.commonsense_coefficients(ctx, self._cs_bitmaps[1], step_d, len(pidx.call_sizes),
+                cs_coef = eng.commonsense_coefficients(ctx, self._cs_bitmaps[1], scene.step.long(), scene.n_steps,
                                                        scene.cats[scene.sub_idx.long()], scene.cats[scene.obj_idx.long()],
                                                        lambda_commonsense, lambda_cs_weak, lambda_cs_strong)
             dp_main = None
             extra = None
             loss_c = None
-            conn_idx = np.nonzero(directed >= 0)[0]
+            if image_feature_aug is not None:
+                directed_h = directed_d.cpu().numpy().astype(np.int64)     # the contrastive branch gathers the connected pairs on the host
+                conn_idx = np.nonzero(directed_h >= 0)[0]
             if image_feature_aug is not None and len(conn_idx) > 0:
-                extra = self._contrast_forward(eng, scene, image_feature_aug, conn_idx, directed, ctx, lambda_contrast)
+                extra = self._contrast_forward(eng, scene, image_feature_aug, conn_idx, directed_h, ctx, lambda_contrast)
                 loss_c, dp_main = extra["loss"], extra["dp_main"]
             loss, grads = eng.train_backward(ctx, coefs_d, sub_csr, obj_csr, img_ptr,
                                              grad_hook=grad_hook if extra is None else None, dp_extra=dp_main,
@@ -198,6 +207,10 @@ class _RelationBase(nn.Module):
                     p.grad = g if g.is_contiguous() else g.contiguous()
                 else:
                     p.grad.add_(g)
+            # connectivity statistics of train_one_direction (train_utils.py:66-87) summed over the minibatch: a [5] device
+            # tensor (not connected, connected, predicted connected, precision numerator, recall numerator), no host sync
+            raw_d = scene.raw_target if (directed is None and scene.raw_target is not None) else directed_d
+            self.last_connectivity_stats = eng.connectivity_stats(ctx.out.connectivity, directed_d, raw_d)
         self.last_outputs = ctx.out
         return loss
 
@@ -216,7 +229,7 @@ class _RelationBase(nn.Module):
         ctx_a = eng_a.train_forward(image_feature_aug.to(dev, torch.float32).contiguous(), scene.image_depth, scene.obj_img,
                                     scene.bbox, scene.cats, scene.super_mh, sub_a, obj_a,
                                     seeds=self._next_seeds() if self.training else (0, 0), dropout=self.training)
-        P = scene.pidx.n_pairs
+        P = scene.n_pairs
         feats = torch.cat((ctx.p[:P * 512].view(P, 512)[cidx], ctx_a.p[:M * 512].view(M, 512)), dim=0).contiguous()
         labels = torch.from_numpy(directed[conn_idx].astype(np.int32)).to(dev)
         lam2 = float(lambda_contrast) * float(lambda_contrast)

@@ -20,7 +20,7 @@ from .pairs import DeviceScene, flatten_scene, match_target_sgd, pair_targets_fa
 def overlap_mask(scene: DeviceScene) -> torch.Tensor:
     """[P] uint8: the pair's two boxes share a grid cell (``train_test.py:403-408``)."""
     lib = _lib.load()
-    P = scene.pidx.n_pairs
+    P = scene.n_pairs
     out = torch.empty(P, dtype=torch.uint8, device=scene.bbox.device)
     _lib.check(lib.sgc_overlap_filter(_lib.ptr(scene.bbox), _lib.ptr(scene.sub_idx), _lib.ptr(scene.obj_idx), _lib.ptr(out), P,
                                       _lib.stream_ptr()), "sgc_overlap_filter")
@@ -59,6 +59,10 @@ def evaluate_minibatch(model, batch, evaluator=None, evaluator_top3=None, overla
     any_overlap = np.bincount(pidx.step[iou_h], minlength=n_steps) > 0
     # the filter is symmetric, and the reference tests it once per (g,e): both directions share the decision
     included = any_overlap[pidx.step]
+    model.last_connectivity_stats = None
+    if scene.directed is not None and select is None:     # connectivity statistics of evaluate_one_direction (train_utils.py:176-184), kept steps only
+        model.last_connectivity_stats = model.engine().connectivity_stats(out.connectivity, scene.directed, scene.raw_target,
+                                                                          torch.from_numpy(included.astype(np.uint8)).to(dev))
     if evaluator is not None or evaluator_top3 is not None:
         sel = torch.from_numpy(np.nonzero(included)[0]).to(dev)
         sizes = pidx.call_sizes[any_overlap]

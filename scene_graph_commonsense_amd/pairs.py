@@ -71,13 +71,13 @@ def slice_norm(i: int, F: int) -> int:
 
 
 def normalise_boxes(bbox: torch.Tensor, F: int) -> np.ndarray:
-    """[n,4] (x0,x1,y0,y1), int or float -> int32 with int() truncation and slice clipping applied."""
+    """[n,4] (x0,x1,y0,y1), int or float -> int32 with int() truncation and Python slice clipping applied
+    (``mask[int(y0):int(y1), int(x0):int(x1)]``, ``train_test.py:164-169``): vectorised ``slice_norm``."""
     b = bbox.detach().cpu().numpy()
-    out = np.zeros((b.shape[0], 4), dtype=np.int32)
-    for r in range(b.shape[0]):
-        for k in range(4):
-            out[r, k] = slice_norm(int(b[r, k]), F)
-    return out
+    if b.dtype.kind == "f":
+        b = np.trunc(b)
+    b = b.astype(np.int64).reshape(-1, 4)
+    return np.where(b < 0, np.maximum(b + F, 0), np.minimum(b, F)).astype(np.int32)
 
 
 def super_multihot(super_categories: Optional[List[List[torch.Tensor]]], num_super: int) -> Optional[np.ndarray]:
@@ -114,52 +114,157 @@ def pair_targets(relationships, subj_or_obj, pidx: PairIndex):
     return directed, raw
 
 
-@dataclass
 class DeviceScene:
-    """A minibatch flattened for the fused path (device tensors) plus its host pair index."""
-    image_feature: torch.Tensor     # [B,256,32,32] f32
-    image_depth: torch.Tensor       # [B,1,32,32] f32
-    obj_img: torch.Tensor           # [n_obj] int32
-    bbox: torch.Tensor              # [n_obj,4] int32 (slice-normalised x0,x1,y0,y1)
-    cats: torch.Tensor              # [n_obj] int64
-    super_mh: Optional[torch.Tensor]  # [n_obj,S] f32 or None
-    sub_idx: torch.Tensor           # [P] int32
-    obj_idx: torch.Tensor           # [P] int32
-    pidx: PairIndex
-    bbox_raw: np.ndarray            # [n_obj,4] as given (evaluator records)
-    img_ptr: Optional[torch.Tensor] = None   # [B+1] int32 object ranges per image
-    pid: Optional[torch.Tensor] = None       # [n_obj, max_n] int32: (subject, object-in-image) -> pair index or -1
-    max_n: int = 0
+    """A minibatch flattened for the fused path.  Every per-pair table lives on the device and is BUILT there
+    (``sgc_scene_tables``); the host pair index ``pidx`` (numpy arrays in reference call order, used by the evaluator feed and
+    by tests) is derived lazily from the object counts and never touched by the training step."""
+
+    def __init__(self, **kw):
+        self._pidx = None
+        self.directed = None          # [P] int32 device: directed target per pair (-1 = not connected), when targets were given
+        self.raw_target = None        # [P] int32 device: stored predicate of the unordered pair (either direction)
+        self.__dict__.update(kw)
+
+    # image_feature [B,256,32,32] f32 | image_depth [B,1,32,32] f32 | obj_img [n_obj] i32 | bbox [n_obj,4] i32 (slice-normalised)
+    # cats [n_obj] i64 | super_mh [n_obj,S] f32 or None | sub_idx, obj_idx, step, image [P] i32 | img_ptr [B+1] i32
+    # pid [n_obj,max_n] i32 | obj_ptr [n_obj+1], sub_list, obj_list [P] i32 (CSR of the pair contraction) | step_ptr [T+1] i32
+    # bbox_raw [n_obj,4] numpy as given | num_objects list | n_pairs, n_steps, max_n ints
 
     @property
-    def n_pairs(self) -> int:
-        return self.pidx.n_pairs
+    def pidx(self) -> PairIndex:
+        if self._pidx is None:
+            self._pidx = enumerate_pairs(self.num_objects)
+        return self._pidx
 
     @property
-    def n_steps(self) -> int:
-        return int(len(self.pidx.call_sizes))
+    def sub_csr(self):
+        return (self.obj_ptr, self.sub_list)
+
+    @property
+    def obj_csr(self):
+        return (self.obj_ptr, self.obj_list)
+
+
+class _PinnedRing:
+    """A few pinned host staging buffers per device so that the one H2D copy of a minibatch's annotations is asynchronous; a
+    buffer is reused only after the copy that read it has completed (which also bounds how far the host runs ahead)."""
+
+    def __init__(self, slots=3):
+        self.slots, self.bufs, self.events, self.k = slots, {}, {}, 0
+
+    def take(self, nbytes):
+        i = self.k % self.slots
+        self.k += 1
+        ev = self.events.get(i)
+        if ev is not None:
+            ev.synchronize()
+        buf = self.bufs.get(i)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(max(int(nbytes), 1 << 16), dtype=torch.uint8).pin_memory()
+            self.bufs[i] = buf
+        return i, buf
+
+    def sent(self, i):
+        ev = self.events.get(i)
+        if ev is None:
+            ev = self.events[i] = torch.cuda.Event()
+        ev.record()
+
+
+_RINGS = {}
+
+
+def graph_iter_offsets(n: np.ndarray):
+    """goff [max_n+1]: first pair of every graph_iter block, goff[g+1] = goff[g] + 2*g*#{images with more than g objects}."""
+    max_n = int(n.max()) if len(n) else 0
+    g = np.arange(max(max_n, 1), dtype=np.int64)
+    k = (n[None, :] > g[:, None]).sum(1) if len(n) else np.zeros(1, dtype=np.int64)
+    goff = np.zeros(max(max_n, 1) + 1, dtype=np.int64)
+    goff[1:] = np.cumsum(2 * g * k)
+    return goff, max_n
 
 
 def flatten_scene(cfg, batch, device) -> DeviceScene:
-    """SceneBatch (reference data contract) -> DeviceScene with all ordered pairs in reference order."""
-    n = [int(b.shape[0]) for b in batch.bbox]
-    pidx = enumerate_pairs(n)
-    obj_img = np.concatenate([np.full(k, i, dtype=np.int32) for i, k in enumerate(n)])
-    F = cfg.feature_size
-    bb = np.concatenate([normalise_boxes(b, F) for b in batch.bbox])
-    raw = np.concatenate([b.detach().cpu().numpy() for b in batch.bbox])
-    cats = torch.cat([c.reshape(-1) for c in batch.categories]).to(torch.int64)
-    mh = super_multihot(batch.super_categories, cfg.num_super_classes) if cfg.dataset == "vg" else None
+    """SceneBatch (reference data contract) -> DeviceScene with all ordered pairs in reference order.
+    Host work is O(objects): concatenating the ragged annotation lists into one pinned staging buffer; one asynchronous
+    H2D copy; the O(pairs) tables (indices, steps, CSR lists, directed targets) are written by ``sgc_scene_tables``."""
+    from . import _lib
     dev = torch.device(device)
-    max_n = max(n) if n else 0
-    pid = np.full((int(sum(n)), max(max_n, 1)), -1, dtype=np.int32)
-    pid[pidx.sub, pidx.obj - pidx.obj_offset[pidx.image]] = np.arange(pidx.n_pairs, dtype=np.int32)
-    return DeviceScene(batch.image_feature.to(dev, torch.float32).contiguous(),
-                       batch.image_depth.to(dev, torch.float32).contiguous(),
-                       torch.from_numpy(obj_img).to(dev), torch.from_numpy(bb).to(dev), cats.to(dev),
-                       None if mh is None else torch.from_numpy(mh).to(dev),
-                       torch.from_numpy(pidx.sub).to(dev), torch.from_numpy(pidx.obj).to(dev), pidx, raw,
-                       torch.from_numpy(pidx.obj_offset.astype(np.int32)).to(dev), torch.from_numpy(pid).to(dev), int(max_n))
+    if dev.type != "cuda":
+        raise RuntimeError("flatten_scene builds the pair tables with a HIP kernel: it needs a GPU device (no CPU fallback)")
+    lib = _lib.load()
+    n_list = [int(b.shape[0]) for b in batch.bbox]
+    B = len(n_list)
+    n = np.asarray(n_list, dtype=np.int64)
+    n_obj = int(n.sum())
+    goff, max_n = graph_iter_offsets(n)
+    P = int(goff[max_n]) if max_n > 0 else 0
+    T = max_n * (max_n - 1) if max_n > 1 else 0
+    img_ptr = np.concatenate([[0], np.cumsum(n)])
+    F = cfg.feature_size
+    raw = np.concatenate([b.detach().cpu().numpy() for b in batch.bbox]) if B else np.zeros((0, 4))
+    bb = normalise_boxes(torch.from_numpy(raw), F) if n_obj else np.zeros((0, 4), dtype=np.int32)
+    cats = torch.cat([c.reshape(-1) for c in batch.categories]).to(torch.int64).cpu().numpy() if n_obj else np.zeros(0, dtype=np.int64)
+    mh = super_multihot(batch.super_categories, cfg.num_super_classes) if cfg.dataset == "vg" else None
+    rel = dirs = None
+    if getattr(batch, "relationships", None) is not None and getattr(batch, "subj_or_obj", None) is not None:
+        cat_i = lambda rows, dt: (torch.cat([torch.as_tensor(r).reshape(-1) for r in rows]).to(dt) if len(rows) else torch.zeros(0, dtype=dt))
+        rel = torch.cat([cat_i(r, torch.int32) for r in batch.relationships]).numpy()
+        dirs = torch.cat([cat_i(r, torch.float32) for r in batch.subj_or_obj]).numpy()
+        if rel.shape[0] != int((n * (n - 1) // 2).sum()) or dirs.shape[0] != rel.shape[0]:
+            raise ValueError("relationships / subj_or_obj must hold g entries for graph_iter g of every image (dataloader.py:144-147)")
+
+    # ---- one staging buffer, one H2D copy
+    parts = [("hdr", np.concatenate([n, img_ptr, goff]).astype(np.int32)), ("bbox", bb.reshape(-1)), ("cats", cats)]
+    if mh is not None:
+        parts.append(("mh", mh.reshape(-1).astype(np.float32)))
+    if rel is not None:
+        parts += [("rel", rel.astype(np.int32)), ("dir", dirs.astype(np.float32))]
+    offs, total = {}, 0
+    for name, a in parts:
+        offs[name] = total
+        total += (a.nbytes + 15) // 16 * 16
+    ring = _RINGS.setdefault(dev, _PinnedRing())
+    with torch.cuda.device(dev):
+        slot, host = ring.take(total)
+        hv = host.numpy()
+        for name, a in parts:
+            hv[offs[name]:offs[name] + a.nbytes] = a.view(np.uint8).reshape(-1)
+        stage = torch.empty(max(total, 16), dtype=torch.uint8, device=dev)
+        stage[:total].copy_(host[:total], non_blocking=True)
+        ring.sent(slot)
+    view = lambda name, a, dt: stage[offs[name]:offs[name] + a.nbytes].view(dt)
+    hdr = view("hdr", parts[0][1], torch.int32)
+    n_d, img_ptr_d, goff_d = hdr[:B], hdr[B:2 * B + 1], hdr[2 * B + 1:]
+    bbox_d = view("bbox", parts[1][1], torch.int32).view(-1, 4)
+    cats_d = view("cats", cats, torch.int64)
+    mh_d = view("mh", parts[3][1], torch.float32).view(n_obj, -1) if mh is not None else None
+    rel_d = view("rel", rel.astype(np.int32), torch.int32) if rel is not None else None
+    dir_d = view("dir", dirs.astype(np.float32), torch.float32) if rel is not None else None
+
+    # ---- O(pairs) tables on the device
+    pid_ld = max(max_n, 1)
+    sizes = dict(sub_idx=P, obj_idx=P, step=P, image=P, directed=P, raw=P, sub_list=P, obj_list=P, pid=max(n_obj, 1) * pid_ld,
+                 obj_ptr=n_obj + 1, obj_img=max(n_obj, 1), step_ptr=T + 1)
+    tab = torch.empty(sum(sizes.values()) + 4 * len(sizes), dtype=torch.int32, device=dev)
+    t, o = {}, 0
+    for k_, sz in sizes.items():
+        t[k_] = tab[o:o + sz]
+        o += (sz + 3) // 4 * 4
+    if n_obj > 0:
+        _lib.check(lib.sgc_scene_tables(_lib.ptr(n_d), _lib.ptr(img_ptr_d), _lib.ptr(goff_d), B, max_n, P, n_obj, pid_ld,
+                                        _lib.ptr(rel_d), _lib.ptr(dir_d), _lib.ptr(t["sub_idx"]), _lib.ptr(t["obj_idx"]), _lib.ptr(t["step"]),
+                                        _lib.ptr(t["image"]), _lib.ptr(t["directed"]), _lib.ptr(t["raw"]), _lib.ptr(t["pid"]),
+                                        _lib.ptr(t["obj_ptr"]), _lib.ptr(t["sub_list"]), _lib.ptr(t["obj_list"]), _lib.ptr(t["obj_img"]),
+                                        _lib.ptr(t["step_ptr"]), _lib.stream_ptr()), "sgc_scene_tables")
+    return DeviceScene(image_feature=batch.image_feature.to(dev, torch.float32).contiguous(),
+                       image_depth=batch.image_depth.to(dev, torch.float32).contiguous(),
+                       obj_img=t["obj_img"][:n_obj], bbox=bbox_d, cats=cats_d, super_mh=mh_d, sub_idx=t["sub_idx"], obj_idx=t["obj_idx"],
+                       step=t["step"], image=t["image"], directed=t["directed"] if rel is not None else None,
+                       raw_target=t["raw"] if rel is not None else None, img_ptr=img_ptr_d, pid=t["pid"].view(max(n_obj, 1), pid_ld),
+                       obj_ptr=t["obj_ptr"], sub_list=t["sub_list"], obj_list=t["obj_list"], step_ptr=t["step_ptr"], bbox_raw=raw,
+                       num_objects=n_list, n_pairs=P, n_steps=T, max_n=int(max_n), _stage=stage, _tables=tab,
+                       _rel_src=getattr(batch, "relationships", None) if rel is not None else None)
 
 
 def pair_targets_fast(relationships, subj_or_obj, pidx: PairIndex) -> np.ndarray:

@@ -1,0 +1,150 @@
+"""Row a2 on the device: the pair tables, directed targets, CSR lists, loss coefficients, label vectors and connectivity
+statistics that the kernels of ``csrc/kernels_scene.hip`` build must equal - bit for bit, these are integers or the same double
+arithmetic - what the host enumeration (pinned to the reference's loop order by ``tests/test_host_cpu.py``) gives."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(5, 2, 4, 1), (3,), (2, 2), (7, 1, 7), (20, 12, 20, 3, 9, 16, 2, 20), (1, 1), (64, 36, 64, 50)]
+
+
+def _batch(nobj, seed, cfg=None, connect=0.4):
+    from scene_graph_commonsense_amd.synthetic import HeadConfig, make_scene_batch
+    cfg = cfg or HeadConfig()
+    return cfg, make_scene_batch(cfg, nobj, seed=seed, connect_frac=connect, edge_boxes=len(nobj) > 2)
+
+
+@pytest.mark.parametrize("nobj", SHAPES)
+def test_device_pair_tables_equal_host_enumeration(nobj):
+    from scene_graph_commonsense_amd.engine import csr_by
+    from scene_graph_commonsense_amd.pairs import enumerate_pairs, flatten_scene, normalise_boxes, pair_targets_fast, pair_targets
+    cfg, batch = _batch(nobj, seed=sum(nobj))
+    sc = flatten_scene(cfg, batch, "cuda:0")
+    torch.cuda.synchronize()
+    pidx = enumerate_pairs(nobj)
+    P, n_obj = pidx.n_pairs, sum(nobj)
+    assert sc.n_pairs == P and sc.n_steps == len(pidx.call_sizes) and sc.max_n == max(nobj)
+    eq = lambda d, h: np.testing.assert_array_equal(d.cpu().numpy(), np.asarray(h))
+    eq(sc.sub_idx, pidx.sub); eq(sc.obj_idx, pidx.obj); eq(sc.step, pidx.step); eq(sc.image, pidx.image)
+    eq(sc.img_ptr, pidx.obj_offset)
+    eq(sc.obj_img, np.concatenate([np.full(k, i) for i, k in enumerate(nobj)]))
+    eq(sc.step_ptr, np.concatenate([[0], np.cumsum(pidx.call_sizes)]))
+    pid = np.full((n_obj, max(max(nobj), 1)), -1, dtype=np.int32)
+    pid[pidx.sub, pidx.obj - pidx.obj_offset[pidx.image]] = np.arange(P, dtype=np.int32)
+    eq(sc.pid, pid)
+    for (ptr_d, lst_d), idx in ((sc.sub_csr, pidx.sub), (sc.obj_csr, pidx.obj)):
+        ptr, order = csr_by(idx, n_obj)
+        eq(ptr_d, ptr); eq(lst_d, order)
+    directed = pair_targets_fast(batch.relationships, batch.subj_or_obj, pidx)
+    eq(sc.directed, directed)
+    if P <= 400:
+        d2, raw = pair_targets(batch.relationships, batch.subj_or_obj, pidx)
+        eq(sc.directed, d2); eq(sc.raw_target, raw)
+    eq(sc.bbox, np.concatenate([normalise_boxes(b, cfg.feature_size) for b in batch.bbox]))
+    eq(sc.cats, torch.cat(batch.categories).numpy())
+
+
+def test_box_normalisation_vectorised_equals_slice_semantics():
+    from scene_graph_commonsense_amd.pairs import normalise_boxes, slice_norm
+    g = torch.Generator().manual_seed(1)
+    b = (torch.rand(500, 4, generator=g) - 0.3) * 60
+    b[:50] = b[:50].round()
+    ref = np.array([[slice_norm(int(v), 32) for v in row] for row in b.tolist()], dtype=np.int32)
+    np.testing.assert_array_equal(normalise_boxes(b, 32), ref)
+    bi = torch.randint(-40, 80, (300, 4), generator=g, dtype=torch.int32)
+    ref = np.array([[slice_norm(int(v), 32) for v in row] for row in bi.tolist()], dtype=np.int32)
+    np.testing.assert_array_equal(normalise_boxes(bi, 32), ref)
+
+
+@pytest.mark.parametrize("hier", [True, False])
+def test_loss_coefficient_kernel_is_the_host_arithmetic(hier):
+    from scene_graph_commonsense_amd.engine import RelHeadEngine, loss_coefficients
+    from scene_graph_commonsense_amd.pairs import flatten_scene
+    from scene_graph_commonsense_amd.synthetic import HeadConfig, predicate_counts
+    cfg = HeadConfig(hierarchical=hier)
+    for nobj, connect in (((6, 3, 5), 0.5), ((20, 20, 11), 0.05), ((4, 4), 0.0), ((9,), 1.0)):
+        _, batch = _batch(nobj, seed=len(nobj) + int(connect * 10), cfg=cfg, connect=connect)
+        sc = flatten_scene(cfg, batch, "cuda:0")
+        counts = predicate_counts(cfg).numpy()
+        cw = (1 - counts / counts.sum()).astype(np.float32)
+        eng = RelHeadEngine(cfg, "cuda:0")
+        for lam_c, lam_nc in ((0.1, 1.0), (0.5, 0.25)):
+            got = eng.loss_coefficients_device(sc.step_ptr, sc.n_steps, sc.directed, torch.from_numpy(cw).cuda(), lam_c, lam_nc)
+            ref = loss_coefficients(cfg, sc.pidx.step, sc.n_steps, sc.directed.cpu().numpy().astype(np.int64), cw, lam_c, lam_nc)
+            for g_, r_ in zip(got, ref):
+                np.testing.assert_array_equal(g_.cpu().numpy(), r_)
+
+
+def test_label_vectors_and_their_gradient():
+    from scene_graph_commonsense_amd import _lib
+    from scene_graph_commonsense_amd.engine import RelHeadEngine
+    from scene_graph_commonsense_amd.synthetic import HeadConfig
+    g = torch.Generator().manual_seed(5)
+    for cfg in (HeadConfig(), HeadConfig(dataset="oiv6", num_classes=601, num_super_classes=0, num_geometric=4, num_possessive=2, num_semantic=24)):
+        eng = RelHeadEngine(cfg, "cuda:0")
+        C, S = cfg.num_classes, cfg.num_super_classes
+        W = torch.randn(512, 4096 + cfg.label_dim, generator=g).cuda()
+        eng.w["fc2_full"] = W
+        n_obj = 37
+        cats = torch.randint(0, C, (n_obj,), generator=g).cuda()
+        cats[1] = cats[0]
+        mh = None
+        if cfg.dataset == "vg":
+            mh = torch.zeros(n_obj, S)
+            for o in range(n_obj):
+                mh[o, int(torch.randint(0, S, (1,), generator=g))] += 1
+                if o % 3 == 0:
+                    mh[o, int(torch.randint(0, S, (1,), generator=g))] += 1
+            mh = mh.cuda()
+        lsub, lobj = eng.label_vectors(cats, mh)
+        ref_s = W[:, 4096 + cats].t().double()
+        ref_o = W[:, 4096 + C + cats].t().double()
+        if mh is not None:
+            ref_s = ref_s + mh.double() @ W[:, 4096 + 2 * C:4096 + 2 * C + S].t().double()
+            ref_o = ref_o + mh.double() @ W[:, 4096 + 2 * C + S:4096 + 2 * C + 2 * S].t().double()
+        assert (lsub.double() - ref_s).abs().max() <= 1e-5 and (lobj.double() - ref_o).abs().max() <= 1e-5
+        dls, dlo = torch.randn(n_obj, 512, generator=g).cuda(), torch.randn(n_obj, 512, generator=g).cuda()
+        gW = torch.full_like(W, float("nan"))
+        _lib.check(eng.lib.sgc_label_grads(_lib.ptr(dls), _lib.ptr(dlo), _lib.ptr(cats), _lib.ptr(mh), n_obj, C, S if mh is not None else 0,
+                                           _lib.ptr(gW), int(W.shape[1]), 4096, _lib.stream_ptr()), "sgc_label_grads")
+        ref = torch.zeros(512, cfg.label_dim, dtype=torch.float64, device="cuda")
+        ref[:, :C].index_add_(1, cats, dls.t().double())
+        ref[:, C:2 * C].index_add_(1, cats, dlo.t().double())
+        if mh is not None:
+            ref[:, 2 * C:2 * C + S] = dls.t().double() @ mh.double()
+            ref[:, 2 * C + S:] = dlo.t().double() @ mh.double()
+        assert torch.isnan(gW[:, :4096]).all()                            # only the label columns are written
+        assert (gW[:, 4096:].double() - ref).abs().max() <= 1e-4
+
+
+def test_connectivity_statistics_match_the_reference_formulas():
+    """train_utils.py:66-87 / :176-184 evaluated literally per direction-step on the host against the one-pass kernel."""
+    from scene_graph_commonsense_amd.engine import RelHeadEngine
+    from scene_graph_commonsense_amd.pairs import flatten_scene
+    cfg, batch = _batch((6, 4, 5), seed=3, connect=0.5)
+    sc = flatten_scene(cfg, batch, "cuda:0")
+    eng = RelHeadEngine(cfg, "cuda:0")
+    g = torch.Generator().manual_seed(0)
+    conn = torch.randn(sc.n_pairs, generator=g) * 2
+    conn[::7] = 0.0                                                          # sigmoid == 0.5 exactly: predicted, but rounds to 0
+    included = (torch.rand(sc.n_pairs, generator=g) < 0.8)
+    directed, raw = sc.directed.cpu(), sc.raw_target.cpu()
+    for inc in (None, included):
+        got = eng.connectivity_stats(conn.cuda(), sc.directed, sc.raw_target, None if inc is None else inc.to(torch.uint8).cuda()).cpu().tolist()
+        ref = [0, 0, 0, 0, 0]
+        start = sc.step_ptr.cpu().tolist()
+        for t in range(sc.n_steps):
+            rows = [p for p in range(start[t], start[t + 1]) if inc is None or bool(inc[p])]
+            if not rows:
+                continue
+            rows = torch.tensor(rows)
+            c, d, r = conn[rows], directed[rows], raw[rows]
+            connected = torch.where(d != -1)[0]
+            pred = torch.nonzero(torch.sigmoid(c) >= 0.5).flatten()
+            ref[0] += int((d == -1).sum()); ref[1] += len(connected); ref[2] += len(pred)
+            ref[3] += int(torch.sum(r[pred] != -1))
+            if len(connected) > 0:
+                ref[4] += int(torch.sum(torch.round(torch.sigmoid(c[connected]))))
+        assert got == ref, (got, ref)
