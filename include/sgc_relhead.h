@@ -119,11 +119,12 @@ int sgc_connectivity_stats(const float* conn, const int* directed, const int* ra
 /* Per-object label vectors (model.py:152-168 one-hot / multi-hot concat as additive rows of fc2): lsub[o] = W[:, col0+cat] +
  * sum_k mh[o][k] * W[:, col0+2C+k], lobj[o] = W[:, col0+C+cat] + sum_k mh[o][k] * W[:, col0+2C+S+k]; W = fc2.weight [512][ld] f32,
  * super_multihot [n_obj][S] f32 or NULL (OIV6).  sgc_label_grads is its transpose: writes columns col0 .. col0+2C+2S-1 of
- * grad_fc2_weight from dlsub / dlobj [n_obj][512] (deterministic object order). */
+ * grad_fc2_weight from dlsub / dlobj [n_obj][512] (deterministic object order); the subject-role and object-role rows may
+ * carry different labels (the per-step call of model.py:170 labels its b subject crops and b object crops separately). */
 int sgc_label_vectors(const float* fc2_weight, int ld, int col0, const long* cats, const float* super_multihot, int n_obj, int C, int S,
                       float* lsub, float* lobj, void* stream);
-int sgc_label_grads(const float* dlsub, const float* dlobj, const long* cats, const float* super_multihot, int n_obj, int C, int S,
-                    float* grad_fc2_weight, int ld, int col0, void* stream);
+int sgc_label_grads(const float* dlsub, const float* dlobj, const long* cats_sub, const long* cats_obj, const float* mh_sub,
+                    const float* mh_obj, int n_obj, int C, int S, float* grad_fc2_weight, int ld, int col0, void* stream);
 
 /* ----------------------------------------------------------------------------------------------- backward */
 
@@ -143,6 +144,13 @@ int sgc_head_loss_bwd(const float* rel, const float* sup, const float* conn, con
                       const float* coef_b, const float* coef_c, const float* conn_y, const float* W, int n_pairs, int ng, int np, int ns,
                       int hier, float T1, float T2, float T3, float drop_scale, float* dl, float* loss, void* dpre, const float* dp_extra,
                       const float* cs_coef, const float* cand_conf, const int* cand_pred, void* stream);
+/* Head backward for ARBITRARY upstream gradients (the per-step `relation_classifier(...)` call of train_utils.py:26-27 under the
+ * caller's autograd, `losses.backward()` train_test.py:276): g_rel [n_pairs][R] = dL/d(relation outputs: log-probs, or raw logits
+ * when hier = 0), g_sup [n_pairs][3] (may be NULL), g_conn [n_pairs] (may be NULL), g_hidden [n_pairs][512] = dL/d(hidden output)
+ * (may be NULL).  Writes dl [n_pairs][64] = dL/d(head logits) and dpre [n_pairs][512] bf16 = dL/d(fc2 pre-activation). */
+int sgc_head_bwd_upstream(const float* rel, const float* sup, const float* p, const float* g_rel, const float* g_sup, const float* g_conn,
+                          const float* g_hidden, const float* W, int n_pairs, int ng, int np, int ns, int hier, float T1, float T2,
+                          float T3, float drop_scale, float* dl, void* dpre, void* stream);
 /* part [ceil(n_pairs/chunk)][64][513] f32 partial head weight (cols 0..511) and bias (col 512) gradients */
 int sgc_head_wgrad(const float* dl, const float* p, float* part, int n_pairs, int chunk, void* stream);
 

@@ -22,6 +22,8 @@ struct HeadBwdParams {
     const float* dp_extra;     // optional [n_pairs][512]: extra dL/d(hidden) (supervised-contrastive term)
     const float* cs_coef;      // optional [n_pairs][3 or 1]: commonsense penalty coefficient per candidate (train_cs)
     const float* cand_conf; const int* cand_pred;   // forward candidates (max log-prob / logit and argmax per segment)
+    // upstream mode (g_rel != NULL): no loss here - the caller's autograd hands over dL/d(outputs) of the per-step forward()
+    const float* g_rel; const float* g_sup; const float* g_conn;
 };
 
 __device__ __forceinline__ float wave_max_f(float x) {
@@ -46,13 +48,41 @@ __global__ __launch_bounds__(256) void head_loss_bwd_kernel(const HeadBwdParams 
     const int R = hp.ng + hp.np + hp.ns;
     float* dlw = dls + w * 64;
     for (int pr = blockIdx.x * 4 + w; pr < hp.n_pairs; pr += gridDim.x * 4) {
-        const int t = hp.tgt[pr];
-        const float a = hp.coef_a[pr], b = hp.coef_b[pr], cc = hp.coef_c[pr], y = hp.conn_y[pr];
-        const float cn = hp.conn[pr];
+        const bool up = hp.g_rel != nullptr;
+        const int t = up ? -1 : hp.tgt[pr];
+        const float a = up ? 0.f : hp.coef_a[pr], b = up ? 0.f : hp.coef_b[pr], cc = up ? 0.f : hp.coef_c[pr], y = up ? 0.f : hp.conn_y[pr];
+        const float cn = up ? 0.f : hp.conn[pr];
         float dl = 0.f, lossv = 0.f;
         if (cc != 0.f) lossv += cc * (y > 0.5f ? softplusf(-cn) : softplusf(cn));
         const float sig = 1.f / (1.f + expf(-cn));
-        if (hp.hier) {
+        if (hp.g_rel) {
+            // backward of model.py:176-184 for arbitrary upstream gradients: rel_k = log_softmax(l_k / T_k) + sup_k,
+            // sup = log_softmax(s).  d l_r = (G_r - softmax_r * sum_seg G) / T_k;  d s_j = Gs_j - exp(sup_j) * sum Gs with
+            // Gs_k = G_sup_k + sum_{r in seg k} G_r;  flat head: the relation output IS the logit.
+            const float gr = lane < R ? hp.g_rel[(long)pr * R + lane] : 0.f;
+            if (hp.hier) {
+                const int seg = lane < hp.ng ? 0 : (lane < hp.ng + hp.np ? 1 : 2);
+                float segsum[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) segsum[k] = wave_sum_f((lane < R && seg == k) ? gr : 0.f);
+                float gs[3], gtot = 0.f;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { gs[k] = segsum[k] + (hp.g_sup ? hp.g_sup[(long)pr * 3 + k] : 0.f); gtot += gs[k]; }
+                if (lane < R) {
+                    const float invT = seg == 0 ? hp.invT1 : (seg == 1 ? hp.invT2 : hp.invT3);
+                    dl = invT * (gr - expf(hp.rel[(long)pr * R + lane] - hp.sup[(long)pr * 3 + seg]) * segsum[seg]);
+                } else if (lane < R + 3) {
+                    const int j = lane - R;
+                    dl = (j == 0 ? gs[0] : (j == 1 ? gs[1] : gs[2])) - expf(hp.sup[(long)pr * 3 + j]) * gtot;
+                } else if (lane == R + 3) {
+                    dl = hp.g_conn ? hp.g_conn[pr] : 0.f;
+                }
+            } else {
+                if (lane < R) dl = gr;
+                else if (lane == R) dl = hp.g_conn ? hp.g_conn[pr] : 0.f;
+            }
+            lossv = 0.f;
+        } else if (hp.hier) {
             if (lane == R + 3) dl = cc * (sig - y);
             if (t >= 0) {
                 const int st = t < hp.ng ? 0 : (t < hp.ng + hp.np ? 1 : 2);
@@ -103,7 +133,7 @@ __global__ __launch_bounds__(256) void head_loss_bwd_kernel(const HeadBwdParams 
             }
         }
         hp.dl[(long)pr * 64 + lane] = dl;
-        if (lane == 0) hp.loss[pr] = lossv;
+        if (lane == 0 && hp.loss) hp.loss[pr] = lossv;
         dlw[lane] = dl;
         __builtin_amdgcn_wave_barrier();
         float acc[8];
@@ -583,6 +613,14 @@ static inline int grid_for(long items, long per_block, int cap) {
     return (int)b;
 }
 
+static int launch_head_bwd(const HeadBwdParams& hp, hipStream_t stream) {
+    const int lds = (64 * 512 + 4 * 64) * 4;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(head_loss_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    SGC_LAUNCH(head_loss_bwd_kernel, dim3(grid_for(hp.n_pairs, 4, 256)), dim3(256), lds, stream, hp);
+    SGC_CHECK_LAUNCH();
+    return SGC_OK;
+}
+
 extern "C" {
 
 int sgc_head_loss_bwd(const float* rel, const float* sup, const float* conn, const float* p, const int* tgt,
@@ -592,17 +630,20 @@ int sgc_head_loss_bwd(const float* rel, const float* sup, const float* conn, con
                       const float* cand_conf, const int* cand_pred, void* stream) {
     if (n_pairs <= 0) return SGC_OK;
     HeadBwdParams hp{rel, sup, conn, p, tgt, coef_a, coef_b, coef_c, conn_y, W, n_pairs, ng, np, ns, hier,
-                     1.f / T1, 1.f / T2, 1.f / T3, drop_scale, dl, loss, (u16*)dpre, dp_extra, cs_coef, cand_conf, cand_pred};
-    const int lds = (64 * 512 + 4 * 64) * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(head_loss_bwd_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_set = true;
-    }
-    SGC_LAUNCH(head_loss_bwd_kernel, dim3(grid_for(n_pairs, 4, 256)), dim3(256), lds, (hipStream_t)stream, hp);
-    SGC_CHECK_LAUNCH();
-    return SGC_OK;
+                     1.f / T1, 1.f / T2, 1.f / T3, drop_scale, dl, loss, (u16*)dpre, dp_extra, cs_coef, cand_conf, cand_pred,
+                     nullptr, nullptr, nullptr};
+    return launch_head_bwd(hp, (hipStream_t)stream);
+}
+
+int sgc_head_bwd_upstream(const float* rel, const float* sup, const float* p, const float* g_rel, const float* g_sup, const float* g_conn,
+                          const float* g_hidden, const float* W, int n_pairs, int ng, int np, int ns, int hier, float T1, float T2,
+                          float T3, float drop_scale, float* dl, void* dpre, void* stream) {
+    if (n_pairs <= 0) return SGC_OK;
+    if (!g_rel || !dl || !dpre) return SGC_ERR_ARG;
+    HeadBwdParams hp{rel, sup, nullptr, p, nullptr, nullptr, nullptr, nullptr, nullptr, W, n_pairs, ng, np, ns, hier,
+                     1.f / T1, 1.f / T2, 1.f / T3, drop_scale, dl, nullptr, (u16*)dpre, g_hidden, nullptr, nullptr, nullptr,
+                     g_rel, g_sup, g_conn};
+    return launch_head_bwd(hp, (hipStream_t)stream);
 }
 
 // part: [n_blocks][64][513] f32, n_blocks = ceil(n_pairs / chunk)

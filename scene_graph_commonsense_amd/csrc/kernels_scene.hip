@@ -180,18 +180,23 @@ __global__ __launch_bounds__(512) void label_vectors_kernel(const float* __restr
 // Transpose of label_vectors: gradient of the label columns of fc2.weight.  One workgroup per label column, objects
 // visited in ascending order (deterministic), one thread per fc2 row.
 __global__ __launch_bounds__(512) void label_grads_kernel(const float* __restrict__ dls, const float* __restrict__ dlo,
-                                                          const long* __restrict__ cats, const float* __restrict__ mh, int n_obj, int C,
-                                                          int S, float* __restrict__ gW, int ld, int col0) {
+                                                          const long* __restrict__ cats_s, const long* __restrict__ cats_o,
+                                                          const float* __restrict__ mh_s, const float* __restrict__ mh_o, int n_obj,
+                                                          int C, int S, float* __restrict__ gW, int ld, int col0) {
     const int c = blockIdx.x, r = threadIdx.x;
     float acc = 0.f;
     if (c < 2 * C) {
-        const float* src = c < C ? dls : dlo;
-        const int cls = c < C ? c : c - C;
+        const bool sub = c < C;
+        const float* src = sub ? dls : dlo;
+        const long* cats = sub ? cats_s : cats_o;
+        const int cls = sub ? c : c - C;
         for (int o = 0; o < n_obj; ++o)
             if ((int)cats[o] == cls) acc += src[(long)o * 512 + r];
     } else {
-        const float* src = c < 2 * C + S ? dls : dlo;
-        const int k = c < 2 * C + S ? c - 2 * C : c - 2 * C - S;
+        const bool sub = c < 2 * C + S;
+        const float* src = sub ? dls : dlo;
+        const float* mh = sub ? mh_s : mh_o;
+        const int k = sub ? c - 2 * C : c - 2 * C - S;
         for (int o = 0; o < n_obj; ++o) {
             const float m = mh[(long)o * S + k];
             if (m != 0.f) acc += m * src[(long)o * 512 + r];
@@ -263,13 +268,13 @@ int sgc_label_vectors(const float* fc2_weight, int ld, int col0, const long* cat
     return SGC_OK;
 }
 
-int sgc_label_grads(const float* dlsub, const float* dlobj, const long* cats, const float* super_multihot, int n_obj, int C, int S,
-                    float* grad_fc2_weight, int ld, int col0, void* stream) {
-    if (super_multihot == nullptr) S = 0;
+int sgc_label_grads(const float* dlsub, const float* dlobj, const long* cats_sub, const long* cats_obj, const float* mh_sub,
+                    const float* mh_obj, int n_obj, int C, int S, float* grad_fc2_weight, int ld, int col0, void* stream) {
+    if (mh_sub == nullptr || mh_obj == nullptr) S = 0;
     const int cols = 2 * C + 2 * S;
     if (cols <= 0) return SGC_OK;
-    SGC_LAUNCH(label_grads_kernel, dim3(cols), dim3(512), 0, (hipStream_t)stream, dlsub, dlobj, cats, super_multihot, n_obj, C, S,
-               grad_fc2_weight, ld, col0);
+    SGC_LAUNCH(label_grads_kernel, dim3(cols), dim3(512), 0, (hipStream_t)stream, dlsub, dlobj, cats_sub, cats_obj, mh_sub, mh_obj, n_obj,
+               C, S, grad_fc2_weight, ld, col0);
     SGC_CHECK_LAUNCH();
     return SGC_OK;
 }

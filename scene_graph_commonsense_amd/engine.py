@@ -131,10 +131,21 @@ class RelHeadEngine:
         self.cfg = cfg
         self.device = torch.device(device)
         self.lib = _lib.load()
-        self.ws = Workspace(self.device)
+        self.ws = Workspace(self.device)          # buffers a training context keeps until its backward has run
+        self.scratch = self.ws                    # transient buffers; a child engine shares its parent's (see ``child``)
         self.w: Dict[str, torch.Tensor] = {}
         self.T = (1.0, 1.0, 1.0)
         self.timers = None          # optional {name: [(start_event, end_event), ...]} filled by bench.py
+
+    def child(self) -> "RelHeadEngine":
+        """An engine that shares this one's weights and transient scratch but owns the buffers of its training context: the
+        per-step ``forward()`` of the drop-in modules keeps many contexts alive until ``losses.backward()``
+        (``train_test.py:189-276``: one classifier call per direction-step, one backward per minibatch)."""
+        c = RelHeadEngine.__new__(RelHeadEngine)
+        c.cfg, c.device, c.lib, c.w, c.T, c.timers = self.cfg, self.device, self.lib, self.w, self.T, None
+        c.head_rows = getattr(self, "head_rows", None)
+        c.ws, c.scratch = Workspace(self.device), self.scratch
+        return c
 
     def _timed(self, name, fn):
         """Run one launch, bracketing it with HIP events on the current stream when bench timers are on."""
@@ -263,7 +274,7 @@ class RelHeadEngine:
             _lib.check(lib.sgc_object_masked_maps(_lib.ptr(a_img[r]), _lib.ptr(obj_img), _lib.ptr(bbox),
                                                   _lib.ptr(self.w["cst"][r]), _lib.ptr(a_pad), n_obj, 32, 128,
                                                   self._st()), "sgc_object_masked_maps")
-            uv = ws.get("uv_%d" % r, n_obj * 1024 * 512, torch.float16)
+            uv = self.scratch.get("uv_%d" % r, n_obj * 1024 * 512, torch.float16)
             self._timed("conv2_fwd", lambda: _lib.check(lib.sgc_conv2_object(_lib.ptr(a_pad), _lib.ptr(self.w["w2r"][r]),
                                             _lib.ptr(self.w["b2"]) if r == 1 else None, _lib.ptr(uv), n_obj, self._st()),
                        "sgc_conv2_object"))
@@ -396,39 +407,52 @@ class RelHeadEngine:
         if blocks is None:
             blocks = max(1, min(512, rows // 64))
         blocks = int(max(1, min(blocks, rows)))
-        part = self.ws.get("colsum_part", blocks * cols, torch.float32)
+        part = self.scratch.get("colsum_part", blocks * cols, torch.float32)
         _lib.check(self.lib.sgc_colsum(elem, _lib.ptr(X), _lib.ptr(part), _c_long(rows), cols, blocks, self._st()), "sgc_colsum")
         return self._slab_sum(part, cols, blocks)
 
 
     def _to_bf16(self, name, src, n):
-        dst = self.ws.get(name, n, torch.bfloat16)
+        dst = self.scratch.get(name, n, torch.bfloat16)
         self._timed("convert", lambda: _lib.check(self.lib.sgc_convert_f16_bf16(_lib.ptr(src), _lib.ptr(dst), _c_long(n), self._st()),
                                                   "sgc_convert_f16_bf16"))
         return dst
 
 
     def train_forward(self, image_feature, image_depth, obj_img, bbox, cats, super_mh, sub_idx, obj_idx, seeds=(0, 0),
-                      dropout=True, dense=None) -> "TrainContext":
-        """Forward that keeps what the backward needs (pool argmaxes, expansion routing mask)."""
-        lib, ws = self.lib, self.ws
+                      dropout=True, dense=None, role_inputs=None, cats_obj=None, super_mh_obj=None) -> "TrainContext":
+        """Forward that keeps what the backward needs (pool argmaxes, expansion routing mask).
+        ``role_inputs=(h_sub, h_obj)``: the reference's per-step call on PRE-MASKED ``[b,257,32,32]`` inputs (``model.py:170``):
+        row k of each is the subject / object crop of pair k, with labels ``cats`` / ``cats_obj``; every crop is its own
+        "image" with one full-size box."""
+        lib, ws, sc = self.lib, self.ws, self.scratch
         ctx = TrainContext()
-        ctx.n_img = int(image_feature.shape[0])
         ctx.n_obj = int(obj_img.shape[0])
         ctx.P = P = int(sub_idx.shape[0])
         ctx.Ppad = Ppad = (P + 63) // 64 * 64
-        ctx.obj_img, ctx.bbox, ctx.cats, ctx.super_mh, ctx.sub_idx, ctx.obj_idx = obj_img, bbox, cats, super_mh, sub_idx, obj_idx
+        ctx.obj_img, ctx.bbox, ctx.sub_idx, ctx.obj_idx = obj_img, bbox, sub_idx, obj_idx
+        ctx.cats = (cats, cats if cats_obj is None else cats_obj)
+        ctx.super_mh = (super_mh, super_mh if role_inputs is None else super_mh_obj)
         ctx.dropout, ctx.seeds = dropout, seeds
-        ctx.a_img = self.image_maps(image_feature, image_depth)
-        ctx.x = self._x
+        if role_inputs is None:
+            ctx.n_img = int(image_feature.shape[0])
+            ctx.a_img = self.image_maps(image_feature, image_depth)
+            ctx.x = (self._x, self._x)
+        else:
+            ctx.n_img = int(role_inputs[0].shape[0])
+            a_s = self.image_maps(role_inputs[0], None, roles=(0,), tag="s")
+            x_s = self._x
+            a_o = self.image_maps(role_inputs[1], None, roles=(1,), tag="o")
+            ctx.a_img, ctx.x = {0: a_s[0], 1: a_o[1]}, (x_s, self._x)
         ctx.uv = self.object_halves(ctx.a_img, obj_img, bbox)
-        ctx.lsub, ctx.lobj = self.label_vectors(cats, super_mh)
-        z = ws.get("z_pad", P * 18 * 18 * 512, torch.float16)
+        ctx.lsub, lobj_same = self.label_vectors(ctx.cats[0], ctx.super_mh[0])
+        ctx.lobj = lobj_same if role_inputs is None else self.label_vectors(ctx.cats[1], ctx.super_mh[1])[1]
+        z = sc.get("z_pad", P * 18 * 18 * 512, torch.float16)
         z_bf = ws.get("z_pad_bf", P * 18 * 18 * 512, torch.bfloat16)
         amz = ws.get("amz", P * 256 * 256, torch.uint8)              # two 4-bit routing codes per byte
         self.expand(ctx.uv[0], ctx.uv[1], sub_idx, obj_idx, P, z, z_bf, amz, dense=dense)
         ctx.z_bf = z_bf
-        y = ws.get("y", Ppad * 65536, torch.float16)
+        y = sc.get("y", Ppad * 65536, torch.float16)
         y_bf = ws.get("y_bf", Ppad * 65536, torch.bfloat16)         # bf16 copy for the fc1 weight gradient, written by the same epilogue
         if Ppad > P:
             y_bf[P * 65536:].zero_()
@@ -449,16 +473,18 @@ class RelHeadEngine:
 
 
     def train_backward(self, ctx: "TrainContext", coefs, sub_csr, obj_csr, img_ptr, splits=8, grad_hook=None, dp_extra=None,
-                       cs_coef=None):
-        """Backward of the whole path.  Returns (loss scalar tensor, {reference parameter name: f32 gradient})."""
-        lib, ws, cfg, dev, w = self.lib, self.ws, self.cfg, self.device, self.w
+                       cs_coef=None, upstream=None):
+        """Backward of the whole path.  Returns (loss scalar tensor, {reference parameter name: f32 gradient}).
+        ``upstream=(g_rel, g_sup, g_conn, g_hidden)`` (``coefs`` None): no loss here - gradients of the outputs handed over by the
+        caller's autograd (per-step ``forward()``); the returned loss is None."""
+        lib, cfg, dev, w = self.lib, self.cfg, self.device, self.w
+        ws = self.scratch              # everything allocated below is transient; what the forward kept lives in ``ctx`` / ``self.ws``
         P, Ppad, n_obj, n_img = ctx.P, ctx.Ppad, ctx.n_obj, ctx.n_img
         st = self._st
         hier = cfg.hierarchical
         R = cfg.num_relations
         scale = 2.0 if ctx.dropout else 1.0
         f = ctypes.c_float
-        tgt, ca, cb, cc, cy = coefs
         grads: Dict[str, torch.Tensor] = {}
         slabs_n = ctypes.c_int(0)
 
@@ -469,15 +495,26 @@ class RelHeadEngine:
         if Ppad > P:
             dpre[P * 512:].zero_()
         T = self.T
-        _lib.check(lib.sgc_head_loss_bwd(_lib.ptr(ctx.out.relation), _lib.ptr(ctx.out.super_relation), _lib.ptr(ctx.out.connectivity),
-                                         _lib.ptr(ctx.p), _lib.ptr(tgt), _lib.ptr(ca), _lib.ptr(cb), _lib.ptr(cc), _lib.ptr(cy),
-                                         _lib.ptr(w["head_w"]), P, cfg.num_geometric if hier else R,
-                                         cfg.num_possessive if hier else 0, cfg.num_semantic if hier else 0, int(hier),
-                                         f(T[0]), f(T[1]), f(T[2]), f(scale), _lib.ptr(dl), _lib.ptr(loss_i), _lib.ptr(dpre),
-                                         _lib.ptr(dp_extra), _lib.ptr(cs_coef), _lib.ptr(ctx.out.cand_conf),
-                                         _lib.ptr(ctx.out.cand_pred), st()),
-                   "sgc_head_loss_bwd")
-        loss = loss_i.sum() if P > 0 else torch.zeros((), device=dev)      # P scalars: host-side glue
+        if upstream is None:
+            tgt, ca, cb, cc, cy = coefs
+            _lib.check(lib.sgc_head_loss_bwd(_lib.ptr(ctx.out.relation), _lib.ptr(ctx.out.super_relation), _lib.ptr(ctx.out.connectivity),
+                                             _lib.ptr(ctx.p), _lib.ptr(tgt), _lib.ptr(ca), _lib.ptr(cb), _lib.ptr(cc), _lib.ptr(cy),
+                                             _lib.ptr(w["head_w"]), P, cfg.num_geometric if hier else R,
+                                             cfg.num_possessive if hier else 0, cfg.num_semantic if hier else 0, int(hier),
+                                             f(T[0]), f(T[1]), f(T[2]), f(scale), _lib.ptr(dl), _lib.ptr(loss_i), _lib.ptr(dpre),
+                                             _lib.ptr(dp_extra), _lib.ptr(cs_coef), _lib.ptr(ctx.out.cand_conf),
+                                             _lib.ptr(ctx.out.cand_pred), st()),
+                       "sgc_head_loss_bwd")
+            loss = loss_i.sum() if P > 0 else torch.zeros((), device=dev)      # P scalars: host-side glue
+        else:
+            g_rel, g_sup, g_conn, g_hid = (None if g is None else g.to(dev, torch.float32).contiguous() for g in upstream)
+            _lib.check(lib.sgc_head_bwd_upstream(_lib.ptr(ctx.out.relation), _lib.ptr(ctx.out.super_relation), _lib.ptr(ctx.p),
+                                                 _lib.ptr(g_rel), _lib.ptr(g_sup), _lib.ptr(g_conn), _lib.ptr(g_hid),
+                                                 _lib.ptr(w["head_w"]), P, cfg.num_geometric if hier else R,
+                                                 cfg.num_possessive if hier else 0, cfg.num_semantic if hier else 0, int(hier),
+                                                 f(T[0]), f(T[1]), f(T[2]), f(scale), _lib.ptr(dl), _lib.ptr(dpre), st()),
+                       "sgc_head_bwd_upstream")
+            loss = None
         chunk = max(16, (P + 255) // 256)
         nb = (P + chunk - 1) // chunk
         part = ws.get("head_part", nb * 64 * 513, torch.float32)
@@ -505,10 +542,11 @@ class RelHeadEngine:
                    "sgc_segment_sum_rows")
         _lib.check(lib.sgc_segment_sum_rows(_lib.ptr(dpre), _lib.ptr(obj_csr[0]), _lib.ptr(obj_csr[1]), _lib.ptr(dlo), n_obj, 512, st()),
                    "sgc_segment_sum_rows")
-        mh = ctx.super_mh if (ctx.super_mh is not None and cfg.dataset == "vg") else None
-        cats = ctx.cats if ctx.cats.dtype == torch.int64 else ctx.cats.long()
-        _lib.check(lib.sgc_label_grads(_lib.ptr(dls), _lib.ptr(dlo), _lib.ptr(cats), _lib.ptr(mh), n_obj, cfg.num_classes,
-                                       cfg.num_super_classes if mh is not None else 0, _lib.ptr(gfc2), ld2, 4096, st()),
+        use_mh = ctx.super_mh[0] is not None and cfg.dataset == "vg"
+        mh_s, mh_o = (ctx.super_mh if use_mh else (None, None))
+        cats_s, cats_o = (c if c.dtype == torch.int64 else c.long() for c in ctx.cats)
+        _lib.check(lib.sgc_label_grads(_lib.ptr(dls), _lib.ptr(dlo), _lib.ptr(cats_s), _lib.ptr(cats_o), _lib.ptr(mh_s), _lib.ptr(mh_o),
+                                       n_obj, cfg.num_classes, cfg.num_super_classes if use_mh else 0, _lib.ptr(gfc2), ld2, 4096, st()),
                    "sgc_label_grads")
         grads["fc2.weight"] = gfc2
         grads["fc2.bias"] = self._colsum(dpre, Ppad, 512)
@@ -565,12 +603,14 @@ class RelHeadEngine:
 
         # ---- pair contraction + conv2 + masks + conv1
         gc2 = torch.empty(512, 256, 3, 3, dtype=torch.float32, device=dev)
-        x_bf = self._to_bf16("x_bf", ctx.x, n_img * 1024 * XC)
+        x_bf = self._to_bf16("x_bf", ctx.x[0], n_img * 1024 * XC)
         for r, csr in ((0, sub_csr), (1, obj_csr)):
+            if r == 1 and ctx.x[1] is not ctx.x[0]:
+                x_bf = self._to_bf16("x_bf", ctx.x[1], n_img * 1024 * XC)
             dU = ws.get("dU_pad_%d" % r, n_obj * 34 * 34 * 512, torch.bfloat16)
             self._timed("contract", lambda: _lib.check(lib.sgc_pair_contract(_lib.ptr(dz), _lib.ptr(ctx.amz), _lib.ptr(csr[0]), _lib.ptr(csr[1]), _lib.ptr(dU), n_obj, st()),
                        "sgc_pair_contract"))
-            a_pad = ws.get("a_pad_%d" % r, n_obj * 34 * 34 * 128, torch.float16)
+            a_pad = self.ws.get("a_pad_%d" % r, n_obj * 34 * 34 * 128, torch.float16)      # kept by the forward
             a_bf = self._to_bf16("a_pad_bf", a_pad, n_obj * 34 * 34 * 128)
             self._timed("conv2_wgrad", lambda: _lib.check(lib.sgc_conv2_wgrad(_lib.ptr(dU), _lib.ptr(a_bf), _lib.ptr(sl), n_obj, 0, ctypes.byref(slabs_n), st()),
                        "sgc_conv2_wgrad"))

@@ -36,6 +36,52 @@ def strip_ddp_prefix(state_dict: Dict[str, torch.Tensor]) -> Dict[str, torch.Ten
     return {k.replace("module.", ""): v for k, v in state_dict.items()}
 
 
+class _PairStepFunction(torch.autograd.Function):
+    """The reference's per-step classifier call (``train_utils.py:26-27``: b pre-masked subject / object crops) as ONE autograd
+    node: forward = the HIP trunk + head on a child engine that keeps its context alive, backward = the HIP backward driven by
+    the gradients of the outputs (``sgc_head_bwd_upstream``), so the reference's own ``training()`` - hundreds of calls, then
+    one ``losses.backward()`` (``train_test.py:189-276``) - trains the f32 master parameters.  The inputs get no gradient (the
+    reference computes them under ``no_grad``, ``train_test.py:154-156``)."""
+
+    @staticmethod
+    def forward(ctx, module, h_sub, h_obj, c1, c2, s1, s2, seeds, *params):
+        cfg = module.head_config()
+        eng = module.refresh_weights(backward=True).child()
+        dev = eng.device
+        b = int(h_sub.shape[0])
+        hs = h_sub.detach().to(dev, torch.float32).contiguous()
+        ho = h_obj.detach().to(dev, torch.float32).contiguous()
+        full = torch.tensor([[0, 32, 0, 32]], dtype=torch.int32, device=dev).repeat(b, 1).contiguous()
+        ids = torch.arange(b, dtype=torch.int32, device=dev)
+        mh1 = mh2 = None
+        if s1 is not None and cfg.dataset == "vg":
+            mh1 = torch.from_numpy(super_multihot([list(s1)], cfg.num_super_classes)).to(dev)
+            mh2 = torch.from_numpy(super_multihot([list(s2)], cfg.num_super_classes)).to(dev)
+        tctx = eng.train_forward(None, None, ids, full, c1.to(dev).long().contiguous(), mh1, ids, ids, seeds=seeds, dropout=module.training,
+                                 role_inputs=(hs, ho), cats_obj=c2.to(dev).long().contiguous(), super_mh_obj=mh2)
+        ctx.eng, ctx.tctx, ctx.module = eng, tctx, module
+        ctx.names = [n for n, _ in module.named_parameters()]
+        ctx.csr = (torch.arange(b + 1, dtype=torch.int32, device=dev), ids)
+        ctx.img_ptr = torch.arange(b + 1, dtype=torch.int32, device=dev)
+        ctx.weights_version = module._weights_version
+        out = tctx.out
+        sup = out.super_relation if out.super_relation is not None else torch.zeros(b, 0, device=dev)
+        return out.relation, sup, out.connectivity.view(-1, 1), out.hidden.clone()
+
+    @staticmethod
+    def backward(ctx, g_rel, g_sup, g_conn, g_hidden):
+        module = ctx.module
+        if module._weights_version is not ctx.weights_version and module._weights_version != ctx.weights_version:
+            raise RuntimeError("parameters changed between the per-step forward and its backward (optimizer.step() before "
+                               "losses.backward()?): the 16-bit weight copies of the forward are gone")
+        hier = module.hierarchical
+        _, grads = ctx.eng.train_backward(ctx.tctx, None, ctx.csr, ctx.csr, ctx.img_ptr,
+                                          upstream=(g_rel, g_sup if hier else None, g_conn.reshape(-1), g_hidden))
+        ctx.eng = ctx.tctx = None                                  # free the step's buffers
+        named = dict(module.named_parameters())
+        return (None,) * 8 + tuple(grads[n].view_as(named[n]) for n in ctx.names)
+
+
 class _RelationBase(nn.Module):
     hierarchical = True
 
@@ -246,6 +292,18 @@ class _RelationBase(nn.Module):
                     sub_csr=sub_csr, obj_csr=obj_csr)
 
     # ------------------------------------------------------------------ reference per-step call
+    def _step(self, h_sub, h_obj, c1, c2, s1, s2):
+        """(relation [b,R], super [b,3] | None, connectivity [b,1], hidden [b,512]) of one per-step call.  With autograd on
+        and trainable parameters the call is an autograd node (``_PairStepFunction``); otherwise the inference trunk."""
+        params = [p for _, p in self.named_parameters()]
+        if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+            seeds = self._next_seeds() if self.training else (0, 0)
+            rel, sup, conn, pred = _PairStepFunction.apply(self, h_sub, h_obj, c1, c2, s1, s2, seeds, *params)
+            return rel, (sup if self.hierarchical else None), conn, pred
+        out = self._compat_forward(h_sub, h_obj, c1, c2, s1, s2)
+        # ``hidden`` is a view of the engine workspace: own it before the trunk runs again (augmented view, next step)
+        return out.relation, out.super_relation, out.connectivity.view(-1, 1), out.hidden.clone()
+
     def _compat_forward(self, h_sub, h_obj, c1, c2, s1, s2):
         """Reference semantics for arbitrary pre-masked inputs: each of the b rows is one (subject, object) pair."""
         cfg = self.head_config()
@@ -294,15 +352,12 @@ class BayesianRelationClassifier(_RelationBase):
                           num_semantic=self.num_semantic, hierarchical=True)
 
     def forward(self, h_sub, h_obj, c1, c2, s1, s2, rank, h_sub_aug=None, h_obj_aug=None):
-        out = self._compat_forward(h_sub, h_obj, c1, c2, s1, s2)
         ng, npos = self.num_geometric, self.num_possessive
-        rel = out.relation
-        pred = out.hidden.clone()      # ``hidden`` is a view of the engine workspace: own it before the trunk runs again
+        rel, sup, conn, pred = self._step(h_sub, h_obj, c1, c2, s1, s2)
         pred_aug = None
         if h_sub_aug is not None:      # second (augmented) view: same trunk, hidden only (model.py:172)
-            pred_aug = self._compat_forward(h_sub_aug, h_obj_aug, c1, c2, s1, s2).hidden.clone()
-        return (rel[:, :ng], rel[:, ng:ng + npos], rel[:, ng + npos:], out.super_relation,
-                out.connectivity.view(-1, 1), pred, pred_aug)
+            pred_aug = self._step(h_sub_aug, h_obj_aug, c1, c2, s1, s2)[3]
+        return (rel[:, :ng], rel[:, ng:ng + npos], rel[:, ng + npos:], sup, conn, pred, pred_aug)
 
 
 class FlatRelationClassifier(_RelationBase):
@@ -322,12 +377,11 @@ class FlatRelationClassifier(_RelationBase):
                           num_geometric=self.output_dim, num_possessive=0, num_semantic=0, hierarchical=False)
 
     def forward(self, h_sub, h_obj, c1, c2, s1, s2, rank, h_sub_aug=None, h_obj_aug=None, one_hot=True):
-        out = self._compat_forward(h_sub, h_obj, c1, c2, s1, s2)
-        pred = out.hidden.clone()      # workspace view: own it before the trunk runs again
+        rel, _, conn, pred = self._step(h_sub, h_obj, c1, c2, s1, s2)
         pred_aug = None
         if h_sub_aug is not None:
-            pred_aug = self._compat_forward(h_sub_aug, h_obj_aug, c1, c2, s1, s2).hidden.clone()
-        return out.relation, out.connectivity.view(-1, 1), pred, pred_aug
+            pred_aug = self._step(h_sub_aug, h_obj_aug, c1, c2, s1, s2)[3]
+        return rel, conn, pred, pred_aug
 
 
 class BayesianHead(nn.Module):

@@ -176,3 +176,27 @@ def test_oracle_train_cs_small(name):
         ref_l2 = gold["gradcs_l2__" + key][0]
         np.testing.assert_allclose(float(g.double().norm()), ref_l2, rtol=1e-4)
         np.testing.assert_allclose(g[::stride][:509].numpy(), gold["gradcs_sample__" + key], rtol=1e-3, atol=1e-5 * max(ref_l2, 1e-12))
+
+
+def test_oracle_bayes_head_and_aug_forward_match_reference_boundary_golden():
+    """oracle.bayes_head with temperatures, and classifier_forward's hidden for the plain / augmented view, against the
+    REAL reference (tests/golden/boundary.npz, made by tests/golden/make_boundary_golden.py)."""
+    import os
+    from tests.boundary_cases import aug_features, head_inputs
+    from tests.golden_cases import CASES, GOLDEN, load_case
+    gold = dict(np.load(os.path.join(GOLDEN, "boundary.npz")))
+    h, sd = head_inputs()
+    r1, r2, r3, sup = O.bayes_head(sd, h, T=(1.0, 2.0, 0.5))
+    for got, key in ((r1, "head_rel1"), (r2, "head_rel2"), (r3, "head_rel3"), (sup, "head_super")):
+        np.testing.assert_allclose(got.numpy(), gold[key], rtol=2e-5, atol=2e-5)
+    cfg, sdm, batch, _ = load_case("vg_full")
+    masks = [O.build_masks(b, 32) for b in batch.bbox]
+    fa = aug_features(batch, CASES["vg_full"][2])
+    gm = torch.stack([masks[i][1].unsqueeze(0) for i in range(3)]); em = torch.stack([masks[i][0].unsqueeze(0) for i in range(3)])
+    cs = torch.tensor([int(batch.categories[i][1]) for i in range(3)]); co = torch.tensor([int(batch.categories[i][0]) for i in range(3)])
+    ss = [batch.super_categories[i][1] for i in range(3)]; so = [batch.super_categories[i][0] for i in range(3)]
+    with torch.no_grad():
+        for feat, key in ((batch.image_feature, "aug_pred"), (fa, "aug_pred_aug")):
+            hs = torch.cat((feat * gm, batch.image_depth * gm), dim=1); ho = torch.cat((feat * em, batch.image_depth * em), dim=1)
+            out = O.classifier_forward(sdm, hs, ho, cs, co, ss, so)
+            np.testing.assert_allclose(out[5].numpy(), gold[key], rtol=2e-5, atol=2e-5)

@@ -107,7 +107,8 @@ def test_label_vectors_and_their_gradient():
         assert (lsub.double() - ref_s).abs().max() <= 1e-5 and (lobj.double() - ref_o).abs().max() <= 1e-5
         dls, dlo = torch.randn(n_obj, 512, generator=g).cuda(), torch.randn(n_obj, 512, generator=g).cuda()
         gW = torch.full_like(W, float("nan"))
-        _lib.check(eng.lib.sgc_label_grads(_lib.ptr(dls), _lib.ptr(dlo), _lib.ptr(cats), _lib.ptr(mh), n_obj, C, S if mh is not None else 0,
+        _lib.check(eng.lib.sgc_label_grads(_lib.ptr(dls), _lib.ptr(dlo), _lib.ptr(cats), _lib.ptr(cats), _lib.ptr(mh), _lib.ptr(mh), n_obj, C,
+                                           S if mh is not None else 0,
                                            _lib.ptr(gW), int(W.shape[1]), 4096, _lib.stream_ptr()), "sgc_label_grads")
         ref = torch.zeros(512, cfg.label_dim, dtype=torch.float64, device="cuda")
         ref[:, :C].index_add_(1, cats, dls.t().double())
