@@ -106,7 +106,7 @@ int sgc_scene_tables(const int* n_per_img, const int* img_ptr, const int* goff, 
  * loss_i = -a*super[st] - b*rel[t] + c*BCE(conn, y); one thread per direction-step, double arithmetic in pair order.
  * class_weight [R] f32 (train_test.py:104-105); hier = 0: one class-weighted cross entropy (model.py:37-102 variant). */
 int sgc_loss_coefficients(const int* step_ptr, int n_steps, const int* directed, const float* class_weight, int ng, int np, int hier,
-                          float lambda_connectivity, float lambda_not_connected, int* tgt, float* coef_a, float* coef_b, float* coef_c,
+                          double lambda_connectivity, double lambda_not_connected, int* tgt, float* coef_a, float* coef_b, float* coef_c,
                           float* conn_y, void* stream);
 
 /* Connectivity statistics of train_one_direction / evaluate_one_direction summed over the minibatch (train_utils.py:66-87,176-184):

@@ -239,11 +239,11 @@ int sgc_scene_tables(const int* n_per_img, const int* img_ptr, const int* goff, 
 }
 
 int sgc_loss_coefficients(const int* step_ptr, int n_steps, const int* directed, const float* class_weight, int ng, int np, int hier,
-                          float lambda_connectivity, float lambda_not_connected, int* tgt, float* coef_a, float* coef_b, float* coef_c,
+                          double lambda_connectivity, double lambda_not_connected, int* tgt, float* coef_a, float* coef_b, float* coef_c,
                           float* conn_y, void* stream) {
     if (n_steps <= 0) return SGC_OK;
     SGC_LAUNCH(loss_coefficients_kernel, dim3((n_steps + 63) / 64), dim3(64), 0, (hipStream_t)stream, step_ptr, n_steps, directed,
-               class_weight, ng, np, hier, (double)lambda_connectivity, (double)lambda_not_connected, tgt, coef_a, coef_b, coef_c, conn_y);
+               class_weight, ng, np, hier, lambda_connectivity, lambda_not_connected, tgt, coef_a, coef_b, coef_c, conn_y);
     SGC_CHECK_LAUNCH();
     return SGC_OK;
 }

@@ -232,8 +232,8 @@ class RelHeadEngine:
         co = torch.empty(4, P, dtype=torch.float32, device=self.device)
         _lib.check(self.lib.sgc_loss_coefficients(_lib.ptr(step_ptr), int(n_steps), _lib.ptr(directed), _lib.ptr(class_weight),
                                                   cfg.num_geometric if cfg.hierarchical else cfg.num_relations, cfg.num_possessive,
-                                                  int(cfg.hierarchical), ctypes.c_float(lambda_connectivity),
-                                                  ctypes.c_float(lambda_not_connected), _lib.ptr(tgt), _lib.ptr(co[0]), _lib.ptr(co[1]),
+                                                  int(cfg.hierarchical), ctypes.c_double(lambda_connectivity),
+                                                  ctypes.c_double(lambda_not_connected), _lib.ptr(tgt), _lib.ptr(co[0]), _lib.ptr(co[1]),
                                                   _lib.ptr(co[2]), _lib.ptr(co[3]), self._st()), "sgc_loss_coefficients")
         return (tgt, co[0], co[1], co[2], co[3])
 

@@ -292,7 +292,7 @@ class _RelationBase(nn.Module):
                     sub_csr=sub_csr, obj_csr=obj_csr)
 
     # ------------------------------------------------------------------ reference per-step call
-    def _step(self, h_sub, h_obj, c1, c2, s1, s2):
+    def _step_call(self, h_sub, h_obj, c1, c2, s1, s2):
         """(relation [b,R], super [b,3] | None, connectivity [b,1], hidden [b,512]) of one per-step call.  With autograd on
         and trainable parameters the call is an autograd node (``_PairStepFunction``); otherwise the inference trunk."""
         params = [p for _, p in self.named_parameters()]
@@ -353,10 +353,10 @@ class BayesianRelationClassifier(_RelationBase):
 
     def forward(self, h_sub, h_obj, c1, c2, s1, s2, rank, h_sub_aug=None, h_obj_aug=None):
         ng, npos = self.num_geometric, self.num_possessive
-        rel, sup, conn, pred = self._step(h_sub, h_obj, c1, c2, s1, s2)
+        rel, sup, conn, pred = self._step_call(h_sub, h_obj, c1, c2, s1, s2)
         pred_aug = None
         if h_sub_aug is not None:      # second (augmented) view: same trunk, hidden only (model.py:172)
-            pred_aug = self._step(h_sub_aug, h_obj_aug, c1, c2, s1, s2)[3]
+            pred_aug = self._step_call(h_sub_aug, h_obj_aug, c1, c2, s1, s2)[3]
         return (rel[:, :ng], rel[:, ng:ng + npos], rel[:, ng + npos:], sup, conn, pred, pred_aug)
 
 
@@ -377,10 +377,10 @@ class FlatRelationClassifier(_RelationBase):
                           num_geometric=self.output_dim, num_possessive=0, num_semantic=0, hierarchical=False)
 
     def forward(self, h_sub, h_obj, c1, c2, s1, s2, rank, h_sub_aug=None, h_obj_aug=None, one_hot=True):
-        rel, _, conn, pred = self._step(h_sub, h_obj, c1, c2, s1, s2)
+        rel, _, conn, pred = self._step_call(h_sub, h_obj, c1, c2, s1, s2)
         pred_aug = None
         if h_sub_aug is not None:
-            pred_aug = self._step(h_sub_aug, h_obj_aug, c1, c2, s1, s2)[3]
+            pred_aug = self._step_call(h_sub_aug, h_obj_aug, c1, c2, s1, s2)[3]
         return rel, conn, pred, pred_aug
 
 

@@ -37,51 +37,76 @@ def _unfiltered_selection(scene: DeviceScene, iou_h: np.ndarray, evaluators) -> 
     return torch.from_numpy(iou_h | (per_image < k_max)[pidx.image]).to(scene.bbox.device)
 
 
+def feed_evaluators(model, scene: DeviceScene, out, evaluator=None, evaluator_top3=None, overlap=None, directed=None):
+    """Append one minibatch to the Recall@K evaluators in the reference's candidate order (``evaluator.py:231-246``).
+    ``overlap`` = [P] uint8 device mask of the overlap filter (``train_test.py:403-410``): direction-steps in which no image's
+    boxes overlap are skipped entirely (no candidates, no targets); ``None`` = no filter (``training()``, ``:209``).
+    Returns ``included`` [P] bool numpy (pairs of the kept steps)."""
+    cfg = model.head_config()
+    dev = scene.bbox.device
+    pidx = scene.pidx
+    P = scene.n_pairs
+    n_steps = len(pidx.call_sizes)
+    if overlap is None:
+        iou = torch.ones(P, dtype=torch.uint8, device=dev)
+        any_overlap = np.ones(n_steps, dtype=bool)
+    else:
+        iou = overlap
+        any_overlap = np.bincount(pidx.step[iou.cpu().numpy().astype(bool)], minlength=n_steps) > 0
+    # the filter is symmetric, and the reference tests it once per (g,e): both directions share the decision
+    included = any_overlap[pidx.step]
+    if evaluator is None and evaluator_top3 is None:
+        return included
+    if directed is None:
+        if scene.directed is None:
+            raise ValueError("the evaluator feed needs relation targets: flatten the scene from a batch with relationships / subj_or_obj")
+        directed = scene.directed
+    sel = torch.from_numpy(np.nonzero(included)[0]).to(dev)
+    sizes = pidx.call_sizes[any_overlap]
+    which = torch.from_numpy(pidx.image[included]).to(dev)
+    tgt = torch.as_tensor(directed).to(dev)[sel].long()
+    scat, ocat = scene.cats[scene.sub_idx.long()][sel], scene.cats[scene.obj_idx.long()][sel]
+    raw = torch.from_numpy(scene.bbox_raw).to(dev)
+    sbox, obox = raw[scene.sub_idx.long()][sel], raw[scene.obj_idx.long()][sel]
+    logsig = torch.log(torch.sigmoid(out.connectivity[sel]))
+    iou_sel = iou[sel].bool()
+    if evaluator is not None:
+        evaluator.accumulate_candidates(which, out.cand_conf[sel], out.cand_pred[sel], tgt, logsig, scat, ocat, sbox, obox,
+                                        iou_mask=iou_sel, call_sizes=sizes)
+    if evaluator_top3 is not None and cfg.hierarchical:
+        conf3 = out.cand_conf[sel].max(dim=1)[0]
+        evaluator_top3.accumulate_candidates(which, conf3, out.cand_pred[sel], tgt, logsig, scat, ocat, sbox, obox, iou_mask=iou_sel)
+    return included
+
+
 def evaluate_minibatch(model, batch, evaluator=None, evaluator_top3=None, overlap_filtering: bool = True,
                        scene: Optional[DeviceScene] = None, skip_filtered: bool = False):
     """Returns (scene, outputs, included[P] bool numpy, directed targets numpy).
     ``skip_filtered=True`` runs the per-pair trunk only for the pairs that pass the overlap filter (about 40 % of the ordered pairs
     on the synthetic boxes) in every image that has at least top-K such pairs: Recall@K is unchanged (a filtered pair's
     confidence is -inf either way, ``evaluator.py:131-134``, and cannot reach the top K there); ``outputs`` of the skipped pairs
-    are zeros.  The reference cannot skip them: its batched per-step call always scores the whole batch."""
+    are zeros.  The reference cannot skip them: its batched per-step call always scores the whole batch.
+    ``model.last_connectivity_stats`` holds the counters of ``evaluate_one_direction`` (``train_utils.py:176-184``) summed over the
+    kept steps ([5] int64 device tensor; None with ``skip_filtered``)."""
     cfg = model.head_config()
     dev = next(model.parameters()).device
     if scene is None:
         scene = flatten_scene(cfg, batch, dev)
-    pidx = scene.pidx
-    P = pidx.n_pairs
-    iou = overlap_mask(scene) if overlap_filtering else torch.ones(P, dtype=torch.uint8, device=dev)
-    iou_h = iou.cpu().numpy().astype(bool)
-    select = _unfiltered_selection(scene, iou_h, (evaluator, evaluator_top3)) if (skip_filtered and overlap_filtering) else None
+    P = scene.n_pairs
+    iou = overlap_mask(scene) if overlap_filtering else None
+    select = None
+    if skip_filtered and overlap_filtering:
+        select = _unfiltered_selection(scene, iou.cpu().numpy().astype(bool), (evaluator, evaluator_top3))
     out = model.forward_pairs(scene, iou_mask=iou, select=select)
-    directed = pair_targets_fast(batch.relationships, batch.subj_or_obj, pidx)
-    n_steps = len(pidx.call_sizes)
-    any_overlap = np.bincount(pidx.step[iou_h], minlength=n_steps) > 0
-    # the filter is symmetric, and the reference tests it once per (g,e): both directions share the decision
-    included = any_overlap[pidx.step]
+    directed_d = scene.directed
+    if directed_d is None:
+        directed_d = torch.from_numpy(pair_targets_fast(batch.relationships, batch.subj_or_obj, scene.pidx).astype(np.int32)).to(dev)
+    included = feed_evaluators(model, scene, out, evaluator, evaluator_top3, overlap=iou, directed=directed_d)
     model.last_connectivity_stats = None
-    if scene.directed is not None and select is None:     # connectivity statistics of evaluate_one_direction (train_utils.py:176-184), kept steps only
-        model.last_connectivity_stats = model.engine().connectivity_stats(out.connectivity, scene.directed, scene.raw_target,
+    if select is None and scene.raw_target is not None:
+        model.last_connectivity_stats = model.engine().connectivity_stats(out.connectivity, directed_d, scene.raw_target,
                                                                           torch.from_numpy(included.astype(np.uint8)).to(dev))
-    if evaluator is not None or evaluator_top3 is not None:
-        sel = torch.from_numpy(np.nonzero(included)[0]).to(dev)
-        sizes = pidx.call_sizes[any_overlap]
-        which = torch.from_numpy(pidx.image[included]).to(dev)
-        tgt = torch.from_numpy(directed[included]).to(dev)
-        scat, ocat = scene.cats[scene.sub_idx.long()][sel], scene.cats[scene.obj_idx.long()][sel]
-        raw = torch.from_numpy(scene.bbox_raw).to(dev)
-        sbox, obox = raw[scene.sub_idx.long()][sel], raw[scene.obj_idx.long()][sel]
-        logsig = torch.log(torch.sigmoid(out.connectivity[sel]))
-        iou_sel = iou[sel].bool()
-        if evaluator is not None:
-            # iou_mask was already folded into cand_conf by the head kernel (-inf), re-applied here for clarity
-            evaluator.accumulate_candidates(which, out.cand_conf[sel], out.cand_pred[sel], tgt, logsig, scat, ocat, sbox, obox,
-                                            iou_mask=iou_sel, call_sizes=sizes)
-        if evaluator_top3 is not None and cfg.hierarchical:
-            conf3 = out.cand_conf[sel].max(dim=1)[0]
-            evaluator_top3.accumulate_candidates(which, conf3, out.cand_pred[sel], tgt, logsig, scat, ocat, sbox, obox,
-                                                 iou_mask=iou_sel)
-    return scene, out, included, directed
+    return scene, out, included, directed_d.cpu().numpy().astype(np.int64)
 
 
 def evaluate_sgdet_minibatch(model, image_feature, image_depth, categories_pred, cat_pred_confidence, bbox_pred, evaluator,
@@ -139,6 +164,7 @@ def train_minibatch(model, batch, optimizer=None, reducer=None, scene: Optional[
     if optimizer is not None:
         optimizer.zero_grad(set_to_none=True)
     loss = model.training_step(scene, batch.relationships, batch.subj_or_obj, reducer=reducer, **loss_kw)
+    model.last_scene = scene
     if optimizer is not None:
         optimizer.step()
     return loss

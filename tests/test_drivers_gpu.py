@@ -1,0 +1,81 @@
+"""The same-named driver modules of SURVEY 8(b) - ``train_test.training`` / ``testing`` and ``evaluate.eval_pc`` with the
+reference's signatures - end to end on one GPU: a tiny dataset of precomputed DETR features in the reference dataloader's
+tuple layout (``dataloader.py:163-165``), RCCL process group of one rank, checkpoint in the reference's naming with the
+``module.`` prefix, per-rank result files."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class TinyVG(torch.utils.data.Dataset):
+    """Items are the reference loader's 9-tuples with the image slot already holding the [256,32,32] encoder features."""
+
+    def __init__(self, cfg, n_items, seed, none_at=()):
+        from scene_graph_commonsense_amd.synthetic import make_scene_batch
+        sizes = [3 + (i * 5) % 4 for i in range(n_items)]
+        self.b = make_scene_batch(cfg, sizes, seed=seed, connect_frac=0.5)
+        self.none_at = set(none_at)
+
+    def __len__(self):
+        return len(self.b.bbox)
+
+    def __getitem__(self, i):
+        if i in self.none_at:
+            return None                                        # the reference's loader drops such images (collate_fn filters them)
+        b = self.b
+        return (b.image_feature[i], b.image_feature[i] * 0.9 + 0.05, b.image_depth[i], b.categories[i], b.super_categories[i], b.bbox[i],
+                b.relationships[i], b.subj_or_obj[i], "img_%d_annotations.pkl" % i)
+
+
+def _args(tmp_path, run_mode):
+    from scene_graph_commonsense_amd.synthetic import HeadConfig
+    from tests.golden_cases import GOLDEN
+    cfg = HeadConfig()
+    args = cfg.args(run_mode=run_mode, fixtures=os.path.join(GOLDEN, "ref_fixtures") + os.sep)
+    args["models"]["feature_encoder"] = "precomputed"
+    args["training"].update(batch_size=2, num_epoch=1, start_epoch=0, continue_train=False, scheduler_param1=5, scheduler_param2=8,
+                            print_freq=1, print_freq_test=1, eval_freq=1, eval_freq_test=1, test_epoch=0, save_vis_results=False,
+                            result_path=str(tmp_path) + os.sep, checkpoint_path=str(tmp_path) + os.sep, learning_rate=1e-5)
+    return cfg, args
+
+
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return str(sk.getsockname()[1])
+
+
+def test_training_then_eval_pc_drivers(tmp_path, monkeypatch):
+    from scene_graph_commonsense_amd import evaluate, train_test
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    monkeypatch.setenv("MASTER_PORT", _free_port())
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    cfg, args = _args(tmp_path, "train")
+    train, test = TinyVG(cfg, 4, seed=41, none_at=(2,)), TinyVG(cfg, 4, seed=42)
+    train_test.training(0, args, train, test)
+    ckpt = os.path.join(str(tmp_path), "HierRelationModel_Baseline_motif0_0.pth")
+    assert os.path.exists(ckpt)
+    sd = torch.load(ckpt, map_location="cpu")
+    assert all(k.startswith("module.") for k in sd) and sd["module.fc1.weight"].shape == (4096, 65536)
+    from scene_graph_commonsense_amd.synthetic import make_state_dict
+    rec = json.load(open(os.path.join(str(tmp_path), "train_results_0.json")))
+    assert len(rec) == 2 and all(np.isfinite(r["total_losses"]) and r["total_losses"] > 0 for r in rec)
+    assert rec[0]["num_connected"] + rec[0]["num_not_connected"] > 0
+    trec = json.load(open(os.path.join(str(tmp_path), "test_results_0.json")))
+    assert len(trec) == 2 and all(0.0 <= r <= 1.0 for r in trec[-1]["recall_relationship"])
+    # evaluation driver on the checkpoint the training driver wrote (the reference loads "<...>_<epoch>_0.pth")
+    monkeypatch.setenv("MASTER_PORT", _free_port())
+    _, args_e = _args(tmp_path, "eval")
+    recall, mean_recall = evaluate.eval_pc(0, args_e, test)
+    assert len(recall) == 3 and all(0.0 <= float(r) <= 1.0 for r in recall)
+    erec = json.load(open(os.path.join(str(tmp_path), "test_results_0.json")))
+    assert len(erec) == 2 and erec[-1]["num_connected"] >= 0
+    assert not torch.distributed.is_initialized()

@@ -309,3 +309,22 @@ def test_bench_launcher_starts_every_rank_gloo_world2():
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--dry-run", "--backend", "gloo"],
                        capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode != 0 and "refusing" in (r.stderr + r.stdout)
+
+
+def test_dropin_shims_resolve_like_main_py(tmp_path):
+    """``from train_test import training`` / ``from evaluate import eval_pc, eval_sgc, eval_sgd`` / ``from model import *`` exactly as
+    main.py / train_test.py of the reference write them, with scene_graph_commonsense_amd/dropin first on sys.path."""
+    import subprocess
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "from train_test import training, testing, setup\n"
+            "from evaluate import eval_pc, eval_sgc, eval_sgd\n"
+            "from model import BayesianRelationClassifier, FlatRelationClassifier, BayesianHead\n"
+            "from evaluator import Evaluator, Evaluator_Top3\n"
+            "from train_utils import train_one_direction, evaluate_one_direction, process_image_features\n"
+            "import inspect\n"
+            "assert list(inspect.signature(training).parameters) == ['gpu', 'args', 'train_subset', 'test_subset']\n"
+            "assert list(inspect.signature(eval_pc).parameters) == ['gpu', 'args', 'test_subset', 'curr_dataset', 'prepare_cs_step']\n"
+            "assert list(inspect.signature(testing).parameters) == ['args', 'detr', 'relation_classifier', 'test_loader', 'test_record', 'epoch', 'rank', 'writer']\n"
+            "print('ok')\n") % (REPO, os.path.join(REPO, "scene_graph_commonsense_amd", "dropin"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
