@@ -25,11 +25,11 @@ def load(build_if_missing: bool = True) -> ctypes.CDLL:
     # with.  Loading the library before torch leaves two runtimes in the process and every launch fails.
     import torch  # noqa: F401
     path = lib_path()
-    if not os.path.exists(path):
+    from .build import build, is_stale
+    if is_stale():                      # missing, or compiled from other sources than the tree holds (content hash, not mtimes)
         if not build_if_missing:
-            raise HipExtensionMissing(path + " is missing; run `python -m scene_graph_commonsense_amd.build`")
-        from .build import build
-        build()
+            raise HipExtensionMissing(path + " is missing or stale; run `python -m scene_graph_commonsense_amd.build`")
+        build(verbose=False)
     try:
         _LIB = ctypes.CDLL(path)
     except OSError as e:  # pragma: no cover

@@ -46,6 +46,31 @@ def lib_path() -> str:
     return os.path.join(LIBDIR, LIBNAME)
 
 
+def source_hash() -> str:
+    """Content hash of everything the library is compiled from (csrc/ + include/ + the flags).  The staleness test uses it
+    rather than mtimes: a snapshot copied to another machine keeps contents, not timestamps."""
+    import hashlib
+    h = hashlib.sha1(" ".join(FLAGS[:5]).encode())
+    for root in (CSRC, os.path.join(os.path.dirname(HERE), "include")):
+        for f in sorted(os.listdir(root)):
+            h.update(f.encode())
+            with open(os.path.join(root, f), "rb") as fh:
+                h.update(fh.read())
+    return h.hexdigest()
+
+
+def _stamp_path() -> str:
+    return os.path.join(LIBDIR, "source_hash.txt")
+
+
+def is_stale() -> bool:
+    """True when the built library is missing or was compiled from other sources than the ones in the tree."""
+    if not os.path.exists(lib_path()) or not os.path.exists(_stamp_path()):
+        return True
+    with open(_stamp_path()) as f:
+        return f.read().strip() != source_hash()
+
+
 def _compile(src: str) -> str:
     obj = os.path.join(OBJDIR, os.path.basename(src)[:-4] + ".o")
     if os.path.exists(obj) and os.path.getmtime(obj) >= _newest_dep():
@@ -60,9 +85,9 @@ def _compile(src: str) -> str:
 def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(OBJDIR, exist_ok=True)
     out = lib_path()
-    if not force and os.path.exists(out) and os.path.getmtime(out) >= _newest_dep():
+    if not force and not is_stale():
         return out
-    if force:
+    if force or not os.path.exists(_stamp_path()):
         for f in os.listdir(OBJDIR):
             os.remove(os.path.join(OBJDIR, f))
     srcs = sources()
@@ -72,6 +97,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+    with open(_stamp_path(), "w") as f:
+        f.write(source_hash())
     if verbose:
         print("built", out)
     return out
