@@ -160,6 +160,7 @@ int sgc_supcon_hierar(const float* F, const int* labels, int M, float temperatur
                       float* dF, void* stream);
 
 int sgc_slab_sum(const float* in, float* out, long n, int slabs, int accumulate, void* stream);          /* out[n] (+)= sum_s in[s][n] */
+int sgc_fill_zero(void* ptr, long nbytes, void* stream);   /* 16-byte aligned ptr; workspace creation (zero halos are written once) */
 int sgc_slab_sum_ld(const float* in, float* out, int rows, int cols, long ld_out, int slabs, void* stream);  /* out[r*ld_out+c] = sum_s in[s][r][c] */
 int sgc_colsum(int elem, const void* X, float* part, long rows, int cols, int row_blocks, void* stream);  /* bias gradients */
 int sgc_segment_sum_rows(const void* X, const int* ptr, const int* list, float* out, int n_seg, int cols, void* stream); /* label-column grads */

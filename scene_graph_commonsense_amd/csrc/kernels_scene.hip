@@ -216,8 +216,27 @@ __global__ __launch_bounds__(256) void slab_sum_ld_kernel(const float* __restric
     }
 }
 
+// Zero fill with 16-byte stores (workspace allocation: the zero halos of the padded activation / gradient tensors are written
+// once, when a buffer is created; the kernels only ever write interiors).
+__global__ __launch_bounds__(256) void fill_zero_kernel(uint4* __restrict__ p, long n16, unsigned char* __restrict__ tail, int ntail) {
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long)gridDim.x * 256) p[i] = z;
+    if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = 0;
+}
+
 // ------------------------------------------------------------------------------------------------ C ABI
 extern "C" {
+
+int sgc_fill_zero(void* ptr, long nbytes, void* stream) {
+    if (nbytes <= 0) return SGC_OK;
+    if (((uintptr_t)ptr & 15) != 0) return SGC_ERR_ARG;
+    const long n16 = nbytes >> 4;
+    const long blocks = (n16 + 255) / 256 < 16384 ? ((n16 + 255) / 256 > 0 ? (n16 + 255) / 256 : 1) : 16384;
+    SGC_LAUNCH(fill_zero_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (uint4*)ptr, n16,
+               (unsigned char*)ptr + (n16 << 4), (int)(nbytes & 15));
+    SGC_CHECK_LAUNCH();
+    return SGC_OK;
+}
 
 int sgc_scene_tables(const int* n_per_img, const int* img_ptr, const int* goff, int n_img, int max_n, int n_pairs, int n_obj, int pid_ld,
                      const int* rel_tri, const float* dir_tri, int* sub_idx, int* obj_idx, int* step, int* image, int* directed,

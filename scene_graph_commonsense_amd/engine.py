@@ -58,11 +58,17 @@ class Workspace:
     def get(self, name, numel, dtype, zero=False):
         t = self.bufs.get(name)
         if t is None or t.numel() < numel or t.dtype != dtype:
-            t = torch.zeros(int(numel), dtype=dtype, device=self.device)
+            t = torch.empty(int(numel), dtype=dtype, device=self.device)
+            self._zero(t)              # created zeroed: padded tensors keep their zero halo, kernels write interiors only
             self.bufs[name] = t
         elif zero:
-            t[:numel].zero_()
+            self._zero(t[:numel])
         return t[:numel]
+
+    @staticmethod
+    def _zero(t):
+        if t.numel():
+            _lib.check(_lib.load().sgc_fill_zero(_lib.ptr(t), _c_long(t.numel() * t.element_size()), _lib.stream_ptr()), "sgc_fill_zero")
 
     def nbytes(self):
         return sum(t.numel() * t.element_size() for t in self.bufs.values())
@@ -455,7 +461,7 @@ class RelHeadEngine:
         y = sc.get("y", Ppad * 65536, torch.float16)
         y_bf = ws.get("y_bf", Ppad * 65536, torch.bfloat16)         # bf16 copy for the fc1 weight gradient, written by the same epilogue
         if Ppad > P:
-            y_bf[P * 65536:].zero_()
+            Workspace._zero(y_bf[P * 65536:])
         am = ws.get("argmax", P * 65536, torch.uint8)
         self._timed("conv3_fwd", lambda: _lib.check(lib.sgc_conv3_relu_pool(_lib.ptr(z), _lib.ptr(self.w["w3r"]), _lib.ptr(self.w["b3"]), _lib.ptr(y), _lib.ptr(am),
                                            _lib.ptr(y_bf), P, self._st()), "sgc_conv3_relu_pool"))
@@ -493,7 +499,7 @@ class RelHeadEngine:
         loss_i = ws.get("loss_i", P, torch.float32)
         dpre = ws.get("dpre", Ppad * 512, torch.bfloat16)
         if Ppad > P:
-            dpre[P * 512:].zero_()
+            Workspace._zero(dpre[P * 512:])
         T = self.T
         if upstream is None:
             tgt, ca, cb, cc, cy = coefs
@@ -552,7 +558,7 @@ class RelHeadEngine:
         grads["fc2.bias"] = self._colsum(dpre, Ppad, 512)
         dh1 = ws.get("dh1", Ppad * 4096, torch.bfloat16)
         if Ppad > P:
-            dh1[P * 4096:].zero_()
+            Workspace._zero(dh1[P * 4096:])
         self._timed("fc2_dgrad", lambda: _lib.check(lib.sgc_fc2_dgrad(_lib.ptr(dpre), _lib.ptr(w["w2mT"]), _lib.ptr(ctx.h1), _lib.ptr(dh1), P, f(scale), st()),
                    "sgc_fc2_dgrad"))
 

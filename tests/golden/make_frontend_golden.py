@@ -27,6 +27,7 @@ import numpy as np
 import torch
 
 from tests.frontend_cases import make_detr_outputs, make_target_boxes      # noqa: E402  (seeded synthetic inputs)
+sys.path.insert(0, HERE)
 from oracle import frontend_oracle as fo                                   # noqa: E402
 
 
@@ -54,47 +55,21 @@ def import_reference():
 
 
 def reference_inline_sgdet(out_dict, args, object_class_alp2fre_dict, torchvision):
-    """evaluate.py:311-366 restated (masks_pred, which only feed the pair loop, omitted)."""
+    """The inline front-end block of ``eval_sgd`` (evaluate.py:311-366), EXECUTED from /root/reference/evaluate.py itself (see
+    ref_extract.py) - no restatement.  Run in two parts to snapshot the lists before the per-class NMS loop."""
     import torch.nn.functional as F
-    logits_pred = torch.argmax(F.softmax(out_dict['pred_logits'], dim=2), dim=2)
-    has_object_pred = logits_pred < args['models']['num_classes']
-    logits_pred = torch.topk(F.softmax(out_dict['pred_logits'], dim=2), dim=2, k=args['models']['topk_cat'])[1].view(-1, 100, args['models']['topk_cat'])
-    logits_pred_value = torch.topk(F.softmax(out_dict['pred_logits'], dim=2), dim=2, k=args['models']['topk_cat'])[0].view(-1, 100, args['models']['topk_cat'])
-    kept = [i for i in range(logits_pred_value.shape[0]) if torch.sum(has_object_pred[i]) > 0]
-    cat_pred_confidence = [logits_pred_value[i, has_object_pred[i], :].flatten() for i in kept]
-    categories_pred = [logits_pred[i, has_object_pred[i], :].flatten() for i in kept]
-    for i in range(len(categories_pred)):
-        for j in range(len(categories_pred[i])):
-            categories_pred[i][j] = object_class_alp2fre_dict[categories_pred[i][j].item()]
-    cat_mask = [categories_pred[i] != args['models']['num_classes'] for i in range(len(categories_pred))]
-    bbox_pred = [out_dict['pred_boxes'][i, has_object_pred[i]] for i in kept]
-    for i in range(len(bbox_pred)):
-        bbox_pred_c = bbox_pred[i].clone()
-        bbox_pred[i][:, [0, 2]] = bbox_pred_c[:, [0, 1]] - bbox_pred_c[:, [2, 3]] / 2
-        bbox_pred[i][:, [1, 3]] = bbox_pred_c[:, [0, 1]] + bbox_pred_c[:, [2, 3]] / 2
-        bbox_pred[i] = torch.clamp(bbox_pred[i], 0, 1)
-        bbox_pred[i] = (bbox_pred[i] * args['models']['feature_size']).repeat_interleave(args['models']['topk_cat'], dim=0)
-    for i in range(len(categories_pred)):
-        categories_pred[i] = categories_pred[i][cat_mask[i]]
-        cat_pred_confidence[i] = cat_pred_confidence[i][cat_mask[i]]
-        bbox_pred[i] = bbox_pred[i][cat_mask[i]]
-    pre_nms = ([c.clone() for c in categories_pred], [c.clone() for c in cat_pred_confidence], [b.clone() for b in bbox_pred])
-    for i in range(len(bbox_pred)):
-        bbox_pred[i] = bbox_pred[i][:, [0, 2, 1, 3]]
-        nms_keep_idx = None
-        for cls in torch.unique(categories_pred[i]):
-            curr_class_idx = categories_pred[i] == cls
-            curr_nms_keep_idx = torchvision.ops.nms(boxes=bbox_pred[i][curr_class_idx], scores=cat_pred_confidence[i][curr_class_idx],
-                                                    iou_threshold=args['models']['nms'])
-            if nms_keep_idx is None:
-                nms_keep_idx = (torch.nonzero(curr_class_idx).flatten())[curr_nms_keep_idx]
-            else:
-                nms_keep_idx = torch.hstack((nms_keep_idx, (torch.nonzero(curr_class_idx).flatten())[curr_nms_keep_idx]))
-        bbox_pred[i] = bbox_pred[i][:, [0, 2, 1, 3]]
-        categories_pred[i] = categories_pred[i][nms_keep_idx]
-        cat_pred_confidence[i] = cat_pred_confidence[i][nms_keep_idx]
-        bbox_pred[i] = bbox_pred[i][nms_keep_idx]
-    return categories_pred, cat_pred_confidence, bbox_pred, kept, pre_nms
+    from ref_extract import reference_block, run_block
+    path = os.path.join(REF, "evaluate.py")
+    part1, l1 = reference_block(path, "eval_sgd", "logits_pred = torch.argmax(F.softmax(out_dict['pred_logits']", "masks_pred[i] = masks_pred[i][cat_mask[i]]")
+    part2, l2 = reference_block(path, "eval_sgd", "# non-maximum suppression", "masks_pred[i] = masks_pred[i][nms_keep_idx]")
+    assert l1[1] < l2[0]
+    ns = dict(torch=torch, F=F, torchvision=torchvision, out_dict=out_dict, args=args, object_class_alp2fre_dict=object_class_alp2fre_dict,
+              rank="cpu")
+    run_block(part1, ns, "evaluate.py:%d-%d" % l1)
+    pre_nms = ([c.clone() for c in ns["categories_pred"]], [c.clone() for c in ns["cat_pred_confidence"]], [b.clone() for b in ns["bbox_pred"]])
+    run_block(part2, ns, "evaluate.py:%d-%d" % l2)
+    kept = [i for i in range(ns["has_object_pred"].shape[0]) if torch.sum(ns["has_object_pred"][i]) > 0]
+    return ns["categories_pred"], ns["cat_pred_confidence"], ns["bbox_pred"], kept, pre_nms
 
 
 def ragged(lst, dtype):

@@ -4,9 +4,9 @@ Recall with predcls=False).  Runs only in the build container.
 
 REAL reference code used: ``model.BayesianRelationClassifier``, ``evaluator.Evaluator`` (accumulate with predcls=False and the
 category confidences, accumulate_target, compute(per_class=True, predcls=False)), ``utils.match_target_sgd``,
-``utils.compare_object_cat`` (through the evaluator).  Restated here because evaluate.py cannot be imported: its inline front-end
-block (see make_frontend_golden.py; torchvision.ops.nms is substituted by oracle.frontend_oracle.nms) and its SGDET pair loop
-(evaluate.py:375-440).
+``utils.compare_object_cat`` (through the evaluator).  evaluate.py cannot be imported (tensorboard, process group, DETR download): its inline
+front-end block (see make_frontend_golden.py; torchvision.ops.nms is substituted by oracle.frontend_oracle.nms) and its SGDET pair
+loop (evaluate.py:375-440) are EXECUTED from the reference's file at generation time (ref_extract.py), not restated here.
 
     PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_sgdet_golden.py
 """
@@ -90,46 +90,27 @@ def main():
         ref_utils.match_target_sgd("cpu", batch.relationships, batch.subj_or_obj, batch.categories, bbox_target)
     # ---- SGDET pair loop (evaluate.py:375-440) with the REAL classifier and evaluator
     Recall = ref_eval.Evaluator(args=args, num_classes=cfg.num_relations, iou_thresh=0.5, top_k=[20, 50, 100])
-    image_feature, image_depth = batch.image_feature, batch.image_depth
-    rank = "cpu"
-    n_calls = 0
+
+    class Counted:
+        """The reference classifier, counting its calls."""
+        def __init__(self, m): self.m, self.n = m, 0
+        def __call__(self, *a, **k):
+            self.n += 1
+            return self.m(*a, **k)
+    counted = Counted(model)
+    sys.path.insert(0, HERE)
+    from ref_extract import reference_block, run_block
+    loop, ln = reference_block(os.path.join(mg.REF, "evaluate.py"), "eval_sgd", "num_graph_iter = torch.as_tensor([len(mask) for mask in masks_pred])",
+                               "iou_mask, False, cat_edge_confidence, cat_graph_confidence)")
+    import torch.nn.functional as F
+    fargs_loop = dict(args)
+    fargs_loop["training"] = dict(args["training"], eval_freq_test=1)
+    ns = dict(torch=torch, F=F, args=fargs_loop, rank="cpu", relation_classifier=counted, Recall=Recall, batch_count=0, test_loader=[0],
+              image_feature=batch.image_feature, image_depth=batch.image_depth, masks_pred=masks_pred, categories_pred=categories_pred,
+              bbox_pred=bbox_pred, cat_pred_confidence=cat_pred_confidence, super_categories_pred=super_categories_pred)
     with torch.no_grad():
-        num_graph_iter = torch.as_tensor([len(mask) for mask in masks_pred])
-        for graph_iter in range(max(num_graph_iter)):
-            keep_in_batch = torch.nonzero(num_graph_iter > graph_iter).view(-1)
-            curr_graph_masks = torch.stack([torch.unsqueeze(masks_pred[i][graph_iter], dim=0) for i in keep_in_batch])
-            h_graph = torch.cat((image_feature[keep_in_batch] * curr_graph_masks, image_depth[keep_in_batch] * curr_graph_masks), dim=1)
-            cat_graph_pred = torch.tensor([torch.unsqueeze(categories_pred[i][graph_iter], dim=0) for i in keep_in_batch])
-            bbox_graph_pred = torch.stack([bbox_pred[i][graph_iter] for i in keep_in_batch])
-            cat_graph_confidence = torch.hstack([cat_pred_confidence[i][graph_iter] for i in keep_in_batch])
-            for edge_iter in range(graph_iter):
-                curr_edge_masks = torch.stack([torch.unsqueeze(masks_pred[i][edge_iter], dim=0) for i in keep_in_batch])
-                h_edge = torch.cat((image_feature[keep_in_batch] * curr_edge_masks, image_depth[keep_in_batch] * curr_edge_masks), dim=1)
-                cat_edge_pred = torch.tensor([torch.unsqueeze(categories_pred[i][edge_iter], dim=0) for i in keep_in_batch])
-                bbox_edge_pred = torch.stack([bbox_pred[i][edge_iter] for i in keep_in_batch])
-                cat_edge_confidence = torch.hstack([cat_pred_confidence[i][edge_iter] for i in keep_in_batch])
-                joint_intersect = torch.logical_or(curr_graph_masks, curr_edge_masks)
-                joint_union = torch.logical_and(curr_graph_masks, curr_edge_masks)
-                joint_iou = (torch.sum(torch.sum(joint_intersect, dim=-1), dim=-1) / torch.sum(torch.sum(joint_union, dim=-1), dim=-1)).flatten()
-                joint_iou[torch.isinf(joint_iou)] = 0
-                iou_mask = joint_iou > 0
-                if torch.sum(iou_mask) == 0:
-                    continue
-                spcat_graph_pred = [super_categories_pred[i][graph_iter] for i in keep_in_batch]
-                spcat_edge_pred = [super_categories_pred[i][edge_iter] for i in keep_in_batch]
-                relation_1, relation_2, relation_3, super_relation, connectivity, _, _ = model(
-                    h_graph, h_edge, cat_graph_pred, cat_edge_pred, spcat_graph_pred, spcat_edge_pred, rank)
-                relation = torch.cat((relation_1, relation_2, relation_3), dim=1)
-                Recall.accumulate(keep_in_batch, relation, None, super_relation, torch.log(torch.sigmoid(connectivity[:, 0])),
-                                  cat_graph_pred, cat_edge_pred, None, None, bbox_graph_pred, bbox_edge_pred, None, None,
-                                  iou_mask, False, cat_graph_confidence, cat_edge_confidence)
-                relation_1, relation_2, relation_3, super_relation, connectivity, _, _ = model(
-                    h_edge, h_graph, cat_edge_pred, cat_graph_pred, spcat_edge_pred, spcat_graph_pred, rank)
-                relation = torch.cat((relation_1, relation_2, relation_3), dim=1)
-                Recall.accumulate(keep_in_batch, relation, None, super_relation, torch.log(torch.sigmoid(connectivity[:, 0])),
-                                  cat_edge_pred, cat_graph_pred, None, None, bbox_edge_pred, bbox_graph_pred, None, None,
-                                  iou_mask, False, cat_edge_confidence, cat_graph_confidence)
-                n_calls += 2
+        run_block(loop, ns, "evaluate.py:%d-%d" % ln)            # the reference's own SGDET pair loop, verbatim from its file
+    n_calls = counted.n
     Recall.accumulate_target(relation_target, cat_subject_target, cat_object_target, bbox_subject_target, bbox_object_target)
     out["ev_conf"] = Recall.confidence.numpy().copy(); out["ev_conn"] = Recall.connectivity.numpy().copy()
     out["ev_pred"] = Recall.relation_pred.numpy().copy(); out["ev_which"] = Recall.which_in_batch.numpy().copy()
