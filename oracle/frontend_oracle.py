@@ -84,7 +84,7 @@ def nms(boxes: Tensor, scores: Tensor, iou_threshold: float) -> Tensor:
             h = torch.maximum(zero, torch.minimum(y2[i], y2[j]) - torch.maximum(y1[i], y1[j]))
             inter = w * h
             ovr = inter / (areas[i] + areas[j] - inter)
-            if bool(ovr > iou_threshold):
+            if float(ovr) > float(iou_threshold):     # the f32 quotient against the DOUBLE threshold (C++ promotion in the kernel)
                 suppressed[j] = True
     return torch.tensor(keep, dtype=torch.int64)
 

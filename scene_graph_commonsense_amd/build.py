@@ -21,6 +21,8 @@ LIBNAME = "libsgc_relhead.so"
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result",
          "-I", CSRC, "-I", os.path.join(os.path.dirname(HERE), "include")]
+if os.environ.get("SGC_EXPERIMENTS") == "1":      # also compile the rejected main-loop variants (tools/gemm_microbench.py)
+    FLAGS.insert(5, "-DSGC_EXPERIMENTS")
 
 
 def hipcc() -> str:
@@ -50,7 +52,7 @@ def source_hash() -> str:
     """Content hash of everything the library is compiled from (csrc/ + include/ + the flags).  The staleness test uses it
     rather than mtimes: a snapshot copied to another machine keeps contents, not timestamps."""
     import hashlib
-    h = hashlib.sha1(" ".join(FLAGS[:5]).encode())
+    h = hashlib.sha1(" ".join(f for f in FLAGS if f.startswith("-") and f != "-I").encode())
     for root in (CSRC, os.path.join(os.path.dirname(HERE), "include")):
         for f in sorted(os.listdir(root)):
             h.update(f.encode())

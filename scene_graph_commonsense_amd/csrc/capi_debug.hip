@@ -25,12 +25,14 @@ int sgc_dbg_gemm_nt_abl(int abl, const void* A, const void* B, void* C, int M, i
         case 2: return launch_gemm_nt_cfg<ELEM_BF16, AMODE_PLAIN, EPI_STORE, 2, 4, 4, 2, 2>(p, (hipStream_t)stream);
         case 3: return launch_gemm_nt_cfg<ELEM_BF16, AMODE_PLAIN, EPI_STORE, 2, 4, 4, 2, 3>(p, (hipStream_t)stream);
         case 5: return launch_gemm_nt_cfg<ELEM_BF16, AMODE_PLAIN, EPI_STORE, 2, 4, 4, 2, 5>(p, (hipStream_t)stream);
-        case 4: return launch_gemm_nt_ring<ELEM_BF16, AMODE_PLAIN, EPI_STORE>(p, (hipStream_t)stream);
         case 6: p.epi_lds = 1; return launch_gemm_nt_pp<ELEM_BF16, EPI_STORE, 0>(p, (hipStream_t)stream);
         case 7: p.epi_lds = 1; return launch_gemm_nt_pp<ELEM_BF16, EPI_STORE, 1>(p, (hipStream_t)stream);
+#ifdef SGC_EXPERIMENTS      // rejected main-loop variants, built with SGC_EXPERIMENTS=1 only
+        case 4: return launch_gemm_nt_ring<ELEM_BF16, AMODE_PLAIN, EPI_STORE>(p, (hipStream_t)stream);
         case 8: return launch_gemm_nt_w4<ELEM_BF16, EPI_STORE, 0>(p, (hipStream_t)stream);
         case 9: return launch_gemm_nt_w4<ELEM_BF16, EPI_STORE, 1>(p, (hipStream_t)stream);
         case 10: p.epi_lds = 1; return launch_gemm_nt_pp1<ELEM_BF16, EPI_STORE>(p, (hipStream_t)stream);
+#endif
     }
     return SGC_ERR_ARG;
 }

@@ -308,11 +308,14 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void gemm_nt_kernel(const NtParams
     nt_epilogue<ELEM, EPI, TM, TN>(p, acc, m0, n0, wr, wc, lane);
 }
 
+#ifdef SGC_EXPERIMENTS
 inline int sgc_gemm_ring() {      // SGC_GEMM_RING=1 selects the 4-stage ring kernel (A/B hook; default off, see below)
     static int v = -1;
     if (v < 0) { const char* e = getenv("SGC_GEMM_RING"); v = e ? atoi(e) : 0; }
     return v;
 }
+
+#endif
 
 inline int sgc_gemm_cfg() {       // test hook: SGC_GEMM_CFG=1 forces the 128x128 block, =2 the 2-stage 256x256 block, =3 the 4-stage ring, =4 the halo-staged conv (2-stage), =5 the ping-pong plain block, =7 the ping-pong halo conv
     static int cfg = -1;
@@ -327,18 +330,15 @@ static int launch_gemm_nt_cfg(NtParams p, hipStream_t stream) {
     constexpr int LDS = (EPI == EPI_STORE && TM == 4 && TN == 2 && WR * WC == 8 && LDS0 < EPI_LDS_BYTES) ? EPI_LDS_BYTES : LDS0;
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = p.N / BN;
-    static bool attr_set = false;
     auto kern = gemm_nt_kernel<ELEM, AMODE, EPI, WR, WC, TM, TN, ABL>;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr_set = true;
-    }
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     SGC_LAUNCH(kern, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(WR * WC * 64), LDS, stream, p);
     SGC_CHECK_LAUNCH();
     return SGC_OK;
 }
 
 
+#ifdef SGC_EXPERIMENTS
 // ---------------------------------------------------------------------------------------------------------------
 // 4-stage ring variant of the 256x256 block (BK = 32 per stage, 32 KiB per stage, 128 KiB LDS): global_load_lds for
 // stage kt+3 is issued while stage kt is being multiplied, a COUNTED s_waitcnt vmcnt leaves two stages in flight
@@ -450,16 +450,13 @@ static int launch_gemm_nt_ring(NtParams p, hipStream_t stream) {
     constexpr int LDS = 4 * 512 * 64;
     p.tiles_m = (p.M + 255) / 256;
     p.tiles_n = p.N / 256;
-    static bool attr_set = false;
     auto kern = gemm_nt_ring_kernel<ELEM, AMODE, EPI>;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr_set = true;
-    }
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     SGC_LAUNCH(kern, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(512), LDS, stream, p);
     SGC_CHECK_LAUNCH();
     return SGC_OK;
 }
+#endif  // SGC_EXPERIMENTS
 
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -592,20 +589,18 @@ static int launch_conv16_halo(NtParams p, hipStream_t stream) {
     constexpr int LDS = 2 * 328 * 128 + 2 * 256 * 128;
     p.tiles_m = p.M / 256;
     p.tiles_n = p.N / 256;
-    static bool attr_set = false;
     auto kern = conv16_halo_kernel<ELEM, EPI>;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr_set = true;
-    }
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     SGC_LAUNCH(kern, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(512), LDS, stream, p);
     SGC_CHECK_LAUNCH();
     return SGC_OK;
 }
 
 #include "gemm_nt_pp.h"
-#include "gemm_nt_w4.h"
+#ifdef SGC_EXPERIMENTS      // main-loop variants that were measured and rejected (profiles/README.md); SGC_EXPERIMENTS=1 builds them
+#include "gemm_nt_w4.h"     // for tools/gemm_microbench.py - they are not part of the product library
 #include "gemm_nt_pp1.h"
+#endif
 
 inline int sgc_gemm_pp() {        // SGC_GEMM_PP=0 falls back to the 2-stage 256x256 loops (A/B hook)
     static int v = -1;
@@ -638,7 +633,9 @@ static int launch_gemm_nt(NtParams p, hipStream_t stream) {
         }
     }
     const bool big = big_ok && (cfg == 2 || cfg == 3 || (cfg == 0 && (long)p.M * p.N >= 256L * 256 * 256));
+#ifdef SGC_EXPERIMENTS
     if (big && (cfg == 3 || (cfg == 0 && sgc_gemm_ring()))) return launch_gemm_nt_ring<ELEM, AMODE, EPI>(p, stream);
+#endif
     if constexpr (AMODE == AMODE_PLAIN) {
         if (big_ok && (cfg == 5 || (big && cfg == 0 && sgc_gemm_pp()))) return launch_gemm_nt_pp<ELEM, EPI>(p, stream);
     }

@@ -204,12 +204,8 @@ static int launch_gemm_nt_pp(NtParams p, hipStream_t stream) {
     constexpr int LDS = (EPI == EPI_STORE) ? EPI_LDS_BYTES : 8 * 16384;
     p.tiles_m = (p.M + 255) / 256;
     p.tiles_n = p.N / 256;
-    static bool attr_set = false;
     auto kern = gemm_nt_pp_kernel<ELEM, EPI, ABL>;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr_set = true;
-    }
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     // whole patches per XCD only pay once every XCD has several of them; small grids keep the even spread of the contiguous walk
     const int grid_aligned = xcd_patch_grid(p.tiles_m, p.tiles_n);
     static int al = -2;               // SGC_NT_ALIGNED=0/1 forces (A/B hook)
@@ -472,12 +468,8 @@ static int launch_conv16_halo_pp(NtParams p, hipStream_t stream) {
         if (hw == -2) { const char* e = getenv("SGC_HALO_WALK"); hw = e ? atoi(e) : -1; }
         p.halo_walk = hw >= 0 ? hw : ((long)p.K * 512 > (3L << 20) ? 1 : 0);
     }
-    static bool attr_set = false;
     auto kern = conv16_halo_pp_kernel<ELEM, EPI>;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr_set = true;
-    }
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     SGC_LAUNCH(kern, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(512), LDS, stream, p);
     SGC_CHECK_LAUNCH();
     return SGC_OK;

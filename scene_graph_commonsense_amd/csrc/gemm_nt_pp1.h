@@ -123,12 +123,8 @@ static int launch_gemm_nt_pp1(NtParams p, hipStream_t stream) {
     constexpr int LDS = (EPI == EPI_STORE) ? EPI_LDS_BYTES : 2 * 65536;
     p.tiles_m = (p.M + 255) / 256;
     p.tiles_n = p.N / 256;
-    static bool attr_set = false;
     auto kern = gemm_nt_pp1_kernel<ELEM, EPI>;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr_set = true;
-    }
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     SGC_LAUNCH(kern, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(512), LDS, stream, p);
     SGC_CHECK_LAUNCH();
     return SGC_OK;

@@ -144,12 +144,8 @@ static int launch_gemm_nt_w4(NtParams p, hipStream_t stream) {
     constexpr int LDS = 2 * 65536;
     p.tiles_m = (p.M + 255) / 256;
     p.tiles_n = p.N / 256;
-    static bool attr_set = false;
     auto kern = gemm_nt_w4_kernel<ELEM, EPI, SCHED>;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr_set = true;
-    }
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     SGC_LAUNCH(kern, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(256), LDS, stream, p);
     SGC_CHECK_LAUNCH();
     return SGC_OK;

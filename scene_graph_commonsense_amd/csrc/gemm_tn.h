@@ -190,12 +190,8 @@ static int launch_gemm_tn_cfg(TnParams p, int splits, int* slabs_out, hipStream_
     if (splits > nk) splits = nk;
     p.ktiles_per_split = (nk + splits - 1) / splits;
     splits = (nk + p.ktiles_per_split - 1) / p.ktiles_per_split;
-    static bool attr_set = false;
     auto kern = gemm_tn_kernel<ELEM, BMODE, ACONV, WR, WC, TM, TN>;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr_set = true;
-    }
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     p.splits = splits;
     {
         static int xm = -1;          // SGC_TN_XCD=0 disables the XCD-aware assignment of the 4 x 18 tile grid (A/B hook; measured -0.7 % time, 2.5x less fabric traffic)
@@ -376,12 +372,8 @@ static int launch_gemm_tn_pp(TnParams p, int splits, int* slabs_out, hipStream_t
     if (splits > nk) splits = nk;
     p.ktiles_per_split = (nk + splits - 1) / splits;
     splits = (nk + p.ktiles_per_split - 1) / p.ktiles_per_split;
-    static bool attr_set = false;
     auto kern = gemm_tn_pp_kernel<ELEM, BMODE, ACONV>;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr_set = true;
-    }
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     p.splits = splits;
     {
         static int xm = -1;

@@ -366,12 +366,8 @@ static int launch_gemm_tn_sp(TnParams p, const u16* Ac, const unsigned* Ic, int 
     if (splits > nk) splits = nk;
     p.ktiles_per_split = (nk + splits - 1) / splits;
     splits = (nk + p.ktiles_per_split - 1) / p.ktiles_per_split;
-    static bool attr_set = false;
     auto kern = gemm_tn_sp_kernel<0>;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr_set = true;
-    }
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     p.splits = splits;
     SGC_LAUNCH(kern, dim3((unsigned)(72 * splits)), dim3(512), LDS, stream, p, Ac, Ic);
     SGC_CHECK_LAUNCH();

@@ -662,14 +662,10 @@ int sgc_supcon_hierar(const float* F, const int* labels, int M, float temperatur
     if (M <= 0) return SGC_OK;
     const int n = 2 * M;
     if (n > 16384) return SGC_ERR_ARG;
-    static bool attr_set = false;
-    if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(supcon_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (512 + 16384) * 4);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(supcon_dfeat_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  16384 * 4);
-        attr_set = true;
-    }
+                              (512 + 16384) * 4);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(supcon_dfeat_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              16384 * 4);
     SGC_LAUNCH(supcon_rows_kernel, dim3(n), dim3(256), (512 + n) * 4, (hipStream_t)stream, F, labels, M, 1.f / temperature, G, loss_rows);
     SGC_CHECK_LAUNCH();
     SGC_LAUNCH(supcon_dfeat_kernel, dim3(n), dim3(256), n * 4, (hipStream_t)stream, F, G, n, grad_scale / temperature, dF);

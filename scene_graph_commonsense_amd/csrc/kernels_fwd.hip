@@ -377,13 +377,8 @@ int sgc_bayes_head(const float* p, const float* Wt, const float* bias, int n_pai
     if (n_pairs <= 0) return SGC_OK;
     HeadParams hp{p, Wt, bias, n_pairs, ng, np, ns, hier, 1.f / T1, 1.f / T2, 1.f / T3, rel, sup, conn, cand_conf,
                   cand_pred, iou_mask};
-    static bool attr_set = false;
     const int lds = (512 * 64 + 4 * 512) * 4;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bayes_head_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_set = true;
-    }
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bayes_head_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     int blocks = (n_pairs + 3) / 4;
     if (blocks > 256) blocks = 256;
     SGC_LAUNCH(bayes_head_kernel, dim3(blocks), dim3(256), lds, (hipStream_t)stream, hp);

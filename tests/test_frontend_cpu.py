@@ -97,3 +97,23 @@ def test_nms_hand_cases():
     # per-class: the same two boxes in different classes both survive
     c, f, b, keep = fo.per_class_nms(t([5, 3, 5]), t([0.9, 0.8, 0.7]), t([[0., 10, 0, 10], [0, 10, 0, 10], [1, 11, 1, 11]]), 0.5)
     assert c.tolist() == [3, 5] and keep.tolist() == [1, 0]
+
+
+def test_nms_oracle_against_independent_restatement_and_hand_vectors():
+    """the oracle's NMS pinned by a second restatement of torchvision 0.15.2's CPU kernel that shares no code
+    with it (tests/nms_cases.py) and by hand-derived vectors; then both on a randomised stress with integer-grid boxes (exact
+    threshold hits and score ties are frequent there)."""
+    from tests.nms_cases import HAND_CASES, nms_matrix
+    t = lambda x: torch.tensor(x, dtype=torch.float32)
+    for boxes, scores, thr, expect, why in HAND_CASES:
+        assert nms_matrix(boxes, scores, thr) == expect, ("independent", why)
+        assert fo.nms(t(boxes).reshape(-1, 4), t(scores), thr).tolist() == expect, ("oracle", why)
+    rng = np.random.default_rng(3)
+    for case in range(400):
+        n = int(rng.integers(1, 40))
+        xy = rng.integers(0, 12, (n, 2)).astype(np.float32)
+        wh = rng.integers(0, 7, (n, 2)).astype(np.float32)                 # zero sizes included
+        boxes = np.concatenate([xy, xy + wh], axis=1)
+        scores = (rng.integers(0, 8, n) / 8.0).astype(np.float32)          # many exact ties
+        thr = [0.25, 1.0 / 3.0, 0.5, 0.0, 0.75][case % 5]
+        assert fo.nms(torch.from_numpy(boxes), torch.from_numpy(scores), thr).tolist() == nms_matrix(boxes, scores, thr), case

@@ -159,3 +159,34 @@ def test_nms_and_matching_random_stress(seed):
     om, omc, otm = fo.match_object_categories([c.cpu() for c in cats], [c.cpu() for c in confs], [b.cpu() for b in bxs], tgt, stable_ties=True)
     for i in range(len(kept)):
         assert torch.equal(m[i].cpu(), torch.stack(om[i])) and torch.equal(mc[i].cpu(), torch.stack(omc[i])) and torch.equal(tm[i].cpu(), otm[i])
+
+
+def test_nms_kernel_on_hand_derived_vectors():
+    """The hand-derived NMS vectors of tests/nms_cases.py (threshold edges, ties, degenerate boxes, chains) through
+    ``sgc_nms_per_class``: one image, one class, one slot per query; kept slots come back highest score first."""
+    import ctypes
+    from scene_graph_commonsense_amd import _lib
+    from tests.nms_cases import HAND_CASES, nms_matrix
+    lib = _lib.load()
+    cases = list(HAND_CASES)
+    rng = np.random.default_rng(11)
+    for k in range(60):                                                    # plus integer-grid stress against the independent restatement
+        n = int(rng.integers(2, 60))
+        xy = rng.integers(0, 12, (n, 2)).astype(np.float32)
+        wh = rng.integers(0, 7, (n, 2)).astype(np.float32)
+        cases.append((np.concatenate([xy, xy + wh], axis=1).tolist(), (rng.integers(0, 8, n) / 8.0).astype(np.float32).tolist(),
+                      [0.25, 1.0 / 3.0, 0.5, 0.0][k % 4], None, "stress %d" % k))
+    for boxes, scores, thr, expect, why in cases:
+        b = torch.tensor(boxes, dtype=torch.float32).reshape(-1, 4)
+        n = b.shape[0]
+        if expect is None:
+            expect = nms_matrix(b.numpy(), scores, thr)
+        cat = torch.zeros(1, n, 1, dtype=torch.int32, device="cuda")
+        conf = torch.tensor(scores, dtype=torch.float32, device="cuda").view(1, n, 1)
+        box = b[:, [0, 2, 1, 3]].contiguous().cuda().view(1, n, 4)            # the kernel takes (x0, x1, y0, y1)
+        slot = torch.empty(1, n, dtype=torch.int32, device="cuda")
+        count = torch.empty(1, dtype=torch.int32, device="cuda")
+        _lib.check(lib.sgc_nms_per_class(_lib.ptr(cat), _lib.ptr(conf), _lib.ptr(box), 1, n, 1, ctypes.c_double(thr), _lib.ptr(slot),
+                                         _lib.ptr(count), _lib.stream_ptr()), "sgc_nms_per_class")
+        got = slot[0, :int(count[0])].tolist()
+        assert got == expect, (why, got, expect)

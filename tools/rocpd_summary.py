@@ -5,7 +5,7 @@ import sqlite3
 import sys
 
 
-def main(db_path, out_path=None, limit=40):
+def main(db_path, out_path=None, limit=90):
     cur = sqlite3.connect(db_path).cursor()
     rows = list(cur.execute("select name, total_calls, total_duration, average, percentage from top_kernels"))
     lines = ["# source: %s (rocprofv3 --kernel-trace --stats, rocpd top_kernels view; durations in ms)" % db_path,
