@@ -170,7 +170,7 @@ class RelHeadEngine:
         cfg, dev = self.cfg, self.device
         g = lambda k: sd[k].detach().to(dev, torch.float32)
         w = self.w
-        w1r = torch.zeros(2, 128, XC, dtype=torch.float16, device=dev)
+        w1r = self.ws.get("w1r", 2 * 128 * XC, torch.float16).view(2, 128, XC)     # created zeroed; the channel padding stays zero
         w1r[0, :, :257] = g("conv1_1.weight").view(128, 257).half()
         w1r[1, :, :257] = g("conv1_2.weight").view(128, 257).half()
         w["w1r"] = w1r
@@ -195,13 +195,14 @@ class RelHeadEngine:
         else:
             rows = [g("fc3.weight"), g("fc4.weight")]
             bias = [g("fc3.bias"), g("fc4.bias")]
-        Wc = torch.zeros(64, 512, device=dev)
-        bc = torch.zeros(64, device=dev)
+        Wc = self.ws.get("head_rows", 64 * 512, torch.float32).view(64, 512)         # created zeroed; rows beyond the head stay zero
+        bc = self.ws.get("head_bias", 64, torch.float32)
         rc = torch.cat(rows)
         Wc[:rc.shape[0]] = rc
         bc[:rc.shape[0]] = torch.cat(bias)
         w["head_wt"] = Wc.t().contiguous()
         w["head_b"] = bc
+        w["head_w"] = Wc                             # row-major copy for the head backward
         self.head_rows = rc.shape[0]
 
     # ------------------------------------------------------------------ helpers
@@ -397,10 +398,6 @@ class RelHeadEngine:
         c2 = g("conv2_1.weight")
         w["wd2"] = torch.stack([conv_k_layout(c2[:, r * 128:(r + 1) * 128].flip(2, 3).permute(1, 0, 2, 3))
                                 for r in (0, 1)]).to(torch.bfloat16).contiguous()
-        rows = self.head_rows
-        Wc = torch.zeros(64, 512, device=dev)
-        Wc[:rows] = w["head_wt"].t()[:rows]
-        w["head_w"] = Wc.contiguous()
 
 
     def _slab_sum(self, slabs, n, count):
@@ -521,41 +518,53 @@ class RelHeadEngine:
                                                  f(T[0]), f(T[1]), f(T[2]), f(scale), _lib.ptr(dl), _lib.ptr(dpre), st()),
                        "sgc_head_bwd_upstream")
             loss = None
-        chunk = max(16, (P + 255) // 256)
-        nb = (P + chunk - 1) // chunk
-        part = ws.get("head_part", nb * 64 * 513, torch.float32)
-        _lib.check(lib.sgc_head_wgrad(_lib.ptr(dl), _lib.ptr(ctx.p), _lib.ptr(part), P, chunk, st()), "sgc_head_wgrad")
-        hw = self._slab_sum(part, 64 * 513, nb).view(64, 513)
-        names = (["fc3_1", "fc3_2", "fc3_3", "fc5", "fc4"] if hier else ["fc3", "fc4"])
-        sizes = ([cfg.num_geometric, cfg.num_possessive, cfg.num_semantic, 3, 1] if hier else [R, 1])
-        r0 = 0
-        for nm, sz in zip(names, sizes):
-            grads[nm + ".weight"] = hw[r0:r0 + sz, :512].contiguous()
-            grads[nm + ".bias"] = hw[r0:r0 + sz, 512].contiguous()
-            r0 += sz
+        # The backward is two chains.  DATA gradients (fc2 -> fc1 -> un-pool -> conv3 -> pair contraction -> conv2 -> masks) run
+        # on the caller's stream: each feeds the next.  WEIGHT gradients (one GEMM per layer + slab sums / transposes / bias
+        # column sums) only have to be there when the optimizer runs, so they go to a side stream as soon as their two operands
+        # exist: the HBM-bound kernels of the data chain (un-pool + pack, pair contraction, converts) and the tails of its GEMMs
+        # then overlap with weight-gradient GEMM blocks instead of leaving the matrix cores idle.  ``side`` orders the side
+        # stream after everything enqueued so far; ``SGC_BWD_STREAMS=0`` keeps one stream (A/B hook, identical results).
+        side = self._side_chain()
+        sl = ws.get("slabs", 32 * 1024 * 4608, torch.float32)      # split-K slabs of the weight-gradient chain (largest user: conv3)
 
-        # ---- fc2
-        h1_bf = self._to_bf16("h1_bf", ctx.h1, Ppad * 4096)
-        sl = ws.get("slabs", 32 * 1024 * 4608, torch.float32)      # split-K slabs (largest user: conv3 wgrad)
-        self._timed("fc2_wgrad", lambda: _lib.check(lib.sgc_fc2_wgrad(_lib.ptr(dpre), _lib.ptr(h1_bf), _lib.ptr(sl), Ppad, 32, ctypes.byref(slabs_n), st()),
-                   "sgc_fc2_wgrad"))
-        gfc2 = torch.empty_like(w["fc2_full"])                       # every column is written: main block + label columns
-        ld2 = int(gfc2.shape[1])
-        _lib.check(lib.sgc_slab_sum_ld(_lib.ptr(sl), _lib.ptr(gfc2), 512, 4096, _c_long(ld2), slabs_n.value, st()), "sgc_slab_sum_ld")
-        dls = torch.empty(n_obj, 512, dtype=torch.float32, device=dev)
-        dlo = torch.empty(n_obj, 512, dtype=torch.float32, device=dev)
-        _lib.check(lib.sgc_segment_sum_rows(_lib.ptr(dpre), _lib.ptr(sub_csr[0]), _lib.ptr(sub_csr[1]), _lib.ptr(dls), n_obj, 512, st()),
-                   "sgc_segment_sum_rows")
-        _lib.check(lib.sgc_segment_sum_rows(_lib.ptr(dpre), _lib.ptr(obj_csr[0]), _lib.ptr(obj_csr[1]), _lib.ptr(dlo), n_obj, 512, st()),
-                   "sgc_segment_sum_rows")
-        use_mh = ctx.super_mh[0] is not None and cfg.dataset == "vg"
-        mh_s, mh_o = (ctx.super_mh if use_mh else (None, None))
-        cats_s, cats_o = (c if c.dtype == torch.int64 else c.long() for c in ctx.cats)
-        _lib.check(lib.sgc_label_grads(_lib.ptr(dls), _lib.ptr(dlo), _lib.ptr(cats_s), _lib.ptr(cats_o), _lib.ptr(mh_s), _lib.ptr(mh_o),
-                                       n_obj, cfg.num_classes, cfg.num_super_classes if use_mh else 0, _lib.ptr(gfc2), ld2, 4096, st()),
-                   "sgc_label_grads")
-        grads["fc2.weight"] = gfc2
-        grads["fc2.bias"] = self._colsum(dpre, Ppad, 512)
+        # ---- head weights
+        with side():
+            chunk = max(16, (P + 255) // 256)
+            nb = (P + chunk - 1) // chunk
+            part = ws.get("head_part", nb * 64 * 513, torch.float32)
+            _lib.check(lib.sgc_head_wgrad(_lib.ptr(dl), _lib.ptr(ctx.p), _lib.ptr(part), P, chunk, st()), "sgc_head_wgrad")
+            hw = self._slab_sum(part, 64 * 513, nb).view(64, 513)
+            names = (["fc3_1", "fc3_2", "fc3_3", "fc5", "fc4"] if hier else ["fc3", "fc4"])
+            sizes = ([cfg.num_geometric, cfg.num_possessive, cfg.num_semantic, 3, 1] if hier else [R, 1])
+            r0 = 0
+            for nm, sz in zip(names, sizes):
+                grads[nm + ".weight"] = hw[r0:r0 + sz, :512].contiguous()
+                grads[nm + ".bias"] = hw[r0:r0 + sz, 512].contiguous()
+                r0 += sz
+
+            # ---- fc2 weights: main block (split-K GEMM) + label columns (per-object row sums scattered by label)
+            h1_bf = self._to_bf16("h1_bf", ctx.h1, Ppad * 4096)
+            self._timed("fc2_wgrad", lambda: _lib.check(lib.sgc_fc2_wgrad(_lib.ptr(dpre), _lib.ptr(h1_bf), _lib.ptr(sl), Ppad, 32, ctypes.byref(slabs_n), st()),
+                       "sgc_fc2_wgrad"))
+            gfc2 = torch.empty_like(w["fc2_full"])                       # every column is written: main block + label columns
+            ld2 = int(gfc2.shape[1])
+            _lib.check(lib.sgc_slab_sum_ld(_lib.ptr(sl), _lib.ptr(gfc2), 512, 4096, _c_long(ld2), slabs_n.value, st()), "sgc_slab_sum_ld")
+            dls = torch.empty(n_obj, 512, dtype=torch.float32, device=dev)
+            dlo = torch.empty(n_obj, 512, dtype=torch.float32, device=dev)
+            _lib.check(lib.sgc_segment_sum_rows(_lib.ptr(dpre), _lib.ptr(sub_csr[0]), _lib.ptr(sub_csr[1]), _lib.ptr(dls), n_obj, 512, st()),
+                       "sgc_segment_sum_rows")
+            _lib.check(lib.sgc_segment_sum_rows(_lib.ptr(dpre), _lib.ptr(obj_csr[0]), _lib.ptr(obj_csr[1]), _lib.ptr(dlo), n_obj, 512, st()),
+                       "sgc_segment_sum_rows")
+            use_mh = ctx.super_mh[0] is not None and cfg.dataset == "vg"
+            mh_s, mh_o = (ctx.super_mh if use_mh else (None, None))
+            cats_s, cats_o = (c if c.dtype == torch.int64 else c.long() for c in ctx.cats)
+            _lib.check(lib.sgc_label_grads(_lib.ptr(dls), _lib.ptr(dlo), _lib.ptr(cats_s), _lib.ptr(cats_o), _lib.ptr(mh_s), _lib.ptr(mh_o),
+                                           n_obj, cfg.num_classes, cfg.num_super_classes if use_mh else 0, _lib.ptr(gfc2), ld2, 4096, st()),
+                       "sgc_label_grads")
+            grads["fc2.weight"] = gfc2
+            grads["fc2.bias"] = self._colsum(dpre, Ppad, 512)
+
+        # ---- fc2 data gradient
         dh1 = ws.get("dh1", Ppad * 4096, torch.bfloat16)
         if Ppad > P:
             Workspace._zero(dh1[P * 4096:])
@@ -563,17 +572,18 @@ class RelHeadEngine:
                    "sgc_fc2_dgrad"))
 
         # ---- fc1
-        y_bf = ctx.y_bf
-        dW1p = ws.get("dW1p", 4096 * 65536, torch.float32)
-        self._timed("fc1_wgrad", lambda: _lib.check(lib.sgc_fc1_wgrad(_lib.ptr(dh1), _lib.ptr(y_bf), _lib.ptr(dW1p), Ppad, 65536, st()), "sgc_fc1_wgrad"))
-        # back to the reference column order (c*64 + window): 64x64 tile transposes, f32 -> f32
-        gfc1 = torch.empty(4096, 65536, dtype=torch.float32, device=dev)
-        _lib.check(lib.sgc_transpose_cast(_lib.ptr(dW1p), _lib.ptr(gfc1), 2, 4096, 16, _c_long(65536), _c_long(64), _c_long(1024),
-                                          _c_long(65536), _c_long(4096), _c_long(64), st()), "sgc_transpose_cast")
-        grads["fc1.weight"] = gfc1
-        if grad_hook is not None:          # largest gradient (97 % of the bytes) is ready first: overlap its all-reduce
-            grad_hook("fc1.weight", grads["fc1.weight"])
-        grads["fc1.bias"] = self._colsum(dh1, Ppad, 4096)
+        with side():
+            y_bf = ctx.y_bf
+            dW1p = ws.get("dW1p", 4096 * 65536, torch.float32)
+            self._timed("fc1_wgrad", lambda: _lib.check(lib.sgc_fc1_wgrad(_lib.ptr(dh1), _lib.ptr(y_bf), _lib.ptr(dW1p), Ppad, 65536, st()), "sgc_fc1_wgrad"))
+            # back to the reference column order (c*64 + window): 64x64 tile transposes, f32 -> f32
+            gfc1 = torch.empty(4096, 65536, dtype=torch.float32, device=dev)
+            _lib.check(lib.sgc_transpose_cast(_lib.ptr(dW1p), _lib.ptr(gfc1), 2, 4096, 16, _c_long(65536), _c_long(64), _c_long(1024),
+                                              _c_long(65536), _c_long(4096), _c_long(64), st()), "sgc_transpose_cast")
+            grads["fc1.weight"] = gfc1
+            if grad_hook is not None:          # largest gradient (97 % of the bytes) is ready first: overlap its all-reduce
+                grad_hook("fc1.weight", grads["fc1.weight"])
+            grads["fc1.bias"] = self._colsum(dh1, Ppad, 4096)
         dy = ws.get("dy", Ppad * 65536, torch.bfloat16)
         self._timed("fc1_dgrad", lambda: _lib.check(lib.sgc_fc1_dgrad(_lib.ptr(dh1), _lib.ptr(w["w1pT"]), _lib.ptr(dy), P, 65536, st()), "sgc_fc1_dgrad"))
 
@@ -594,55 +604,100 @@ class RelHeadEngine:
         else:
             self._timed("unpool", lambda: _lib.check(lib.sgc_unpool_relu_bwd(_lib.ptr(dy), _lib.ptr(ctx.am), _lib.ptr(dy3), _lib.ptr(bpart), ctypes.byref(nparts), P, st()),
                        "sgc_unpool_relu_bwd"))
-        grads["conv3_1.bias"] = self._slab_sum(bpart, 1024, nparts.value)
-        if sparse_w3:
-            self._timed("conv3_wgrad", lambda: _lib.check(lib.sgc_conv3_wgrad_sparse(
-                None, None, _lib.ptr(z_bf), _lib.ptr(pack_a), _lib.ptr(pack_i), _lib.ptr(sl), P, 0,
-                ctypes.byref(slabs_n), st()), "sgc_conv3_wgrad_sparse"))
-        else:
-            self._timed("conv3_wgrad", lambda: _lib.check(lib.sgc_conv3_wgrad(_lib.ptr(dy3), _lib.ptr(z_bf), _lib.ptr(sl), P, 0, ctypes.byref(slabs_n), st()),
-                       "sgc_conv3_wgrad"))
-        dW3r = self._slab_sum(sl, 1024 * 4608, slabs_n.value)
-        grads["conv3_1.weight"] = dW3r.view(1024, 3, 3, 512).permute(0, 3, 1, 2).contiguous()
+        n_b3 = nparts.value
+        with side():
+            grads["conv3_1.bias"] = self._slab_sum(bpart, 1024, n_b3)
+            if sparse_w3:
+                self._timed("conv3_wgrad", lambda: _lib.check(lib.sgc_conv3_wgrad_sparse(
+                    None, None, _lib.ptr(z_bf), _lib.ptr(pack_a), _lib.ptr(pack_i), _lib.ptr(sl), P, 0,
+                    ctypes.byref(slabs_n), st()), "sgc_conv3_wgrad_sparse"))
+            else:
+                self._timed("conv3_wgrad", lambda: _lib.check(lib.sgc_conv3_wgrad(_lib.ptr(dy3), _lib.ptr(z_bf), _lib.ptr(sl), P, 0, ctypes.byref(slabs_n), st()),
+                           "sgc_conv3_wgrad"))
+            dW3r = self._slab_sum(sl, 1024 * 4608, slabs_n.value)
+            grads["conv3_1.weight"] = dW3r.view(1024, 3, 3, 512).permute(0, 3, 1, 2).contiguous()
         dz = ws.get("dz", P * 256 * 512, torch.bfloat16)
         self._timed("conv3_dgrad", lambda: _lib.check(lib.sgc_conv3_dgrad(_lib.ptr(dy3), _lib.ptr(w["wd3"]), _lib.ptr(dz), P, st()), "sgc_conv3_dgrad"))
 
-        # ---- pair contraction + conv2 + masks + conv1
+        # ---- pair contraction + conv2 + masks + conv1 (per-role buffers: the side stream may still read role 0's while role 1 runs)
         gc2 = torch.empty(512, 256, 3, 3, dtype=torch.float32, device=dev)
-        x_bf = self._to_bf16("x_bf", ctx.x[0], n_img * 1024 * XC)
         for r, csr in ((0, sub_csr), (1, obj_csr)):
-            if r == 1 and ctx.x[1] is not ctx.x[0]:
-                x_bf = self._to_bf16("x_bf", ctx.x[1], n_img * 1024 * XC)
             dU = ws.get("dU_pad_%d" % r, n_obj * 34 * 34 * 512, torch.bfloat16)
             self._timed("contract", lambda: _lib.check(lib.sgc_pair_contract(_lib.ptr(dz), _lib.ptr(ctx.amz), _lib.ptr(csr[0]), _lib.ptr(csr[1]), _lib.ptr(dU), n_obj, st()),
                        "sgc_pair_contract"))
-            a_pad = self.ws.get("a_pad_%d" % r, n_obj * 34 * 34 * 128, torch.float16)      # kept by the forward
-            a_bf = self._to_bf16("a_pad_bf", a_pad, n_obj * 34 * 34 * 128)
-            self._timed("conv2_wgrad", lambda: _lib.check(lib.sgc_conv2_wgrad(_lib.ptr(dU), _lib.ptr(a_bf), _lib.ptr(sl), n_obj, 0, ctypes.byref(slabs_n), st()),
-                       "sgc_conv2_wgrad"))
-            dW2r = self._slab_sum(sl, 512 * 1152, slabs_n.value)
-            gc2[:, r * 128:(r + 1) * 128] = dW2r.view(512, 3, 3, 128).permute(0, 3, 1, 2)
-            if r == 1:
-                grads["conv2_1.bias"] = self._colsum(dU, n_obj * 34 * 34, 512)
+            with side():
+                a_pad = self.ws.get("a_pad_%d" % r, n_obj * 34 * 34 * 128, torch.float16)      # kept by the forward
+                a_bf = self._to_bf16("a_pad_bf", a_pad, n_obj * 34 * 34 * 128)
+                self._timed("conv2_wgrad", lambda: _lib.check(lib.sgc_conv2_wgrad(_lib.ptr(dU), _lib.ptr(a_bf), _lib.ptr(sl), n_obj, 0, ctypes.byref(slabs_n), st()),
+                           "sgc_conv2_wgrad"))
+                dW2r = self._slab_sum(sl, 512 * 1152, slabs_n.value)
+                gc2[:, r * 128:(r + 1) * 128] = dW2r.view(512, 3, 3, 128).permute(0, 3, 1, 2)
+                if r == 1:
+                    grads["conv2_1.bias"] = self._colsum(dU, n_obj * 34 * 34, 512)
             da = ws.get("da", n_obj * 1024 * 128, torch.bfloat16)
             self._timed("conv2_dgrad", lambda: _lib.check(lib.sgc_conv2_dgrad(_lib.ptr(dU), _lib.ptr(w["wd2"][r]), _lib.ptr(da), n_obj, st()), "sgc_conv2_dgrad"))
             dA = ws.get("dA", n_img * 1024 * 128, torch.float32)
-            cpart = ws.get("dcst_part", n_img * 64 * 128, torch.float32)
+            cpart = ws.get("dcst_part_%d" % r, n_img * 64 * 128, torch.float32)
             _lib.check(lib.sgc_object_masked_maps_bwd(_lib.ptr(da), _lib.ptr(img_ptr), _lib.ptr(ctx.bbox), _lib.ptr(dA), _lib.ptr(cpart),
                                                       ctypes.byref(nparts), n_img, 32, 128, st()), "sgc_object_masked_maps_bwd")
-            dcst = self._slab_sum(cpart, 128, nparts.value)
-            dp1 = ws.get("dpre1", n_img * 1024 * 128, torch.bfloat16)
+            n_cst = nparts.value
+            dp1 = ws.get("dpre1_%d" % r, n_img * 1024 * 128, torch.bfloat16)
             _lib.check(lib.sgc_tanh_bwd(_lib.ptr(dA), _lib.ptr(ctx.a_img[r]), _lib.ptr(dp1), _c_long(n_img * 1024 * 128), st()),
                        "sgc_tanh_bwd")
-            _lib.check(lib.sgc_conv1_wgrad(_lib.ptr(dp1), _lib.ptr(x_bf), _lib.ptr(sl), n_img * 1024, XC, 16, ctypes.byref(slabs_n), st()),
-                       "sgc_conv1_wgrad")
-            dW1 = self._slab_sum(sl, 128 * XC, slabs_n.value).view(128, XC)
-            nm = "conv1_%d" % (r + 1)
-            grads[nm + ".weight"] = dW1[:, :257].reshape(128, 257, 1, 1).contiguous()
-            tb = torch.tanh(w["b1"][r])
-            grads[nm + ".bias"] = self._colsum(dp1, n_img * 1024, 128) + dcst * (1 - tb * tb)
-        grads["conv2_1.weight"] = gc2
+            with side():
+                x_bf = self._to_bf16("x_bf", ctx.x[r], n_img * 1024 * XC)
+                _lib.check(lib.sgc_conv1_wgrad(_lib.ptr(dp1), _lib.ptr(x_bf), _lib.ptr(sl), n_img * 1024, XC, 16, ctypes.byref(slabs_n), st()),
+                           "sgc_conv1_wgrad")
+                dW1 = self._slab_sum(sl, 128 * XC, slabs_n.value).view(128, XC)
+                nm = "conv1_%d" % (r + 1)
+                grads[nm + ".weight"] = dW1[:, :257].reshape(128, 257, 1, 1).contiguous()
+                tb = torch.tanh(w["b1"][r])
+                dcst = self._slab_sum(cpart, 128, n_cst)
+                grads[nm + ".bias"] = self._colsum(dp1, n_img * 1024, 128) + dcst * (1 - tb * tb)
+        with side():
+            grads["conv2_1.weight"] = gc2
+        side.join()                              # the caller's stream continues only after every gradient is complete
         return loss, grads
+
+    # ------------------------------------------------------------------ two-stream backward
+    def _side_chain(self):
+        """Callable context manager that runs its body on this device's side stream, ordered after everything enqueued on the
+        caller's stream so far; ``join()`` orders the caller's stream after the side stream.  With ``SGC_BWD_STREAMS=0`` both
+        are no-ops."""
+        import contextlib
+        eng = self
+        enabled = os.environ.get("SGC_BWD_STREAMS", "1") != "0"
+
+        class Chain:
+            def __init__(self):
+                self.main = torch.cuda.current_stream(eng.device)
+                if enabled:
+                    if RelHeadEngine._side_streams.get(eng.device) is None:
+                        RelHeadEngine._side_streams[eng.device] = torch.cuda.Stream(device=eng.device)
+                    self.side = RelHeadEngine._side_streams[eng.device]
+                    ev = torch.cuda.Event()
+                    ev.record(self.main)
+                    self.side.wait_event(ev)         # the side stream's previous work may not overtake buffers reused by this step
+
+            @contextlib.contextmanager
+            def __call__(self):
+                if not enabled:
+                    yield
+                    return
+                ev = torch.cuda.Event()
+                ev.record(self.main)
+                self.side.wait_event(ev)
+                with torch.cuda.stream(self.side):
+                    yield
+
+            def join(self):
+                if enabled:
+                    ev = torch.cuda.Event()
+                    ev.record(self.side)
+                    self.main.wait_event(ev)
+        return Chain()
+
+    _side_streams: Dict = {}
 
 
     def commonsense_coefficients(self, ctx: "TrainContext", bitmaps, step: torch.Tensor, n_steps: int, scat: torch.Tensor,
