@@ -127,14 +127,25 @@ __global__ __launch_bounds__(512) void pair_expand_dense_kernel(const u16* __res
     const int Y = W >> 4, X = W & 15;
     const long zoff = ((long)(Y + 1) * 18 + X + 1) * 512 + lane * 8;
     const long aoff = (long)W * 256 + lane * 4;
+    // the U quad of the wave's NEXT subject is requested before the current one is expanded: the 16-object store loop covers its latency
+    uint4 unext[4];
+    if (wid < n) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            unext[q] = *reinterpret_cast<const uint4*>(U + ((long)(o0 + wid) * 1024 + 4 * W + q) * 512 + lane * 8);
+    }
     for (int i = wid; i < n; i += 8) {
         float uf[4][8];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const uint4 a = *reinterpret_cast<const uint4*>(U + ((long)(o0 + i) * 1024 + 4 * W + q) * 512 + lane * 8);
-            const u16* ah = reinterpret_cast<const u16*>(&a);
+            const u16* ah = reinterpret_cast<const u16*>(&unext[q]);
 #pragma unroll
             for (int k = 0; k < 8; ++k) uf[q][k] = f16_bits_to_f32(ah[k]);
+        }
+        if (i + 8 < n) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                unext[q] = *reinterpret_cast<const uint4*>(U + ((long)(o0 + i + 8) * 1024 + 4 * W + q) * 512 + lane * 8);
         }
         const int* prow = pid + (long)(o0 + i) * pid_ld + j0;
         for (int jj = 0; jj < nj; ++jj) {
