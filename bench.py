@@ -30,7 +30,7 @@ sys.path.insert(0, REPO)
 MFMA_PEAK_TFLOPS = 2500.0      # dense bf16/f16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
 DOMINANT_KERNEL = "conv16_halo_pp_kernel<0, 3>"      # conv3 forward: f16, halo-staged implicit 3x3 conv, ReLU + max-pool epilogue
-PMC_TAGS = ("r02_final", "r01_final")                # newest committed counter passes first
+PMC_TAGS = ("r02_final", "r02_mid", "r01_final")                # newest committed counter passes first
 
 
 def parse_args(argv=None):

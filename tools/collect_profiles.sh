@@ -20,4 +20,8 @@ python3 "$R/tools/pmc_summary.py" "$(find /tmp/prof_w -name '*counter_collection
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_VALU_MFMA_MOPS_BF16 \
     -d /tmp/prof_s -o s --output-format csv -- python3 "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline > /tmp/s.log 2>&1
 python3 "$R/tools/pmc_summary.py" "$(find /tmp/prof_s -name '*counter_collection.csv' | head -1)" "$OUT/${TAG}_pmc_s.csv"
+# MFMA-busy cycles in their own pass (SQ_VALU_MFMA_BUSY_CYCLES counts cycles, = 32 x N_mfma for the 32x32x16 instructions)
+rm -rf /tmp/prof_m
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE -d /tmp/prof_m -o m --output-format csv -- python3 "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline > /tmp/m.log 2>&1
+python3 "$R/tools/pmc_summary.py" "$(find /tmp/prof_m -name '*counter_collection.csv' | head -1)" "$OUT/${TAG}_pmc_m.csv"
 ls -la "$OUT"/${TAG}_*
