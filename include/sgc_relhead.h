@@ -73,6 +73,16 @@ int sgc_bayes_head(const float* p, const float* Wt, const float* bias, int n_pai
  * indices (-1 padded), out_count [n_img]. */
 int sgc_topk_per_image(const float* conf, const int* seg_ptr, int n_img, int K, int* out_idx, int* out_count, void* stream);
 
+/* Recall@K hit test (evaluator.py:306-356; Evaluator_Top3 :720-760 with n_pred = 3): for each of n_targets connected ground-truth
+ * triples (t_row = row of its image in keep_pos; t_rel / t_scat / t_ocat int64; boxes f32 (x0,x1,y0,y1), int() truncation and slice
+ * clipping applied inside) the rank of the first of the image's ranked candidates (keep_pos [n_img][K] flat positions, keep_cnt
+ * [n_img]) whose labels match (equiv: optional n_equiv x n_equiv u8 equivalence table of utils.compare_object_cat, SGDET/SGCLS),
+ * both rasterised-grid IoUs are >= iou_thresh and one of its n_pred predicates equals t_rel; K when there is none. */
+int sgc_recall_hits(const long* c_scat, const long* c_ocat, const long* c_pred, int n_pred, const float* c_sbox, const float* c_obox,
+                    const int* keep_pos, const int* keep_cnt, int K, const int* t_row, const long* t_rel, const long* t_scat,
+                    const long* t_ocat, const float* t_sbox, const float* t_obox, int n_targets, const unsigned char* equiv, int n_equiv,
+                    int feature_size, double iou_thresh, int* hit, void* stream);
+
 /* "iou_mask" of testing(): the two boxes overlap on the FxF grid   (train_test.py:403-408).  bbox [n_obj][4], out u8 [n_pairs]. */
 int sgc_overlap_filter(const int* bbox, const int* sub_idx, const int* obj_idx, unsigned char* out, int n_pairs, void* stream);
 

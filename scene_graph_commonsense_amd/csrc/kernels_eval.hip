@@ -146,7 +146,80 @@ __global__ void commonsense_flags_kernel(const long* __restrict__ scat, const lo
     strong[i] = in_no ? 1.f : 0.f;
 }
 
+// Recall@K hit test (reference evaluator.py:306-356, Top-3 variant :720-760): for every connected ground-truth triple, the rank
+// j of the first of its image's K ranked candidates with matching subject / object labels, both grid IoUs >= the threshold AND a
+// matching predicate (a candidate whose labels and boxes match but whose predicate differs does not end the scan), or K.
+// One wavefront per triple: lane l tests candidates l, l+64, ...; a ballot gives the first matching rank.
+struct RecallParams {
+    const long* c_scat; const long* c_ocat; const long* c_pred;      // candidates (flat); c_pred [n][n_pred]
+    const float* c_sbox; const float* c_obox;                         // [n][4] (x0,x1,y0,y1) as stored (int() truncation applied here)
+    const int* keep_pos; const int* keep_cnt;                         // [n_img][K] flat candidate positions in ranked order, [n_img]
+    const int* t_row; const long* t_rel; const long* t_scat; const long* t_ocat; const float* t_sbox; const float* t_obox;
+    const unsigned char* equiv; int n_equiv;                          // label equivalence table (SGDET/SGCLS, utils.py:355-373) or NULL
+    int n_t, K, n_pred, F; double iou_thresh;
+    int* hit;
+};
+
+__device__ __forceinline__ int slice_clip(float v, int F) {           // int(v) then Python slice clipping on an axis of length F
+    int i = (int)v;
+    return i < 0 ? max(i + F, 0) : min(i, F);
+}
+__device__ __forceinline__ bool grid_iou_ok(const float* a, const float* b, int F, double thr) {
+    const int ax0 = slice_clip(a[0], F), ax1 = slice_clip(a[1], F), ay0 = slice_clip(a[2], F), ay1 = slice_clip(a[3], F);
+    const int bx0 = slice_clip(b[0], F), bx1 = slice_clip(b[1], F), by0 = slice_clip(b[2], F), by1 = slice_clip(b[3], F);
+    const int aa = max(ax1 - ax0, 0) * max(ay1 - ay0, 0), ab = max(bx1 - bx0, 0) * max(by1 - by0, 0);
+    int inter = max(min(ax1, bx1) - max(ax0, bx0), 0) * max(min(ay1, by1) - max(ay0, by0), 0);
+    if (aa <= 0 || ab <= 0) inter = 0;
+    const int uni = aa + ab - inter;
+    const double iou = uni > 0 ? (double)inter / (double)uni : 0.0;
+    return iou >= thr;
+}
+
+__global__ __launch_bounds__(256) void recall_hits_kernel(const RecallParams p) {
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= p.n_t) return;
+    const int row = p.t_row[t], cnt = p.keep_cnt[row];
+    const long rel = p.t_rel[t], sc = p.t_scat[t], oc = p.t_ocat[t];
+    int hit = p.K;
+    for (int j0 = 0; j0 < cnt; j0 += 64) {
+        const int j = j0 + lane;
+        bool ok = false;
+        if (j < cnt) {
+            const long c = p.keep_pos[(long)row * p.K + j];
+            const long cs = p.c_scat[c], co = p.c_ocat[c];
+            bool label = (cs == sc) && (co == oc);
+            if (p.equiv && !label) {
+                const bool in = sc >= 0 && sc < p.n_equiv && oc >= 0 && oc < p.n_equiv && cs >= 0 && cs < p.n_equiv && co >= 0 && co < p.n_equiv;
+                label = in && p.equiv[sc * p.n_equiv + cs] && p.equiv[oc * p.n_equiv + co];
+            }
+            if (label) {
+                bool pred = false;
+                for (int k = 0; k < p.n_pred; ++k) pred |= p.c_pred[c * p.n_pred + k] == rel;
+                ok = pred && grid_iou_ok(p.t_sbox + 4L * t, p.c_sbox + 4 * c, p.F, p.iou_thresh) &&
+                     grid_iou_ok(p.t_obox + 4L * t, p.c_obox + 4 * c, p.F, p.iou_thresh);
+            }
+        }
+        const unsigned long long m = __ballot(ok);
+        if (m) { hit = j0 + __ffsll((long long)m) - 1; break; }
+    }
+    if (lane == 0) p.hit[t] = hit;
+}
+
 extern "C" {
+
+int sgc_recall_hits(const long* c_scat, const long* c_ocat, const long* c_pred, int n_pred, const float* c_sbox, const float* c_obox,
+                    const int* keep_pos, const int* keep_cnt, int K, const int* t_row, const long* t_rel, const long* t_scat,
+                    const long* t_ocat, const float* t_sbox, const float* t_obox, int n_targets, const unsigned char* equiv, int n_equiv,
+                    int feature_size, double iou_thresh, int* hit, void* stream) {
+    if (n_targets <= 0) return SGC_OK;
+    if (n_pred < 1 || K < 1) return SGC_ERR_ARG;
+    RecallParams p{c_scat, c_ocat, c_pred, c_sbox, c_obox, keep_pos, keep_cnt, t_row, t_rel, t_scat, t_ocat, t_sbox, t_obox, equiv, n_equiv,
+                   n_targets, K, n_pred, feature_size, iou_thresh, hit};
+    SGC_LAUNCH(recall_hits_kernel, dim3((n_targets + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
+    SGC_CHECK_LAUNCH();
+    return SGC_OK;
+}
 
 int sgc_commonsense_flags(const long* scat, const long* ocat, const int* cand_pred, int n_pairs, int n_cand, const unsigned* aligned,
                           const unsigned* violated, int C, int R, float* weak, float* strong, void* stream) {

@@ -94,6 +94,51 @@ def first_hit(label_ok: np.ndarray, iou_ok: np.ndarray, pred_ok: np.ndarray) -> 
     return np.where(ok.any(1), ok.argmax(1), K)
 
 
+def rank_topk_device(conf: torch.Tensor, which: torch.Tensor, K: int):
+    """``rank_topk`` without the host copies: (images [n_img] sorted, keep_pos [n_img,K] int32 flat candidate positions in ranked
+    order (-1 padded), keep_cnt [n_img] int32, top [n_img,K] image-local indices, seg [n_img+1], order)."""
+    if not conf.is_cuda:
+        raise RuntimeError("Evaluator ranking runs on the GPU (sgc_topk_per_image); move the evaluator inputs to cuda")
+    lib = _lib.load()
+    images, counts = torch.unique(which, return_counts=True)
+    order = torch.sort(which, stable=True)[1]                       # grouped by image, append order kept
+    conf_g = conf[order].contiguous().float()
+    seg = torch.zeros(len(images) + 1, dtype=torch.int32, device=conf.device)
+    seg[1:] = torch.cumsum(counts, 0).int()
+    top = torch.empty(len(images), K, dtype=torch.int32, device=conf.device)
+    cnt = torch.empty(len(images), dtype=torch.int32, device=conf.device)
+    _lib.check(lib.sgc_topk_per_image(_lib.ptr(conf_g), _lib.ptr(seg), len(images), K, _lib.ptr(top), _lib.ptr(cnt),
+                                      _lib.stream_ptr()), "sgc_topk_per_image")
+    flat = (seg[:-1, None].long() + top.clamp(min=0).long()).clamp(max=max(int(order.numel()) - 1, 0))
+    keep_pos = torch.where(top >= 0, order[flat], torch.full_like(flat, -1)).int().contiguous()
+    return images, keep_pos, cnt, top, seg, order
+
+
+def recall_hits(cand, keep_pos, keep_cnt, targets, K, feature_size, iou_thresh, equiv=None):
+    """Device hit test (``sgc_recall_hits``).  ``cand`` = dict(scat, ocat int64 [n]; pred int64 [n] or [n,3]; sbox, obox [n,4]),
+    ``targets`` = dict(row int32, rel / scat / ocat int64, sbox / obox [t,4]) of the connected ground-truth triples.  Returns the
+    hit ranks as a host int array [t] (K = no hit)."""
+    lib = _lib.load()
+    dev = keep_pos.device
+    n_t = int(targets["rel"].shape[0])
+    if n_t == 0:
+        return np.zeros(0, dtype=np.int32)
+    i64 = lambda x: x.to(dev, torch.int64).contiguous()
+    f32 = lambda x: x.to(dev, torch.float32).contiguous().view(-1, 4)
+    pred = i64(cand["pred"])
+    n_pred = 1 if pred.dim() == 1 else int(pred.shape[1])
+    hit = torch.empty(n_t, dtype=torch.int32, device=dev)
+    c_s, c_o, c_sb, c_ob = i64(cand["scat"]), i64(cand["ocat"]), f32(cand["sbox"]), f32(cand["obox"])
+    t_row, t_rel, t_s, t_o = targets["row"].to(dev, torch.int32).contiguous(), i64(targets["rel"]), i64(targets["scat"]), i64(targets["ocat"])
+    t_sb, t_ob = f32(targets["sbox"]), f32(targets["obox"])
+    eq = None if equiv is None else equiv.to(dev, torch.uint8).contiguous()
+    _lib.check(lib.sgc_recall_hits(_lib.ptr(c_s), _lib.ptr(c_o), _lib.ptr(pred), n_pred, _lib.ptr(c_sb), _lib.ptr(c_ob), _lib.ptr(keep_pos),
+                                   _lib.ptr(keep_cnt), int(K), _lib.ptr(t_row), _lib.ptr(t_rel), _lib.ptr(t_s), _lib.ptr(t_o), _lib.ptr(t_sb),
+                                   _lib.ptr(t_ob), n_t, _lib.ptr(eq), 0 if eq is None else int(eq.shape[0]), int(feature_size),
+                                   ctypes.c_double(float(iou_thresh)), _lib.ptr(hit), _lib.stream_ptr()), "sgc_recall_hits")
+    return hit.cpu().numpy()
+
+
 class Evaluator:
     def __init__(self, args, num_classes, iou_thresh, top_k, max_cache_size=10000):
         self.args = args
@@ -267,49 +312,58 @@ class Evaluator:
 
     # ------------------------------------------------------------------ compute
     def compute(self, per_class=False, predcls=True):
+        """Recall@K / mR@K / zero-shot recall (``evaluator.py:280-367``).  Ranking (``sgc_topk_per_image``) and the hit test
+        (``sgc_recall_hits``: one wavefront per ground-truth triple) run on the device; only the connected ground-truth triples
+        and their hit ranks come back to the host for the counters and the zero-shot key lookup."""
         if self._cat("conf") is not None:
             conf = self._cat("conf")
             conf += self._cat("conn")                         # reference mutates its state the same way
             which = self._cat("which")
-            images, order, seg, top, cnt = rank_topk(conf, which, self.top_k[-1])
-            h = {k: self._cat(k).cpu().numpy() for k in ("pred", "scat", "ocat", "sbox", "obox")}
+            K = self.top_k[-1]
+            images, keep_pos, keep_cnt, top, _, _ = rank_topk_device(conf, which, K)
+            dev = conf.device
+            top_h, cnt_h, images_h = top.cpu().numpy(), keep_cnt.cpu().numpy(), images.cpu().numpy()
+            for r, image in enumerate(images_h):
+                self.last_topk[int(image)] = top_h[r, :cnt_h[r]].copy()
             if self._targets_by_image is None:
-                t = {k: self._cat(k).cpu().numpy() for k in ("which_t", "rel_t", "scat_t", "ocat_t", "sbox_t", "obox_t")}
-            F = self.feature_size
-            for r, image in enumerate(images):
-                pos = order[seg[r]:seg[r + 1]]                 # flat positions of this image's candidates
-                keep = pos[top[r, :cnt[r]]]
-                self.last_topk[int(image)] = top[r, :cnt[r]].copy()
-                if self._targets_by_image is None:
-                    sel = t["which_t"] == image
-                    rel_t, scat_t, ocat_t = t["rel_t"][sel], t["scat_t"][sel], t["ocat_t"][sel]
-                    sbox_t, obox_t = t["sbox_t"][sel], t["obox_t"][sel]
-                else:
-                    tb = self._targets_by_image
+                rel_all = self._cat("rel_t")
+                sel = torch.nonzero(rel_all != -1).flatten()
+                wt = self._cat("which_t")[sel]
+                row = torch.searchsorted(images, wt)
+                known = images[row.clamp(max=len(images) - 1)] == wt              # targets of images without any candidate are not scanned
+                sel, row = sel[known], row[known]
+                tg = dict(row=row.int(), rel=rel_all[sel], scat=self._cat("scat_t")[sel], ocat=self._cat("ocat_t")[sel],
+                          sbox=self._cat("sbox_t")[sel], obox=self._cat("obox_t")[sel])
+            else:                                              # per-image lists (SGDET / SGCLS, accumulate_target)
+                tb = self._targets_by_image
+                rows, parts = [], [[] for _ in range(5)]
+                for r, image in enumerate(images_h):
                     if tb[0][int(image)] is None:
                         continue
-                    rel_t, scat_t, ocat_t, sbox_t, obox_t = (np.asarray(torch.as_tensor(x[int(image)]).cpu()) for x in tb)
-                conn_t = np.nonzero(rel_t != -1)[0]
-                if len(conn_t) == 0:
-                    continue
-                rel_c, sc_c, oc_c = rel_t[conn_t], scat_t[conn_t], ocat_t[conn_t]
-                if predcls:
-                    label_ok = (sc_c[:, None] == h["scat"][keep][None, :]) & (oc_c[:, None] == h["ocat"][keep][None, :])
+                    vals = [torch.as_tensor(x[int(image)]).to(dev) for x in tb]
+                    ok = torch.nonzero(vals[0] != -1).flatten()
+                    rows.append(torch.full((len(ok),), r, dtype=torch.int32, device=dev))
+                    for k_ in range(5):
+                        parts[k_].append(vals[k_][ok].reshape(len(ok), -1) if k_ >= 3 else vals[k_][ok].reshape(-1))
+                if rows:
+                    tg = dict(row=torch.cat(rows), rel=torch.cat(parts[0]), scat=torch.cat(parts[1]), ocat=torch.cat(parts[2]),
+                              sbox=torch.cat(parts[3]).float(), obox=torch.cat(parts[4]).float())
                 else:
-                    label_ok = self._equiv[sc_c[:, None], h["scat"][keep][None, :]] & \
-                        self._equiv[oc_c[:, None], h["ocat"][keep][None, :]]
-                iou_ok = (grid_iou_matrix(sbox_t[conn_t], h["sbox"][keep], F) >= self.iou_thresh) & \
-                    (grid_iou_matrix(obox_t[conn_t], h["obox"][keep], F) >= self.iou_thresh)
-                pred_ok = rel_c[:, None] == h["pred"][keep][None, :]
-                hit = first_hit(label_ok, iou_ok, pred_ok)
-                for i in range(len(conn_t)):
-                    ti = int(rel_c[i])
+                    tg = dict(row=torch.zeros(0, dtype=torch.int32, device=dev), rel=torch.zeros(0, dtype=torch.int64, device=dev))
+            if int(tg["rel"].shape[0]) > 0:
+                cand = dict(scat=self._cat("scat"), ocat=self._cat("ocat"), pred=self._cat("pred"), sbox=self._cat("sbox"), obox=self._cat("obox"))
+                hit = recall_hits(cand, keep_pos, keep_cnt, tg, K, self.feature_size, self.iou_thresh,
+                                  None if predcls else torch.from_numpy(self._equiv.astype(np.uint8)))
+                rel_h = tg["rel"].cpu().numpy().astype(np.int64)
+                sc_h, oc_h = tg["scat"].cpu().numpy().astype(np.int64), tg["ocat"].cpu().numpy().astype(np.int64)
+                n_keep = cnt_h[tg["row"].cpu().numpy()]
+                for i in range(len(rel_h)):
+                    ti = int(rel_h[i])
                     zs = False
                     if self.dataset == "vg":
-                        trip = "%d_%d_%d" % (int(sc_c[i]), ti, int(oc_c[i]))
-                        zs = trip in self.zero_shot_triplets
+                        zs = ("%d_%d_%d" % (int(sc_h[i]), ti, int(oc_h[i]))) in self.zero_shot_triplets
                     for k in self.top_k:
-                        if hit[i] < k and hit[i] < len(keep):
+                        if hit[i] < k and hit[i] < n_keep[i]:
                             self.result_dict[k] += 1.0
                             if per_class:
                                 self.result_per_class[k][ti] += 1.0
@@ -429,27 +483,21 @@ class Evaluator_Top3:
             cat = lambda k: (torch.vstack(self._l[k]) if self._l[k][0].dim() == 2 else torch.hstack(self._l[k]))
             which = cat("which")
             conf = cat("conf") + cat("conn")
-            images, order, seg, top, cnt = rank_topk(conf, which, self.top_k[-1])
-            h = {k: cat(k).cpu().numpy() for k in ("args3", "rel_t", "scat", "ocat", "sbox", "obox")}
-            F = self.feature_size
-            for r, image in enumerate(images):
-                pos = order[seg[r]:seg[r + 1]]
-                keep = pos[top[r, :cnt[r]]]
-                rel_t = h["rel_t"][pos]
-                ct = np.nonzero(rel_t != -1)[0]
-                if len(ct) == 0:
-                    continue
-                num_target = len(ct)
-                tp = pos[ct]
-                label_ok = (h["scat"][tp][:, None] == h["scat"][keep][None, :]) & (h["ocat"][tp][:, None] == h["ocat"][keep][None, :])
-                iou_ok = (grid_iou_matrix(h["sbox"][tp], h["sbox"][keep], F) >= self.iou_thresh) & \
-                    (grid_iou_matrix(h["obox"][tp], h["obox"][keep], F) >= self.iou_thresh)
-                pred_ok = (rel_t[ct][:, None, None] == h["args3"][keep][None, :, :]).any(2)
-                hit = first_hit(label_ok, iou_ok, pred_ok)
-                for i in range(len(ct)):
-                    ti = int(rel_t[ct][i])
+            K = self.top_k[-1]
+            images, keep_pos, keep_cnt, top, _, _ = rank_topk_device(conf, which, K)
+            rel_all = cat("rel_t")
+            sel = torch.nonzero(rel_all != -1).flatten()                       # every candidate row is also a (possible) target row
+            if int(sel.numel()) > 0:
+                row = torch.searchsorted(images, which[sel])
+                tg = dict(row=row.int(), rel=rel_all[sel], scat=cat("scat")[sel], ocat=cat("ocat")[sel], sbox=cat("sbox")[sel], obox=cat("obox")[sel])
+                cand = dict(scat=cat("scat"), ocat=cat("ocat"), pred=cat("args3"), sbox=cat("sbox"), obox=cat("obox"))
+                hit = recall_hits(cand, keep_pos, keep_cnt, tg, K, self.feature_size, self.iou_thresh)
+                rel_h, row_h, cnt_h = tg["rel"].cpu().numpy().astype(np.int64), row.cpu().numpy(), keep_cnt.cpu().numpy()
+                num_target = np.bincount(row_h, minlength=len(cnt_h))           # connected targets per image
+                for i in range(len(rel_h)):
+                    ti = int(rel_h[i])
                     for k in self.top_k:
-                        if hit[i] < len(keep) and hit[i] < max(k, num_target):
+                        if hit[i] < cnt_h[row_h[i]] and hit[i] < max(k, num_target[row_h[i]]):
                             self.result_dict[k] += 1.0
                             if per_class:
                                 self.result_per_class[k][ti] += 1.0

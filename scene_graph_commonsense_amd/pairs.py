@@ -209,8 +209,8 @@ def flatten_scene(cfg, batch, device) -> DeviceScene:
     rel = dirs = None
     if getattr(batch, "relationships", None) is not None and getattr(batch, "subj_or_obj", None) is not None:
         cat_i = lambda rows, dt: (torch.cat([torch.as_tensor(r).reshape(-1) for r in rows]).to(dt) if len(rows) else torch.zeros(0, dtype=dt))
-        rel = torch.cat([cat_i(r, torch.int32) for r in batch.relationships]).numpy()
-        dirs = torch.cat([cat_i(r, torch.float32) for r in batch.subj_or_obj]).numpy()
+        rel = torch.cat([cat_i(r, torch.int32) for r in batch.relationships]).cpu().numpy()
+        dirs = torch.cat([cat_i(r, torch.float32) for r in batch.subj_or_obj]).cpu().numpy()
         if rel.shape[0] != int((n * (n - 1) // 2).sum()) or dirs.shape[0] != rel.shape[0]:
             raise ValueError("relationships / subj_or_obj must hold g entries for graph_iter g of every image (dataloader.py:144-147)")
 
