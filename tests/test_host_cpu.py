@@ -97,23 +97,45 @@ def test_grid_iou_closed_form_equals_rasterised():
 
 @pytest.mark.parametrize("name", ["vg_small", "vg_bert_small"])
 def test_evaluator_host_matching_against_reference(name, monkeypatch):
-    """Evaluator host logic (append order, blocked candidates, matching, counters) with the ranking kernel replaced
-    by a CPU stable sort FOR THIS TEST ONLY (the product refuses CPU tensors)."""
+    """Evaluator host logic (append order, blocked candidates, target selection, counters) with the two device steps - ranking
+    and hit test - replaced by CPU stand-ins FOR THIS TEST ONLY (the product refuses CPU tensors; the kernels are pinned to
+    the same goldens by tests/test_evaluator_gpu.py)."""
     from scene_graph_commonsense_amd import evaluator as EV
 
     def cpu_rank(conf, which, K):
+        """CPU stand-in of ``rank_topk_device``: stable descending sort per image."""
         images, counts = torch.unique(which, return_counts=True)
         order = torch.sort(which, stable=True)[1]
-        seg = np.concatenate([[0], np.cumsum(counts.numpy())]).astype(np.int32)
-        top = np.full((len(images), K), -1, dtype=np.int32)
-        cnt = np.zeros(len(images), dtype=np.int32)
+        seg = torch.zeros(len(images) + 1, dtype=torch.int32)
+        seg[1:] = torch.cumsum(counts, 0).int()
+        top = torch.full((len(images), K), -1, dtype=torch.int32)
+        cnt = torch.zeros(len(images), dtype=torch.int32)
+        keep_pos = torch.full((len(images), K), -1, dtype=torch.int32)
         for r in range(len(images)):
-            c = conf[order[seg[r]:seg[r + 1]]]
-            o = torch.sort(c, descending=True, stable=True)[1][:K].numpy()
-            top[r, :len(o)] = o
+            pos = order[int(seg[r]):int(seg[r + 1])]
+            o = torch.sort(conf[pos], descending=True, stable=True)[1][:K]
+            top[r, :len(o)] = o.int()
+            keep_pos[r, :len(o)] = pos[o].int()
             cnt[r] = len(o)
-        return images.numpy(), order.numpy(), seg, top, cnt
-    monkeypatch.setattr(EV, "rank_topk", cpu_rank)
+        return images, keep_pos, cnt, top, seg, order
+
+    def cpu_hits(cand, keep_pos, keep_cnt, targets, K, feature_size, iou_thresh, equiv=None):
+        """CPU stand-in of ``recall_hits`` built on the module's numpy helpers (the kernel itself is pinned by the GPU tests)."""
+        n_t = int(targets["rel"].shape[0])
+        hit = np.full(n_t, K, dtype=np.int32)
+        pred = cand["pred"].numpy().reshape(len(cand["scat"]), -1)
+        for t in range(n_t):
+            r = int(targets["row"][t])
+            keep = keep_pos[r, :int(keep_cnt[r])].long().numpy()
+            label = (cand["scat"].numpy()[keep] == int(targets["scat"][t])) & (cand["ocat"].numpy()[keep] == int(targets["ocat"][t]))
+            iou = (EV.grid_iou_matrix(targets["sbox"][t:t + 1].numpy(), cand["sbox"].numpy()[keep], feature_size)[0] >= iou_thresh) & \
+                (EV.grid_iou_matrix(targets["obox"][t:t + 1].numpy(), cand["obox"].numpy()[keep], feature_size)[0] >= iou_thresh)
+            ok = label & iou & (pred[keep] == int(targets["rel"][t])).any(1)
+            if ok.any():
+                hit[t] = int(np.argmax(ok))
+        return hit
+    monkeypatch.setattr(EV, "rank_topk_device", cpu_rank)
+    monkeypatch.setattr(EV, "recall_hits", cpu_hits)
     cfg, sd, batch, gold = load_case(name)
     args = cfg.args(fixtures=os.path.join(GOLDEN, "ref_fixtures") + os.sep)
     ev = EV.Evaluator(args, cfg.num_relations, 0.5, [20, 50, 100])
