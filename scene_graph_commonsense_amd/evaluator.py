@@ -250,7 +250,7 @@ class Evaluator:
         P = cand_conf.shape[0]
         if call_sizes is not None and rep > 1:
             # position of candidate (pair p, super s) in the reference's append order
-            sizes = torch.as_tensor(np.asarray(call_sizes), device=cand_conf.device)
+            sizes = (call_sizes if torch.is_tensor(call_sizes) else torch.as_tensor(np.asarray(call_sizes))).to(cand_conf.device).long()
             starts = torch.cumsum(sizes, 0) - sizes
             step_of = torch.repeat_interleave(torch.arange(len(sizes), device=sizes.device), sizes)
             within = torch.arange(P, device=sizes.device) - starts[step_of]

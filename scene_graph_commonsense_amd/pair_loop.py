@@ -27,47 +27,54 @@ def overlap_mask(scene: DeviceScene) -> torch.Tensor:
     return out
 
 
-def _unfiltered_selection(scene: DeviceScene, iou_h: np.ndarray, evaluators) -> torch.Tensor:
-    """[P] bool: the pairs whose trunk must be computed when the overlap filter is on.  A filtered candidate can only matter when
-    its image has fewer unfiltered pairs than the evaluator ranks (then -inf entries enter the top K and may still match a
-    ground-truth triple): such images are computed completely."""
-    pidx = scene.pidx
+def _step_filter(scene: DeviceScene, iou: Optional[torch.Tensor]):
+    """(included [P] bool, any_overlap [T] bool) on the device: a direction-step is kept when at least one image's two boxes
+    overlap (``train_test.py:403-410``; the filter is symmetric and tested once per (g, e), so both directions share the decision)."""
+    dev = scene.bbox.device
+    if iou is None:
+        return torch.ones(scene.n_pairs, dtype=torch.bool, device=dev), torch.ones(scene.n_steps, dtype=torch.bool, device=dev)
+    step = scene.step.long()
+    per_step = torch.zeros(scene.n_steps, dtype=torch.int32, device=dev).index_add_(0, step, iou.int())
+    any_overlap = per_step > 0
+    return any_overlap[step], any_overlap
+
+
+def _unfiltered_selection(scene: DeviceScene, iou: torch.Tensor, evaluators) -> torch.Tensor:
+    """[P] bool (device): the pairs whose trunk must be computed when the overlap filter is on.  A filtered candidate can only
+    matter when its image has fewer unfiltered pairs than the evaluator ranks (then -inf entries enter the top K and may still
+    match a ground-truth triple): such images are computed completely."""
     k_max = max([100] + [int(e.top_k[-1]) for e in evaluators if e is not None])
-    per_image = np.bincount(pidx.image[iou_h], minlength=int(scene.image_feature.shape[0]))
-    return torch.from_numpy(iou_h | (per_image < k_max)[pidx.image]).to(scene.bbox.device)
+    image = scene.image.long()
+    per_image = torch.zeros(int(scene.image_feature.shape[0]), dtype=torch.int32, device=iou.device).index_add_(0, image, iou.int())
+    return iou.bool() | (per_image < k_max)[image]
 
 
 def feed_evaluators(model, scene: DeviceScene, out, evaluator=None, evaluator_top3=None, overlap=None, directed=None):
     """Append one minibatch to the Recall@K evaluators in the reference's candidate order (``evaluator.py:231-246``).
     ``overlap`` = [P] uint8 device mask of the overlap filter (``train_test.py:403-410``): direction-steps in which no image's
     boxes overlap are skipped entirely (no candidates, no targets); ``None`` = no filter (``training()``, ``:209``).
-    Returns ``included`` [P] bool numpy (pairs of the kept steps)."""
+    Everything stays on the device (the pair tables of the scene are device tensors); the only host synchronisation is the size
+    of the kept set.  Returns ``included`` [P] bool device tensor (pairs of the kept steps)."""
     cfg = model.head_config()
     dev = scene.bbox.device
-    pidx = scene.pidx
-    P = scene.n_pairs
-    n_steps = len(pidx.call_sizes)
-    if overlap is None:
-        iou = torch.ones(P, dtype=torch.uint8, device=dev)
-        any_overlap = np.ones(n_steps, dtype=bool)
-    else:
-        iou = overlap
-        any_overlap = np.bincount(pidx.step[iou.cpu().numpy().astype(bool)], minlength=n_steps) > 0
-    # the filter is symmetric, and the reference tests it once per (g,e): both directions share the decision
-    included = any_overlap[pidx.step]
+    included, any_overlap = _step_filter(scene, overlap)
     if evaluator is None and evaluator_top3 is None:
         return included
     if directed is None:
         if scene.directed is None:
             raise ValueError("the evaluator feed needs relation targets: flatten the scene from a batch with relationships / subj_or_obj")
         directed = scene.directed
-    sel = torch.from_numpy(np.nonzero(included)[0]).to(dev)
-    sizes = pidx.call_sizes[any_overlap]
-    which = torch.from_numpy(pidx.image[included]).to(dev)
+    iou = overlap if overlap is not None else torch.ones(scene.n_pairs, dtype=torch.uint8, device=dev)
+    sel = torch.nonzero(included).flatten()
+    sizes = (scene.step_ptr[1:] - scene.step_ptr[:-1])[any_overlap]            # pairs per kept direction-step, in order
+    which = scene.image.long()[sel]
     tgt = torch.as_tensor(directed).to(dev)[sel].long()
-    scat, ocat = scene.cats[scene.sub_idx.long()][sel], scene.cats[scene.obj_idx.long()][sel]
-    raw = torch.from_numpy(scene.bbox_raw).to(dev)
-    sbox, obox = raw[scene.sub_idx.long()][sel], raw[scene.obj_idx.long()][sel]
+    sub, obj = scene.sub_idx.long()[sel], scene.obj_idx.long()[sel]
+    scat, ocat = scene.cats[sub], scene.cats[obj]
+    raw = getattr(scene, "_bbox_raw_d", None)
+    if raw is None:
+        raw = scene._bbox_raw_d = torch.from_numpy(scene.bbox_raw).to(dev)
+    sbox, obox = raw[sub], raw[obj]
     logsig = torch.log(torch.sigmoid(out.connectivity[sel]))
     iou_sel = iou[sel].bool()
     if evaluator is not None:
@@ -92,11 +99,10 @@ def evaluate_minibatch(model, batch, evaluator=None, evaluator_top3=None, overla
     dev = next(model.parameters()).device
     if scene is None:
         scene = flatten_scene(cfg, batch, dev)
-    P = scene.n_pairs
     iou = overlap_mask(scene) if overlap_filtering else None
     select = None
     if skip_filtered and overlap_filtering:
-        select = _unfiltered_selection(scene, iou.cpu().numpy().astype(bool), (evaluator, evaluator_top3))
+        select = _unfiltered_selection(scene, iou, (evaluator, evaluator_top3))
     out = model.forward_pairs(scene, iou_mask=iou, select=select)
     directed_d = scene.directed
     if directed_d is None:
@@ -105,8 +111,8 @@ def evaluate_minibatch(model, batch, evaluator=None, evaluator_top3=None, overla
     model.last_connectivity_stats = None
     if select is None and scene.raw_target is not None:
         model.last_connectivity_stats = model.engine().connectivity_stats(out.connectivity, directed_d, scene.raw_target,
-                                                                          torch.from_numpy(included.astype(np.uint8)).to(dev))
-    return scene, out, included, directed_d.cpu().numpy().astype(np.int64)
+                                                                          included.to(torch.uint8))
+    return scene, out, included.cpu().numpy(), directed_d.cpu().numpy().astype(np.int64)
 
 
 def evaluate_sgdet_minibatch(model, image_feature, image_depth, categories_pred, cat_pred_confidence, bbox_pred, evaluator,
@@ -131,28 +137,23 @@ def evaluate_sgdet_minibatch(model, image_feature, image_depth, categories_pred,
     batch = SceneBatch(image_feature, image_depth, [b.detach().float().cpu() for b in bbox_pred],
                        [c.detach().cpu().long() for c in categories_pred], sp, None, None)
     scene = flatten_scene(cfg, batch, dev)
-    pidx = scene.pidx
-    P = pidx.n_pairs
-    iou = overlap_mask(scene) if overlap_filtering else torch.ones(P, dtype=torch.uint8, device=dev)
-    iou_h = iou.cpu().numpy().astype(bool)
-    select = _unfiltered_selection(scene, iou_h, (evaluator,)) if (skip_filtered and overlap_filtering) else None
+    iou = overlap_mask(scene) if overlap_filtering else None
+    select = _unfiltered_selection(scene, iou, (evaluator,)) if (skip_filtered and overlap_filtering) else None
     out = model.forward_pairs(scene, iou_mask=iou, select=select)
-    any_overlap = np.bincount(pidx.step[iou_h], minlength=len(pidx.call_sizes)) > 0
-    included = any_overlap[pidx.step]
-    sel = torch.from_numpy(np.nonzero(included)[0]).to(dev)
-    which = torch.from_numpy(pidx.image[included]).to(dev)
+    included, any_overlap = _step_filter(scene, iou)
+    sel = torch.nonzero(included).flatten()
+    sub, obj = scene.sub_idx.long()[sel], scene.obj_idx.long()[sel]
     conf_obj = torch.cat([c.reshape(-1).to(dev, torch.float32) for c in cat_pred_confidence])
-    csum = (conf_obj[scene.sub_idx.long()] + conf_obj[scene.obj_idx.long()])[sel]
-    scat, ocat = scene.cats[scene.sub_idx.long()][sel], scene.cats[scene.obj_idx.long()][sel]
     raw = torch.from_numpy(scene.bbox_raw).to(dev)
-    sbox, obox = raw[scene.sub_idx.long()][sel], raw[scene.obj_idx.long()][sel]
-    evaluator.accumulate_candidates(which, out.cand_conf[sel], out.cand_pred[sel], None, torch.log(torch.sigmoid(out.connectivity[sel])),
-                                    scat, ocat, sbox, obox, iou_mask=iou[sel].bool(), call_sizes=pidx.call_sizes[any_overlap],
-                                    cat_confidence=csum)
+    iou_sel = iou[sel].bool() if iou is not None else torch.ones(int(sel.numel()), dtype=torch.bool, device=dev)
+    evaluator.accumulate_candidates(scene.image.long()[sel], out.cand_conf[sel], out.cand_pred[sel], None,
+                                    torch.log(torch.sigmoid(out.connectivity[sel])), scene.cats[sub], scene.cats[obj], raw[sub], raw[obj],
+                                    iou_mask=iou_sel, call_sizes=(scene.step_ptr[1:] - scene.step_ptr[:-1])[any_overlap],
+                                    cat_confidence=conf_obj[sub] + conf_obj[obj])
     if targets is not None:
         cs, co, bs, bo, rt = match_target_sgd(*targets)
         evaluator.accumulate_target(rt, cs, co, bs, bo)
-    return scene, out, included
+    return scene, out, included.cpu().numpy()
 
 
 def train_minibatch(model, batch, optimizer=None, reducer=None, scene: Optional[DeviceScene] = None, **loss_kw):
