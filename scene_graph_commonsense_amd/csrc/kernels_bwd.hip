@@ -276,7 +276,15 @@ __global__ __launch_bounds__(256) void supcon_dfeat_kernel(const float* __restri
 __global__ void slab_sum_kernel(const float* __restrict__ in, float* __restrict__ out, long n, int slabs, int accumulate) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         float s = accumulate ? out[i] : 0.f;
-        for (int k = 0; k < slabs; ++k) s += in[(long)k * n + i];
+        int k = 0;
+        for (; k + 8 <= slabs; k += 8) {          // eight loads in flight, added in slab order (same sums as the plain loop)
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = in[(long)(k + u) * n + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; k < slabs; ++k) s += in[(long)k * n + i];
         out[i] = s;
     }
 }

@@ -210,7 +210,15 @@ __global__ __launch_bounds__(256) void slab_sum_ld_kernel(const float* __restric
     const long n = (long)rows * cols;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         float s = 0.f;
-        for (int k = 0; k < slabs; ++k) s += in[(long)k * n + i];
+        int k = 0;
+        for (; k + 8 <= slabs; k += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = in[(long)(k + u) * n + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; k < slabs; ++k) s += in[(long)k * n + i];
         const long r = i / cols;
         out[r * ld_out + (i - r * cols)] = s;
     }
