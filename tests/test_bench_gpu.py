@@ -36,3 +36,15 @@ def test_bench_refuses_a_world_size_that_is_not_gpus():
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode != 0 and "refusing" in (r.stderr + r.stdout)
+
+
+def test_bench_launcher_refuses_more_ranks_than_gpus():
+    """``--gpus N`` with fewer than N devices: the launcher says so instead of starting ranks that would share a GPU."""
+    import torch
+    n = torch.cuda.device_count()
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", str(n + 1), "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0 and "GPU(s) visible" in (r.stderr + r.stdout)
