@@ -183,6 +183,16 @@ def _dp_worker(rank, world, port, q):
     params[2][1].grad = torch.full((3,), 10.0 * rank)
     red.finish(params)
     cnt = D.allreduce_counters(torch.tensor([rank + 1, 7]))
+    # the form training_step uses: the step's gradient dict is reduced BEFORE accumulation into param.grad; a non-contiguous
+    # view (conv weights come out of a permute) must survive the flat bucket, and the early tensor must not be reduced twice
+    red2 = D.GradReducer(w)
+    g_fc1 = torch.full((8, 4), 10.0 * (rank + 1))
+    red2.hook("fc1.weight", g_fc1)
+    grads = {"fc1.weight": g_fc1, "conv3_1.weight": (torch.arange(12.0).view(3, 4) * (rank + 1)).t(), "fc2.bias": torch.ones(5) * rank}
+    red2.finish_grads(grads)
+    assert grads["fc1.weight"][0, 0].item() == 15.0 and grads["conv3_1.weight"].is_contiguous()
+    assert torch.equal(grads["conv3_1.weight"], torch.arange(12.0).view(3, 4).t() * 1.5) and grads["fc2.bias"].tolist() == [0.5] * 5
+    assert not red2.pending and not red2.done
     q.put((rank, params[0][1].grad[0, 0].item(), params[1][1].grad.tolist(), params[2][1].grad.tolist(), cnt.tolist()))
     dist.destroy_process_group()
 
