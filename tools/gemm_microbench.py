@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Attribute the time of the 256x256 NT GEMM main loop (GPU box): normal vs no-loads vs no-loads-no-barrier vs
-loads-only.  Random bf16 operands (zero-filled data inflates clocks)."""
+loads-only.  Random bf16 operands (zero-filled data inflates clocks).
+Variants 4, 8, 9, 10 (the rejected main loops: 4-stage ring, 4 waves x 128x128, one-phase ping-pong) are compiled only into a
+library built with SGC_EXPERIMENTS=1 (``SGC_EXPERIMENTS=1 python -m scene_graph_commonsense_amd.build --force``)."""
 import ctypes
 import os
 import sys
