@@ -189,13 +189,18 @@ int sgc_fc1_dgrad(const void* dh1, const void* w1pT, void* dy, int n_pairs, int 
 int sgc_fc1_wgrad(const void* dh1, const void* y_bf16, float* dw, int n_rows, int K, void* stream);
 int sgc_unpool_relu_bwd(const void* dy, const unsigned char* argmax, void* dy3_pad, float* dbias_part, int* n_parts, int n_pairs, void* stream);
 int sgc_conv3_dgrad(const void* dy3_pad, const void* wd3, void* dz, int n_pairs, void* stream);
+/* The same data gradient with the un-pool fused into the operand staging: dy [n_pairs*64][1024] bf16 = gradient of the POOLED conv3
+ * output (what sgc_fc1_dgrad writes), argmax = the routing byte of sgc_conv3_relu_pool (model.py:145-146 backward: ReLU + 2x2 max-pool
+ * route the gradient to one pixel per window and channel); no un-pooled tensor is materialised. */
+int sgc_conv3_dgrad_pooled(const void* dy, const unsigned char* argmax, const void* wd3, void* dz, int n_pairs, void* stream);
 int sgc_conv3_wgrad(const void* dy3_pad, const void* z_pad_bf16, float* slabs, int n_pairs, int splits, int* n_slabs, void* stream);
 /* The same weight gradient on the sparse matrix cores (2:4 structured sparsity: at most one non-zero per 2x2 pooling window):
  * dy [n_pairs*64][1024] bf16 = the POOLED gradient (output of sgc_fc1_dgrad), argmax = the routing byte of sgc_conv3_relu_pool;
  * pack_ac (n_pairs*4*1024*64 bytes) and pack_ic (n_pairs*4*1024*8 bytes) are scratch for the packed operand. */
 int sgc_conv3_wgrad_sparse(const void* dy, const unsigned char* argmax, const void* z_pad_bf16, void* pack_ac, void* pack_ic,
                            float* slabs, int n_pairs, int splits, int* n_slabs, void* stream);
-/* sgc_unpool_relu_bwd that also writes the packed operand in the same pass (dbias_part: at most 768 partials);
+/* sgc_unpool_relu_bwd that also writes the packed operand in the same pass (dbias_part: at most 768 partials; dy3_pad may be NULL
+ * when the data gradient un-pools on the fly, sgc_conv3_dgrad_pooled);
  * sgc_conv3_wgrad_sparse called afterwards with dy == NULL uses pack_ac / pack_ic as they are. */
 int sgc_unpool_relu_bwd_pack(const void* dy, const unsigned char* argmax, void* dy3_pad, float* dbias_part, int* n_parts,
                              void* pack_ac, void* pack_ic, int n_pairs, void* stream);

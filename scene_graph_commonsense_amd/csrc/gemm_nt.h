@@ -36,6 +36,8 @@ struct NtParams {
     int epi_lds;                // 1: LDS-staged 16-byte stores for EPI_STORE in the 8-wave kernels (set by the launcher)
     int halo_walk;              // conv16_halo_pp_kernel: 0 = block id -> (image, N tile) directly, 1 = XCD-contiguous image ranges
     int patch_aligned;          // gemm_nt_pp_kernel: 1 = grid padded to whole 32-tile patches (set by the launcher for large grids)
+    const u16* Apool; const unsigned char* Acode;   // conv16_halo_pp_kernel<.., ASRC = 1>: the A operand as POOLED rows [img*64 windows][Cin]
+                                                    // + routing byte (0..3 = position inside the 2x2 window, 4 = none); un-pooled on the fly
 };
 
 template <int ELEM>

@@ -288,7 +288,13 @@ __device__ __forceinline__ void nt_epilogue_pool16(const NtParams& p, f32x16 (&a
 // Per wave and step: phase Y issues the four weight loads of step s+2 (replacing what phase X(s) read) and, in the first
 // taps of a chunk, one piece of the NEXT chunk's patch; it ends with vmcnt(4 or 5): only its own loads may still be in
 // flight, so the weights of step s+1 and every older patch piece have landed.  Phase X issues nothing and has no vmcnt wait.
-template <int ELEM, int EPI>
+// ASRC = 1 (conv3 data gradient in the training step): the A operand is the gradient BEFORE the 2x2 max-pool, which has one
+// non-zero per pooling window and channel.  Instead of DMA-ing a materialised un-pooled tensor (21 GB written by the un-pool pass
+// and read back here), the block reads the POOLED gradient (p.Apool, 8x8 windows x Cin) and the routing byte of the forward
+// arg-max (p.Acode) and scatters them into the LDS patch itself: thread = (window, 8-channel group) issues one 16-byte and one
+// 8-byte global load per chunk in tap 0, and four ds_write_b128 (the four pixels of its window, value or zero) in tap 2, into the
+// patch buffer of the NEXT chunk.  The zero border of both patch buffers is written once at kernel start.
+template <int ELEM, int EPI, int ASRC = 0>
 __global__ __launch_bounds__(512, 2) void conv16_halo_pp_kernel(const NtParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int A_BYTES = 328 * 128;            // 324 patch rows, padded to 41 x 8 rows
@@ -320,10 +326,41 @@ __global__ __launch_bounds__(512, 2) void conv16_halo_pp_kernel(const NtParams p
         const int f = ((px >> 1) + 4 * (py & 1)) & 7;
         a_off[i] = r * Cin + ((cpos ^ f) << 3);
     }
-    const u16* const a_img = p.A + (long)img * (324L * Cin);
-    const int npiece = (wid == 0) ? 6 : 5;
+    const u16* const a_img = ASRC ? p.A : p.A + (long)img * (324L * Cin);
+    const int npiece = ASRC ? 0 : ((wid == 0) ? 6 : 5);
     auto stage_a_piece = [&](int i, int cc) __attribute__((always_inline)) {
         buf_load_lds16(a_img, a_off[i] * 2, cc << 7, abuf0 + (cc & 1) * A_BYTES + (wid + 8 * i) * 1024);
+    };
+    // ---- ASRC = 1: pooled source.  thread -> window pw (8x8) and channel group pg (8 channels of the 64-channel chunk).
+    // The pooled values (64 windows x 128 B) and routing bytes (64 x 64 B) of a chunk go through a 12 KiB LDS scratch by DMA
+    // (no registers are live across taps: a register-staged version made the compiler drain vmcnt right after the loads);
+    // every wave DMAs its own 8 windows of values, waves 0-3 also 16 windows of routing bytes each.
+    char* const pscr = smem + 2 * A_BYTES + 4 * HT;               // [64][128] values, then [64][64] routing bytes
+    const int pw = tid >> 3, pg = tid & 7;
+    const int pool_voff = (int)((((long)img * 64 + pw) * Cin + pg * 8) * 2);                 // byte offset into Apool
+    const int pool_coff = (int)(((long)img * 64 + wid * 16 + (lane >> 2)) * Cin + (lane & 3) * 16);   // byte offset into Acode
+    const int npool = (wid < 4) ? 2 : 1;                           // DMA instructions this wave issues per chunk
+    auto pool_dma = [&](int cc) __attribute__((always_inline)) {
+        buf_load_lds16(p.Apool, pool_voff, cc << 7, pscr + wid * 1024);
+        if (wid < 4) buf_load_lds16(p.Acode, pool_coff, cc << 6, pscr + 8192 + wid * 1024);
+    };
+    auto pool_scatter = [&](int cc) __attribute__((always_inline)) {
+        char* ab = abuf0 + (cc & 1) * A_BYTES;
+        const uint4 pool_v = *reinterpret_cast<const uint4*>(pscr + tid * 16);
+        const uint2 pool_c = *reinterpret_cast<const uint2*>(pscr + 8192 + pw * 64 + pg * 8);
+        const u16* vh = reinterpret_cast<const u16*>(&pool_v);
+        const unsigned char* ch = reinterpret_cast<const unsigned char*>(&pool_c);
+        const int wy = pw >> 3, wx = pw & 7;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            uint4 o;
+            u16* oh = reinterpret_cast<u16*>(&o);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) oh[k] = (ch[k] == q) ? vh[k] : (u16)0;
+            const int py = 2 * wy + (q >> 1) + 1, px = 2 * wx + (q & 1) + 1;
+            const int f = ((px >> 1) + 4 * (py & 1)) & 7;
+            *reinterpret_cast<uint4*>(ab + (py * 18 + px) * 128 + ((pg ^ f) << 4)) = o;
+        }
     };
     // ---- B (weight) half tiles: LDS row r of half h <-> output channel n0 + (r>>5)*64 + h*32 + (r&31)
     const u16* const b_blk = p.B + (long)n0 * p.ldb;
@@ -402,11 +439,23 @@ __global__ __launch_bounds__(512, 2) void conv16_halo_pp_kernel(const NtParams p
     const int ncc = Cin >> 6;
     const int nsteps = ncc * 9;
     // ---- prologue: patch of chunk 0, weights of steps 0 and 1
+    if constexpr (ASRC) {
+        pool_dma(0);
+        for (int i = tid; i < 2 * A_BYTES / 16; i += 512)       // both patch buffers: the border stays zero for the whole kernel
+            *reinterpret_cast<uint4*>(abuf0 + i * 16) = make_uint4(0, 0, 0, 0);
+        SGC_WAIT_VM(0);
+        __syncthreads();                                          // scratch of chunk 0 landed (all waves), zero fill visible
+        pool_scatter(0);
+        stage_b(0);
+        if (nsteps > 1) { stage_b(1); SGC_WAIT_VM(4); } else SGC_WAIT_VM(0);
+        SGC_WAIT_LGKM0();
+    } else {
 #pragma unroll
-    for (int i = 0; i < 6; ++i)
-        if (i < npiece) stage_a_piece(i, 0);
-    stage_b(0);
-    if (nsteps > 1) { stage_b(1); SGC_WAIT_VM(4); } else SGC_WAIT_VM(0);
+        for (int i = 0; i < 6; ++i)
+            if (i < npiece) stage_a_piece(i, 0);
+        stage_b(0);
+        if (nsteps > 1) { stage_b(1); SGC_WAIT_VM(4); } else SGC_WAIT_VM(0);
+    }
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();
 
@@ -423,7 +472,20 @@ __global__ __launch_bounds__(512, 2) void conv16_halo_pp_kernel(const NtParams p
             half(0);
             // phase Y: rows a1
             read_a(1, cc, ky, kx);
-            if (step + 2 < nsteps) {
+            if constexpr (ASRC) {
+                // pooled source: tap 0 DMAs the next chunk's window values + routing bytes into the scratch (issued AFTER this phase's
+                // four weight loads so that the counted wait leaves them in flight), tap 1's vmcnt(4) retires them in every wave
+                // (they are older than its own weight loads) and its barrier publishes them, tap 2 scatters them into the other
+                // patch buffer (last read in chunk cc-1; the scratch itself is next written in tap 0 of chunk cc+1).
+                if (step + 2 < nsteps) {
+                    stage_b(step + 2);
+                    if (more_cc && tap == 0) {
+                        pool_dma(cc + 1);
+                        if (npool == 2) SGC_WAIT_VM(6); else SGC_WAIT_VM(5);
+                    } else SGC_WAIT_VM(4);
+                } else SGC_WAIT_VM(0);                      // last two steps: more_cc is false there (nsteps = 9 * ncc)
+                if (more_cc && tap == 2) pool_scatter(cc + 1);
+            } else if (step + 2 < nsteps) {
                 stage_b(step + 2);
                 if (more_cc && tap < npiece) {
                     switch (tap) {          // a_off[] must be indexed by a constant to stay in registers
@@ -457,6 +519,7 @@ template <int ELEM, int EPI>
 static int launch_conv16_halo_pp(NtParams p, hipStream_t stream) {
     constexpr int LDS0 = 2 * 328 * 128 + 4 * 16384;
     constexpr int LDS = (EPI == EPI_STORE && LDS0 < EPI_LDS_BYTES) ? EPI_LDS_BYTES : LDS0;
+    constexpr int LDS_POOLED = LDS0 + 64 * 128 + 64 * 64;        // + the 12 KiB scratch of the pooled source (158 KiB of 160)
     p.tiles_m = p.M / 256;
     p.tiles_n = p.N / 256;
     {
@@ -467,6 +530,15 @@ static int launch_conv16_halo_pp(NtParams p, hipStream_t stream) {
         static int hw = -2;
         if (hw == -2) { const char* e = getenv("SGC_HALO_WALK"); hw = e ? atoi(e) : -1; }
         p.halo_walk = hw >= 0 ? hw : ((long)p.K * 512 > (3L << 20) ? 1 : 0);
+    }
+    if constexpr (ELEM == ELEM_BF16 && EPI == EPI_STORE) {
+        if (p.Apool) {                                 // A operand given as pooled rows + routing byte: un-pooled inside the block
+            auto kern = conv16_halo_pp_kernel<ELEM, EPI, 1>;
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_POOLED);
+            SGC_LAUNCH(kern, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(512), LDS_POOLED, stream, p);
+            SGC_CHECK_LAUNCH();
+            return SGC_OK;
+        }
     }
     auto kern = conv16_halo_pp_kernel<ELEM, EPI>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);

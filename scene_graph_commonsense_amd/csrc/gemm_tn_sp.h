@@ -115,7 +115,7 @@ __global__ __launch_bounds__(512) void unpool_pack_kernel(const u16* __restrict_
 #pragma unroll
                 for (int k = 0; k < 8; ++k) oh[k] = (ab[k] == q) ? gh[k] : (u16)0;
                 const int Y = 2 * py + (q >> 1) + 1, X = 2 * px + (q & 1) + 1;
-                *reinterpret_cast<uint4*>(dy3 + ((p * 18 + Y) * 18 + X) * 1024 + ch * 8) = o;
+                if (dy3) *reinterpret_cast<uint4*>(dy3 + ((p * 18 + Y) * 18 + X) * 1024 + ch * 8) = o;
             }
 #pragma unroll
             for (int k = 0; k < 8; ++k) if (ab[k] < 4) bs[k] += bf16_bits_to_f32(gh[k]);

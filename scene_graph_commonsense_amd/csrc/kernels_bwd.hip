@@ -823,6 +823,15 @@ int sgc_conv3_dgrad(const void* dy3_pad, const void* wd3, void* dz, int n_pairs,
     p.ldb = 9 * 1024; p.ldc = 512; p.lgS = 4; p.Cin = 1024;
     return launch_gemm_nt<ELEM_BF16, AMODE_CONV, EPI_STORE>(p, (hipStream_t)stream);
 }
+// The same data gradient straight from the POOLED gradient dy [n_pairs*64][1024] bf16 and the forward routing byte: the block
+// un-pools into its LDS patch (conv16_halo_pp_kernel<.., ASRC = 1>), no un-pooled tensor exists in memory.
+int sgc_conv3_dgrad_pooled(const void* dy, const unsigned char* argmax, const void* wd3, void* dz, int n_pairs, void* stream) {
+    if (!dy || !argmax) return SGC_ERR_ARG;
+    NtParams p{};
+    p.A = (const u16*)dy; p.Apool = (const u16*)dy; p.Acode = argmax; p.B = (const u16*)wd3; p.C = dz; p.M = n_pairs * 256; p.N = 512;
+    p.K = 9 * 1024; p.ldb = 9 * 1024; p.ldc = 512; p.lgS = 4; p.Cin = 1024;
+    return launch_conv16_halo_pp<ELEM_BF16, EPI_STORE>(p, (hipStream_t)stream);
+}
 // slabs [splits][1024][9*512] f32 = sum_pix dy3[pix][n] * z_pad_bf16[pix+tap][c]
 int sgc_conv3_wgrad(const void* dy3_pad, const void* z_pad_bf16, float* slabs, int n_pairs, int splits, int* n_slabs, void* stream) {
     TnParams p{};

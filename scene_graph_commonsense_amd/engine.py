@@ -590,10 +590,13 @@ class RelHeadEngine:
         self._timed("fc1_dgrad", lambda: _lib.check(lib.sgc_fc1_dgrad(_lib.ptr(dh1), _lib.ptr(w["w1pT"]), _lib.ptr(dy), P, 65536, st()), "sgc_fc1_dgrad"))
 
         # ---- conv3
-        dy3 = ws.get("dy3_pad", P * 18 * 18 * 1024, torch.bfloat16)
         bpart = ws.get("b3_part", 2048 * 1024, torch.float32)
         nparts = ctypes.c_int(0)
         sparse_w3 = os.environ.get("SGC_W3_SPARSE", "1") != "0"
+        # the data gradient un-pools inside its operand staging (sgc_conv3_dgrad_pooled): the 21 GB un-pooled tensor is neither
+        # written nor read.  Needs the sparse weight gradient (the dense one reads the un-pooled tensor); SGC_DGRAD_POOLED=0 = A/B hook.
+        pooled_dgrad = sparse_w3 and os.environ.get("SGC_DGRAD_POOLED", "1") != "0"
+        dy3 = None if pooled_dgrad else ws.get("dy3_pad", P * 18 * 18 * 1024, torch.bfloat16)
         z_bf = ctx.z_bf
         if sparse_w3:
             # sparse matrix cores: the pooled gradient + the arg-max byte ARE the 2:4-compressed operand (csrc/gemm_tn_sp.h);
@@ -619,7 +622,11 @@ class RelHeadEngine:
             dW3r = self._slab_sum(sl, 1024 * 4608, slabs_n.value)
             grads["conv3_1.weight"] = dW3r.view(1024, 3, 3, 512).permute(0, 3, 1, 2).contiguous()
         dz = ws.get("dz", P * 256 * 512, torch.bfloat16)
-        self._timed("conv3_dgrad", lambda: _lib.check(lib.sgc_conv3_dgrad(_lib.ptr(dy3), _lib.ptr(w["wd3"]), _lib.ptr(dz), P, st()), "sgc_conv3_dgrad"))
+        if pooled_dgrad:
+            self._timed("conv3_dgrad", lambda: _lib.check(lib.sgc_conv3_dgrad_pooled(_lib.ptr(dy), _lib.ptr(ctx.am), _lib.ptr(w["wd3"]), _lib.ptr(dz), P, st()),
+                                                          "sgc_conv3_dgrad_pooled"))
+        else:
+            self._timed("conv3_dgrad", lambda: _lib.check(lib.sgc_conv3_dgrad(_lib.ptr(dy3), _lib.ptr(w["wd3"]), _lib.ptr(dz), P, st()), "sgc_conv3_dgrad"))
 
         # ---- pair contraction + conv2 + masks + conv1 (per-role buffers: the side stream may still read role 0's while role 1 runs)
         gc2 = torch.empty(512, 256, 3, 3, dtype=torch.float32, device=dev)

@@ -238,3 +238,48 @@ def test_conv3_wgrad_sparse_matches_dense(n_pairs, splits):
                                       L.stream_ptr()) == 0
     torch.cuda.synchronize()
     assert ns3.value == ns2.value and torch.equal(sl3[:ns3.value], sl2[:ns2.value])
+
+
+@pytest.mark.parametrize("P", [1, 5, 160])
+def test_conv3_dgrad_with_fused_unpool_equals_materialised_unpool(P):
+    """``sgc_conv3_dgrad_pooled`` (the block un-pools the pooled gradient + routing byte into its LDS patch) against the two-pass
+    form (``sgc_unpool_relu_bwd_pack`` writes the un-pooled tensor, ``sgc_conv3_dgrad`` reads it): the operand values and the
+    accumulation order are the same, so the results must be bit-identical whenever both run the halo block (P >= 128), and
+    equal to f32 summation order otherwise (small P takes the generic block in the two-pass form)."""
+    import ctypes
+    from scene_graph_commonsense_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(P)
+    dy = (torch.randn(P * 64, 1024, generator=g) * 0.5).bfloat16().cuda()
+    am = torch.randint(0, 5, (P * 64, 1024), generator=g, dtype=torch.uint8).cuda()              # 0..3 position, 4 = killed by the ReLU
+    wd3 = (torch.randn(512, 9 * 1024, generator=g) * 0.02).bfloat16().cuda()
+    dy3 = torch.zeros(P, 18, 18, 1024, dtype=torch.bfloat16, device="cuda")
+    bpart = torch.zeros(2048, 1024, device="cuda")
+    pack_a = torch.empty(P * 4 * 1024 * 64, dtype=torch.uint8, device="cuda")
+    pack_i = torch.empty(P * 4 * 1024 * 8, dtype=torch.uint8, device="cuda")
+    nparts = ctypes.c_int(0)
+    st = _lib.stream_ptr()
+    _lib.check(lib.sgc_unpool_relu_bwd_pack(_lib.ptr(dy), _lib.ptr(am), _lib.ptr(dy3), _lib.ptr(bpart), ctypes.byref(nparts), _lib.ptr(pack_a),
+                                            _lib.ptr(pack_i), P, st), "unpool")
+    # the un-pooled tensor is what the routing says: value at the coded pixel of every window, zero elsewhere
+    ref3 = torch.zeros(P, 16, 16, 1024)
+    dyc, amc = dy.float().cpu().view(P, 8, 8, 1024), am.cpu().view(P, 8, 8, 1024)
+    for q in range(4):
+        ref3[:, (q >> 1)::2, (q & 1)::2] = torch.where(amc == q, dyc, torch.zeros(()))
+    assert torch.equal(dy3[:, 1:17, 1:17].float().cpu(), ref3)
+    dz_a = torch.empty(P * 256, 512, dtype=torch.bfloat16, device="cuda")
+    dz_b = torch.full((P * 256, 512), float("nan"), dtype=torch.bfloat16, device="cuda")
+    _lib.check(lib.sgc_conv3_dgrad(_lib.ptr(dy3), _lib.ptr(wd3), _lib.ptr(dz_a), P, st), "dgrad")
+    _lib.check(lib.sgc_conv3_dgrad_pooled(_lib.ptr(dy), _lib.ptr(am), _lib.ptr(wd3), _lib.ptr(dz_b), P, st), "dgrad pooled")
+    # a second pass with the packed operand only (dy3 == NULL) leaves the same packed bytes
+    pa2, pi2 = torch.empty_like(pack_a), torch.empty_like(pack_i)
+    _lib.check(lib.sgc_unpool_relu_bwd_pack(_lib.ptr(dy), _lib.ptr(am), None, _lib.ptr(bpart), ctypes.byref(nparts), _lib.ptr(pa2), _lib.ptr(pi2), P, st),
+               "unpool, pack only")
+    torch.cuda.synchronize()
+    assert torch.equal(pa2, pack_a) and torch.equal(pi2, pack_i)
+    assert torch.isfinite(dz_b.float()).all()
+    if P >= 128:
+        assert torch.equal(dz_a, dz_b)
+    else:
+        err = (dz_a.float() - dz_b.float()).abs().max() / dz_a.float().abs().max()
+        assert float(err) <= 1e-2                               # bf16 outputs of two accumulation orders: at most a rounding step apart
