@@ -337,12 +337,15 @@ __global__ __launch_bounds__(512, 2) void conv16_halo_pp_kernel(const NtParams p
     // every wave DMAs its own 8 windows of values, waves 0-3 also 16 windows of routing bytes each.
     char* const pscr = smem + 2 * A_BYTES + 4 * HT;               // [64][128] values, then [64][64] routing bytes
     const int pw = tid >> 3, pg = tid & 7;
-    const int pool_voff = (int)((((long)img * 64 + pw) * Cin + pg * 8) * 2);                 // byte offset into Apool
-    const int pool_coff = (int)(((long)img * 64 + wid * 16 + (lane >> 2)) * Cin + (lane & 3) * 16);   // byte offset into Acode
+    // descriptor bases per image (64-bit), lane offsets inside the image's 64 windows (32-bit: < 128 KiB)
+    const u16* const apool_img = ASRC ? p.Apool + (long)img * 64 * Cin : nullptr;
+    const unsigned char* const acode_img = ASRC ? p.Acode + (long)img * 64 * Cin : nullptr;
+    const int pool_voff = (pw * Cin + pg * 8) * 2;                                         // byte offset of the thread's 8 values
+    const int pool_coff = (wid * 16 + (lane >> 2)) * Cin + (lane & 3) * 16;                // byte offset of the lane's 16 routing bytes
     const int npool = (wid < 4) ? 2 : 1;                           // DMA instructions this wave issues per chunk
     auto pool_dma = [&](int cc) __attribute__((always_inline)) {
-        buf_load_lds16(p.Apool, pool_voff, cc << 7, pscr + wid * 1024);
-        if (wid < 4) buf_load_lds16(p.Acode, pool_coff, cc << 6, pscr + 8192 + wid * 1024);
+        buf_load_lds16(apool_img, pool_voff, cc << 7, pscr + wid * 1024);
+        if (wid < 4) buf_load_lds16(acode_img, pool_coff, cc << 6, pscr + 8192 + wid * 1024);
     };
     auto pool_scatter = [&](int cc) __attribute__((always_inline)) {
         char* ab = abuf0 + (cc & 1) * A_BYTES;
