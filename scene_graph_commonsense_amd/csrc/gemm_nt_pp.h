@@ -347,8 +347,6 @@ __global__ __launch_bounds__(512, 2) void conv16_halo_pp_kernel(const NtParams p
         buf_load_lds16(apool_img, pool_voff, cc << 7, pscr + wid * 1024);
         if (wid < 4) buf_load_lds16(acode_img, pool_coff, cc << 6, pscr + 8192 + wid * 1024);
     };
-    // one pixel position q of every window per call (the main loop spreads the four over taps 2..5: one ds_write_b128 and a
-    // dozen VALU operations per phase instead of a 50-operation burst in one - measured +4.5 % on the launch as a burst)
     auto pool_scatter_q = [&](int cc, int q) __attribute__((always_inline)) {
         char* ab = abuf0 + (cc & 1) * A_BYTES;
         const uint4 pool_v = *reinterpret_cast<const uint4*>(pscr + tid * 16);
@@ -473,6 +471,13 @@ __global__ __launch_bounds__(512, 2) void conv16_halo_pp_kernel(const NtParams p
             const int ky = tap / 3, kx = tap - 3 * ky;
             // phase X: rows a0 x both weight halves
             read_a(0, cc, ky, kx); read_b(step);
+            if constexpr (ASRC) {
+                // The scatter of the next chunk's patch sits in phase X of tap 2: this phase issues no DMA (phase Y issues four
+                // weight pieces at 100-185 cycles each), so it has the slack for ~50 VALU operations, two small ds_reads and four
+                // ds_write_b128.  Measured on the launch: in phase Y +4.5 %, spread over four phases Y +18 %, inside the wave's own
+                // MFMA phase the register file overflows (spills inside the counted-vmcnt loop are not an option).
+                if (more_cc && tap == 2) pool_scatter(cc + 1);
+            }
             SGC_WAIT_LGKM0();
             SGC_PP_BARRIER();
             half(0);
@@ -481,8 +486,8 @@ __global__ __launch_bounds__(512, 2) void conv16_halo_pp_kernel(const NtParams p
             if constexpr (ASRC) {
                 // pooled source: tap 0 DMAs the next chunk's window values + routing bytes into the scratch (issued AFTER this phase's
                 // four weight loads so that the counted wait leaves them in flight), tap 1's vmcnt(4) retires them in every wave
-                // (they are older than its own weight loads) and its barrier publishes them, taps 2..5 scatter them (one window position each)
-                // into the other patch buffer (last read in chunk cc-1; the scratch itself is next written in tap 0 of chunk cc+1).
+                // (they are older than its own weight loads) and its barrier publishes them, tap 2 (phase X) scatters them into the other
+                // patch buffer (last read in chunk cc-1; the scratch itself is next written in tap 0 of chunk cc+1).
                 if (step + 2 < nsteps) {
                     stage_b(step + 2);
                     if (more_cc && tap == 0) {
@@ -490,7 +495,7 @@ __global__ __launch_bounds__(512, 2) void conv16_halo_pp_kernel(const NtParams p
                         if (npool == 2) SGC_WAIT_VM(6); else SGC_WAIT_VM(5);
                     } else SGC_WAIT_VM(4);
                 } else SGC_WAIT_VM(0);                      // last two steps: more_cc is false there (nsteps = 9 * ncc)
-                if (more_cc && tap >= 2 && tap < 6) pool_scatter_q(cc + 1, tap - 2);
+
             } else if (step + 2 < nsteps) {
                 stage_b(step + 2);
                 if (more_cc && tap < npiece) {
