@@ -354,10 +354,18 @@ __global__ __launch_bounds__(512, 2) void conv16_halo_pp_kernel(const NtParams p
         const u16* vh = reinterpret_cast<const u16*>(&pool_v);
         const unsigned char* ch = reinterpret_cast<const unsigned char*>(&pool_c);
         const int wy = pw >> 3, wx = pw & 7;
+        // SWAR select: byte k of (code ^ q*0x01010101) is zero where channel k routes to position q; the classic zero-byte test
+        // (exact for bytes < 0x80) flags it with 0x80, a sign-extending 1-bit field extract turns the flag into a 16-bit lane mask.
+        const unsigned qq = (unsigned)q * 0x01010101u;
+        const unsigned x0 = pool_c.x ^ qq, x1 = pool_c.y ^ qq;
+        const unsigned m0 = (x0 - 0x01010101u) & ~x0 & 0x80808080u, m1 = (x1 - 0x01010101u) & ~x1 & 0x80808080u;
+        auto lanes = [](unsigned m, int e) __attribute__((always_inline)) {           // elements e (low half) and e+1 (high half) of m's four
+            const unsigned lo = (unsigned)__builtin_amdgcn_sbfe(m, 8 * e + 7, 1), hi = (unsigned)__builtin_amdgcn_sbfe(m, 8 * e + 15, 1);
+            return (lo & 0x0000ffffu) | (hi & 0xffff0000u);
+        };
         uint4 o;
-        u16* oh = reinterpret_cast<u16*>(&o);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) oh[k] = (ch[k] == q) ? vh[k] : (u16)0;
+        o.x = pool_v.x & lanes(m0, 0); o.y = pool_v.y & lanes(m0, 2); o.z = pool_v.z & lanes(m1, 0); o.w = pool_v.w & lanes(m1, 2);
+        (void)vh; (void)ch;
         const int py = 2 * wy + (q >> 1) + 1, px = 2 * wx + (q & 1) + 1;
         const int f = ((px >> 1) + 4 * (py & 1)) & 7;
         *reinterpret_cast<uint4*>(ab + (py * 18 + px) * 128 + ((pg ^ f) << 4)) = o;
@@ -471,13 +479,6 @@ __global__ __launch_bounds__(512, 2) void conv16_halo_pp_kernel(const NtParams p
             const int ky = tap / 3, kx = tap - 3 * ky;
             // phase X: rows a0 x both weight halves
             read_a(0, cc, ky, kx); read_b(step);
-            if constexpr (ASRC) {
-                // The scatter of the next chunk's patch sits in phase X of tap 2: this phase issues no DMA (phase Y issues four
-                // weight pieces at 100-185 cycles each), so it has the slack for ~50 VALU operations, two small ds_reads and four
-                // ds_write_b128.  Measured on the launch: in phase Y +4.5 %, spread over four phases Y +18 %, inside the wave's own
-                // MFMA phase the register file overflows (spills inside the counted-vmcnt loop are not an option).
-                if (more_cc && tap == 2) pool_scatter(cc + 1);
-            }
             SGC_WAIT_LGKM0();
             SGC_PP_BARRIER();
             half(0);
@@ -486,7 +487,7 @@ __global__ __launch_bounds__(512, 2) void conv16_halo_pp_kernel(const NtParams p
             if constexpr (ASRC) {
                 // pooled source: tap 0 DMAs the next chunk's window values + routing bytes into the scratch (issued AFTER this phase's
                 // four weight loads so that the counted wait leaves them in flight), tap 1's vmcnt(4) retires them in every wave
-                // (they are older than its own weight loads) and its barrier publishes them, tap 2 (phase X) scatters them into the other
+                // (they are older than its own weight loads) and its barrier publishes them, tap 2 scatters them into the other
                 // patch buffer (last read in chunk cc-1; the scratch itself is next written in tap 0 of chunk cc+1).
                 if (step + 2 < nsteps) {
                     stage_b(step + 2);
@@ -495,6 +496,11 @@ __global__ __launch_bounds__(512, 2) void conv16_halo_pp_kernel(const NtParams p
                         if (npool == 2) SGC_WAIT_VM(6); else SGC_WAIT_VM(5);
                     } else SGC_WAIT_VM(4);
                 } else SGC_WAIT_VM(0);                      // last two steps: more_cc is false there (nsteps = 9 * ncc)
+                // The scatter (~180 VALU operations, re-reads of the scratch, four ds_write_b128) costs the launch +4.5 % here (tap 2,
+                // phase Y) - about what the un-pool pass saves by not writing the 21 GB tensor.  Measured alternatives: phase X of
+                // tap 2 +5.6 %, spread over taps 2..5 +18 %, inside the wave's own MFMA phase the register file overflows (spills
+                // inside the counted-vmcnt loop are not an option).
+                if (more_cc && tap == 2) pool_scatter(cc + 1);
 
             } else if (step + 2 < nsteps) {
                 stage_b(step + 2);
