@@ -354,11 +354,13 @@ __global__ __launch_bounds__(512, 2) void conv16_halo_pp_kernel(const NtParams p
         const u16* vh = reinterpret_cast<const u16*>(&pool_v);
         const unsigned char* ch = reinterpret_cast<const unsigned char*>(&pool_c);
         const int wy = pw >> 3, wx = pw & 7;
-        // SWAR select: byte k of (code ^ q*0x01010101) is zero where channel k routes to position q; the classic zero-byte test
-        // (exact for bytes < 0x80) flags it with 0x80, a sign-extending 1-bit field extract turns the flag into a 16-bit lane mask.
+        // SWAR select: byte k of (code ^ q*0x01010101) is zero where channel k routes to position q.  Per-byte exact zero test
+        // without cross-byte carries (bytes are < 0x80): ((x & 0x7f..) + 0x7f..) sets bit 7 of every NON-zero byte; a sign-extending
+        // 1-bit field extract turns the inverted flag into a 16-bit lane mask.
         const unsigned qq = (unsigned)q * 0x01010101u;
         const unsigned x0 = pool_c.x ^ qq, x1 = pool_c.y ^ qq;
-        const unsigned m0 = (x0 - 0x01010101u) & ~x0 & 0x80808080u, m1 = (x1 - 0x01010101u) & ~x1 & 0x80808080u;
+        const unsigned m0 = ~(((x0 & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x0) & 0x80808080u;
+        const unsigned m1 = ~(((x1 & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x1) & 0x80808080u;
         auto lanes = [](unsigned m, int e) __attribute__((always_inline)) {           // elements e (low half) and e+1 (high half) of m's four
             const unsigned lo = (unsigned)__builtin_amdgcn_sbfe(m, 8 * e + 7, 1), hi = (unsigned)__builtin_amdgcn_sbfe(m, 8 * e + 15, 1);
             return (lo & 0x0000ffffu) | (hi & 0xffff0000u);
