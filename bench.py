@@ -29,7 +29,8 @@ sys.path.insert(0, REPO)
 
 MFMA_PEAK_TFLOPS = 2500.0      # dense bf16/f16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
-DOMINANT_KERNEL = "conv16_halo_pp_kernel<0, 3>"      # conv3 forward: f16, halo-staged implicit 3x3 conv, ReLU + max-pool epilogue
+# conv3 forward: f16, halo-staged implicit 3x3 conv, ReLU + max-pool epilogue (template <ELEM, EPI[, ASRC]>; older profiles lack ASRC)
+DOMINANT_KERNEL = ("conv16_halo_pp_kernel<0, 3, 0>", "conv16_halo_pp_kernel<0, 3>")
 PMC_TAGS = ("r02_final", "r02_mid", "r01_final")                # newest committed counter passes first
 
 
@@ -102,7 +103,7 @@ def pmc_traffic():
             if not os.path.exists(path):
                 break
             for line in open(path):
-                if DOMINANT_KERNEL in line and "," + ctr + "," in line:
+                if any(k in line for k in DOMINANT_KERNEL) and "," + ctr + "," in line:
                     vals[ctr] = float(line.rsplit(",", 1)[1])
         if len(vals) == 2:
             return int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024), tag
