@@ -79,3 +79,73 @@ def test_training_then_eval_pc_drivers(tmp_path, monkeypatch):
     erec = json.load(open(os.path.join(str(tmp_path), "test_results_0.json")))
     assert len(erec) == 2 and erec[-1]["num_connected"] >= 0
     assert not torch.distributed.is_initialized()
+
+
+class FakeDetr:
+    """Stands in for DETR-101 in the driver tests: features pass through (the image slot holds precomputed encoder features) and
+    ``detect`` returns the decoder outputs carried in the second image slot ([100, 151 + 4] = logits | cxcywh boxes)."""
+
+    def eval(self):
+        return self
+
+    def __call__(self, images):
+        return images
+
+    def detect(self, images):
+        x = torch.stack(list(images))
+        return {"pred_logits": x[:, :, :151].contiguous(), "pred_boxes": x[:, :, 151:].contiguous()}
+
+
+class TinySGDet(torch.utils.data.Dataset):
+    def __init__(self, cfg, n_items, seed):
+        from scene_graph_commonsense_amd.synthetic import make_scene_batch
+        from tests import sgdet_case
+        self.b = make_scene_batch(cfg, [4 + i % 3 for i in range(n_items)], seed=seed, connect_frac=0.6)
+        inv = np.argsort(sgdet_case.alp2fre_table())
+        g = torch.Generator().manual_seed(seed)
+        self.det = []
+        for i in range(n_items):
+            lg = torch.randn(100, 151, generator=g) * 0.3
+            lg[:, 150] += 10.0
+            bx = torch.rand(100, 4, generator=g) * 0.2 + 0.4
+            for o in range(self.b.bbox[i].shape[0]):
+                c = int(self.b.categories[i][o])
+                lg[2 * o + 1, 150] -= 10.0
+                lg[2 * o + 1, int(inv[c])] += 14.0
+                lg[2 * o + 1, int(inv[(c * 7 + 3) % 150])] += 9.0
+                x0, x1, y0, y1 = [float(v) for v in self.b.bbox[i][o]]
+                bx[2 * o + 1] = torch.tensor([(x0 + x1) / 64.0, (y0 + y1) / 64.0, (x1 - x0) / 32.0, (y1 - y0) / 32.0])
+            self.det.append(torch.cat((lg, bx.clamp(0, 1)), dim=1))
+
+    def __len__(self):
+        return len(self.det)
+
+    def __getitem__(self, i):
+        b = self.b
+        return (b.image_feature[i], self.det[i], b.image_depth[i], b.categories[i], b.super_categories[i], b.bbox[i],
+                b.relationships[i], b.subj_or_obj[i], "img_%d_annotations.pkl" % i)
+
+
+@pytest.mark.parametrize("mode", ["sgd", "sgc"])
+def test_eval_sgd_and_sgc_drivers(tmp_path, monkeypatch, mode):
+    """``evaluate.eval_sgd`` / ``eval_sgc`` (evaluate.py:230-461, 464-702) end to end: DETR decoder outputs -> HIP object
+    front-end (-> label matching for SGCLS) -> fused pair path over the predicted objects -> Evaluator(predcls=False)."""
+    from scene_graph_commonsense_amd import evaluate, train_test
+    from scene_graph_commonsense_amd.synthetic import make_state_dict
+    from tests import sgdet_case
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    monkeypatch.setenv("MASTER_PORT", _free_port())
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    cfg, args = _args(tmp_path, "eval")
+    args["models"].update(feature_encoder=FakeDetr(), topk_cat=2, nms=0.5)
+    args["dataset"]["object_class_alp2fre"] = sgdet_case.alp2fre_table().tolist()
+    args["training"]["eval_mode"] = mode
+    model = train_test.build_classifier(args, 0)
+    model.load_state_dict(make_state_dict(cfg, seed=9, head_gain=5.0))
+    train_test.save_checkpoint(model, train_test.checkpoint_name(args, 0, False)[1])       # "<...>_0_0.pth", the spelling the reference loads
+    data = TinySGDet(cfg, 4, seed=77)
+    recall, mean_recall = (evaluate.eval_sgd if mode == "sgd" else evaluate.eval_sgc)(0, args, data)
+    assert len(recall) == 3 and all(0.0 <= float(r) <= 1.0 for r in recall)
+    rec = json.load(open(os.path.join(str(tmp_path), "test_results_0.json")))
+    assert len(rec) == 2 and len(rec[-1]["recall_relationship"]) == 3
+    assert not torch.distributed.is_initialized()
