@@ -253,6 +253,8 @@ def run_rank(args):
                  "conv3_wgrad": 2.0 * P * 256 * 1024 * 4608, "fc1_fwd": 2.0 * P * 65536 * 4096,
                  "fc1_dgrad": 2.0 * P * 65536 * 4096, "fc1_wgrad": 2.0 * P * 65536 * 4096}
         dom = "conv3_fwd"
+        two_streams = os.environ.get("SGC_BWD_STREAMS", "1") != "0" and not args.forward_only
+        fwd_only = ("conv2_fwd", "expand_dense", "expand", "expand_train", "conv3_fwd", "fc1_fwd", "fc2_fwd")
         roof = None
         if dom in kern and kern[dom] > 0:
             ach = flops[dom] / (kern[dom] * 1e-3) / 1e12
@@ -275,9 +277,14 @@ def run_rank(args):
                        "parallelism": "dp%d" % world},
             "loss": None if loss is None else float(loss), "loss_first_step": first_loss,
             "roofline": roof,
-            "kernels_ms": {k: round(v, 3) for k, v in sorted(kern.items())},
-            "kernels_tflops": {k: round(flops[k] / (kern[k] * 1e-3) / 1e12, 1) for k in kern if k in flops and kern[k] > 0},
+            "kernels_ms": {k: round(v, 3) for k, v in sorted(kern.items()) if k in fwd_only or not two_streams},
+            "kernels_tflops": {k: round(flops[k] / (kern[k] * 1e-3) / 1e12, 1) for k in kern
+                               if k in flops and kern[k] > 0 and (k in fwd_only or not two_streams)},
+            "backward_streams": 2 if two_streams else 1,
         }
+        if two_streams:
+            out["kernels_note"] = ("backward launches run on two streams and overlap: their HIP-event durations are not kernel times and "
+                                   "are omitted (SGC_BWD_STREAMS=0 for single-stream per-kernel numbers, as in profiles/)")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, sd)
         print(json.dumps(out), flush=True)

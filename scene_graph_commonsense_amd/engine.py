@@ -523,9 +523,10 @@ class RelHeadEngine:
         # column sums) only have to be there when the optimizer runs, so they go to a side stream as soon as their two operands
         # exist: the HBM-bound kernels of the data chain (un-pool + pack, pair contraction, converts) and the tails of its GEMMs
         # then overlap with weight-gradient GEMM blocks instead of leaving the matrix cores idle.  ``side`` orders the side
-        # stream after everything enqueued so far.  OPT-IN (``SGC_BWD_STREAMS=1``): measured -0.1 ... -1 % per step only (every GEMM
-        # block owns its CU - 146 KiB LDS, all VGPRs - so kernels of two streams interleave block by block instead of
-        # co-residing; profiles/README.md), results bit-identical either way (tests/test_configs_gpu.py).
+        # stream after everything enqueued so far.  Measured -0.3 ... -2.2 ms per step in five alternated A/B pairs on three boxes
+        # (small: every GEMM block owns its CU - 146 KiB LDS, all VGPRs - so kernels of two streams interleave block by block
+        # instead of co-residing; profiles/README.md); results bit-identical either way (tests/test_configs_gpu.py).
+        # ``SGC_BWD_STREAMS=0`` = one stream (used for per-kernel profiles: durations of overlapped launches mean little).
         side = self._side_chain()
         sl = ws.get("slabs", 32 * 1024 * 4608, torch.float32)      # split-K slabs of the weight-gradient chain (largest user: conv3)
 
@@ -671,11 +672,11 @@ class RelHeadEngine:
     # ------------------------------------------------------------------ two-stream backward
     def _side_chain(self):
         """Callable context manager that runs its body on this device's side stream, ordered after everything enqueued on the
-        caller's stream so far; ``join()`` orders the caller's stream after the side stream.  Both are no-ops unless
-        ``SGC_BWD_STREAMS=1``."""
+        caller's stream so far; ``join()`` orders the caller's stream after the side stream.  Both are no-ops with
+        ``SGC_BWD_STREAMS=0``."""
         import contextlib
         eng = self
-        enabled = os.environ.get("SGC_BWD_STREAMS", "0") == "1"
+        enabled = os.environ.get("SGC_BWD_STREAMS", "1") != "0"
 
         class Chain:
             def __init__(self):

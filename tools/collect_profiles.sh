@@ -9,6 +9,9 @@ OUT=$R/gpurun_out
 mkdir -p "$OUT"
 python3 bench.py --steps 5 --warmup 2 2>/dev/null | tail -1 > "$OUT/${TAG}_bench.json"
 cd /tmp && export TMPDIR=/tmp
+# per-kernel passes run the backward on ONE stream (durations of launches that overlap on two streams mean little); the bench
+# line above is the shipped default (two streams)
+export SGC_BWD_STREAMS=0
 rm -rf /tmp/prof_ks /tmp/prof_f /tmp/prof_w /tmp/prof_s
 rocprofv3 --kernel-trace --stats -d /tmp/prof_ks -o ks -- python3 "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > /tmp/ks.log 2>&1
 grep '^{"metric"' /tmp/ks.log | tail -1 > "$OUT/${TAG}_bench_under_rocprof.json"
