@@ -543,14 +543,15 @@ static int launch_conv16_halo_pp(NtParams p, hipStream_t stream) {
     p.tiles_n = p.N / 256;
     {
         // Walk 0 (N tile = block id mod tiles_n) keeps ONE weight tile per XCD L2-resident when it is < ~3 MiB (conv3 forward:
-        // 2.4 MiB) but makes the 4 XCD groups of an image's 4 N tiles each fetch its patch; walk 1 (XCD-contiguous image ranges)
-        // fetches every patch once and streams the weight tiles.  Round 2, one box, alternated twice: forward FETCH_SIZE 25.6e6 vs
-        // 28.7e6 KiB but 60.2 vs 59.6 ms per launch (-1 %, both pairs) - the traffic counter is not what decides, the launch is
-        // power-bound (profiles/r02_halo_walk_ab.txt).  The data gradient (4.7 MiB weight tiles) always preferred walk 1.
-        // Default: walk 1 for both; SGC_HALO_WALK=0/1 forces.
+        // 2.4 MiB; FETCH_SIZE 25.6e6 KiB, stable) but makes the 4 XCD groups of an image's 4 N tiles each fetch its patch; walk 1
+        // (XCD-contiguous image ranges) fetches every patch once and streams the weight tiles, which thrash the 4 MiB L2:
+        // 28.7e6 - 45.5e6 KiB from run to run.  Launch time is the same within box noise (round 2: 60.2 vs 59.6 ms in one
+        // alternated pair, 60.8 / 61.2 vs 60.9 / 61.0 in another; profiles/r02_halo_walk_ab.txt, r02_hook_sweep.txt) - the launch
+        // is power-bound, not traffic-bound - so the forward keeps the walk with the lower, stable traffic.  A larger weight tile
+        // (conv3 data gradient: 4.7 MiB) thrashes either way and takes walk 1.  SGC_HALO_WALK=0/1 forces.
         static int hw = -2;
         if (hw == -2) { const char* e = getenv("SGC_HALO_WALK"); hw = e ? atoi(e) : -1; }
-        p.halo_walk = hw >= 0 ? hw : 1;
+        p.halo_walk = hw >= 0 ? hw : ((long)p.K * 512 > (3L << 20) ? 1 : 0);
     }
     if constexpr (ELEM == ELEM_BF16 && EPI == EPI_STORE) {
         if (p.Apool) {                                 // A operand given as pooled rows + routing byte: un-pooled inside the block
