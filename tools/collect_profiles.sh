@@ -7,7 +7,6 @@ TAG=${1:-rXX}
 R=$(pwd)
 OUT=$R/gpurun_out
 mkdir -p "$OUT"
-python3 bench.py --steps 5 --warmup 2 2>/dev/null | tail -1 > "$OUT/${TAG}_bench.json"
 cd /tmp && export TMPDIR=/tmp
 # per-kernel passes run the backward on ONE stream (durations of launches that overlap on two streams mean little); the bench
 # line above is the shipped default (two streams)
@@ -27,4 +26,8 @@ python3 "$R/tools/pmc_summary.py" "$(find /tmp/prof_s -name '*counter_collection
 rm -rf /tmp/prof_m
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE -d /tmp/prof_m -o m --output-format csv -- python3 "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline > /tmp/m.log 2>&1
 python3 "$R/tools/pmc_summary.py" "$(find /tmp/prof_m -name '*counter_collection.csv' | head -1)" "$OUT/${TAG}_pmc_m.csv"
+# the bench line comes LAST and reads the counter passes just taken (roofline.traffic is derived from them): shipped defaults again
+unset SGC_BWD_STREAMS
+mkdir -p "$R/profiles" && cp "$OUT"/${TAG}_pmc_*.csv "$R/profiles/" 2>/dev/null
+cd "$R" && python3 bench.py --steps 5 --warmup 2 2>/dev/null | tail -1 > "$OUT/${TAG}_bench.json"
 ls -la "$OUT"/${TAG}_*
