@@ -57,7 +57,7 @@ def parse_args(argv=None):
 def launch_ranks(args, argv):
     """Start ``args.gpus`` child ranks of this script (one per GPU) and wait.  Runs before anything in this process has
     initialised the GPU; children are fresh interpreters, never an exec of this one."""
-    if not args.dry_run:
+    if not args.dry_run and os.environ.get("SGC_BENCH_SHARE_GPU") != "1":
         import torch
         have = torch.cuda.device_count()                     # counting devices does not initialise the runtime
         if have < args.gpus:
@@ -172,6 +172,10 @@ def run_rank(args):
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    if os.environ.get("SGC_BENCH_SHARE_GPU") == "1":
+        # TEST HOOK: every rank on the devices that exist (rank % device_count) - exercises the whole multi-rank path (launcher,
+        # rendezvous, early + flat gradient reduction, MAX-reduced time) on a one-GPU box over gloo; RCCL refuses to share a device
+        os.environ["LOCAL_RANK"] = str(int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1))
     rank, world, local = sgd_dist.init_from_env(backend=args.backend)
     if world != args.gpus:
         raise SystemExit("bench.py --gpus %d but WORLD_SIZE=%d: refusing to report a number for the wrong rank count" % (args.gpus, world))

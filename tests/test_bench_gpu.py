@@ -48,3 +48,20 @@ def test_bench_launcher_refuses_more_ranks_than_gpus():
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", str(n + 1), "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode != 0 and "GPU(s) visible" in (r.stderr + r.stdout)
+
+
+def test_bench_two_ranks_end_to_end_on_one_gpu_over_gloo():
+    """The whole multi-rank bench path on hardware - launcher, rendezvous, per-rank synthetic shards, early fc1 reduction from the
+    side stream + flat bucket, barrier, MAX-reduced time, one JSON line with n_gpus = 2 - with both ranks sharing the one GPU of
+    the test box over gloo (test hook SGC_BENCH_SHARE_GPU; RCCL itself needs one GPU per rank and is the driver's to run)."""
+    env = dict(os.environ, SGC_BENCH_SHARE_GPU="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--objects", "20",
+                        "--images", "4", "--backend", "gloo", "--no-cpu-baseline"], capture_output=True, text=True, timeout=1200, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "dp2" and out["value"] > 0
+    assert out["loss"] == out["loss"] and out["scaling"] == "weak"
