@@ -46,6 +46,22 @@ def _args(tmp_path, run_mode):
     return cfg, args
 
 
+class TinyOIV6(torch.utils.data.Dataset):
+    """OpenImages-style items: 601 classes, no super-categories (``None`` in that slot, ``dataloader.py`` OpenImageV6Dataset)."""
+
+    def __init__(self, cfg, n_items, seed):
+        from scene_graph_commonsense_amd.synthetic import make_scene_batch
+        self.b = make_scene_batch(cfg, [3 + (i * 3) % 4 for i in range(n_items)], seed=seed, connect_frac=0.5)
+
+    def __len__(self):
+        return len(self.b.bbox)
+
+    def __getitem__(self, i):
+        b = self.b
+        return (b.image_feature[i], b.image_feature[i] * 0.9 + 0.05, b.image_depth[i], b.categories[i], None, b.bbox[i],
+                b.relationships[i], b.subj_or_obj[i], "img_%d_annotations.pkl" % i)
+
+
 def _free_port():
     import socket
     with socket.socket() as sk:
@@ -149,3 +165,27 @@ def test_eval_sgd_and_sgc_drivers(tmp_path, monkeypatch, mode):
     rec = json.load(open(os.path.join(str(tmp_path), "test_results_0.json")))
     assert len(rec) == 2 and len(rec[-1]["recall_relationship"]) == 3
     assert not torch.distributed.is_initialized()
+
+
+def test_training_driver_on_openimages_shaped_data(tmp_path, monkeypatch):
+    """The OIV6 branch of ``training`` / ``testing`` (601 classes, (4,2,24) head, no super-categories, weighted mean AP through
+    ``Evaluator.compute_precision`` instead of zero-shot recall / Top-3)."""
+    from scene_graph_commonsense_amd import train_test
+    from scene_graph_commonsense_amd.synthetic import HeadConfig
+    from tests.golden_cases import GOLDEN
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    monkeypatch.setenv("MASTER_PORT", _free_port())
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    cfg = HeadConfig(dataset="oiv6", num_classes=601, num_super_classes=0, num_geometric=4, num_possessive=2, num_semantic=24)
+    args = cfg.args(run_mode="train", fixtures=os.path.join(GOLDEN, "ref_fixtures") + os.sep)
+    args["models"]["feature_encoder"] = "precomputed"
+    args["training"].update(batch_size=2, num_epoch=1, start_epoch=0, continue_train=False, scheduler_param1=5, scheduler_param2=8,
+                            print_freq=1, print_freq_test=1, eval_freq=1, eval_freq_test=1, test_epoch=0, save_vis_results=False,
+                            result_path=str(tmp_path) + os.sep, checkpoint_path=str(tmp_path) + os.sep, learning_rate=1e-5)
+    train_test.training(0, args, TinyOIV6(cfg, 4, seed=51), TinyOIV6(cfg, 2, seed=52))
+    rec = json.load(open(os.path.join(str(tmp_path), "train_results_0.json")))
+    assert len(rec) == 2 and all(np.isfinite(r["total_losses"]) for r in rec) and "wmap_rel" in rec[-1]
+    trec = json.load(open(os.path.join(str(tmp_path), "test_results_0.json")))
+    assert len(trec) == 1 and "wmap_rel" in trec[-1]
+    sd = torch.load(os.path.join(str(tmp_path), "HierRelationModel_Baseline_motif0_0.pth"), map_location="cpu")
+    assert sd["module.fc2.weight"].shape == (512, 4096 + 2 * 601)
