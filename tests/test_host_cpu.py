@@ -360,3 +360,25 @@ def test_dropin_shims_resolve_like_main_py(tmp_path):
             "print('ok')\n") % (REPO, os.path.join(REPO, "scene_graph_commonsense_amd", "dropin"))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+
+
+def test_graph_iter_offsets_describe_the_reference_enumeration():
+    """``pairs.graph_iter_offsets`` is all the host tells ``sgc_scene_tables`` about the pair order: block g starts at goff[g] and
+    holds 2g rows of k_g pairs (k_g = #{images with more than g objects}); it must agree with the explicit enumeration that
+    ``test_pair_enumeration_matches_reference_order`` pins to the reference's loops - for random ragged shapes."""
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        n = rng.integers(0, 9, size=int(rng.integers(1, 7)))
+        goff, max_n = PR.graph_iter_offsets(np.asarray(n, dtype=np.int64))
+        pidx = PR.enumerate_pairs(n.tolist())
+        assert max_n == int(n.max())
+        assert int(goff[max(max_n, 1)]) == pidx.n_pairs == int(sum(k * (k - 1) for k in n))
+        if pidx.n_pairs:
+            # every pair's block, row and column follow from goff alone
+            g = np.searchsorted(goff, np.arange(pidx.n_pairs), side="right") - 1
+            assert np.array_equal(g, pidx.g)
+            k = np.array([(n > gg).sum() for gg in g])
+            local = np.arange(pidx.n_pairs) - goff[g]
+            row = local // k
+            assert np.array_equal(row // 2, pidx.e) and np.array_equal(row % 2 == 0, pidx.first)
+            assert np.array_equal(g * (g - 1) + row, pidx.step)
