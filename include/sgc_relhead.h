@@ -52,6 +52,26 @@ int sgc_pair_expand_dense(const void* U, const void* V, const int* img_ptr, cons
 int sgc_conv3_relu_pool(const void* z_pad, const void* w3r, const float* b3, void* y, unsigned char* argmax, void* y_bf16, int n_pairs,
                         void* stream);
 
+/* conv3 over SHARED windows (csrc/kernels_shared.hip).  Outside its box an object's masked map is the constant tanh(b1)
+ * (train_test.py:194-195), so the part of conv3_1 -> ReLU -> max-pool (model.py:145-147) that depends on BOTH objects of a pair is
+ * confined to the intersection X_ij = R_i n R_j of two rectangles of conv3's 8x8 pooling-window grid; every other window of the pair
+ * equals the same window of the pseudo-pair (i, empty-box object) or (empty-box object, j), computed once per object.
+ * bbox [n_obj][4] int (x0,x1,y0,y1, slice semantics); sub_idx / obj_idx [n_pairs] index it.
+ *   sgc_shared_windows_count   count[p] = |X_p|
+ *   sgc_shared_windows_fill    gather[e] = pair*64 + window for all X windows, given the INCLUSIVE prefix sum of count
+ *   sgc_conv3_relu_pool_windows  sgc_conv3_relu_pool for the listed windows only, results written to rows gather[e] of y / argmax /
+ *                              y_bf16 (max_entries bounds the launch, *gather_n on the device is the list length)
+ *   sgc_shared_windows_assemble  the remaining rows: copies of y_obj [2*n_obj*64][1024] (rows of pseudo-pair (i, bg) = i,
+ *                              of (bg, j) = n_obj + j), likewise argmax_obj and y_obj_bf16 (each may be NULL with its output) */
+int sgc_shared_windows_count(const int* bbox, const int* sub_idx, const int* obj_idx, int n_pairs, int* count, void* stream);
+int sgc_shared_windows_fill(const int* bbox, const int* sub_idx, const int* obj_idx, int n_pairs, const int* count_incl, int* gather,
+                            void* stream);
+int sgc_conv3_relu_pool_windows(const void* z_pad, const void* w3r, const float* b3, const int* gather, const int* gather_n,
+                                int max_entries, void* y, unsigned char* argmax, void* y_bf16, void* stream);
+int sgc_shared_windows_assemble(const int* bbox, const int* sub_idx, const int* obj_idx, int n_pairs, int n_obj, const void* y_obj,
+                                const unsigned char* argmax_obj, const void* y_obj_bf16, void* y, unsigned char* argmax, void* y_bf16,
+                                void* stream);
+
 /* h1 [n_pairs][4096] f16 = dropout(relu(y[n_pairs][K] * w1p[4096][K]^T + b))   (model.py:148-149; columns of w1p in (window, channel) order) */
 int sgc_fc1_relu(const void* y, const void* w1p, const float* b, void* h1, int n_pairs, int K, int drop_enable, unsigned drop_seed, void* stream);
 

@@ -17,7 +17,7 @@
 #include "common.h"
 #include <type_traits>
 
-enum { AMODE_PLAIN = 0, AMODE_CONV = 1 };
+enum { AMODE_PLAIN = 0, AMODE_CONV = 1, AMODE_CONV_GATHER = 2 };   // GATHER: conv rows come from a list of 2x2 windows (see NtParams::gather)
 enum { EPI_STORE = 0, EPI_BIAS_TANH = 1, EPI_BIAS_RELU = 2, EPI_POOL = 3, EPI_FC2 = 4, EPI_RELUMASK = 5 };
 
 struct NtParams {
@@ -38,6 +38,9 @@ struct NtParams {
     int patch_aligned;          // gemm_nt_pp_kernel: 1 = grid padded to whole 32-tile patches (set by the launcher for large grids)
     const u16* Apool; const unsigned char* Acode;   // conv16_halo_pp_kernel<.., ASRC = 1>: the A operand as POOLED rows [img*64 windows][Cin]
                                                     // + routing byte (0..3 = position inside the 2x2 window, 4 = none); un-pooled on the fly
+    const int* gather; const int* gather_n;         // AMODE_CONV_GATHER: row m = 4*e + q is pixel q of window gather[e] = image*(S/2)^2 + window;
+                                                    // *gather_n = number of list entries (device side; p.M is only the launch bound);
+                                                    // EPI_POOL writes entry e to pooled row gather[e]
 };
 
 template <int ELEM>
@@ -60,8 +63,9 @@ __device__ __forceinline__ long conv_row_base(int m, int lgS, int Cin) {
     return ((long)(img * (S + 2) + y) * (S + 2) + x) * Cin;
 }
 
-template <int ELEM, int EPI, int TM, int TN>
-__device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wr, int wc, int lane) {
+template <int ELEM, int EPI, int TM, int TN, bool GATHER = false>
+__device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wr, int wc, int lane, int m_limit = -1) {
+    const int M = GATHER ? m_limit : p.M;
     const int h = lane >> 5, cl = lane & 31;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -82,8 +86,9 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x16 (&acc)[TM]
                         if (t > v) { v = t; am = q; }
                     }
                     v += bias;
-                    const int prow = (rbase >> 2) + 2 * w + h;
-                    if (prow * 4 < p.M) {
+                    int prow = (rbase >> 2) + 2 * w + h;
+                    if (prow * 4 < M) {
+                        if constexpr (GATHER) prow = p.gather[prow];
                         if (!(v > 0.f)) { v = 0.f; am = 4; }        // ReLU killed: no gradient path
                         out[(long)prow * p.ldc + col] = to_elem<ELEM>(v);
                         if (p.C2) p.C2[(long)prow * p.ldc + col] = f32_to_bf16_bits(v);
@@ -94,7 +99,7 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x16 (&acc)[TM]
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = rbase + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (row >= p.M) continue;
+                    if (row >= M) continue;
                     float v = acc[i][j][r];
                     const long o = (long)row * p.ldc + col;
                     if constexpr (EPI == EPI_STORE) {
@@ -211,6 +216,11 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void gemm_nt_kernel(const NtParams
     int tm, tn;
     supertile_map(blockIdx.x, p.tiles_m, p.tiles_n, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
+    int Mlim = p.M;
+    if constexpr (AMODE == AMODE_CONV_GATHER) {
+        Mlim = min(p.M, 4 * *p.gather_n);
+        if (m0 >= Mlim) return;                     // the grid is sized for the bound, the list is usually shorter
+    }
 
     // ---- loader addresses: wave w stages rows w*AI*8 .. of A and w*BI*8 .. of B, 8 rows (1 KiB) per instruction
     const int lrow = lane >> 3, cpos = lane & 7;
@@ -220,8 +230,9 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void gemm_nt_kernel(const NtParams
     for (int i = 0; i < AI; ++i) {
         const int row = wid * AI * 8 + i * 8 + lrow;
         const int chunk = cpos ^ ((row >> 1) & 7);
-        int m = m0 + row; if (m > p.M - 1) m = p.M - 1;
-        if constexpr (AMODE == AMODE_CONV) a_ptr[i] = p.A + conv_row_base(m, p.lgS, p.Cin) + chunk * 8;
+        int m = m0 + row; if (m > Mlim - 1) m = Mlim - 1;
+        if constexpr (AMODE == AMODE_CONV_GATHER) m = p.gather[m >> 2] * 4 + (m & 3);
+        if constexpr (AMODE != AMODE_PLAIN) a_ptr[i] = p.A + conv_row_base(m, p.lgS, p.Cin) + chunk * 8;
         else a_ptr[i] = p.A + (long)m * p.lda + chunk * 8;
     }
 #pragma unroll
@@ -234,7 +245,7 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void gemm_nt_kernel(const NtParams
 
     auto stage = [&](int buf, int kt) {
         long aoff;
-        if constexpr (AMODE == AMODE_CONV) {
+        if constexpr (AMODE != AMODE_PLAIN) {
             // K order = (64-channel chunk, tap, channel): the nine taps of one chunk are consecutive K tiles, so
             // the shifted re-reads of a pixel row hit L2 (working set 18x18x64 ch per block) instead of the fabric.
             const int cc = kt / 9, tap = kt - cc * 9;
@@ -307,7 +318,8 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void gemm_nt_kernel(const NtParams
     if constexpr (EPI == EPI_STORE && TM == 4 && TN == 2 && WR * WC == 8) {
         if (p.epi_lds) { nt_epilogue_store16<ELEM>(p, acc, m0, n0, wr, wc, lane, wid, smem); return; }
     }
-    nt_epilogue<ELEM, EPI, TM, TN>(p, acc, m0, n0, wr, wc, lane);
+    if constexpr (AMODE == AMODE_CONV_GATHER) nt_epilogue<ELEM, EPI, TM, TN, true>(p, acc, m0, n0, wr, wc, lane, Mlim);
+    else nt_epilogue<ELEM, EPI, TM, TN>(p, acc, m0, n0, wr, wc, lane);
 }
 
 #ifdef SGC_EXPERIMENTS

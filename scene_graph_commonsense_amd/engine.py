@@ -126,6 +126,11 @@ class TrainContext:
     pass
 
 
+def shared_conv3_enabled() -> bool:
+    """``SGC_SHARED_CONV3=0`` computes conv3 for every window of every pair (A/B hook; default: per-object sharing on)."""
+    return os.environ.get("SGC_SHARED_CONV3", "1") != "0"
+
+
 class RelHeadEngine:
     """Forward and backward of the relation head over explicit pair lists (one instance = one GPU, one workspace)."""
 
@@ -271,9 +276,14 @@ class RelHeadEngine:
         self._x = x
         return out
 
-    def object_halves(self, a_img, obj_img: torch.Tensor, bbox: torch.Tensor, roles=(0, 1)):
-        """Per-object masked maps and conv2 halves U (role 0) / V (role 1, carries the bias)."""
+    def object_halves(self, a_img, obj_img: torch.Tensor, bbox: torch.Tensor, roles=(0, 1), with_bg=False):
+        """Per-object masked maps and conv2 halves U (role 0) / V (role 1, carries the bias).
+        ``with_bg``: one more object with an EMPTY box is appended (index n_obj) - the constant map tanh(b1) every masked map
+        equals outside its box; its halves are the background of ``conv3_shared``."""
         lib, ws = self.lib, self.ws
+        if with_bg:
+            obj_img = torch.cat([obj_img, obj_img.new_zeros(1)])
+            bbox = torch.cat([bbox, bbox.new_zeros(1, 4)])
         n_obj = obj_img.shape[0]
         res = {}
         for r in roles:
@@ -305,8 +315,44 @@ class RelHeadEngine:
                 _lib.ptr(U), _lib.ptr(V), _lib.ptr(sub_idx), _lib.ptr(obj_idx), _lib.ptr(z), _lib.ptr(z_bf), _lib.ptr(amz), P,
                 self._st()), "sgc_pair_expand_train"))
 
+    def conv3_shared(self, z, U, V, bbox, n_obj, sub_idx, obj_idx, P, y, am, y_bf, bound=None):
+        """conv3 + ReLU + pool with the per-object part computed once per object (``csrc/kernels_shared.hip``): U / V hold
+        n_obj + 1 objects, the last one the empty-box background.  ``bound``: an upper bound of the number of pair-specific
+        windows known on the host (``DeviceScene.shared_windows``), else 64 per pair."""
+        lib, sc = self.lib, self.scratch
+        n2 = 2 * n_obj
+        ps = getattr(self, "_pseudo", None)
+        if ps is None or ps[0] != n_obj:
+            ar = torch.arange(n_obj, dtype=torch.int32, device=self.device)
+            bg = torch.full((n_obj,), n_obj, dtype=torch.int32, device=self.device)
+            ps = self._pseudo = (n_obj, torch.cat([ar, bg]).contiguous(), torch.cat([bg, ar]).contiguous())
+        z_ps = sc.get("z_ps", n2 * 18 * 18 * 512, torch.float16)                 # created zeroed: the halo stays zero
+        _lib.check(lib.sgc_pair_expand(_lib.ptr(U), _lib.ptr(V), _lib.ptr(ps[1]), _lib.ptr(ps[2]), _lib.ptr(z_ps), n2, ELEM_F16, self._st()),
+                   "sgc_pair_expand")
+        y_ps = sc.get("y_ps", n2 * 65536, torch.float16)
+        am_ps = sc.get("am_ps", n2 * 65536, torch.uint8) if am is not None else None
+        ybf_ps = sc.get("ybf_ps", n2 * 65536, torch.bfloat16) if y_bf is not None else None
+        self._timed("conv3_fwd_objects", lambda: _lib.check(lib.sgc_conv3_relu_pool(
+            _lib.ptr(z_ps), _lib.ptr(self.w["w3r"]), _lib.ptr(self.w["b3"]), _lib.ptr(y_ps), _lib.ptr(am_ps), _lib.ptr(ybf_ps), n2,
+            self._st()), "sgc_conv3_relu_pool"))
+        cnt = sc.get("xw_count", P, torch.int32)
+        _lib.check(lib.sgc_shared_windows_count(_lib.ptr(bbox), _lib.ptr(sub_idx), _lib.ptr(obj_idx), P, _lib.ptr(cnt), self._st()),
+                   "sgc_shared_windows_count")
+        incl = torch.cumsum(cnt, 0, dtype=torch.int32)
+        gather = sc.get("xw_gather", P * 64, torch.int32)
+        _lib.check(lib.sgc_shared_windows_fill(_lib.ptr(bbox), _lib.ptr(sub_idx), _lib.ptr(obj_idx), P, _lib.ptr(incl), _lib.ptr(gather),
+                                               self._st()), "sgc_shared_windows_fill")
+        bound = P * 64 if bound is None else max(0, min(int(bound), P * 64))
+        self._timed("conv3_fwd_windows", lambda: _lib.check(lib.sgc_conv3_relu_pool_windows(
+            _lib.ptr(z), _lib.ptr(self.w["w3r"]), _lib.ptr(self.w["b3"]), _lib.ptr(gather), _lib.ptr(incl[P - 1:]), bound, _lib.ptr(y),
+            _lib.ptr(am), _lib.ptr(y_bf), self._st()), "sgc_conv3_relu_pool_windows"))
+        self._timed("conv3_fwd_assemble", lambda: _lib.check(lib.sgc_shared_windows_assemble(
+            _lib.ptr(bbox), _lib.ptr(sub_idx), _lib.ptr(obj_idx), P, n_obj, _lib.ptr(y_ps), _lib.ptr(am_ps), _lib.ptr(ybf_ps),
+            _lib.ptr(y), _lib.ptr(am), _lib.ptr(y_bf), self._st()), "sgc_shared_windows_assemble"))
+        self._xw = (gather, incl)
+
     def pair_trunk(self, U, V, sub_idx, obj_idx, lsub, lobj, train=False, seeds=(0, 0), keep_argmax=False,
-                   iou_mask=None, dense=None) -> PairOutputs:
+                   iou_mask=None, dense=None, shared=None) -> PairOutputs:
         lib, ws, cfg = self.lib, self.ws, self.cfg
         P = int(sub_idx.shape[0])
         Ppad = (P + 63) // 64 * 64
@@ -314,8 +360,11 @@ class RelHeadEngine:
         self.expand(U, V, sub_idx, obj_idx, P, z, dense=dense)
         y = ws.get("y", Ppad * 65536, torch.float16)
         am = ws.get("argmax", P * 65536, torch.uint8) if keep_argmax else None
-        self._timed("conv3_fwd", lambda: _lib.check(lib.sgc_conv3_relu_pool(_lib.ptr(z), _lib.ptr(self.w["w3r"]), _lib.ptr(self.w["b3"]), _lib.ptr(y),
-                                           _lib.ptr(am), _lib.ptr(None), P, self._st()), "sgc_conv3_relu_pool"))
+        if shared is not None:
+            self.conv3_shared(z, U, V, shared[0], shared[1], sub_idx, obj_idx, P, y, am, None, shared[2])
+        else:
+            self._timed("conv3_fwd", lambda: _lib.check(lib.sgc_conv3_relu_pool(_lib.ptr(z), _lib.ptr(self.w["w3r"]), _lib.ptr(self.w["b3"]), _lib.ptr(y),
+                                               _lib.ptr(am), _lib.ptr(None), P, self._st()), "sgc_conv3_relu_pool"))
         h1 = ws.get("h1", Ppad * 4096, torch.float16)
         self._timed("fc1_fwd", lambda: _lib.check(lib.sgc_fc1_relu(_lib.ptr(y), _lib.ptr(self.w["w1p"]), _lib.ptr(self.w["bf1"]), _lib.ptr(h1), P, 65536,
                                     int(train), ctypes.c_uint(seeds[0]), self._st()), "sgc_fc1_relu"))
@@ -346,17 +395,19 @@ class RelHeadEngine:
 
     # ------------------------------------------------------------------ fused entry
     def forward_pairs(self, image_feature, image_depth, obj_img, bbox, cats, super_mh, sub_idx, obj_idx, train=False,
-                      seeds=(0, 0), keep_argmax=False, iou_mask=None, dense=None, select=None) -> PairOutputs:
+                      seeds=(0, 0), keep_argmax=False, iou_mask=None, dense=None, select=None, shared_windows=None) -> PairOutputs:
         """One call per minibatch: image maps -> per-object halves -> all pairs.
         ``select`` ([P] bool / uint8 device tensor): run the per-pair trunk (expansion, conv3, fc1, fc2, head) ONLY for the selected
         pairs and scatter the results into full-size outputs; the other pairs get confidence -inf (exactly what the overlap filter
         gives them in the evaluator, ``evaluator.py:131-134``), prediction 0, zero log-probs and hidden vectors."""
         a_img = self.image_maps(image_feature, image_depth)
-        uv = self.object_halves(a_img, obj_img, bbox)
+        share = shared_conv3_enabled()
+        uv = self.object_halves(a_img, obj_img, bbox, with_bg=share)
+        shared = (bbox, int(obj_img.shape[0]), shared_windows) if share else None
         lsub, lobj = self.label_vectors(cats, super_mh)
         self._lsub, self._lobj = lsub, lobj
         if select is None:
-            return self.pair_trunk(uv[0], uv[1], sub_idx, obj_idx, lsub, lobj, train, seeds, keep_argmax, iou_mask, dense)
+            return self.pair_trunk(uv[0], uv[1], sub_idx, obj_idx, lsub, lobj, train, seeds, keep_argmax, iou_mask, dense, shared)
         sel = select.bool()
         idx = torch.nonzero(sel).flatten()
         P, Ps = int(sub_idx.shape[0]), int(idx.shape[0])
@@ -375,7 +426,7 @@ class RelHeadEngine:
             pc = pid.clamp(min=0).long()
             dense_s = (img_ptr, torch.where(ok & sel[pc], rank[pc], torch.full_like(pid, -1)).contiguous(), max_n)
         out = self.pair_trunk(uv[0], uv[1], sub_idx[idx].contiguous(), obj_idx[idx].contiguous(), lsub, lobj, train, seeds, keep_argmax,
-                              None if iou_mask is None else iou_mask[idx].contiguous(), dense_s)
+                              None if iou_mask is None else iou_mask[idx].contiguous(), dense_s, shared)
         full.relation[idx] = out.relation
         if full.super_relation is not None:
             full.super_relation[idx] = out.super_relation
@@ -423,7 +474,7 @@ class RelHeadEngine:
 
 
     def train_forward(self, image_feature, image_depth, obj_img, bbox, cats, super_mh, sub_idx, obj_idx, seeds=(0, 0),
-                      dropout=True, dense=None, role_inputs=None, cats_obj=None, super_mh_obj=None) -> "TrainContext":
+                      dropout=True, dense=None, role_inputs=None, cats_obj=None, super_mh_obj=None, shared_windows=None) -> "TrainContext":
         """Forward that keeps what the backward needs (pool argmaxes, expansion routing mask).
         ``role_inputs=(h_sub, h_obj)``: the reference's per-step call on PRE-MASKED ``[b,257,32,32]`` inputs (``model.py:170``):
         row k of each is the subject / object crop of pair k, with labels ``cats`` / ``cats_obj``; every crop is its own
@@ -447,7 +498,8 @@ class RelHeadEngine:
             x_s = self._x
             a_o = self.image_maps(role_inputs[1], None, roles=(1,), tag="o")
             ctx.a_img, ctx.x = {0: a_s[0], 1: a_o[1]}, (x_s, self._x)
-        ctx.uv = self.object_halves(ctx.a_img, obj_img, bbox)
+        share = role_inputs is None and shared_conv3_enabled()     # per-step calls: every crop is one full-size box, nothing is shared
+        ctx.uv = self.object_halves(ctx.a_img, obj_img, bbox, with_bg=share)
         ctx.lsub, lobj_same = self.label_vectors(ctx.cats[0], ctx.super_mh[0])
         ctx.lobj = lobj_same if role_inputs is None else self.label_vectors(ctx.cats[1], ctx.super_mh[1])[1]
         z = sc.get("z_pad", P * 18 * 18 * 512, torch.float16)
@@ -460,8 +512,11 @@ class RelHeadEngine:
         if Ppad > P:
             Workspace._zero(y_bf[P * 65536:])
         am = ws.get("argmax", P * 65536, torch.uint8)
-        self._timed("conv3_fwd", lambda: _lib.check(lib.sgc_conv3_relu_pool(_lib.ptr(z), _lib.ptr(self.w["w3r"]), _lib.ptr(self.w["b3"]), _lib.ptr(y), _lib.ptr(am),
-                                           _lib.ptr(y_bf), P, self._st()), "sgc_conv3_relu_pool"))
+        if share:
+            self.conv3_shared(z, ctx.uv[0], ctx.uv[1], bbox, ctx.n_obj, sub_idx, obj_idx, P, y, am, y_bf, shared_windows)
+        else:
+            self._timed("conv3_fwd", lambda: _lib.check(lib.sgc_conv3_relu_pool(_lib.ptr(z), _lib.ptr(self.w["w3r"]), _lib.ptr(self.w["b3"]), _lib.ptr(y), _lib.ptr(am),
+                                               _lib.ptr(y_bf), P, self._st()), "sgc_conv3_relu_pool"))
         ctx.y_bf = y_bf
         h1 = ws.get("h1", Ppad * 4096, torch.float16)
         self._timed("fc1_fwd", lambda: _lib.check(lib.sgc_fc1_relu(_lib.ptr(y), _lib.ptr(self.w["w1p"]), _lib.ptr(self.w["bf1"]), _lib.ptr(h1), P, 65536,

@@ -154,7 +154,8 @@ class _RelationBase(nn.Module):
         with torch.no_grad():
             return eng.forward_pairs(scene.image_feature, scene.image_depth, scene.obj_img, scene.bbox, scene.cats,
                                      scene.super_mh, scene.sub_idx, scene.obj_idx, train=self.training, seeds=seeds,
-                                     iou_mask=iou_mask, dense=_dense(scene), select=select)
+                                     iou_mask=iou_mask, dense=_dense(scene), select=select,
+                                     shared_windows=getattr(scene, "shared_windows", None))
 
     def _next_seeds(self):
         self._step += 1
@@ -212,7 +213,7 @@ class _RelationBase(nn.Module):
             ctx = eng.train_forward(scene.image_feature, scene.image_depth, scene.obj_img, scene.bbox, scene.cats,
                                     scene.super_mh, scene.sub_idx, scene.obj_idx,
                                     seeds=self._next_seeds() if self.training else (0, 0), dropout=self.training,
-                                    dense=_dense(scene))
+                                    dense=_dense(scene), shared_windows=getattr(scene, "shared_windows", None))
             cs_coef = None
             if commonsense is not None:
                 from .commonsense import TripletBitmaps

@@ -184,6 +184,39 @@ def graph_iter_offsets(n: np.ndarray):
     return goff, max_n
 
 
+def object_window_rects(bb: np.ndarray) -> np.ndarray:
+    """[n,4] normalised boxes (x0,x1,y0,y1 on the 32-grid) -> [n,4] half-open rectangles (x0,x1,y0,y1) on the 8x8 grid of conv3's
+    pooling windows outside which the object cannot influence a pair's conv3 output (host replica of
+    ``csrc/kernels_shared.hip:object_windows``; zero rectangle for an empty box)."""
+    bb = np.asarray(bb, dtype=np.int64).reshape(-1, 4)
+    out = np.zeros_like(bb)
+    for a in (0, 2):
+        lo, hi = np.clip(bb[:, a], 0, None), np.clip(bb[:, a + 1], None, 32)
+        ok = hi > lo
+        lo, hi = np.maximum(lo - 1, 0), np.minimum(hi + 1, 32)
+        lo, hi = lo >> 1, (hi + 1) >> 1
+        lo, hi = np.maximum(lo - 1, 0), np.minimum(hi + 1, 16)
+        out[:, a], out[:, a + 1] = np.where(ok, lo >> 1, 0), np.where(ok, (hi + 1) >> 1, 0)
+    empty = (out[:, 1] <= out[:, 0]) | (out[:, 3] <= out[:, 2])
+    out[empty] = 0
+    return out
+
+
+def count_shared_windows(bb: np.ndarray, img_ptr) -> int:
+    """Number of pair-specific (X) windows over all ordered pairs of every image: sum of |R_i n R_j|."""
+    r = object_window_rects(bb)
+    total = 0
+    for b in range(len(img_ptr) - 1):
+        q = r[int(img_ptr[b]):int(img_ptr[b + 1])]
+        if len(q) < 2:
+            continue
+        ox = np.clip(np.minimum(q[:, None, 1], q[None, :, 1]) - np.maximum(q[:, None, 0], q[None, :, 0]), 0, None)
+        oy = np.clip(np.minimum(q[:, None, 3], q[None, :, 3]) - np.maximum(q[:, None, 2], q[None, :, 2]), 0, None)
+        a = ox * oy
+        total += int(a.sum() - np.trace(a))
+    return total
+
+
 def flatten_scene(cfg, batch, device) -> DeviceScene:
     """SceneBatch (reference data contract) -> DeviceScene with all ordered pairs in reference order.
     Host work is O(objects): concatenating the ragged annotation lists into one pinned staging buffer; one asynchronous
@@ -264,6 +297,7 @@ def flatten_scene(cfg, batch, device) -> DeviceScene:
                        raw_target=t["raw"] if rel is not None else None, img_ptr=img_ptr_d, pid=t["pid"].view(max(n_obj, 1), pid_ld),
                        obj_ptr=t["obj_ptr"], sub_list=t["sub_list"], obj_list=t["obj_list"], step_ptr=t["step_ptr"], bbox_raw=raw,
                        num_objects=n_list, n_pairs=P, n_steps=T, max_n=int(max_n), _stage=stage, _tables=tab,
+                       shared_windows=count_shared_windows(bb, img_ptr) if (n_obj and F == 32) else None,
                        _rel_src=getattr(batch, "relationships", None) if rel is not None else None)
 
 

@@ -382,3 +382,44 @@ def test_graph_iter_offsets_describe_the_reference_enumeration():
             row = local // k
             assert np.array_equal(row // 2, pidx.e) and np.array_equal(row % 2 == 0, pidx.first)
             assert np.array_equal(g * (g - 1) + row, pidx.step)
+
+
+def test_object_window_rects_match_a_brute_force_influence_propagation():
+    """The closed-form rectangle of conv3 pooling windows an object can influence (pairs.object_window_rects, replicated in
+    csrc/kernels_shared.hip) against the literal chain: box mask -> 3x3 dilation (conv2_1) -> 2x2 any (max-pool) -> 3x3 dilation
+    (conv3_1) -> 2x2 any (max-pool)."""
+    from scene_graph_commonsense_amd import pairs as PR
+    rng = np.random.default_rng(3)
+
+    def dil(m):
+        p = np.pad(m, 1)
+        o = np.zeros_like(m)
+        for dy in range(3):
+            for dx in range(3):
+                o |= p[dy:dy + m.shape[0], dx:dx + m.shape[1]]
+        return o
+
+    boxes = [[0, 32, 0, 32], [5, 6, 7, 8], [0, 1, 0, 1], [31, 32, 31, 32], [10, 10, 4, 9], [3, 4, 0, 32], [0, 0, 0, 0], [2, 3, 29, 31]]
+    for _ in range(300):
+        x0, y0 = rng.integers(0, 32, 2)
+        boxes.append([x0, rng.integers(x0, 33), y0, rng.integers(y0, 33)])
+    bb = np.asarray(boxes)
+    rects = PR.object_window_rects(bb)
+    for (x0, x1, y0, y1), r in zip(bb, rects):
+        m = np.zeros((32, 32), dtype=bool)
+        m[y0:y1, x0:x1] = True
+        d16 = dil(m).reshape(16, 2, 16, 2).any(axis=(1, 3)) if m.any() else np.zeros((16, 16), dtype=bool)
+        d8 = dil(d16).reshape(8, 2, 8, 2).any(axis=(1, 3)) if m.any() else np.zeros((8, 8), dtype=bool)
+        want = np.zeros((8, 8), dtype=bool)
+        want[r[2]:r[3], r[0]:r[1]] = True
+        assert (want == d8).all(), (x0, x1, y0, y1, r)
+    # pair count: sum over ordered pairs of the rectangle intersections
+    img_ptr = [0, 100, 180, len(bb)]
+    total = 0
+    for b in range(3):
+        q = rects[img_ptr[b]:img_ptr[b + 1]]
+        for i in range(len(q)):
+            for j in range(len(q)):
+                if i != j:
+                    total += max(0, min(q[i, 1], q[j, 1]) - max(q[i, 0], q[j, 0])) * max(0, min(q[i, 3], q[j, 3]) - max(q[i, 2], q[j, 2]))
+    assert total == PR.count_shared_windows(bb, img_ptr)

@@ -1,0 +1,113 @@
+"""conv3 over shared windows (csrc/kernels_shared.hip) against the plain per-pair conv3: the two must agree BIT FOR BIT - a
+window outside an object's rectangle sees exactly the inputs the per-object pseudo-pair sees, in the same arithmetic - on boxes
+that include full-image, 1x1, border-touching, empty and identical boxes, ragged images, pair subsets and the training outputs
+(bf16 copy and routing codes the backward reads)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(cfg, seed=1):
+    from scene_graph_commonsense_amd.model import BayesianRelationClassifier
+    from scene_graph_commonsense_amd.synthetic import make_state_dict
+    m = BayesianRelationClassifier(cfg.args()).cuda()
+    m.load_state_dict(make_state_dict(cfg, seed=seed, head_gain=4.0))
+    m.eval()
+    return m
+
+
+def _edge_boxes(batch):
+    """Overwrite the first boxes of every image with the edge cases."""
+    special = torch.tensor([[0, 32, 0, 32], [5, 6, 7, 8], [0, 3, 0, 2], [29, 32, 30, 32], [10, 10, 4, 9], [12, 20, 12, 20],
+                            [12, 20, 12, 20], [0, 32, 15, 17], [3, 4, 0, 32]])
+    for b in batch.bbox:
+        k = min(len(special), b.shape[0])
+        b[:k] = special[:k].to(b.dtype)
+    return batch
+
+
+def _with(flag, fn):
+    old = os.environ.get("SGC_SHARED_CONV3")
+    os.environ["SGC_SHARED_CONV3"] = flag
+    try:
+        return fn()
+    finally:
+        if old is None:
+            del os.environ["SGC_SHARED_CONV3"]
+        else:
+            os.environ["SGC_SHARED_CONV3"] = old
+
+
+@pytest.mark.parametrize("nobj,edge", [([9, 4, 12], True), ([36] * 3, False), ([64] * 2, True)])
+def test_forward_is_bit_identical_to_the_per_pair_convolution(nobj, edge):
+    from scene_graph_commonsense_amd.pairs import count_shared_windows, flatten_scene
+    from scene_graph_commonsense_amd.synthetic import HeadConfig, make_scene_batch
+    cfg = HeadConfig()
+    model = _model(cfg)
+    batch = make_scene_batch(cfg, nobj, seed=5)
+    if edge:
+        batch = _edge_boxes(batch)
+    sc = flatten_scene(cfg, batch, "cuda:0")
+    eng = model.refresh_weights()
+    P = sc.n_pairs
+
+    def run():
+        out = model.forward_pairs(sc)
+        torch.cuda.synchronize()
+        return out, eng.ws.bufs["y"][:P * 65536].clone()
+    o0, y0 = _with("0", run)
+    o1, y1 = _with("1", run)
+    assert torch.equal(y0.view(torch.int16), y1.view(torch.int16))
+    for a, b in ((o0.relation, o1.relation), (o0.connectivity, o1.connectivity), (o0.hidden, o1.hidden), (o0.cand_pred, o1.cand_pred)):
+        assert torch.equal(a, b)
+    # the device list of pair-specific windows has the length the host predicted
+    gather, incl = eng._xw
+    n = int(incl[-1])
+    assert n == sc.shared_windows == count_shared_windows(sc.bbox.cpu().numpy(), sc.img_ptr.cpu().numpy())
+    g = gather[:n].cpu().numpy()
+    assert (np.diff(g) > 0).all() and g.max(initial=0) < P * 64
+    if not edge:
+        assert n < 0.3 * P * 64            # the point of it: most windows are shared
+
+
+def test_pair_subset_and_overlap_filtered_evaluation():
+    from scene_graph_commonsense_amd.pair_loop import evaluate_minibatch
+    from scene_graph_commonsense_amd.synthetic import HeadConfig, make_scene_batch
+    cfg = HeadConfig()
+    model = _model(cfg)
+    batch = _edge_boxes(make_scene_batch(cfg, [14, 9], seed=8, connect_frac=0.3))
+
+    def run():
+        _, out, _, _ = evaluate_minibatch(model, batch, overlap_filtering=True, skip_filtered=True)
+        torch.cuda.synchronize()
+        return out
+    a, b = _with("0", run), _with("1", run)
+    assert torch.equal(a.relation, b.relation) and torch.equal(a.cand_conf, b.cand_conf) and torch.equal(a.cand_pred, b.cand_pred)
+
+
+def test_training_forward_keeps_what_the_backward_reads_and_gives_the_same_gradients():
+    from scene_graph_commonsense_amd.pairs import flatten_scene
+    from scene_graph_commonsense_amd.synthetic import HeadConfig, make_scene_batch
+    cfg = HeadConfig()
+    model = _model(cfg)
+    batch = _edge_boxes(make_scene_batch(cfg, [20, 11, 16], seed=9, connect_frac=0.2))
+    sc = flatten_scene(cfg, batch, "cuda:0")
+    eng = model.refresh_weights(backward=True)
+    P = sc.n_pairs
+
+    def run():
+        model.zero_grad(set_to_none=True)
+        loss = model.training_step(sc)
+        torch.cuda.synchronize()
+        return (float(loss), eng.ws.bufs["y_bf"][:P * 65536].clone(), eng.ws.bufs["argmax"][:P * 65536].clone(),
+                {n: p.grad.clone() for n, p in model.named_parameters()})
+    l0, yb0, am0, g0 = _with("0", run)
+    l1, yb1, am1, g1 = _with("1", run)
+    assert l0 == l1
+    assert torch.equal(yb0.view(torch.int16), yb1.view(torch.int16)) and torch.equal(am0, am1)
+    for n in g0:
+        assert torch.equal(g0[n], g1[n]), n
