@@ -72,6 +72,34 @@ int sgc_shared_windows_assemble(const int* bbox, const int* sub_idx, const int* 
                                 const unsigned char* argmax_obj, const void* y_obj_bf16, void* y, unsigned char* argmax, void* y_bf16,
                                 void* stream);
 
+/* Backward of the shared-window conv3 (autodiff of the graph above; same citations).  All gradients bf16, sums f32.
+ *   sgc_shared_windows_assemble_bwd  dy_obj [2*n_obj*64][1024] = per-object sums of the rows of dy [n_pairs*64][1024] that were copies
+ *                                    (I windows -> subject's row, J windows -> object's row); sub_ptr/sub_list, obj_ptr/obj_list =
+ *                                    CSR lists of the pairs of every object in each role (sgc_scene_tables)
+ *   sgc_windows_unpool               dy3x [4*entries_pad][1024]: ReLU + max-pool backward of the listed (X) windows, row 4e+q = pixel q
+ *                                    of window gather[e]; rows of entries >= *gather_n are zero; bias_part [*n_parts <= 1024][1024]
+ *   sgc_windows_im2col               zcol [4*entries_pad][9][512] = the 3x3 neighbourhoods of those pixels in z_pad_bf16
+ *   sgc_windows_wgrad                conv3 weight-gradient slabs [splits][1024][9*512] of the X windows = dy3x^T * zcol
+ *   sgc_windows_dgrad_cols           col [rows][9][512] = dy3x * w3col^T, w3col [(tap, c_in)][c_out] bf16
+ *   sgc_windows_col2im               dz [pair*256 + pixel][512] = sum over taps of col, for the pixels within one pixel of a pair's X
+ *                                    windows (the other rows of a real pair's dz are never written nor read)
+ *   sgc_pair_contract_windows        sgc_pair_contract over those rows + the pseudo-pairs (pair index n_real_pairs + o for (o, bg),
+ *                                    n_real_pairs + n_obj + o for (bg, o)); dU_pad has n_obj + n_img objects, object n_obj + b = the
+ *                                    background of image b (objects img_ptr[b] .. img_ptr[b+1]); partner_idx = obj_idx for role 0
+ *                                    (subject lists), sub_idx for role 1 */
+int sgc_shared_windows_assemble_bwd(const int* bbox, const int* sub_idx, const int* obj_idx, const int* sub_ptr, const int* sub_list,
+                                    const int* obj_ptr, const int* obj_list, int n_obj, const void* dy, void* dy_obj, void* stream);
+int sgc_windows_unpool(const void* dy, const unsigned char* argmax, const int* gather, const int* gather_n, int entries_pad, void* dy3x,
+                       float* bias_part, int* n_parts, void* stream);
+int sgc_windows_im2col(const void* z_pad_bf16, const int* gather, const int* gather_n, int entries_pad, void* zcol, void* stream);
+int sgc_windows_wgrad(const void* dy3x, const void* zcol, float* slabs, int rows, int splits, int* n_slabs, void* stream);
+int sgc_windows_dgrad_cols(const void* dy3x, const void* w3col, void* col, int rows, void* stream);
+int sgc_windows_col2im(const void* col, const int* bbox, const int* sub_idx, const int* obj_idx, const int* count_incl, int n_pairs,
+                       void* dz, void* stream);
+int sgc_pair_contract_windows(const void* dz, const unsigned char* amz, const int* ptr, const int* list, const int* bbox,
+                              const int* partner_idx, const int* img_ptr, int role, int n_real_pairs, int n_obj, int n_img, void* dU_pad,
+                              void* stream);
+
 /* h1 [n_pairs][4096] f16 = dropout(relu(y[n_pairs][K] * w1p[4096][K]^T + b))   (model.py:148-149; columns of w1p in (window, channel) order) */
 int sgc_fc1_relu(const void* y, const void* w1p, const float* b, void* h1, int n_pairs, int K, int drop_enable, unsigned drop_seed, void* stream);
 

@@ -11,7 +11,7 @@
 //   J : inside R_j, outside R_i     -> y_ij[w] = y of the pseudo-pair (bg, j)[w]
 //   X : inside R_i and R_j          -> computed for the pair (`gemm_nt_kernel<AMODE_CONV_GATHER>` over the list of X windows)
 // On the benchmark's boxes 11.5 % of the windows are X (13 % on VG-like box statistics, tools/background_sparsity.py).
-#include "gemm_nt.h"
+#include "gemm_tn.h"
 
 struct WRect { int x0, x1, y0, y1; };                  // half-open on the 8x8 window grid; x1 <= x0: empty
 
@@ -92,6 +92,261 @@ __global__ __launch_bounds__(256) void shared_assemble_kernel(const int* __restr
     }
 }
 
+
+__device__ __forceinline__ bool in_rect(const WRect& r, int wx, int wy) { return wx >= r.x0 && wx < r.x1 && wy >= r.y0 && wy < r.y1; }
+
+// ------------------------------------------------------------------------------------------------ backward
+// Transpose of the assembly: the gradient of a per-object row is the sum of the gradients of its copies.
+//   dy_obj[o*64 + w]           = sum over pairs p with subject o whose window w is I (outside the object's rectangle)   of dy[p*64 + w]
+//   dy_obj[(n_obj + o)*64 + w] = sum over pairs p with object  o whose window w is J (inside R_o, outside the subject's) of dy[p*64 + w]
+// One wavefront per (role, object, window): f32 sums in pair-list order (no atomics), four 2 KiB rows in flight.
+__global__ __launch_bounds__(256) void shared_assemble_bwd_kernel(const int* __restrict__ bbox, const int* __restrict__ sub,
+                                                                  const int* __restrict__ obj, const int* __restrict__ sub_ptr,
+                                                                  const int* __restrict__ sub_list, const int* __restrict__ obj_ptr,
+                                                                  const int* __restrict__ obj_list, int n_obj,
+                                                                  const u16* __restrict__ dy, u16* __restrict__ dy_obj, long n_items) {
+    const int lane = threadIdx.x & 63;
+    for (long it = (long)blockIdx.x * 4 + (threadIdx.x >> 6); it < n_items; it += (long)gridDim.x * 4) {
+        const int role = it >= (long)n_obj * 64 ? 1 : 0;
+        const int rem = (int)(it - (long)role * n_obj * 64);
+        const int o = rem >> 6, w = rem & 63, wy = w >> 3, wx = w & 7;
+        float acc[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+        long vp[4];
+        int nv = 0;
+        auto flush = [&]() __attribute__((always_inline)) {
+            uint4 a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (u < nv) {
+                    const u16* r = dy + (vp[u] * 64 + w) * 1024 + lane * 8;
+                    a[u] = *reinterpret_cast<const uint4*>(r);
+                    b[u] = *reinterpret_cast<const uint4*>(r + 512);
+                }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (u < nv) {
+                    const u16* ah = reinterpret_cast<const u16*>(&a[u]);
+                    const u16* bh = reinterpret_cast<const u16*>(&b[u]);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) { acc[k] += bf16_bits_to_f32(ah[k]); acc[8 + k] += bf16_bits_to_f32(bh[k]); }
+                }
+            nv = 0;
+        };
+        const WRect ro = object_windows(bbox + 4 * o);
+        if (role == 0) {
+            for (int i = sub_ptr[o]; i < sub_ptr[o + 1]; ++i) {
+                const int p = sub_list[i];
+                if (!in_rect(object_windows(bbox + 4 * obj[p]), wx, wy)) { vp[nv++] = p; if (nv == 4) flush(); }
+            }
+        } else if (in_rect(ro, wx, wy)) {
+            for (int i = obj_ptr[o]; i < obj_ptr[o + 1]; ++i) {
+                const int p = obj_list[i];
+                if (!in_rect(object_windows(bbox + 4 * sub[p]), wx, wy)) { vp[nv++] = p; if (nv == 4) flush(); }
+            }
+        }
+        if (nv) flush();
+        uint4 oa, ob;
+        u16* oah = reinterpret_cast<u16*>(&oa);
+        u16* obh = reinterpret_cast<u16*>(&ob);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { oah[k] = f32_to_bf16_bits(acc[k]); obh[k] = f32_to_bf16_bits(acc[8 + k]); }
+        u16* dst = dy_obj + it * 1024 + lane * 8;
+        *reinterpret_cast<uint4*>(dst) = oa;
+        *reinterpret_cast<uint4*>(dst + 512) = ob;
+    }
+}
+
+// Un-pool of the listed windows: dy3x[4e + q][c] = (argmax[gather[e]][c] == q) ? dy[gather[e]][c] : 0  (ReLU + max-pool backward,
+// model.py:146-147), rows e >= *gather_n up to entries_pad are zero (padding of the K dimension of the weight-gradient GEMM);
+// bias_part[block][c] = the block's share of sum_e dy[..][c] over live routes (conv3 bias gradient).
+__global__ __launch_bounds__(256) void windows_unpool_kernel(const u16* __restrict__ dy, const unsigned char* __restrict__ am,
+                                                             const int* __restrict__ gather, const int* __restrict__ gather_n,
+                                                             int entries_pad, u16* __restrict__ dy3x, float* __restrict__ bias_part) {
+    __shared__ float red[4][1024];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int E = *gather_n;
+    float bs[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) bs[k] = 0.f;
+    for (int e = blockIdx.x * 4 + wv; e < entries_pad; e += gridDim.x * 4) {
+        uint4 o[4][2];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { o[q][0] = make_uint4(0, 0, 0, 0); o[q][1] = make_uint4(0, 0, 0, 0); }
+        if (e < E) {
+            const long row = gather[e];
+            uint4 v[2];
+            v[0] = *reinterpret_cast<const uint4*>(dy + row * 1024 + lane * 16);
+            v[1] = *reinterpret_cast<const uint4*>(dy + row * 1024 + lane * 16 + 8);
+            const uint4 cd = *reinterpret_cast<const uint4*>(am + row * 1024 + lane * 16);
+            const u16* vh = reinterpret_cast<const u16*>(v);
+            const unsigned char* ch = reinterpret_cast<const unsigned char*>(&cd);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const unsigned code = ch[k];
+                if (code < 4u) bs[k] += bf16_bits_to_f32(vh[k]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) reinterpret_cast<u16*>(o[q])[k] = code == (unsigned)q ? vh[k] : (u16)0;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            u16* dst = dy3x + ((long)e * 4 + q) * 1024 + lane * 16;
+            *reinterpret_cast<uint4*>(dst) = o[q][0];
+            *reinterpret_cast<uint4*>(dst + 8) = o[q][1];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) red[wv][lane * 16 + k] = bs[k];
+    __syncthreads();
+    for (int c = threadIdx.x; c < 1024; c += 256)
+        bias_part[(long)blockIdx.x * 1024 + c] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+}
+
+// zcol[4e + q][tap][512] = z_pad_bf16[pair][y + ky][x + kx][:]: the rows of the weight-gradient GEMM's second operand
+__global__ __launch_bounds__(256) void windows_im2col_kernel(const u16* __restrict__ zbf, const int* __restrict__ gather,
+                                                             const int* __restrict__ gather_n, long n_items, u16* __restrict__ zcol) {
+    const int lane = threadIdx.x & 63;
+    const int E = *gather_n;
+    for (long it = (long)blockIdx.x * 4 + (threadIdx.x >> 6); it < n_items; it += (long)gridDim.x * 4) {
+        const long row = it / 9;
+        const int tap = (int)(it - row * 9);
+        const int e = (int)(row >> 2), q = (int)(row & 3);
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (e < E) {
+            const int g = gather[e];
+            const int pair = g >> 6, w = g & 63;
+            const int y = 2 * (w >> 3) + (q >> 1), x = 2 * (w & 7) + (q & 1);
+            const int ky = tap / 3, kx = tap - 3 * ky;
+            v = *reinterpret_cast<const uint4*>(zbf + (((long)pair * 18 + y + ky) * 18 + x + kx) * 512 + lane * 8);
+        }
+        *reinterpret_cast<uint4*>(zcol + it * 512 + lane * 8) = v;
+    }
+}
+
+// dz[pair][pixel] = sum over the taps of col[row of the source pixel][tap]: the scatter half of the transposed convolution, written
+// as a gather so that every dz row has one writer.  Only the pixels within one pixel of the pair's X windows exist; one workgroup
+// per pair.
+__global__ __launch_bounds__(256) void windows_col2im_kernel(const u16* __restrict__ col, const int* __restrict__ bbox,
+                                                             const int* __restrict__ sub, const int* __restrict__ obj,
+                                                             const int* __restrict__ incl, u16* __restrict__ dz) {
+    const int p = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const WRect x = pair_windows(object_windows(bbox + 4 * sub[p]), object_windows(bbox + 4 * obj[p]));
+    if (x.x1 <= x.x0) return;
+    const int off = p ? incl[p - 1] : 0, wdt = x.x1 - x.x0;
+    const int Y0 = max(2 * x.y0 - 1, 0), Y1 = min(2 * x.y1 + 1, 16), X0 = max(2 * x.x0 - 1, 0), X1 = min(2 * x.x1 + 1, 16);
+    const int nx = X1 - X0, n = (Y1 - Y0) * nx;
+    for (int t = wv; t < n; t += 4) {
+        const int y = Y0 + t / nx, xx = X0 + t % nx;
+        float acc[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap % 3;
+            const int qy = y - ky + 1, qx = xx - kx + 1;
+            if (qy >= 2 * x.y0 && qy < 2 * x.y1 && qx >= 2 * x.x0 && qx < 2 * x.x1) {
+                const long row = 4L * (off + ((qy >> 1) - x.y0) * wdt + ((qx >> 1) - x.x0)) + (qy & 1) * 2 + (qx & 1);
+                const uint4 v = *reinterpret_cast<const uint4*>(col + (row * 9 + tap) * 512 + lane * 8);
+                const u16* vh = reinterpret_cast<const u16*>(&v);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc[k] += bf16_bits_to_f32(vh[k]);
+            }
+        }
+        uint4 ov;
+        u16* oh = reinterpret_cast<u16*>(&ov);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) oh[k] = f32_to_bf16_bits(acc[k]);
+        const int m3 = 4 * ((y >> 1) * 8 + (xx >> 1)) + (y & 1) * 2 + (xx & 1);
+        *reinterpret_cast<uint4*>(dz + ((long)p * 256 + m3) * 512 + lane * 8) = ov;
+    }
+}
+
+// Pair contraction (csrc/kernels_bwd.hip:pair_contract_kernel) for the shared-window backward: a real pair contributes to pixel
+// (Y, X) only if the pixel lies within one pixel of its X windows (elsewhere dz does not exist); every object also has its
+// pseudo-pair (o, bg) / (bg, o) at pair index n_real + o / n_real + n_obj + o, and the background object of image b (index
+// n_obj + b) collects the other side of the pseudo-pairs of that image's objects.
+__global__ __launch_bounds__(256) void pair_contract_windows_kernel(const u16* __restrict__ dz, const unsigned char* __restrict__ amz,
+                                                                    const int* __restrict__ ptr, const int* __restrict__ list,
+                                                                    const int* __restrict__ bbox, const int* __restrict__ partner,
+                                                                    const int* __restrict__ img_ptr, int role, int n_real, int n_obj,
+                                                                    u16* __restrict__ dU, long n_items) {
+    const int lane = threadIdx.x & 63;
+    for (long it = (long)blockIdx.x * 4 + (threadIdx.x >> 6); it < n_items; it += (long)gridDim.x * 4) {
+        const int o = (int)(it >> 8), W = (int)(it & 255);
+        const int Y = W >> 4, X = W & 15;
+        const int m3 = 4 * ((Y >> 1) * 8 + (X >> 1)) + (Y & 1) * 2 + (X & 1);
+        float acc[4][8];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[q][k] = 0.f;
+        long vp[4];
+        int nv = 0;
+        auto flush = [&]() __attribute__((always_inline)) {
+            uint4 g[4];
+            unsigned a[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (u < nv) {
+                    g[u] = *reinterpret_cast<const uint4*>(dz + (vp[u] * 256 + m3) * 512 + lane * 8);
+                    a[u] = *reinterpret_cast<const unsigned*>(amz + (vp[u] * 256 + W) * 256 + lane * 4);
+                }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (u < nv) {
+                    const u16* gh = reinterpret_cast<const u16*>(&g[u]);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const float v = bf16_bits_to_f32(gh[k]);
+                        const unsigned code = (a[u] >> (4 * k)) & 15u;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) acc[q][k] += (code == (unsigned)q) ? v : 0.f;
+                    }
+                }
+            nv = 0;
+        };
+        if (o < n_obj) {
+            const WRect ro = object_windows(bbox + 4 * o);
+            if (ro.x1 > ro.x0) {
+                for (int i = ptr[o]; i < ptr[o + 1]; ++i) {
+                    const int p = list[i];
+                    const WRect x = pair_windows(ro, object_windows(bbox + 4 * partner[p]));
+                    if (x.x1 > x.x0 && Y >= 2 * x.y0 - 1 && Y < 2 * x.y1 + 1 && X >= 2 * x.x0 - 1 && X < 2 * x.x1 + 1) {
+                        vp[nv++] = p;
+                        if (nv == 4) flush();
+                    }
+                }
+            }
+            vp[nv++] = (long)n_real + (role ? n_obj + o : o);
+            if (nv == 4) flush();
+        } else {
+            for (int k = img_ptr[o - n_obj]; k < img_ptr[o - n_obj + 1]; ++k) {
+                vp[nv++] = (long)n_real + (role ? k : n_obj + k);
+                if (nv == 4) flush();
+            }
+        }
+        if (nv) flush();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            uint4 ov;
+            u16* oh = reinterpret_cast<u16*>(&ov);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) oh[k] = f32_to_bf16_bits(acc[q][k]);
+            const int yy = 2 * Y + (q >> 1) + 1, xx = 2 * X + (q & 1) + 1;
+            *reinterpret_cast<uint4*>(dU + (((long)o * 34 + yy) * 34 + xx) * 512 + lane * 8) = ov;
+        }
+    }
+}
+
+static inline int grid_cap(long items, long per_block, int cap) {
+    long b = (items + per_block - 1) / per_block;
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
 extern "C" {
 
 int sgc_shared_windows_count(const int* bbox, const int* sub_idx, const int* obj_idx, int n_pairs, int* count, void* stream) {
@@ -132,6 +387,74 @@ int sgc_shared_windows_assemble(const int* bbox, const int* sub_idx, const int* 
     const int blocks = (int)(want > 131072 ? 131072 : want);
     SGC_LAUNCH(shared_assemble_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, bbox, sub_idx, obj_idx, rows, n_obj,
                (const uint4*)y_obj, (const uint4*)argmax_obj, (const uint4*)y_obj_bf16, (uint4*)y, (uint4*)argmax, (uint4*)y_bf16);
+    SGC_CHECK_LAUNCH();
+    return SGC_OK;
+}
+
+int sgc_shared_windows_assemble_bwd(const int* bbox, const int* sub_idx, const int* obj_idx, const int* sub_ptr, const int* sub_list,
+                                    const int* obj_ptr, const int* obj_list, int n_obj, const void* dy, void* dy_obj, void* stream) {
+    if (n_obj <= 0) return SGC_OK;
+    const long items = 2L * n_obj * 64;
+    SGC_LAUNCH(shared_assemble_bwd_kernel, dim3(grid_cap(items, 4, 262144)), dim3(256), 0, (hipStream_t)stream, bbox, sub_idx, obj_idx,
+               sub_ptr, sub_list, obj_ptr, obj_list, n_obj, (const u16*)dy, (u16*)dy_obj, items);
+    SGC_CHECK_LAUNCH();
+    return SGC_OK;
+}
+
+int sgc_windows_unpool(const void* dy, const unsigned char* argmax, const int* gather, const int* gather_n, int entries_pad, void* dy3x,
+                       float* bias_part, int* n_parts, void* stream) {
+    if (entries_pad <= 0) { if (n_parts) *n_parts = 0; return SGC_OK; }
+    const int blocks = grid_cap(entries_pad, 4 * 8, 1024);
+    if (n_parts) *n_parts = blocks;
+    SGC_LAUNCH(windows_unpool_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const u16*)dy, argmax, gather, gather_n,
+               entries_pad, (u16*)dy3x, bias_part);
+    SGC_CHECK_LAUNCH();
+    return SGC_OK;
+}
+
+int sgc_windows_im2col(const void* z_pad_bf16, const int* gather, const int* gather_n, int entries_pad, void* zcol, void* stream) {
+    if (entries_pad <= 0) return SGC_OK;
+    const long items = (long)entries_pad * 4 * 9;
+    SGC_LAUNCH(windows_im2col_kernel, dim3(grid_cap(items, 4 * 4, 262144)), dim3(256), 0, (hipStream_t)stream, (const u16*)z_pad_bf16,
+               gather, gather_n, items, (u16*)zcol);
+    SGC_CHECK_LAUNCH();
+    return SGC_OK;
+}
+
+// slabs [splits][1024][9*512] f32 = sum_rows dy3x[row][n] * zcol[row][(tap, c)]   (rows = 4 * entries_pad, a multiple of 64)
+int sgc_windows_wgrad(const void* dy3x, const void* zcol, float* slabs, int rows, int splits, int* n_slabs, void* stream) {
+    if (rows <= 0) { if (n_slabs) *n_slabs = 0; return SGC_OK; }
+    TnParams p{};
+    p.A = (const u16*)dy3x; p.B = (const u16*)zcol; p.C = slabs; p.M = 1024; p.N = 9 * 512; p.K = rows;
+    p.lda = 1024; p.ldb = 9 * 512; p.ldc = 9 * 512; p.slab_stride = 1024L * 9 * 512;
+    return launch_gemm_tn<ELEM_BF16, BMODE_PLAIN>(p, splits, n_slabs, (hipStream_t)stream);
+}
+
+// col [rows][9*512] bf16 = dy3x [rows][1024] * w3col[(tap, c)][1024]^T
+int sgc_windows_dgrad_cols(const void* dy3x, const void* w3col, void* col, int rows, void* stream) {
+    if (rows <= 0) return SGC_OK;
+    NtParams p{};
+    p.A = (const u16*)dy3x; p.B = (const u16*)w3col; p.C = col; p.M = rows; p.N = 9 * 512; p.K = 1024;
+    p.lda = 1024; p.ldb = 1024; p.ldc = 9 * 512;
+    return launch_gemm_nt<ELEM_BF16, AMODE_PLAIN, EPI_STORE>(p, (hipStream_t)stream);
+}
+
+int sgc_windows_col2im(const void* col, const int* bbox, const int* sub_idx, const int* obj_idx, const int* count_incl, int n_pairs,
+                       void* dz, void* stream) {
+    if (n_pairs <= 0) return SGC_OK;
+    SGC_LAUNCH(windows_col2im_kernel, dim3(n_pairs), dim3(256), 0, (hipStream_t)stream, (const u16*)col, bbox, sub_idx, obj_idx,
+               count_incl, (u16*)dz);
+    SGC_CHECK_LAUNCH();
+    return SGC_OK;
+}
+
+int sgc_pair_contract_windows(const void* dz, const unsigned char* amz, const int* ptr, const int* list, const int* bbox,
+                              const int* partner_idx, const int* img_ptr, int role, int n_real_pairs, int n_obj, int n_img, void* dU_pad,
+                              void* stream) {
+    if (n_obj <= 0) return SGC_OK;
+    const long items = (long)(n_obj + n_img) * 256;
+    SGC_LAUNCH(pair_contract_windows_kernel, dim3(grid_cap(items, 4, 262144)), dim3(256), 0, (hipStream_t)stream, (const u16*)dz, amz,
+               ptr, list, bbox, partner_idx, img_ptr, role, n_real_pairs, n_obj, (u16*)dU_pad, items);
     SGC_CHECK_LAUNCH();
     return SGC_OK;
 }

@@ -278,12 +278,14 @@ class RelHeadEngine:
 
     def object_halves(self, a_img, obj_img: torch.Tensor, bbox: torch.Tensor, roles=(0, 1), with_bg=False):
         """Per-object masked maps and conv2 halves U (role 0) / V (role 1, carries the bias).
-        ``with_bg``: one more object with an EMPTY box is appended (index n_obj) - the constant map tanh(b1) every masked map
-        equals outside its box; its halves are the background of ``conv3_shared``."""
+        ``with_bg``: one object with an EMPTY box per image is appended (index n_obj + image) - the constant map tanh(b1) every
+        masked map equals outside its box; its halves are the background of ``conv3_shared``.  (One per image rather than one in
+        all: the backward sums the background's gradient per image, so a step over B images stays the sum of B one-image steps.)"""
         lib, ws = self.lib, self.ws
         if with_bg:
-            obj_img = torch.cat([obj_img, obj_img.new_zeros(1)])
-            bbox = torch.cat([bbox, bbox.new_zeros(1, 4)])
+            n_img = int(a_img[roles[0]].numel()) // (1024 * 128)
+            obj_img = torch.cat([obj_img, torch.arange(n_img, dtype=obj_img.dtype, device=obj_img.device)])
+            bbox = torch.cat([bbox, bbox.new_zeros(n_img, 4)])
         n_obj = obj_img.shape[0]
         res = {}
         for r in roles:
@@ -315,22 +317,28 @@ class RelHeadEngine:
                 _lib.ptr(U), _lib.ptr(V), _lib.ptr(sub_idx), _lib.ptr(obj_idx), _lib.ptr(z), _lib.ptr(z_bf), _lib.ptr(amz), P,
                 self._st()), "sgc_pair_expand_train"))
 
-    def conv3_shared(self, z, U, V, bbox, n_obj, sub_idx, obj_idx, P, y, am, y_bf, bound=None):
+    def conv3_shared(self, z, U, V, bbox, obj_img, sub_idx, obj_idx, P, y, am, y_bf, bound=None, keep=None):
         """conv3 + ReLU + pool with the per-object part computed once per object (``csrc/kernels_shared.hip``): U / V hold
-        n_obj + 1 objects, the last one the empty-box background.  ``bound``: an upper bound of the number of pair-specific
-        windows known on the host (``DeviceScene.shared_windows``), else 64 per pair."""
+        n_obj + n_img objects, the last n_img the empty-box backgrounds of the images.  ``bound``: the number of pair-specific windows when the host
+        knows it (``DeviceScene.shared_windows``), else 64 per pair bounds the launch.
+        ``keep=(z_bf_tail, amz_tail)`` (training): the pseudo-pairs' bf16 expansion and routing codes go there and the window list
+        lives in buffers this engine owns; returns what the backward needs."""
         lib, sc = self.lib, self.scratch
+        own = self.ws if keep is not None else sc
+        n_obj = int(obj_img.shape[0])
         n2 = 2 * n_obj
-        ps = getattr(self, "_pseudo", None)
-        if ps is None or ps[0] != n_obj:
-            ar = torch.arange(n_obj, dtype=torch.int32, device=self.device)
-            bg = torch.full((n_obj,), n_obj, dtype=torch.int32, device=self.device)
-            ps = self._pseudo = (n_obj, torch.cat([ar, bg]).contiguous(), torch.cat([bg, ar]).contiguous())
+        ar = torch.arange(n_obj, dtype=torch.int32, device=self.device)
+        bg = obj_img.to(torch.int32) + n_obj                                     # every object's background = its image's
+        ps = (n_obj, torch.cat([ar, bg]).contiguous(), torch.cat([bg, ar]).contiguous())
         z_ps = sc.get("z_ps", n2 * 18 * 18 * 512, torch.float16)                 # created zeroed: the halo stays zero
-        _lib.check(lib.sgc_pair_expand(_lib.ptr(U), _lib.ptr(V), _lib.ptr(ps[1]), _lib.ptr(ps[2]), _lib.ptr(z_ps), n2, ELEM_F16, self._st()),
-                   "sgc_pair_expand")
+        if keep is None:
+            _lib.check(lib.sgc_pair_expand(_lib.ptr(U), _lib.ptr(V), _lib.ptr(ps[1]), _lib.ptr(ps[2]), _lib.ptr(z_ps), n2, ELEM_F16, self._st()),
+                       "sgc_pair_expand")
+        else:
+            _lib.check(lib.sgc_pair_expand_train(_lib.ptr(U), _lib.ptr(V), _lib.ptr(ps[1]), _lib.ptr(ps[2]), _lib.ptr(z_ps), _lib.ptr(keep[0]),
+                                                 _lib.ptr(keep[1]), n2, self._st()), "sgc_pair_expand_train")
         y_ps = sc.get("y_ps", n2 * 65536, torch.float16)
-        am_ps = sc.get("am_ps", n2 * 65536, torch.uint8) if am is not None else None
+        am_ps = own.get("am_ps", n2 * 65536, torch.uint8) if am is not None else None
         ybf_ps = sc.get("ybf_ps", n2 * 65536, torch.bfloat16) if y_bf is not None else None
         self._timed("conv3_fwd_objects", lambda: _lib.check(lib.sgc_conv3_relu_pool(
             _lib.ptr(z_ps), _lib.ptr(self.w["w3r"]), _lib.ptr(self.w["b3"]), _lib.ptr(y_ps), _lib.ptr(am_ps), _lib.ptr(ybf_ps), n2,
@@ -339,9 +347,12 @@ class RelHeadEngine:
         _lib.check(lib.sgc_shared_windows_count(_lib.ptr(bbox), _lib.ptr(sub_idx), _lib.ptr(obj_idx), P, _lib.ptr(cnt), self._st()),
                    "sgc_shared_windows_count")
         incl = torch.cumsum(cnt, 0, dtype=torch.int32)
-        gather = sc.get("xw_gather", P * 64, torch.int32)
+        gather = own.get("xw_gather", P * 64, torch.int32)
         _lib.check(lib.sgc_shared_windows_fill(_lib.ptr(bbox), _lib.ptr(sub_idx), _lib.ptr(obj_idx), P, _lib.ptr(incl), _lib.ptr(gather),
                                                self._st()), "sgc_shared_windows_fill")
+        if bound is None and keep is not None:
+            bound = int(incl[P - 1])              # pair subsets in training (augmented-view pass): one sync buys exact GEMM sizes
+        exact = bound is not None
         bound = P * 64 if bound is None else max(0, min(int(bound), P * 64))
         self._timed("conv3_fwd_windows", lambda: _lib.check(lib.sgc_conv3_relu_pool_windows(
             _lib.ptr(z), _lib.ptr(self.w["w3r"]), _lib.ptr(self.w["b3"]), _lib.ptr(gather), _lib.ptr(incl[P - 1:]), bound, _lib.ptr(y),
@@ -350,6 +361,7 @@ class RelHeadEngine:
             _lib.ptr(bbox), _lib.ptr(sub_idx), _lib.ptr(obj_idx), P, n_obj, _lib.ptr(y_ps), _lib.ptr(am_ps), _lib.ptr(ybf_ps),
             _lib.ptr(y), _lib.ptr(am), _lib.ptr(y_bf), self._st()), "sgc_shared_windows_assemble"))
         self._xw = (gather, incl)
+        return dict(gather=gather, incl=incl, entries=bound if exact else None, am_ps=am_ps, n2=n2)
 
     def pair_trunk(self, U, V, sub_idx, obj_idx, lsub, lobj, train=False, seeds=(0, 0), keep_argmax=False,
                    iou_mask=None, dense=None, shared=None) -> PairOutputs:
@@ -403,7 +415,7 @@ class RelHeadEngine:
         a_img = self.image_maps(image_feature, image_depth)
         share = shared_conv3_enabled()
         uv = self.object_halves(a_img, obj_img, bbox, with_bg=share)
-        shared = (bbox, int(obj_img.shape[0]), shared_windows) if share else None
+        shared = (bbox, obj_img, shared_windows) if share else None
         lsub, lobj = self.label_vectors(cats, super_mh)
         self._lsub, self._lobj = lsub, lobj
         if select is None:
@@ -446,6 +458,8 @@ class RelHeadEngine:
         w["w1pT"] = self._transpose_cast(g("fc1.weight").contiguous(), "w1pT", torch.bfloat16, 1, 64, 1024, 64 * 65536, 64, 65536,
                                          64, 4096, 1024 * 4096)
         w["wd3"] = conv_k_layout(g("conv3_1.weight").flip(2, 3).permute(1, 0, 2, 3)).to(torch.bfloat16).contiguous()
+        # [(tap, c_in)][c_out]: second operand of the column form of the data gradient over pair-specific windows
+        w["w3col"] = g("conv3_1.weight").permute(2, 3, 1, 0).reshape(9 * 512, 1024).to(torch.bfloat16).contiguous()
         c2 = g("conv2_1.weight")
         w["wd2"] = torch.stack([conv_k_layout(c2[:, r * 128:(r + 1) * 128].flip(2, 3).permute(1, 0, 2, 3))
                                 for r in (0, 1)]).to(torch.bfloat16).contiguous()
@@ -503,8 +517,9 @@ class RelHeadEngine:
         ctx.lsub, lobj_same = self.label_vectors(ctx.cats[0], ctx.super_mh[0])
         ctx.lobj = lobj_same if role_inputs is None else self.label_vectors(ctx.cats[1], ctx.super_mh[1])[1]
         z = sc.get("z_pad", P * 18 * 18 * 512, torch.float16)
-        z_bf = ws.get("z_pad_bf", P * 18 * 18 * 512, torch.bfloat16)
-        amz = ws.get("amz", P * 256 * 256, torch.uint8)              # two 4-bit routing codes per byte
+        Pt = P + (2 * ctx.n_obj if share else 0)                     # the pseudo-pairs (object, background) live behind the real pairs
+        z_bf = ws.get("z_pad_bf", Pt * 18 * 18 * 512, torch.bfloat16)
+        amz = ws.get("amz", Pt * 256 * 256, torch.uint8)             # two 4-bit routing codes per byte
         self.expand(ctx.uv[0], ctx.uv[1], sub_idx, obj_idx, P, z, z_bf, amz, dense=dense)
         ctx.z_bf = z_bf
         y = sc.get("y", Ppad * 65536, torch.float16)
@@ -512,8 +527,10 @@ class RelHeadEngine:
         if Ppad > P:
             Workspace._zero(y_bf[P * 65536:])
         am = ws.get("argmax", P * 65536, torch.uint8)
+        ctx.shared = None
         if share:
-            self.conv3_shared(z, ctx.uv[0], ctx.uv[1], bbox, ctx.n_obj, sub_idx, obj_idx, P, y, am, y_bf, shared_windows)
+            ctx.shared = self.conv3_shared(z, ctx.uv[0], ctx.uv[1], bbox, obj_img, sub_idx, obj_idx, P, y, am, y_bf, shared_windows,
+                                           keep=(z_bf[P * 18 * 18 * 512:], amz[P * 256 * 256:]))
         else:
             self._timed("conv3_fwd", lambda: _lib.check(lib.sgc_conv3_relu_pool(_lib.ptr(z), _lib.ptr(self.w["w3r"]), _lib.ptr(self.w["b3"]), _lib.ptr(y), _lib.ptr(am),
                                                _lib.ptr(y_bf), P, self._st()), "sgc_conv3_relu_pool"))
@@ -646,6 +663,70 @@ class RelHeadEngine:
         self._timed("fc1_dgrad", lambda: _lib.check(lib.sgc_fc1_dgrad(_lib.ptr(dh1), _lib.ptr(w["w1pT"]), _lib.ptr(dy), P, 65536, st()), "sgc_fc1_dgrad"))
 
         # ---- conv3
+        nparts = ctypes.c_int(0)
+        shared = ctx.shared if (getattr(ctx, "shared", None) is not None and os.environ.get("SGC_SHARED_BWD", "1") != "0") else None
+        n_objx = n_obj + (n_img if shared is not None else 0)      # the images' background objects take part in the conv2 backward
+        if shared is not None:
+            dz = self._conv3_backward_shared(ctx, shared, dy, sub_csr, obj_csr, side, sl, grads)
+        else:
+            dz = self._conv3_backward_pairs(ctx, dy, side, sl, grads)
+
+        # ---- pair contraction + conv2 + masks + conv1 (per-role buffers: the side stream may still read role 0's while role 1 runs)
+        gc2 = torch.empty(512, 256, 3, 3, dtype=torch.float32, device=dev)
+        for r, csr in ((0, sub_csr), (1, obj_csr)):
+            dU = ws.get("dU_pad_%d" % r, n_objx * 34 * 34 * 512, torch.bfloat16)
+            if shared is not None:
+                partner = ctx.obj_idx if r == 0 else ctx.sub_idx
+                self._timed("contract", lambda: _lib.check(lib.sgc_pair_contract_windows(
+                    _lib.ptr(dz), _lib.ptr(ctx.amz), _lib.ptr(csr[0]), _lib.ptr(csr[1]), _lib.ptr(ctx.bbox), _lib.ptr(partner), _lib.ptr(img_ptr),
+                    r, P, n_obj, n_img, _lib.ptr(dU), st()), "sgc_pair_contract_windows"))
+            else:
+                self._timed("contract", lambda: _lib.check(lib.sgc_pair_contract(_lib.ptr(dz), _lib.ptr(ctx.amz), _lib.ptr(csr[0]), _lib.ptr(csr[1]), _lib.ptr(dU), n_obj, st()),
+                           "sgc_pair_contract"))
+            with side():
+                a_pad = self.ws.get("a_pad_%d" % r, n_objx * 34 * 34 * 128, torch.float16)      # kept by the forward
+                a_bf = self._to_bf16("a_pad_bf", a_pad, n_objx * 34 * 34 * 128)
+                self._timed("conv2_wgrad", lambda: _lib.check(lib.sgc_conv2_wgrad(_lib.ptr(dU), _lib.ptr(a_bf), _lib.ptr(sl), n_objx, 0, ctypes.byref(slabs_n), st()),
+                           "sgc_conv2_wgrad"))
+                dW2r = self._slab_sum(sl, 512 * 1152, slabs_n.value)
+                gc2[:, r * 128:(r + 1) * 128] = dW2r.view(512, 3, 3, 128).permute(0, 3, 1, 2)
+                if r == 1:
+                    grads["conv2_1.bias"] = self._colsum(dU, n_objx * 34 * 34, 512)
+            da = ws.get("da", n_objx * 1024 * 128, torch.bfloat16)
+            self._timed("conv2_dgrad", lambda: _lib.check(lib.sgc_conv2_dgrad(_lib.ptr(dU), _lib.ptr(w["wd2"][r]), _lib.ptr(da), n_objx, st()), "sgc_conv2_dgrad"))
+            dcst_bg = None
+            if shared is not None:                   # the background objects are constant everywhere: all of their gradient goes to tanh(b1)
+                dcst_bg = self.ws.get("dcst_bg_%d" % r, 128, torch.float32)      # on THIS stream: ``da`` is rewritten by the next role
+                torch.sum(da[n_obj * 1024 * 128:].view(-1, 128).float(), 0, out=dcst_bg)
+            dA = ws.get("dA", n_img * 1024 * 128, torch.float32)
+            cpart = ws.get("dcst_part_%d" % r, n_img * 64 * 128, torch.float32)
+            _lib.check(lib.sgc_object_masked_maps_bwd(_lib.ptr(da), _lib.ptr(img_ptr), _lib.ptr(ctx.bbox), _lib.ptr(dA), _lib.ptr(cpart),
+                                                      ctypes.byref(nparts), n_img, 32, 128, st()), "sgc_object_masked_maps_bwd")
+            n_cst = nparts.value
+            dp1 = ws.get("dpre1_%d" % r, n_img * 1024 * 128, torch.bfloat16)
+            _lib.check(lib.sgc_tanh_bwd(_lib.ptr(dA), _lib.ptr(ctx.a_img[r]), _lib.ptr(dp1), _c_long(n_img * 1024 * 128), st()),
+                       "sgc_tanh_bwd")
+            with side():
+                x_bf = self._to_bf16("x_bf", ctx.x[r], n_img * 1024 * XC)
+                _lib.check(lib.sgc_conv1_wgrad(_lib.ptr(dp1), _lib.ptr(x_bf), _lib.ptr(sl), n_img * 1024, XC, 16, ctypes.byref(slabs_n), st()),
+                           "sgc_conv1_wgrad")
+                dW1 = self._slab_sum(sl, 128 * XC, slabs_n.value).view(128, XC)
+                nm = "conv1_%d" % (r + 1)
+                grads[nm + ".weight"] = dW1[:, :257].reshape(128, 257, 1, 1).contiguous()
+                tb = torch.tanh(w["b1"][r])
+                dcst = self._slab_sum(cpart, 128, n_cst)
+                if dcst_bg is not None:
+                    dcst = dcst + dcst_bg
+                grads[nm + ".bias"] = self._colsum(dp1, n_img * 1024, 128) + dcst * (1 - tb * tb)
+        with side():
+            grads["conv2_1.weight"] = gc2
+        side.join()                              # the caller's stream continues only after every gradient is complete
+        return loss, grads
+
+    def _conv3_backward_pairs(self, ctx, dy, side, sl, grads):
+        """conv3 backward over every window of every pair (no per-object sharing): bias + weight gradient, returns dz."""
+        lib, w, ws, st, P = self.lib, self.w, self.scratch, self._st, ctx.P
+        slabs_n = ctypes.c_int(0)
         bpart = ws.get("b3_part", 2048 * 1024, torch.float32)
         nparts = ctypes.c_int(0)
         sparse_w3 = os.environ.get("SGC_W3_SPARSE", "1") != "0"
@@ -683,46 +764,68 @@ class RelHeadEngine:
                                                           "sgc_conv3_dgrad_pooled"))
         else:
             self._timed("conv3_dgrad", lambda: _lib.check(lib.sgc_conv3_dgrad(_lib.ptr(dy3), _lib.ptr(w["wd3"]), _lib.ptr(dz), P, st()), "sgc_conv3_dgrad"))
+        return dz
 
-        # ---- pair contraction + conv2 + masks + conv1 (per-role buffers: the side stream may still read role 0's while role 1 runs)
-        gc2 = torch.empty(512, 256, 3, 3, dtype=torch.float32, device=dev)
-        for r, csr in ((0, sub_csr), (1, obj_csr)):
-            dU = ws.get("dU_pad_%d" % r, n_obj * 34 * 34 * 512, torch.bfloat16)
-            self._timed("contract", lambda: _lib.check(lib.sgc_pair_contract(_lib.ptr(dz), _lib.ptr(ctx.amz), _lib.ptr(csr[0]), _lib.ptr(csr[1]), _lib.ptr(dU), n_obj, st()),
-                       "sgc_pair_contract"))
-            with side():
-                a_pad = self.ws.get("a_pad_%d" % r, n_obj * 34 * 34 * 128, torch.float16)      # kept by the forward
-                a_bf = self._to_bf16("a_pad_bf", a_pad, n_obj * 34 * 34 * 128)
-                self._timed("conv2_wgrad", lambda: _lib.check(lib.sgc_conv2_wgrad(_lib.ptr(dU), _lib.ptr(a_bf), _lib.ptr(sl), n_obj, 0, ctypes.byref(slabs_n), st()),
-                           "sgc_conv2_wgrad"))
-                dW2r = self._slab_sum(sl, 512 * 1152, slabs_n.value)
-                gc2[:, r * 128:(r + 1) * 128] = dW2r.view(512, 3, 3, 128).permute(0, 3, 1, 2)
-                if r == 1:
-                    grads["conv2_1.bias"] = self._colsum(dU, n_obj * 34 * 34, 512)
-            da = ws.get("da", n_obj * 1024 * 128, torch.bfloat16)
-            self._timed("conv2_dgrad", lambda: _lib.check(lib.sgc_conv2_dgrad(_lib.ptr(dU), _lib.ptr(w["wd2"][r]), _lib.ptr(da), n_obj, st()), "sgc_conv2_dgrad"))
-            dA = ws.get("dA", n_img * 1024 * 128, torch.float32)
-            cpart = ws.get("dcst_part_%d" % r, n_img * 64 * 128, torch.float32)
-            _lib.check(lib.sgc_object_masked_maps_bwd(_lib.ptr(da), _lib.ptr(img_ptr), _lib.ptr(ctx.bbox), _lib.ptr(dA), _lib.ptr(cpart),
-                                                      ctypes.byref(nparts), n_img, 32, 128, st()), "sgc_object_masked_maps_bwd")
-            n_cst = nparts.value
-            dp1 = ws.get("dpre1_%d" % r, n_img * 1024 * 128, torch.bfloat16)
-            _lib.check(lib.sgc_tanh_bwd(_lib.ptr(dA), _lib.ptr(ctx.a_img[r]), _lib.ptr(dp1), _c_long(n_img * 1024 * 128), st()),
-                       "sgc_tanh_bwd")
-            with side():
-                x_bf = self._to_bf16("x_bf", ctx.x[r], n_img * 1024 * XC)
-                _lib.check(lib.sgc_conv1_wgrad(_lib.ptr(dp1), _lib.ptr(x_bf), _lib.ptr(sl), n_img * 1024, XC, 16, ctypes.byref(slabs_n), st()),
-                           "sgc_conv1_wgrad")
-                dW1 = self._slab_sum(sl, 128 * XC, slabs_n.value).view(128, XC)
-                nm = "conv1_%d" % (r + 1)
-                grads[nm + ".weight"] = dW1[:, :257].reshape(128, 257, 1, 1).contiguous()
-                tb = torch.tanh(w["b1"][r])
-                dcst = self._slab_sum(cpart, 128, n_cst)
-                grads[nm + ".bias"] = self._colsum(dp1, n_img * 1024, 128) + dcst * (1 - tb * tb)
+    def _conv3_backward_shared(self, ctx, sh, dy, sub_csr, obj_csr, side, sl, grads):
+        """Backward of ``conv3_shared`` (autodiff of that graph): the gradient rows of copied windows are summed per object and go
+        through the ordinary conv3 backward of the 2*n_obj pseudo-pairs; the pair-specific windows go through a compact column
+        form (un-pool -> [rows,1024]; weight gradient = rows^T x im2col(z); data gradient = rows x W^T -> col2im).  Returns dz
+        [(P + 2 n_obj) * 256, 512]: pseudo-pairs behind the real pairs, a real pair's rows exist only next to its X windows."""
+        lib, w, ws, st, P, n_obj = self.lib, self.w, self.scratch, self._st, ctx.P, ctx.n_obj
+        n2 = sh["n2"]
+        E = sh["entries"]
+        Epad = (E + 15) // 16 * 16                                   # 4 rows per entry: the GEMMs want a multiple of 64 rows
+        slabs_n, slabs_x, nparts, nparts_x = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+        gather, gn = sh["gather"], sh["incl"][P - 1:]
+        am_tail = sh["am_ps"]
+        z_bf, z_bf_tail = ctx.z_bf, ctx.z_bf[P * 18 * 18 * 512:]
+        dz = ws.get("dz", (P + n2) * 256 * 512, torch.bfloat16)
+        dz_tail = dz[P * 256 * 512:]
+        # ---- copies: per-object sums, then the pseudo-pairs' ordinary backward
+        dy_ps = ws.get("dy_ps", n2 * 65536, torch.bfloat16)
+        self._timed("conv3_bwd_assemble", lambda: _lib.check(lib.sgc_shared_windows_assemble_bwd(
+            _lib.ptr(ctx.bbox), _lib.ptr(ctx.sub_idx), _lib.ptr(ctx.obj_idx), _lib.ptr(sub_csr[0]), _lib.ptr(sub_csr[1]), _lib.ptr(obj_csr[0]),
+            _lib.ptr(obj_csr[1]), n_obj, _lib.ptr(dy), _lib.ptr(dy_ps), st()), "sgc_shared_windows_assemble_bwd"))
+        bpart = ws.get("b3_part", 2048 * 1024, torch.float32)
+        bpart_x = ws.get("b3_part_x", 1024 * 1024, torch.float32)
+        pack_a = ws.get("w3_pack_a", n2 * 4 * 1024 * 64, torch.uint8)
+        pack_i = ws.get("w3_pack_i", n2 * 4 * 1024 * 8, torch.uint8)
+        self._timed("unpool_objects", lambda: _lib.check(lib.sgc_unpool_relu_bwd_pack(
+            _lib.ptr(dy_ps), _lib.ptr(am_tail), None, _lib.ptr(bpart), ctypes.byref(nparts), _lib.ptr(pack_a), _lib.ptr(pack_i), n2, st()),
+            "sgc_unpool_relu_bwd_pack"))
+        # ---- pair-specific windows: compact un-pool
+        dy3x = ws.get("dy3x", max(Epad, 16) * 4 * 1024, torch.bfloat16)
+        self._timed("unpool_windows", lambda: _lib.check(lib.sgc_windows_unpool(
+            _lib.ptr(dy), _lib.ptr(ctx.am), _lib.ptr(gather), _lib.ptr(gn), Epad, _lib.ptr(dy3x), _lib.ptr(bpart_x), ctypes.byref(nparts_x), st()),
+            "sgc_windows_unpool"))
         with side():
-            grads["conv2_1.weight"] = gc2
-        side.join()                              # the caller's stream continues only after every gradient is complete
-        return loss, grads
+            gb = self._slab_sum(bpart, 1024, nparts.value)
+            if nparts_x.value:
+                gb = gb + self._slab_sum(bpart_x, 1024, nparts_x.value)
+            grads["conv3_1.bias"] = gb
+            self._timed("conv3_wgrad_objects", lambda: _lib.check(lib.sgc_conv3_wgrad_sparse(
+                None, None, _lib.ptr(z_bf_tail), _lib.ptr(pack_a), _lib.ptr(pack_i), _lib.ptr(sl), n2, 0, ctypes.byref(slabs_n), st()),
+                "sgc_conv3_wgrad_sparse"))
+            if Epad:
+                zcol = ws.get("zcol", Epad * 4 * 9 * 512, torch.bfloat16)
+                self._timed("im2col_windows", lambda: _lib.check(lib.sgc_windows_im2col(_lib.ptr(z_bf), _lib.ptr(gather), _lib.ptr(gn), Epad, _lib.ptr(zcol), st()),
+                                                                 "sgc_windows_im2col"))
+                slx = sl[slabs_n.value * 1024 * 4608:]
+                self._timed("conv3_wgrad_windows", lambda: _lib.check(lib.sgc_windows_wgrad(
+                    _lib.ptr(dy3x), _lib.ptr(zcol), _lib.ptr(slx), Epad * 4, 0, ctypes.byref(slabs_x), st()), "sgc_windows_wgrad"))
+            dW3r = self._slab_sum(sl, 1024 * 4608, slabs_n.value + slabs_x.value)
+            grads["conv3_1.weight"] = dW3r.view(1024, 3, 3, 512).permute(0, 3, 1, 2).contiguous()
+        # ---- data gradients
+        self._timed("conv3_dgrad_objects", lambda: _lib.check(lib.sgc_conv3_dgrad_pooled(
+            _lib.ptr(dy_ps), _lib.ptr(am_tail), _lib.ptr(w["wd3"]), _lib.ptr(dz_tail), n2, st()), "sgc_conv3_dgrad_pooled"))
+        if Epad:
+            col = ws.get("xcol", Epad * 4 * 9 * 512, torch.bfloat16)
+            self._timed("conv3_dgrad_windows", lambda: _lib.check(lib.sgc_windows_dgrad_cols(_lib.ptr(dy3x), _lib.ptr(w["w3col"]), _lib.ptr(col), Epad * 4, st()),
+                                                                  "sgc_windows_dgrad_cols"))
+            self._timed("col2im_windows", lambda: _lib.check(lib.sgc_windows_col2im(
+                _lib.ptr(col), _lib.ptr(ctx.bbox), _lib.ptr(ctx.sub_idx), _lib.ptr(ctx.obj_idx), _lib.ptr(sh["incl"]), P, _lib.ptr(dz), st()),
+                "sgc_windows_col2im"))
+        return dz
 
     # ------------------------------------------------------------------ two-stream backward
     def _side_chain(self):

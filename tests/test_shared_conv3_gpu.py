@@ -89,12 +89,31 @@ def test_pair_subset_and_overlap_filtered_evaluation():
     assert torch.equal(a.relation, b.relation) and torch.equal(a.cand_conf, b.cand_conf) and torch.equal(a.cand_pred, b.cand_pred)
 
 
-def test_training_forward_keeps_what_the_backward_reads_and_gives_the_same_gradients():
+def _with_env(env, fn):
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        return fn()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("nobj,edge,cfrac", [([20, 11, 16], True, 0.2), ([36] * 3, False, 0.03), ([1, 2, 5], True, 0.5)])
+def test_training_step_shared_forward_is_bit_identical_and_shared_backward_agrees(nobj, edge, cfrac):
+    """Forward: what the backward reads (bf16 copy, routing codes) and the loss are bit-identical, and with the per-pair backward
+    (SGC_SHARED_BWD=0) so is every gradient.  The shared backward sums gradient rows per object BEFORE the conv3 backward and
+    rounds the sums to bf16 once (instead of rounding every pair's rows), so it agrees to bf16 round-off, not bit for bit."""
     from scene_graph_commonsense_amd.pairs import flatten_scene
     from scene_graph_commonsense_amd.synthetic import HeadConfig, make_scene_batch
     cfg = HeadConfig()
     model = _model(cfg)
-    batch = _edge_boxes(make_scene_batch(cfg, [20, 11, 16], seed=9, connect_frac=0.2))
+    batch = make_scene_batch(cfg, nobj, seed=9, connect_frac=cfrac)
+    if edge:
+        batch = _edge_boxes(batch)
     sc = flatten_scene(cfg, batch, "cuda:0")
     eng = model.refresh_weights(backward=True)
     P = sc.n_pairs
@@ -105,9 +124,22 @@ def test_training_forward_keeps_what_the_backward_reads_and_gives_the_same_gradi
         torch.cuda.synchronize()
         return (float(loss), eng.ws.bufs["y_bf"][:P * 65536].clone(), eng.ws.bufs["argmax"][:P * 65536].clone(),
                 {n: p.grad.clone() for n, p in model.named_parameters()})
-    l0, yb0, am0, g0 = _with("0", run)
-    l1, yb1, am1, g1 = _with("1", run)
-    assert l0 == l1
+    l0, yb0, am0, g0 = _with_env({"SGC_SHARED_CONV3": "0"}, run)
+    l1, yb1, am1, g1 = _with_env({"SGC_SHARED_CONV3": "1", "SGC_SHARED_BWD": "0"}, run)
+    l2, yb2, am2, g2 = _with_env({"SGC_SHARED_CONV3": "1", "SGC_SHARED_BWD": "1"}, run)
+    assert l0 == l1 == l2
     assert torch.equal(yb0.view(torch.int16), yb1.view(torch.int16)) and torch.equal(am0, am1)
     for n in g0:
         assert torch.equal(g0[n], g1[n]), n
+    worst = {}
+    for n in g0:
+        ref = g0[n].double()
+        err = float((g2[n].double() - ref).norm() / ref.norm().clamp(min=1e-30))
+        worst[n] = err
+        # layers above conv3 do not see the change at all; below it the per-object sums are rounded once to bf16 (2^-9)
+        tol = 0.0 if n.startswith(("fc", "conv3_1.bias")) and n != "conv3_1.bias" else 6e-3
+        if n.startswith("fc"):
+            assert torch.equal(g2[n], g0[n]), n
+        else:
+            assert err <= tol, (n, err)
+    print({k: "%.2e" % v for k, v in worst.items() if v > 0})
