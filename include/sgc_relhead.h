@@ -46,6 +46,10 @@ int sgc_pair_expand(const void* U, const void* V, const int* sub_idx, const int*
  * img_ptr [n_img+1]; any output may be NULL. */
 int sgc_pair_expand_dense(const void* U, const void* V, const int* img_ptr, const int* pid, int pid_ld, int n_img, int max_n,
                           void* z_pad_f16, void* z_pad_bf16, unsigned char* amz, void* stream);
+/* The same, writing only the pixels pixel_rect[pair] names (sgc_shared_windows_count): with conv3 over shared windows a pair's
+ * expansion is read only next to its pair-specific windows; NULL = every pixel. */
+int sgc_pair_expand_dense_windows(const void* U, const void* V, const int* img_ptr, const int* pid, int pid_ld, int n_img, int max_n,
+                                  void* z_pad_f16, void* z_pad_bf16, unsigned char* amz, const int* pixel_rect, void* stream);
 
 /* y [n_pairs*64][1024] f16 (+ argmax u8, may be NULL; + y_bf16, the same values rounded to bf16 for the fc1 weight gradient, may be
  * NULL) = maxpool2(relu(conv3x3(z_pad, w3r[1024][8][9][64]) + b3))   (model.py:145-146) */
@@ -57,13 +61,15 @@ int sgc_conv3_relu_pool(const void* z_pad, const void* w3r, const float* b3, voi
  * confined to the intersection X_ij = R_i n R_j of two rectangles of conv3's 8x8 pooling-window grid; every other window of the pair
  * equals the same window of the pseudo-pair (i, empty-box object) or (empty-box object, j), computed once per object.
  * bbox [n_obj][4] int (x0,x1,y0,y1, slice semantics); sub_idx / obj_idx [n_pairs] index it.
- *   sgc_shared_windows_count   count[p] = |X_p|
+ *   sgc_shared_windows_count   count[p] = |X_p|; pixel_rect[p] (may be NULL) = the 16-grid pixels within one pixel of X_p, packed
+ *                              Y0 | Y1<<5 | X0<<10 | X1<<15 (0 = none): where the pair's z, routing codes and dz are needed
  *   sgc_shared_windows_fill    gather[e] = pair*64 + window for all X windows, given the INCLUSIVE prefix sum of count
  *   sgc_conv3_relu_pool_windows  sgc_conv3_relu_pool for the listed windows only, results written to rows gather[e] of y / argmax /
  *                              y_bf16 (max_entries bounds the launch, *gather_n on the device is the list length)
  *   sgc_shared_windows_assemble  the remaining rows: copies of y_obj [2*n_obj*64][1024] (rows of pseudo-pair (i, bg) = i,
  *                              of (bg, j) = n_obj + j), likewise argmax_obj and y_obj_bf16 (each may be NULL with its output) */
-int sgc_shared_windows_count(const int* bbox, const int* sub_idx, const int* obj_idx, int n_pairs, int* count, void* stream);
+int sgc_shared_windows_count(const int* bbox, const int* sub_idx, const int* obj_idx, int n_pairs, int* count, int* pixel_rect,
+                             void* stream);
 int sgc_shared_windows_fill(const int* bbox, const int* sub_idx, const int* obj_idx, int n_pairs, const int* count_incl, int* gather,
                             void* stream);
 int sgc_conv3_relu_pool_windows(const void* z_pad, const void* w3r, const float* b3, const int* gather, const int* gather_n,
@@ -85,8 +91,8 @@ int sgc_shared_windows_assemble(const int* bbox, const int* sub_idx, const int* 
  *                                    windows (the other rows of a real pair's dz are never written nor read)
  *   sgc_pair_contract_windows        sgc_pair_contract over those rows + the pseudo-pairs (pair index n_real_pairs + o for (o, bg),
  *                                    n_real_pairs + n_obj + o for (bg, o)); dU_pad has n_obj + n_img objects, object n_obj + b = the
- *                                    background of image b (objects img_ptr[b] .. img_ptr[b+1]); partner_idx = obj_idx for role 0
- *                                    (subject lists), sub_idx for role 1 */
+ *                                    background of image b (objects img_ptr[b] .. img_ptr[b+1]); pixel_rect from
+ *                                    sgc_shared_windows_count */
 int sgc_shared_windows_assemble_bwd(const int* bbox, const int* sub_idx, const int* obj_idx, const int* sub_ptr, const int* sub_list,
                                     const int* obj_ptr, const int* obj_list, int n_obj, const void* dy, void* dy_obj, void* stream);
 int sgc_windows_unpool(const void* dy, const unsigned char* argmax, const int* gather, const int* gather_n, int entries_pad, void* dy3x,
@@ -96,9 +102,8 @@ int sgc_windows_wgrad(const void* dy3x, const void* zcol, float* slabs, int rows
 int sgc_windows_dgrad_cols(const void* dy3x, const void* w3col, void* col, int rows, void* stream);
 int sgc_windows_col2im(const void* col, const int* bbox, const int* sub_idx, const int* obj_idx, const int* count_incl, int n_pairs,
                        void* dz, void* stream);
-int sgc_pair_contract_windows(const void* dz, const unsigned char* amz, const int* ptr, const int* list, const int* bbox,
-                              const int* partner_idx, const int* img_ptr, int role, int n_real_pairs, int n_obj, int n_img, void* dU_pad,
-                              void* stream);
+int sgc_pair_contract_windows(const void* dz, const unsigned char* amz, const int* ptr, const int* list, const int* pixel_rect,
+                              const int* img_ptr, int role, int n_real_pairs, int n_obj, int n_img, void* dU_pad, void* stream);
 
 /* h1 [n_pairs][4096] f16 = dropout(relu(y[n_pairs][K] * w1p[4096][K]^T + b))   (model.py:148-149; columns of w1p in (window, channel) order) */
 int sgc_fc1_relu(const void* y, const void* w1p, const float* b, void* h1, int n_pairs, int K, int drop_enable, unsigned drop_seed, void* stream);

@@ -59,6 +59,12 @@ __device__ __host__ __forceinline__ bool dropout_keep(uint32_t seed, uint32_t id
     return (lowbias32(idx ^ (seed * 0x9E3779B1U + 0x7F4A7C15U)) >> 16) & 1U;
 }
 
+// Packed half-open pixel rectangle on the 16-grid (Y0 | Y1 << 5 | X0 << 10 | X1 << 15, 0 = empty): the pixels of a pair that the
+// shared-window conv3 path needs (csrc/kernels_shared.hip).
+__device__ __forceinline__ bool in_pixel_rect(int r, int Y, int X) {
+    return Y >= (r & 31) && Y < ((r >> 5) & 31) && X >= ((r >> 10) & 31) && X < ((r >> 15) & 31);
+}
+
 #define SGC_OK 0
 #define SGC_ERR_ARG 1
 #define SGC_ERR_LAUNCH 2

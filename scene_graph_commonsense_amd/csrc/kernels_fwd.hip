@@ -108,7 +108,7 @@ constexpr int EXPAND_JT = 16;
 __global__ __launch_bounds__(512) void pair_expand_dense_kernel(const u16* __restrict__ U, const u16* __restrict__ V,
                                                                 const int* __restrict__ img_ptr, const int* __restrict__ pid,
                                                                 int pid_ld, u16* __restrict__ z, u16* __restrict__ zb,
-                                                                unsigned char* __restrict__ amz) {
+                                                                unsigned char* __restrict__ amz, const int* __restrict__ pixrect) {
     __shared__ __attribute__((aligned(16))) char sv[EXPAND_JT * 4096];
     const int W = blockIdx.x, jt = blockIdx.y, img = blockIdx.z;
     const int o0 = img_ptr[img], n = img_ptr[img + 1] - o0;
@@ -148,9 +148,17 @@ __global__ __launch_bounds__(512) void pair_expand_dense_kernel(const u16* __res
                 unext[q] = *reinterpret_cast<const uint4*>(U + ((long)(o0 + i + 8) * 1024 + 4 * W + q) * 512 + lane * 8);
         }
         const int* prow = pid + (long)(o0 + i) * pid_ld + j0;
-        for (int jj = 0; jj < nj; ++jj) {
-            const int p = __builtin_amdgcn_readfirstlane(prow[jj]);
-            if (p < 0) continue;                       // diagonal (or a pair that is not requested)
+        // lane jj looks up pair jj of the tile: not requested (diagonal) or - with pixrect - a pair that does not need this pixel
+        int pl = -1;
+        if (lane < nj) {
+            pl = prow[lane];
+            if (pl >= 0 && pixrect && !in_pixel_rect(pixrect[pl], Y, X)) pl = -1;
+        }
+        unsigned long long todo = __ballot(pl >= 0);
+        while (todo) {
+            const int jj = __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1);
+            todo &= todo - 1;
+            const int p = __builtin_amdgcn_readlane(pl, jj);
             float best[8];
             unsigned char arg[8];
 #pragma unroll
@@ -342,14 +350,18 @@ int sgc_pair_expand(const void* U, const void* V, const int* sub_idx, const int*
 // Dense form of the expansion: every ordered pair (i, j) of every image, pair index looked up in pid[n_obj][pid_ld]
 // (-1 = skip).  img_ptr [n_img+1] object ranges; max_n = largest object count of an image (<= 150).
 // Any of z_pad_f16 / z_pad_bf16 / amz may be NULL.
-int sgc_pair_expand_dense(const void* U, const void* V, const int* img_ptr, const int* pid, int pid_ld, int n_img, int max_n,
-                          void* z_pad_f16, void* z_pad_bf16, unsigned char* amz, void* stream) {
+int sgc_pair_expand_dense_windows(const void* U, const void* V, const int* img_ptr, const int* pid, int pid_ld, int n_img, int max_n,
+                                  void* z_pad_f16, void* z_pad_bf16, unsigned char* amz, const int* pixel_rect, void* stream) {
     if (max_n > 150 || max_n < 1) return SGC_ERR_ARG;
     if (n_img <= 0) return SGC_OK;
     SGC_LAUNCH(pair_expand_dense_kernel, dim3(256, (max_n + EXPAND_JT - 1) / EXPAND_JT, n_img), dim3(512), 0, (hipStream_t)stream,
-               (const u16*)U, (const u16*)V, img_ptr, pid, pid_ld, (u16*)z_pad_f16, (u16*)z_pad_bf16, amz);
+               (const u16*)U, (const u16*)V, img_ptr, pid, pid_ld, (u16*)z_pad_f16, (u16*)z_pad_bf16, amz, pixel_rect);
     SGC_CHECK_LAUNCH();
     return SGC_OK;
+}
+int sgc_pair_expand_dense(const void* U, const void* V, const int* img_ptr, const int* pid, int pid_ld, int n_img, int max_n,
+                          void* z_pad_f16, void* z_pad_bf16, unsigned char* amz, void* stream) {
+    return sgc_pair_expand_dense_windows(U, V, img_ptr, pid, pid_ld, n_img, max_n, z_pad_f16, z_pad_bf16, amz, nullptr, stream);
 }
 
 // y [n_pairs*64][1024] (+argmax u8) = maxpool2(relu(conv3x3(z_pad, w3r[1024][8][9][64]) + b3))

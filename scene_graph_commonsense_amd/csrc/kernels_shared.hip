@@ -39,12 +39,21 @@ __device__ __forceinline__ WRect pair_windows(const WRect& a, const WRect& b) {
     return r;
 }
 
+// Pixels of the 16-grid within one pixel of a pair's X windows, packed Y0 | Y1 << 5 | X0 << 10 | X1 << 15 (half-open; 0 = none):
+// the only pixels where a real pair's z (conv3 input), routing codes and dz exist in the shared-window path.
+__device__ __forceinline__ int pack_pixel_rect(const WRect& x) {
+    if (x.x1 <= x.x0) return 0;
+    const int Y0 = max(2 * x.y0 - 1, 0), Y1 = min(2 * x.y1 + 1, 16), X0 = max(2 * x.x0 - 1, 0), X1 = min(2 * x.x1 + 1, 16);
+    return Y0 | (Y1 << 5) | (X0 << 10) | (X1 << 15);
+}
 __global__ __launch_bounds__(256) void shared_count_kernel(const int* __restrict__ bbox, const int* __restrict__ sub,
-                                                           const int* __restrict__ obj, int n_pairs, int* __restrict__ count) {
+                                                           const int* __restrict__ obj, int n_pairs, int* __restrict__ count,
+                                                           int* __restrict__ pixrect) {
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= n_pairs) return;
     const WRect x = pair_windows(object_windows(bbox + 4 * sub[p]), object_windows(bbox + 4 * obj[p]));
     count[p] = (x.x1 - x.x0) * (x.y1 - x.y0);
+    if (pixrect) pixrect[p] = pack_pixel_rect(x);
 }
 
 // gather[e] = pair * 64 + window for the X windows of every pair, pairs in list order, windows row-major
@@ -269,9 +278,8 @@ __global__ __launch_bounds__(256) void windows_col2im_kernel(const u16* __restri
 // n_obj + b) collects the other side of the pseudo-pairs of that image's objects.
 __global__ __launch_bounds__(256) void pair_contract_windows_kernel(const u16* __restrict__ dz, const unsigned char* __restrict__ amz,
                                                                     const int* __restrict__ ptr, const int* __restrict__ list,
-                                                                    const int* __restrict__ bbox, const int* __restrict__ partner,
-                                                                    const int* __restrict__ img_ptr, int role, int n_real, int n_obj,
-                                                                    u16* __restrict__ dU, long n_items) {
+                                                                    const int* __restrict__ pixrect, const int* __restrict__ img_ptr,
+                                                                    int role, int n_real, int n_obj, u16* __restrict__ dU, long n_items) {
     const int lane = threadIdx.x & 63;
     for (long it = (long)blockIdx.x * 4 + (threadIdx.x >> 6); it < n_items; it += (long)gridDim.x * 4) {
         const int o = (int)(it >> 8), W = (int)(it & 255);
@@ -282,9 +290,7 @@ __global__ __launch_bounds__(256) void pair_contract_windows_kernel(const u16* _
         for (int q = 0; q < 4; ++q)
 #pragma unroll
             for (int k = 0; k < 8; ++k) acc[q][k] = 0.f;
-        long vp[4];
-        int nv = 0;
-        auto flush = [&]() __attribute__((always_inline)) {
+        auto add4 = [&](const long (&vp)[4], int nv) __attribute__((always_inline)) {
             uint4 g[4];
             unsigned a[4];
 #pragma unroll
@@ -305,29 +311,41 @@ __global__ __launch_bounds__(256) void pair_contract_windows_kernel(const u16* _
                         for (int q = 0; q < 4; ++q) acc[q][k] += (code == (unsigned)q) ? v : 0.f;
                     }
                 }
-            nv = 0;
         };
-        if (o < n_obj) {
-            const WRect ro = object_windows(bbox + 4 * o);
-            if (ro.x1 > ro.x0) {
-                for (int i = ptr[o]; i < ptr[o + 1]; ++i) {
-                    const int p = list[i];
-                    const WRect x = pair_windows(ro, object_windows(bbox + 4 * partner[p]));
-                    if (x.x1 > x.x0 && Y >= 2 * x.y0 - 1 && Y < 2 * x.y1 + 1 && X >= 2 * x.x0 - 1 && X < 2 * x.x1 + 1) {
-                        vp[nv++] = p;
-                        if (nv == 4) flush();
-                    }
+        // candidates of this (object, pixel), 64 at a time: lane k looks at the k-th one, a ballot keeps those whose rows exist
+        auto scan = [&](int i0, int i1, bool real) __attribute__((always_inline)) {
+            for (int base = i0; base < i1; base += 64) {
+                const int i = base + lane;
+                int pk = 0;
+                bool ok = false;
+                if (i < i1) {
+                    if (real) { pk = list[i]; ok = in_pixel_rect(pixrect[pk], Y, X); }
+                    else { pk = n_real + (role ? i : n_obj + i); ok = true; }
+                }
+                unsigned long long m = __ballot(ok);
+                while (m) {
+                    long vp[4];
+                    int nv = 0;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (m) {
+                            const int b = __ffsll((long long)m) - 1;
+                            m &= m - 1;
+                            vp[u] = (long)__shfl(pk, b);
+                            nv = u + 1;
+                        }
+                    add4(vp, nv);
                 }
             }
-            vp[nv++] = (long)n_real + (role ? n_obj + o : o);
-            if (nv == 4) flush();
+        };
+        if (o < n_obj) {
+            scan(ptr[o], ptr[o + 1], true);
+            long vp[4];
+            vp[0] = (long)n_real + (role ? n_obj + o : o);
+            add4(vp, 1);
         } else {
-            for (int k = img_ptr[o - n_obj]; k < img_ptr[o - n_obj + 1]; ++k) {
-                vp[nv++] = (long)n_real + (role ? k : n_obj + k);
-                if (nv == 4) flush();
-            }
+            scan(img_ptr[o - n_obj], img_ptr[o - n_obj + 1], false);
         }
-        if (nv) flush();
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             uint4 ov;
@@ -349,9 +367,11 @@ static inline int grid_cap(long items, long per_block, int cap) {
 
 extern "C" {
 
-int sgc_shared_windows_count(const int* bbox, const int* sub_idx, const int* obj_idx, int n_pairs, int* count, void* stream) {
+int sgc_shared_windows_count(const int* bbox, const int* sub_idx, const int* obj_idx, int n_pairs, int* count, int* pixel_rect,
+                             void* stream) {
     if (n_pairs <= 0) return SGC_OK;
-    SGC_LAUNCH(shared_count_kernel, dim3((n_pairs + 255) / 256), dim3(256), 0, (hipStream_t)stream, bbox, sub_idx, obj_idx, n_pairs, count);
+    SGC_LAUNCH(shared_count_kernel, dim3((n_pairs + 255) / 256), dim3(256), 0, (hipStream_t)stream, bbox, sub_idx, obj_idx, n_pairs, count,
+               pixel_rect);
     SGC_CHECK_LAUNCH();
     return SGC_OK;
 }
@@ -448,13 +468,12 @@ int sgc_windows_col2im(const void* col, const int* bbox, const int* sub_idx, con
     return SGC_OK;
 }
 
-int sgc_pair_contract_windows(const void* dz, const unsigned char* amz, const int* ptr, const int* list, const int* bbox,
-                              const int* partner_idx, const int* img_ptr, int role, int n_real_pairs, int n_obj, int n_img, void* dU_pad,
-                              void* stream) {
+int sgc_pair_contract_windows(const void* dz, const unsigned char* amz, const int* ptr, const int* list, const int* pixel_rect,
+                              const int* img_ptr, int role, int n_real_pairs, int n_obj, int n_img, void* dU_pad, void* stream) {
     if (n_obj <= 0) return SGC_OK;
     const long items = (long)(n_obj + n_img) * 256;
     SGC_LAUNCH(pair_contract_windows_kernel, dim3(grid_cap(items, 4, 262144)), dim3(256), 0, (hipStream_t)stream, (const u16*)dz, amz,
-               ptr, list, bbox, partner_idx, img_ptr, role, n_real_pairs, n_obj, (u16*)dU_pad, items);
+               ptr, list, pixel_rect, img_ptr, role, n_real_pairs, n_obj, (u16*)dU_pad, items);
     SGC_CHECK_LAUNCH();
     return SGC_OK;
 }

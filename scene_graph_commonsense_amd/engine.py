@@ -300,15 +300,16 @@ class RelHeadEngine:
             res[r] = uv
         return res
 
-    def expand(self, U, V, sub_idx, obj_idx, P, z, z_bf=None, amz=None, dense=None):
+    def expand(self, U, V, sub_idx, obj_idx, P, z, z_bf=None, amz=None, dense=None, pixrect=None):
         """Pair expansion: dense LDS-staged kernel when the pair list is "all ordered pairs of every image"
-        (dense = (img_ptr, pid, max_n)), generic pair-list kernel otherwise."""
+        (dense = (img_ptr, pid, max_n)), generic pair-list kernel otherwise.  ``pixrect`` ([P] packed rectangles from
+        ``shared_plan``): only the pixels conv3 over shared windows reads are written (dense kernel only)."""
         lib = self.lib
         if dense is not None and 0 < dense[2] <= 150:
             img_ptr, pid, max_n = dense
-            self._timed("expand_dense", lambda: _lib.check(lib.sgc_pair_expand_dense(
+            self._timed("expand_dense", lambda: _lib.check(lib.sgc_pair_expand_dense_windows(
                 _lib.ptr(U), _lib.ptr(V), _lib.ptr(img_ptr), _lib.ptr(pid), int(pid.shape[1]), int(img_ptr.shape[0]) - 1, max_n,
-                _lib.ptr(z), _lib.ptr(z_bf), _lib.ptr(amz), self._st()), "sgc_pair_expand_dense"))
+                _lib.ptr(z), _lib.ptr(z_bf), _lib.ptr(amz), _lib.ptr(pixrect), self._st()), "sgc_pair_expand_dense_windows"))
         elif z_bf is None and amz is None:
             self._timed("expand", lambda: _lib.check(lib.sgc_pair_expand(_lib.ptr(U), _lib.ptr(V), _lib.ptr(sub_idx), _lib.ptr(obj_idx),
                                                                        _lib.ptr(z), P, ELEM_F16, self._st()), "sgc_pair_expand"))
@@ -317,12 +318,33 @@ class RelHeadEngine:
                 _lib.ptr(U), _lib.ptr(V), _lib.ptr(sub_idx), _lib.ptr(obj_idx), _lib.ptr(z), _lib.ptr(z_bf), _lib.ptr(amz), P,
                 self._st()), "sgc_pair_expand_train"))
 
-    def conv3_shared(self, z, U, V, bbox, obj_img, sub_idx, obj_idx, P, y, am, y_bf, bound=None, keep=None):
+    def shared_plan(self, bbox, sub_idx, obj_idx, P, bound=None, keep=False):
+        """The pair-specific (X) windows of a pair list (``csrc/kernels_shared.hip``): ``gather`` [E] = pair*64 + window in pair
+        order, ``incl`` [P] inclusive prefix counts, ``pixrect`` [P] the packed pixel rectangle around each pair's X windows, and
+        ``entries`` = E when the host knows it (``bound`` from ``DeviceScene.shared_windows``; with ``keep`` - training, where the
+        backward's GEMMs need exact sizes - one sync reads it back otherwise).  ``keep``: the lists live in buffers this engine owns."""
+        lib = self.lib
+        own = self.ws if keep else self.scratch
+        cnt = self.scratch.get("xw_count", P, torch.int32)
+        pixrect = own.get("xw_pixrect", P, torch.int32)
+        _lib.check(lib.sgc_shared_windows_count(_lib.ptr(bbox), _lib.ptr(sub_idx), _lib.ptr(obj_idx), P, _lib.ptr(cnt), _lib.ptr(pixrect),
+                                                self._st()), "sgc_shared_windows_count")
+        incl = torch.cumsum(cnt, 0, dtype=torch.int32)
+        gather = own.get("xw_gather", P * 64, torch.int32)
+        _lib.check(lib.sgc_shared_windows_fill(_lib.ptr(bbox), _lib.ptr(sub_idx), _lib.ptr(obj_idx), P, _lib.ptr(incl), _lib.ptr(gather),
+                                               self._st()), "sgc_shared_windows_fill")
+        if bound is None and keep:
+            bound = int(incl[P - 1])
+        exact = bound is not None
+        bound = P * 64 if bound is None else max(0, min(int(bound), P * 64))
+        self._xw = (gather, incl)
+        return dict(gather=gather, incl=incl, pixrect=pixrect, bound=bound, entries=bound if exact else None)
+
+    def conv3_shared(self, plan, z, U, V, bbox, obj_img, sub_idx, obj_idx, P, y, am, y_bf, keep=None):
         """conv3 + ReLU + pool with the per-object part computed once per object (``csrc/kernels_shared.hip``): U / V hold
-        n_obj + n_img objects, the last n_img the empty-box backgrounds of the images.  ``bound``: the number of pair-specific windows when the host
-        knows it (``DeviceScene.shared_windows``), else 64 per pair bounds the launch.
-        ``keep=(z_bf_tail, amz_tail)`` (training): the pseudo-pairs' bf16 expansion and routing codes go there and the window list
-        lives in buffers this engine owns; returns what the backward needs."""
+        n_obj + n_img objects, the last n_img the empty-box backgrounds of the images; ``plan`` from ``shared_plan``.
+        ``keep=(z_bf_tail, amz_tail)`` (training): the pseudo-pairs' bf16 expansion and routing codes go there; returns what the
+        backward needs."""
         lib, sc = self.lib, self.scratch
         own = self.ws if keep is not None else sc
         n_obj = int(obj_img.shape[0])
@@ -343,25 +365,14 @@ class RelHeadEngine:
         self._timed("conv3_fwd_objects", lambda: _lib.check(lib.sgc_conv3_relu_pool(
             _lib.ptr(z_ps), _lib.ptr(self.w["w3r"]), _lib.ptr(self.w["b3"]), _lib.ptr(y_ps), _lib.ptr(am_ps), _lib.ptr(ybf_ps), n2,
             self._st()), "sgc_conv3_relu_pool"))
-        cnt = sc.get("xw_count", P, torch.int32)
-        _lib.check(lib.sgc_shared_windows_count(_lib.ptr(bbox), _lib.ptr(sub_idx), _lib.ptr(obj_idx), P, _lib.ptr(cnt), self._st()),
-                   "sgc_shared_windows_count")
-        incl = torch.cumsum(cnt, 0, dtype=torch.int32)
-        gather = own.get("xw_gather", P * 64, torch.int32)
-        _lib.check(lib.sgc_shared_windows_fill(_lib.ptr(bbox), _lib.ptr(sub_idx), _lib.ptr(obj_idx), P, _lib.ptr(incl), _lib.ptr(gather),
-                                               self._st()), "sgc_shared_windows_fill")
-        if bound is None and keep is not None:
-            bound = int(incl[P - 1])              # pair subsets in training (augmented-view pass): one sync buys exact GEMM sizes
-        exact = bound is not None
-        bound = P * 64 if bound is None else max(0, min(int(bound), P * 64))
+        gather, incl = plan["gather"], plan["incl"]
         self._timed("conv3_fwd_windows", lambda: _lib.check(lib.sgc_conv3_relu_pool_windows(
-            _lib.ptr(z), _lib.ptr(self.w["w3r"]), _lib.ptr(self.w["b3"]), _lib.ptr(gather), _lib.ptr(incl[P - 1:]), bound, _lib.ptr(y),
+            _lib.ptr(z), _lib.ptr(self.w["w3r"]), _lib.ptr(self.w["b3"]), _lib.ptr(gather), _lib.ptr(incl[P - 1:]), plan["bound"], _lib.ptr(y),
             _lib.ptr(am), _lib.ptr(y_bf), self._st()), "sgc_conv3_relu_pool_windows"))
         self._timed("conv3_fwd_assemble", lambda: _lib.check(lib.sgc_shared_windows_assemble(
             _lib.ptr(bbox), _lib.ptr(sub_idx), _lib.ptr(obj_idx), P, n_obj, _lib.ptr(y_ps), _lib.ptr(am_ps), _lib.ptr(ybf_ps),
             _lib.ptr(y), _lib.ptr(am), _lib.ptr(y_bf), self._st()), "sgc_shared_windows_assemble"))
-        self._xw = (gather, incl)
-        return dict(gather=gather, incl=incl, entries=bound if exact else None, am_ps=am_ps, n2=n2)
+        return dict(plan, am_ps=am_ps, n2=n2)
 
     def pair_trunk(self, U, V, sub_idx, obj_idx, lsub, lobj, train=False, seeds=(0, 0), keep_argmax=False,
                    iou_mask=None, dense=None, shared=None) -> PairOutputs:
@@ -369,11 +380,12 @@ class RelHeadEngine:
         P = int(sub_idx.shape[0])
         Ppad = (P + 63) // 64 * 64
         z = ws.get("z_pad", P * 18 * 18 * 512, torch.float16)      # border stays zero: only interiors are written
-        self.expand(U, V, sub_idx, obj_idx, P, z, dense=dense)
+        plan = self.shared_plan(shared[0], sub_idx, obj_idx, P, shared[2]) if shared is not None else None
+        self.expand(U, V, sub_idx, obj_idx, P, z, dense=dense, pixrect=None if plan is None else plan["pixrect"])
         y = ws.get("y", Ppad * 65536, torch.float16)
         am = ws.get("argmax", P * 65536, torch.uint8) if keep_argmax else None
         if shared is not None:
-            self.conv3_shared(z, U, V, shared[0], shared[1], sub_idx, obj_idx, P, y, am, None, shared[2])
+            self.conv3_shared(plan, z, U, V, shared[0], shared[1], sub_idx, obj_idx, P, y, am, None)
         else:
             self._timed("conv3_fwd", lambda: _lib.check(lib.sgc_conv3_relu_pool(_lib.ptr(z), _lib.ptr(self.w["w3r"]), _lib.ptr(self.w["b3"]), _lib.ptr(y),
                                                _lib.ptr(am), _lib.ptr(None), P, self._st()), "sgc_conv3_relu_pool"))
@@ -520,7 +532,10 @@ class RelHeadEngine:
         Pt = P + (2 * ctx.n_obj if share else 0)                     # the pseudo-pairs (object, background) live behind the real pairs
         z_bf = ws.get("z_pad_bf", Pt * 18 * 18 * 512, torch.bfloat16)
         amz = ws.get("amz", Pt * 256 * 256, torch.uint8)             # two 4-bit routing codes per byte
-        self.expand(ctx.uv[0], ctx.uv[1], sub_idx, obj_idx, P, z, z_bf, amz, dense=dense)
+        plan = self.shared_plan(bbox, sub_idx, obj_idx, P, shared_windows, keep=True) if share else None
+        # the per-pair backward (SGC_SHARED_BWD=0, A/B hook) reads every pixel of z / amz; the shared one only those next to X windows
+        narrow = share and os.environ.get("SGC_SHARED_BWD", "1") != "0"
+        self.expand(ctx.uv[0], ctx.uv[1], sub_idx, obj_idx, P, z, z_bf, amz, dense=dense, pixrect=plan["pixrect"] if narrow else None)
         ctx.z_bf = z_bf
         y = sc.get("y", Ppad * 65536, torch.float16)
         y_bf = ws.get("y_bf", Ppad * 65536, torch.bfloat16)         # bf16 copy for the fc1 weight gradient, written by the same epilogue
@@ -529,7 +544,7 @@ class RelHeadEngine:
         am = ws.get("argmax", P * 65536, torch.uint8)
         ctx.shared = None
         if share:
-            ctx.shared = self.conv3_shared(z, ctx.uv[0], ctx.uv[1], bbox, obj_img, sub_idx, obj_idx, P, y, am, y_bf, shared_windows,
+            ctx.shared = self.conv3_shared(plan, z, ctx.uv[0], ctx.uv[1], bbox, obj_img, sub_idx, obj_idx, P, y, am, y_bf,
                                            keep=(z_bf[P * 18 * 18 * 512:], amz[P * 256 * 256:]))
         else:
             self._timed("conv3_fwd", lambda: _lib.check(lib.sgc_conv3_relu_pool(_lib.ptr(z), _lib.ptr(self.w["w3r"]), _lib.ptr(self.w["b3"]), _lib.ptr(y), _lib.ptr(am),
@@ -676,9 +691,8 @@ class RelHeadEngine:
         for r, csr in ((0, sub_csr), (1, obj_csr)):
             dU = ws.get("dU_pad_%d" % r, n_objx * 34 * 34 * 512, torch.bfloat16)
             if shared is not None:
-                partner = ctx.obj_idx if r == 0 else ctx.sub_idx
                 self._timed("contract", lambda: _lib.check(lib.sgc_pair_contract_windows(
-                    _lib.ptr(dz), _lib.ptr(ctx.amz), _lib.ptr(csr[0]), _lib.ptr(csr[1]), _lib.ptr(ctx.bbox), _lib.ptr(partner), _lib.ptr(img_ptr),
+                    _lib.ptr(dz), _lib.ptr(ctx.amz), _lib.ptr(csr[0]), _lib.ptr(csr[1]), _lib.ptr(shared["pixrect"]), _lib.ptr(img_ptr),
                     r, P, n_obj, n_img, _lib.ptr(dU), st()), "sgc_pair_contract_windows"))
             else:
                 self._timed("contract", lambda: _lib.check(lib.sgc_pair_contract(_lib.ptr(dz), _lib.ptr(ctx.amz), _lib.ptr(csr[0]), _lib.ptr(csr[1]), _lib.ptr(dU), n_obj, st()),

@@ -30,6 +30,21 @@ def _edge_boxes(batch):
     return batch
 
 
+def _poison(eng):
+    """NaN into every per-pair buffer the shared path writes only partly (the pair expansion next to the pair-specific windows,
+    dz likewise): a read outside what was written shows up in the results instead of finding the previous run's values."""
+    for ws in (eng.ws, eng.scratch):
+        for name, t in ws.bufs.items():
+            if name in ("z_pad", "z_pad_bf"):
+                v = t[:t.numel() // (18 * 18 * 512) * (18 * 18 * 512)].view(-1, 18, 18, 512)
+                v[:, 1:17, 1:17, :] = float("nan")           # the halo has to stay zero
+            elif name == "amz":
+                t.fill_(0x44)                                # "no route" everywhere
+            elif name in ("dz", "xcol", "zcol", "dy3x"):
+                t.view(torch.int16).fill_(0x7FC0)            # bf16 NaN
+    torch.cuda.synchronize()
+
+
 def _with(flag, fn):
     old = os.environ.get("SGC_SHARED_CONV3")
     os.environ["SGC_SHARED_CONV3"] = flag
@@ -60,6 +75,7 @@ def test_forward_is_bit_identical_to_the_per_pair_convolution(nobj, edge):
         torch.cuda.synchronize()
         return out, eng.ws.bufs["y"][:P * 65536].clone()
     o0, y0 = _with("0", run)
+    _poison(eng)
     o1, y1 = _with("1", run)
     assert torch.equal(y0.view(torch.int16), y1.view(torch.int16))
     for a, b in ((o0.relation, o1.relation), (o0.connectivity, o1.connectivity), (o0.hidden, o1.hidden), (o0.cand_pred, o1.cand_pred)):
@@ -126,7 +142,10 @@ def test_training_step_shared_forward_is_bit_identical_and_shared_backward_agree
                 {n: p.grad.clone() for n, p in model.named_parameters()})
     l0, yb0, am0, g0 = _with_env({"SGC_SHARED_CONV3": "0"}, run)
     l1, yb1, am1, g1 = _with_env({"SGC_SHARED_CONV3": "1", "SGC_SHARED_BWD": "0"}, run)
+    _poison(eng)
     l2, yb2, am2, g2 = _with_env({"SGC_SHARED_CONV3": "1", "SGC_SHARED_BWD": "1"}, run)
+    for n in g2:
+        assert torch.isfinite(g2[n]).all(), n
     assert l0 == l1 == l2
     assert torch.equal(yb0.view(torch.int16), yb1.view(torch.int16)) and torch.equal(am0, am1)
     for n in g0:
