@@ -18,7 +18,7 @@
 #include <type_traits>
 
 enum { AMODE_PLAIN = 0, AMODE_CONV = 1, AMODE_CONV_GATHER = 2 };   // GATHER: conv rows come from a list of 2x2 windows (see NtParams::gather)
-enum { EPI_STORE = 0, EPI_BIAS_TANH = 1, EPI_BIAS_RELU = 2, EPI_POOL = 3, EPI_FC2 = 4, EPI_RELUMASK = 5 };
+enum { EPI_STORE = 0, EPI_BIAS_TANH = 1, EPI_BIAS_RELU = 2, EPI_POOL = 3, EPI_FC2 = 4, EPI_RELUMASK = 5, EPI_STORE_F32 = 6 };
 
 struct NtParams {
     const u16* A; const u16* B; void* C;
@@ -41,6 +41,10 @@ struct NtParams {
     const int* gather; const int* gather_n;         // AMODE_CONV_GATHER: row m = 4*e + q is pixel q of window gather[e] = image*(S/2)^2 + window;
                                                     // *gather_n = number of list entries (device side; p.M is only the launch bound);
                                                     // EPI_POOL writes entry e to pooled row gather[e]
+    // window-major row space of the shared fc1 (csrc/kernels_shared.hip): rows grouped by pooling window, groups padded to 256 rows
+    const int* dest;                                // AMODE_CONV_GATHER + EPI_POOL: y / bf16 copy of entry e go to row dest[e] (argmax stays at gather[e])
+    const int* wm_goff;                             // EPI_POOL: y / bf16 copy of pooled row r go to row wm_goff[r & 63] + (r >> 6) (argmax stays at r)
+    const int* tile_group; long group_stride;       // gemm_nt_pp_kernel: M tile t multiplies with B + tile_group[t] * group_stride
 };
 
 template <int ELEM>
@@ -86,13 +90,15 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x16 (&acc)[TM]
                         if (t > v) { v = t; am = q; }
                     }
                     v += bias;
-                    int prow = (rbase >> 2) + 2 * w + h;
+                    const int prow = (rbase >> 2) + 2 * w + h;
                     if (prow * 4 < M) {
-                        if constexpr (GATHER) prow = p.gather[prow];
+                        long arow = prow, yrow = prow;
+                        if constexpr (GATHER) { arow = p.gather[prow]; yrow = p.dest ? p.dest[prow] : arow; }
+                        else if (p.wm_goff) yrow = p.wm_goff[prow & 63] + (prow >> 6);
                         if (!(v > 0.f)) { v = 0.f; am = 4; }        // ReLU killed: no gradient path
-                        out[(long)prow * p.ldc + col] = to_elem<ELEM>(v);
-                        if (p.C2) p.C2[(long)prow * p.ldc + col] = f32_to_bf16_bits(v);
-                        if (p.argmax) p.argmax[(long)prow * p.ldc + col] = (unsigned char)am;
+                        out[yrow * p.ldc + col] = to_elem<ELEM>(v);
+                        if (p.C2) p.C2[yrow * p.ldc + col] = f32_to_bf16_bits(v);
+                        if (p.argmax) p.argmax[arow * p.ldc + col] = (unsigned char)am;
                     }
                 }
             } else {
@@ -104,6 +110,8 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x16 (&acc)[TM]
                     const long o = (long)row * p.ldc + col;
                     if constexpr (EPI == EPI_STORE) {
                         reinterpret_cast<u16*>(p.C)[o] = to_elem<ELEM>(v + bias);
+                    } else if constexpr (EPI == EPI_STORE_F32) {
+                        reinterpret_cast<float*>(p.C)[o] = v + bias;
                     } else if constexpr (EPI == EPI_BIAS_TANH) {
                         reinterpret_cast<u16*>(p.C)[o] = to_elem<ELEM>(tanhf(v + bias));
                     } else if constexpr (EPI == EPI_BIAS_RELU) {

@@ -97,7 +97,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(const NtParams p) {
     // ---- staging sources: wave w writes LDS rows (2w+q)*8 .. +7 of every half tile (q = 0,1), 8 lanes per 128-B row
     const int lrow = lane >> 3, cpos = lane & 7;
     const u16* const a_blk = p.A + (long)m0 * p.lda;
-    const u16* const b_blk = p.B + (long)n0 * p.ldb;
+    const u16* const b_blk = p.B + (long)n0 * p.ldb + (p.tile_group ? (long)p.tile_group[tm] * p.group_stride : 0L);
     int voff[4][2];                                  // byte offsets from a_blk / b_blk
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -264,7 +264,9 @@ __device__ __forceinline__ void nt_epilogue_pool16(const NtParams& p, f32x16 (&a
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
         const int row = it * 8 + r8;
-        const long o = (prow0 + row) * p.ldc + n0 + wc * 64 + c8 * 8;
+        long orow = prow0 + row;
+        if (p.wm_goff) orow = p.wm_goff[orow & 63] + (orow >> 6);      // window-major row space (shared fc1); argmax stays pair-major
+        const long o = orow * p.ldc + n0 + wc * 64 + c8 * 8;
         *reinterpret_cast<uint4*>(out + o) = *reinterpret_cast<const uint4*>(ty + row * 144 + c8 * 16);
         if (p.C2) *reinterpret_cast<uint4*>(p.C2 + o) = *reinterpret_cast<const uint4*>(tb + row * 144 + c8 * 16);
     }
