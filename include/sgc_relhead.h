@@ -105,6 +105,24 @@ int sgc_windows_col2im(const void* col, const int* bbox, const int* sub_idx, con
 int sgc_pair_contract_windows(const void* dz, const unsigned char* amz, const int* ptr, const int* list, const int* pixel_rect,
                               const int* img_ptr, int role, int n_real_pairs, int n_obj, int n_img, void* dU_pad, void* stream);
 
+/* fc1 over shared windows (csrc/kernels_shared.hip; model.py:148-149).  fc1 is a sum over conv3's 64 pooling windows and the I / J
+ * windows of a pair are copies of per-object rows, so every row fc1 multiplies lives in one WINDOW-MAJOR row space: group w =
+ * [2*n_obj pseudo-pair rows][X entries of window w in pair order][zero rows up to a multiple of 256]; goff [65] = group offsets.
+ *   sgc_conv3_relu_pool_wm          sgc_conv3_relu_pool of the pseudo-pairs, y / y_bf16 rows written at goff[w] + pseudo-pair
+ *   sgc_conv3_relu_pool_windows_wm  ... of the X windows, y / y_bf16 of entry e written at dest[e] (argmax at gather[e] as before)
+ *   sgc_fc1_windows_gemm            owm [rows][4096] f32 = ywm [rows][1024] * (columns g*1024.. of w1p)^T, g = tile_group[row/256]
+ *   sgc_fc1_integral                S [n_pseudo][9][9][4096] = 2-D inclusive prefix sums (zero border) of the pseudo rows of owm
+ *   sgc_fc1_assemble                h1[p] = dropout(relu(b + S_i[all] - S_i[R_j] + S'_j[R_j] - S'_j[X_p] + sum_{e in X_p} owm[dest[e]])) */
+int sgc_conv3_relu_pool_wm(const void* z_pad, const void* w3r, const float* b3, const int* goff, void* ywm, unsigned char* argmax,
+                           void* ywm_bf16, int n_pairs, void* stream);
+int sgc_conv3_relu_pool_windows_wm(const void* z_pad, const void* w3r, const float* b3, const int* gather, const int* gather_n,
+                                   const int* dest, int max_entries, void* ywm, unsigned char* argmax, void* ywm_bf16, void* stream);
+int sgc_fc1_windows_gemm(const void* ywm, const void* w1p, const int* tile_group, float* owm, int rows, void* stream);
+int sgc_fc1_integral(const float* owm, const int* goff, int n_pseudo, float* S, void* stream);
+int sgc_fc1_assemble(const float* S, const float* owm, const int* bbox, const int* sub_idx, const int* obj_idx, const int* count_incl,
+                     const int* dest, int n_obj, const float* bias, int drop_enable, unsigned drop_seed, void* h1, int n_pairs,
+                     void* stream);
+
 /* h1 [n_pairs][4096] f16 = dropout(relu(y[n_pairs][K] * w1p[4096][K]^T + b))   (model.py:148-149; columns of w1p in (window, channel) order) */
 int sgc_fc1_relu(const void* y, const void* w1p, const float* b, void* h1, int n_pairs, int K, int drop_enable, unsigned drop_seed, void* stream);
 

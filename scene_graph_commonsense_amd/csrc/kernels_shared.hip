@@ -358,6 +358,102 @@ __global__ __launch_bounds__(256) void pair_contract_windows_kernel(const u16* _
     }
 }
 
+// ================================================================================================ fc1 over shared windows
+// fc1 is a sum over conv3's 64 pooling windows, h_pre[p] = b + sum_w W1[w] * y_p[w], and y_p[w] is a copy of a per-object row on the
+// I / J windows.  All rows that fc1 multiplies live in ONE "window-major" row space: group w = [the 2*n_obj pseudo-pair rows of
+// window w][the X entries of window w, pair order][zero rows up to a multiple of 256], so that fc1 is one grouped GEMM
+// (row tile t multiplies with the weight slice of its group) instead of a [P, 65536] GEMM:
+//   O[r] = Y[r] * W1[w(r)]^T                      (f32; pseudo rows: T_o[w], X rows: the pair's partial product for that window)
+//   S_o  = 2-D inclusive prefix sums of T_o over the 8x8 window grid (9x9 with a zero border)
+//   h_pre[p] = b + S_i[all] - S_i[R_j] + S'_j[R_j] - S'_j[X_p] + sum_{e in X_p} O[dest[e]]          (rectangle sums = 4 look-ups)
+// which is the same sum in a different order (f32 round-off instead of bit equality with the [P, 65536] GEMM).
+__global__ __launch_bounds__(256) void fc1_integral_kernel(const float* __restrict__ owm, const int* __restrict__ goff, int n2,
+                                                           float* __restrict__ S) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const int c = (int)(idx & 4095);
+    const int ps = (int)(idx >> 12);
+    if (ps >= n2) return;
+    float* So = S + (long)ps * 81 * 4096 + c;
+    float col[8];
+#pragma unroll
+    for (int x = 0; x < 8; ++x) col[x] = 0.f;
+#pragma unroll
+    for (int x = 0; x < 9; ++x) So[(long)x * 4096] = 0.f;
+    for (int y = 0; y < 8; ++y) {
+        float run = 0.f;
+        So[(long)((y + 1) * 9) * 4096] = 0.f;
+#pragma unroll
+        for (int x = 0; x < 8; ++x) {
+            run += owm[((long)goff[y * 8 + x] + ps) * 4096 + c];
+            col[x] += run;
+            So[(long)((y + 1) * 9 + x + 1) * 4096] = col[x];
+        }
+    }
+}
+
+__device__ __forceinline__ void rect_acc(float (&acc)[16], const float* __restrict__ So, const WRect& r, float sign, int c0) {
+    const float* a = So + (long)(r.y1 * 9 + r.x1) * 4096 + c0;
+    const float* b = So + (long)(r.y0 * 9 + r.x1) * 4096 + c0;
+    const float* c = So + (long)(r.y1 * 9 + r.x0) * 4096 + c0;
+    const float* d = So + (long)(r.y0 * 9 + r.x0) * 4096 + c0;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const float4 fa = reinterpret_cast<const float4*>(a)[v], fb = reinterpret_cast<const float4*>(b)[v];
+        const float4 fc = reinterpret_cast<const float4*>(c)[v], fd = reinterpret_cast<const float4*>(d)[v];
+        acc[4 * v + 0] += sign * ((fa.x - fb.x) - (fc.x - fd.x));
+        acc[4 * v + 1] += sign * ((fa.y - fb.y) - (fc.y - fd.y));
+        acc[4 * v + 2] += sign * ((fa.z - fb.z) - (fc.z - fd.z));
+        acc[4 * v + 3] += sign * ((fa.w - fb.w) - (fc.w - fd.w));
+    }
+}
+
+// h1[p] = dropout(relu(h_pre[p])) as above; one workgroup per pair, thread t owns channels 16t .. 16t+15
+// (reference model.py:148-149: fc1 -> ReLU -> dropout; the keep bit is the one sgc_fc1_relu uses: hash(seed, p*4096 + c))
+__global__ __launch_bounds__(256) void fc1_assemble_kernel(const float* __restrict__ S, const float* __restrict__ owm,
+                                                           const int* __restrict__ bbox, const int* __restrict__ sub,
+                                                           const int* __restrict__ obj, const int* __restrict__ incl,
+                                                           const int* __restrict__ dest, int n_obj, const float* __restrict__ bias,
+                                                           int drop_enable, unsigned seed, float scale, u16* __restrict__ h1) {
+    const int p = blockIdx.x, c0 = threadIdx.x * 16;
+    const int i = sub[p], j = obj[p];
+    const WRect ri = object_windows(bbox + 4 * i), rj = object_windows(bbox + 4 * j);
+    const WRect x = pair_windows(ri, rj);
+    const float* Si = S + (long)i * 81 * 4096;
+    const float* Sj = S + ((long)n_obj + j) * 81 * 4096;
+    float acc[16];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const float4 b = reinterpret_cast<const float4*>(bias + c0)[v];
+        const float4 t = reinterpret_cast<const float4*>(Si + (long)80 * 4096 + c0)[v];
+        acc[4 * v + 0] = b.x + t.x; acc[4 * v + 1] = b.y + t.y; acc[4 * v + 2] = b.z + t.z; acc[4 * v + 3] = b.w + t.w;
+    }
+    if (rj.x1 > rj.x0) {
+        rect_acc(acc, Si, rj, -1.f, c0);
+        rect_acc(acc, Sj, rj, 1.f, c0);
+        if (x.x1 > x.x0) rect_acc(acc, Sj, x, -1.f, c0);
+    }
+    const int e0 = p ? incl[p - 1] : 0, e1 = incl[p];
+    for (int e = e0; e < e1; ++e) {
+        const float* o = owm + (long)dest[e] * 4096 + c0;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const float4 t = reinterpret_cast<const float4*>(o)[v];
+            acc[4 * v + 0] += t.x; acc[4 * v + 1] += t.y; acc[4 * v + 2] += t.z; acc[4 * v + 3] += t.w;
+        }
+    }
+    uint4 out[2];
+    u16* oh = reinterpret_cast<u16*>(out);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        float v = fmaxf(acc[k], 0.f);
+        if (drop_enable) v = dropout_keep(seed, (uint32_t)(p * 4096 + c0 + k)) ? v * scale : 0.f;
+        oh[k] = f32_to_f16_bits(v);
+    }
+    uint4* dst = reinterpret_cast<uint4*>(h1 + (long)p * 4096 + c0);
+    dst[0] = out[0];
+    dst[1] = out[1];
+}
+
 static inline int grid_cap(long items, long per_block, int cap) {
     long b = (items + per_block - 1) / per_block;
     if (b > cap) b = cap;
@@ -474,6 +570,51 @@ int sgc_pair_contract_windows(const void* dz, const unsigned char* amz, const in
     const long items = (long)(n_obj + n_img) * 256;
     SGC_LAUNCH(pair_contract_windows_kernel, dim3(grid_cap(items, 4, 262144)), dim3(256), 0, (hipStream_t)stream, (const u16*)dz, amz,
                ptr, list, pixel_rect, img_ptr, role, n_real_pairs, n_obj, (u16*)dU_pad, items);
+    SGC_CHECK_LAUNCH();
+    return SGC_OK;
+}
+
+// ---- conv3 forward writing the window-major row space (see "fc1 over shared windows")
+// pseudo-pairs: y / y_bf16 row of (pseudo-pair ps, window w) = goff[w] + ps; argmax stays [ps*64 + w]
+int sgc_conv3_relu_pool_wm(const void* z_pad, const void* w3r, const float* b3, const int* goff, void* ywm, unsigned char* argmax,
+                           void* ywm_bf16, int n_pairs, void* stream) {
+    NtParams p{};
+    p.A = (const u16*)z_pad; p.B = (const u16*)w3r; p.C = ywm; p.M = n_pairs * 256; p.N = 1024; p.K = 9 * 512;
+    p.ldb = 9 * 512; p.ldc = 1024; p.lgS = 4; p.Cin = 512; p.bias = b3; p.argmax = argmax; p.C2 = (u16*)ywm_bf16; p.wm_goff = goff;
+    return launch_gemm_nt<ELEM_F16, AMODE_CONV, EPI_POOL>(p, (hipStream_t)stream);
+}
+// X windows: y / y_bf16 of entry e go to row dest[e]; argmax to row gather[e] of the pair-major argmax
+int sgc_conv3_relu_pool_windows_wm(const void* z_pad, const void* w3r, const float* b3, const int* gather, const int* gather_n,
+                                   const int* dest, int max_entries, void* ywm, unsigned char* argmax, void* ywm_bf16, void* stream) {
+    if (max_entries <= 0) return SGC_OK;
+    NtParams p{};
+    p.A = (const u16*)z_pad; p.B = (const u16*)w3r; p.C = ywm; p.M = max_entries * 4; p.N = 1024; p.K = 9 * 512;
+    p.ldb = 9 * 512; p.ldc = 1024; p.lgS = 4; p.Cin = 512; p.bias = b3; p.argmax = argmax; p.C2 = (u16*)ywm_bf16;
+    p.gather = gather; p.gather_n = gather_n; p.dest = dest;
+    return launch_gemm_nt_cfg<ELEM_F16, AMODE_CONV_GATHER, EPI_POOL, 2, 4, 4, 2>(p, (hipStream_t)stream);
+}
+// owm [rows][4096] f32 = ywm [rows][1024] f16 * w1p[:, g*1024 .. +1024]^T, g = tile_group[row / 256]  (rows a multiple of 256)
+int sgc_fc1_windows_gemm(const void* ywm, const void* w1p, const int* tile_group, float* owm, int rows, void* stream) {
+    if (rows <= 0) return SGC_OK;
+    if (rows & 255) return SGC_ERR_ARG;
+    NtParams p{};
+    p.A = (const u16*)ywm; p.B = (const u16*)w1p; p.C = owm; p.M = rows; p.N = 4096; p.K = 1024;
+    p.lda = 1024; p.ldb = 65536; p.ldc = 4096; p.tile_group = tile_group; p.group_stride = 1024;
+    return launch_gemm_nt_pp<ELEM_F16, EPI_STORE_F32>(p, (hipStream_t)stream);
+}
+int sgc_fc1_integral(const float* owm, const int* goff, int n_pseudo, float* S, void* stream) {
+    if (n_pseudo <= 0) return SGC_OK;
+    SGC_LAUNCH(fc1_integral_kernel, dim3((unsigned)(((long)n_pseudo * 4096 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, owm, goff,
+               n_pseudo, S);
+    SGC_CHECK_LAUNCH();
+    return SGC_OK;
+}
+int sgc_fc1_assemble(const float* S, const float* owm, const int* bbox, const int* sub_idx, const int* obj_idx, const int* count_incl,
+                     const int* dest, int n_obj, const float* bias, int drop_enable, unsigned drop_seed, void* h1, int n_pairs,
+                     void* stream) {
+    if (n_pairs <= 0) return SGC_OK;
+    SGC_LAUNCH(fc1_assemble_kernel, dim3(n_pairs), dim3(256), 0, (hipStream_t)stream, S, owm, bbox, sub_idx, obj_idx, count_incl, dest,
+               n_obj, bias, drop_enable, drop_seed, 2.f, (u16*)h1);
     SGC_CHECK_LAUNCH();
     return SGC_OK;
 }

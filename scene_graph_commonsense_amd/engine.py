@@ -126,6 +126,11 @@ class TrainContext:
     pass
 
 
+def shared_fc1_enabled() -> bool:
+    """``SGC_SHARED_FC1=0``: fc1 as one [pairs, 65536] GEMM over assembled rows (A/B hook; default: grouped window-major GEMM)."""
+    return os.environ.get("SGC_SHARED_FC1", "1") != "0"
+
+
 def shared_conv3_enabled() -> bool:
     """``SGC_SHARED_CONV3=0`` computes conv3 for every window of every pair (A/B hook; default: per-object sharing on)."""
     return os.environ.get("SGC_SHARED_CONV3", "1") != "0"
@@ -324,6 +329,9 @@ class RelHeadEngine:
         ``entries`` = E when the host knows it (``bound`` from ``DeviceScene.shared_windows``; with ``keep`` - training, where the
         backward's GEMMs need exact sizes - one sync reads it back otherwise).  ``keep``: the lists live in buffers this engine owns."""
         lib = self.lib
+        window_entries = None
+        if isinstance(bound, tuple):
+            bound, window_entries = bound
         own = self.ws if keep else self.scratch
         cnt = self.scratch.get("xw_count", P, torch.int32)
         pixrect = own.get("xw_pixrect", P, torch.int32)
@@ -338,9 +346,44 @@ class RelHeadEngine:
         exact = bound is not None
         bound = P * 64 if bound is None else max(0, min(int(bound), P * 64))
         self._xw = (gather, incl)
-        return dict(gather=gather, incl=incl, pixrect=pixrect, bound=bound, entries=bound if exact else None)
+        return dict(gather=gather, incl=incl, pixrect=pixrect, bound=bound, entries=bound if exact else None, window_entries=window_entries)
 
-    def conv3_shared(self, plan, z, U, V, bbox, obj_img, sub_idx, obj_idx, P, y, am, y_bf, keep=None):
+    def window_major_rows(self, plan, P, n2):
+        """Window-major row space of the shared fc1 (``csrc/kernels_shared.hip``): device group offsets, tile -> group table and the
+        row ``dest[e]`` of every X entry.  Per-window entry counts come from the host when it knows them (full scenes,
+        ``DeviceScene.window_entries``); a pair subset costs one read-back."""
+        from .pairs import window_major_layout
+        dev = self.device
+        gather = plan["gather"]
+        counts = plan.get("window_entries")
+        if counts is None:
+            E = int(plan["incl"][P - 1]) if P else 0
+            counts = torch.bincount((gather[:E] & 63).long(), minlength=64).cpu().numpy()
+        E = int(np.asarray(counts).sum())
+        goff, tile_group = window_major_layout(counts, n2)
+        cex = np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(np.int64)
+        goff_d = torch.from_numpy(goff).to(dev)
+        keys = (gather[:E] & 63).long()
+        skeys, order = torch.sort(keys, stable=True)
+        base = torch.from_numpy(goff[:64].astype(np.int64) + n2 - cex).to(dev)
+        dest = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
+        dest[order] = (base[skeys] + torch.arange(E, device=dev)).int()
+        return dict(goff=goff_d, goff_host=goff, tile_group=torch.from_numpy(tile_group).to(dev), dest=dest, rows=int(goff[64]), E=E, n2=n2)
+
+    def fc1_shared(self, wm, ywm, bbox, sub_idx, obj_idx, incl, P, n_obj, h1, dropout, seed):
+        """fc1 + ReLU (+ dropout) from the window-major rows: grouped GEMM, per-object 2-D prefix sums, per-pair assembly."""
+        lib, sc = self.lib, self.scratch
+        owm = sc.get("owm", wm["rows"] * 4096, torch.float32)
+        self._timed("fc1_fwd_windows", lambda: _lib.check(lib.sgc_fc1_windows_gemm(
+            _lib.ptr(ywm), _lib.ptr(self.w["w1p"]), _lib.ptr(wm["tile_group"]), _lib.ptr(owm), wm["rows"], self._st()), "sgc_fc1_windows_gemm"))
+        S = sc.get("fc1_S", wm["n2"] * 81 * 4096, torch.float32)
+        self._timed("fc1_fwd_integral", lambda: _lib.check(lib.sgc_fc1_integral(_lib.ptr(owm), _lib.ptr(wm["goff"]), wm["n2"], _lib.ptr(S), self._st()),
+                                                           "sgc_fc1_integral"))
+        self._timed("fc1_fwd_assemble", lambda: _lib.check(lib.sgc_fc1_assemble(
+            _lib.ptr(S), _lib.ptr(owm), _lib.ptr(bbox), _lib.ptr(sub_idx), _lib.ptr(obj_idx), _lib.ptr(incl), _lib.ptr(wm["dest"]), n_obj,
+            _lib.ptr(self.w["bf1"]), int(dropout), ctypes.c_uint(seed), _lib.ptr(h1), P, self._st()), "sgc_fc1_assemble"))
+
+    def conv3_shared(self, plan, z, U, V, bbox, obj_img, sub_idx, obj_idx, P, y, am, y_bf, keep=None, wm=None):
         """conv3 + ReLU + pool with the per-object part computed once per object (``csrc/kernels_shared.hip``): U / V hold
         n_obj + n_img objects, the last n_img the empty-box backgrounds of the images; ``plan`` from ``shared_plan``.
         ``keep=(z_bf_tail, amz_tail)`` (training): the pseudo-pairs' bf16 expansion and routing codes go there; returns what the
@@ -359,13 +402,22 @@ class RelHeadEngine:
         else:
             _lib.check(lib.sgc_pair_expand_train(_lib.ptr(U), _lib.ptr(V), _lib.ptr(ps[1]), _lib.ptr(ps[2]), _lib.ptr(z_ps), _lib.ptr(keep[0]),
                                                  _lib.ptr(keep[1]), n2, self._st()), "sgc_pair_expand_train")
-        y_ps = sc.get("y_ps", n2 * 65536, torch.float16)
         am_ps = own.get("am_ps", n2 * 65536, torch.uint8) if am is not None else None
+        gather, incl = plan["gather"], plan["incl"]
+        if wm is not None:
+            # window-major rows for the shared fc1: ``y`` / ``y_bf`` ARE the window-major buffers, nothing is assembled per pair
+            self._timed("conv3_fwd_objects", lambda: _lib.check(lib.sgc_conv3_relu_pool_wm(
+                _lib.ptr(z_ps), _lib.ptr(self.w["w3r"]), _lib.ptr(self.w["b3"]), _lib.ptr(wm["goff"]), _lib.ptr(y), _lib.ptr(am_ps), _lib.ptr(y_bf),
+                n2, self._st()), "sgc_conv3_relu_pool_wm"))
+            self._timed("conv3_fwd_windows", lambda: _lib.check(lib.sgc_conv3_relu_pool_windows_wm(
+                _lib.ptr(z), _lib.ptr(self.w["w3r"]), _lib.ptr(self.w["b3"]), _lib.ptr(gather), _lib.ptr(incl[P - 1:]), _lib.ptr(wm["dest"]),
+                plan["bound"], _lib.ptr(y), _lib.ptr(am), _lib.ptr(y_bf), self._st()), "sgc_conv3_relu_pool_windows_wm"))
+            return dict(plan, am_ps=am_ps, n2=n2, wm=wm)
+        y_ps = sc.get("y_ps", n2 * 65536, torch.float16)
         ybf_ps = sc.get("ybf_ps", n2 * 65536, torch.bfloat16) if y_bf is not None else None
         self._timed("conv3_fwd_objects", lambda: _lib.check(lib.sgc_conv3_relu_pool(
             _lib.ptr(z_ps), _lib.ptr(self.w["w3r"]), _lib.ptr(self.w["b3"]), _lib.ptr(y_ps), _lib.ptr(am_ps), _lib.ptr(ybf_ps), n2,
             self._st()), "sgc_conv3_relu_pool"))
-        gather, incl = plan["gather"], plan["incl"]
         self._timed("conv3_fwd_windows", lambda: _lib.check(lib.sgc_conv3_relu_pool_windows(
             _lib.ptr(z), _lib.ptr(self.w["w3r"]), _lib.ptr(self.w["b3"]), _lib.ptr(gather), _lib.ptr(incl[P - 1:]), plan["bound"], _lib.ptr(y),
             _lib.ptr(am), _lib.ptr(y_bf), self._st()), "sgc_conv3_relu_pool_windows"))
@@ -382,16 +434,26 @@ class RelHeadEngine:
         z = ws.get("z_pad", P * 18 * 18 * 512, torch.float16)      # border stays zero: only interiors are written
         plan = self.shared_plan(shared[0], sub_idx, obj_idx, P, shared[2]) if shared is not None else None
         self.expand(U, V, sub_idx, obj_idx, P, z, dense=dense, pixrect=None if plan is None else plan["pixrect"])
-        y = ws.get("y", Ppad * 65536, torch.float16)
         am = ws.get("argmax", P * 65536, torch.uint8) if keep_argmax else None
-        if shared is not None:
+        h1 = ws.get("h1", Ppad * 4096, torch.float16)
+        wm = None
+        if shared is not None and shared_fc1_enabled():
+            n_obj = int(shared[1].shape[0])
+            wm = self.window_major_rows(plan, P, 2 * n_obj)
+            ywm = ws.get("ywm", wm["rows"] * 1024, torch.float16)
+            self.conv3_shared(plan, z, U, V, shared[0], shared[1], sub_idx, obj_idx, P, ywm, am, None, wm=wm)
+            self.fc1_shared(wm, ywm, shared[0], sub_idx, obj_idx, plan["incl"], P, n_obj, h1, train, seeds[0])
+        y = ws.get("y", Ppad * 65536, torch.float16) if wm is None else None
+        if wm is not None:
+            pass
+        elif shared is not None:
             self.conv3_shared(plan, z, U, V, shared[0], shared[1], sub_idx, obj_idx, P, y, am, None)
         else:
             self._timed("conv3_fwd", lambda: _lib.check(lib.sgc_conv3_relu_pool(_lib.ptr(z), _lib.ptr(self.w["w3r"]), _lib.ptr(self.w["b3"]), _lib.ptr(y),
                                                _lib.ptr(am), _lib.ptr(None), P, self._st()), "sgc_conv3_relu_pool"))
-        h1 = ws.get("h1", Ppad * 4096, torch.float16)
-        self._timed("fc1_fwd", lambda: _lib.check(lib.sgc_fc1_relu(_lib.ptr(y), _lib.ptr(self.w["w1p"]), _lib.ptr(self.w["bf1"]), _lib.ptr(h1), P, 65536,
-                                    int(train), ctypes.c_uint(seeds[0]), self._st()), "sgc_fc1_relu"))
+        if wm is None:
+            self._timed("fc1_fwd", lambda: _lib.check(lib.sgc_fc1_relu(_lib.ptr(y), _lib.ptr(self.w["w1p"]), _lib.ptr(self.w["bf1"]), _lib.ptr(h1), P, 65536,
+                                        int(train), ctypes.c_uint(seeds[0]), self._st()), "sgc_fc1_relu"))
         p = ws.get("p", Ppad * 512, torch.float32)
         self._timed("fc2_fwd", lambda: _lib.check(lib.sgc_fc2_labels_relu(_lib.ptr(h1), _lib.ptr(self.w["w2m"]), _lib.ptr(self.w["bf2"]), _lib.ptr(lsub),
                                            _lib.ptr(lobj), _lib.ptr(sub_idx), _lib.ptr(obj_idx), _lib.ptr(p), P,
@@ -449,6 +511,8 @@ class RelHeadEngine:
             ok = pid >= 0
             pc = pid.clamp(min=0).long()
             dense_s = (img_ptr, torch.where(ok & sel[pc], rank[pc], torch.full_like(pid, -1)).contiguous(), max_n)
+        if shared is not None and isinstance(shared[2], tuple):
+            shared = (shared[0], shared[1], shared[2][0])        # the per-window counts describe the full pair list, not a subset
         out = self.pair_trunk(uv[0], uv[1], sub_idx[idx].contiguous(), obj_idx[idx].contiguous(), lsub, lobj, train, seeds, keep_argmax,
                               None if iou_mask is None else iou_mask[idx].contiguous(), dense_s, shared)
         full.relation[idx] = out.relation

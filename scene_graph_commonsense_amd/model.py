@@ -24,6 +24,12 @@ from .pairs import DeviceScene, pair_targets_fast, super_multihot
 from .synthetic import HeadConfig, predicate_counts
 
 
+def _shared_hint(scene):
+    """What the host already knows about the scene's pair-specific windows (count, per-window counts) - saves a device read-back."""
+    n = getattr(scene, "shared_windows", None)
+    return None if n is None else (n, getattr(scene, "window_entries", None))
+
+
 def _dense(scene):
     """(img_ptr, pid, max_n) when the scene carries the all-pairs lookup table (flatten_scene builds it)."""
     if getattr(scene, "pid", None) is None or scene.max_n <= 0:
@@ -155,7 +161,7 @@ class _RelationBase(nn.Module):
             return eng.forward_pairs(scene.image_feature, scene.image_depth, scene.obj_img, scene.bbox, scene.cats,
                                      scene.super_mh, scene.sub_idx, scene.obj_idx, train=self.training, seeds=seeds,
                                      iou_mask=iou_mask, dense=_dense(scene), select=select,
-                                     shared_windows=getattr(scene, "shared_windows", None))
+                                     shared_windows=_shared_hint(scene))
 
     def _next_seeds(self):
         self._step += 1
@@ -213,7 +219,7 @@ class _RelationBase(nn.Module):
             ctx = eng.train_forward(scene.image_feature, scene.image_depth, scene.obj_img, scene.bbox, scene.cats,
                                     scene.super_mh, scene.sub_idx, scene.obj_idx,
                                     seeds=self._next_seeds() if self.training else (0, 0), dropout=self.training,
-                                    dense=_dense(scene), shared_windows=getattr(scene, "shared_windows", None))
+                                    dense=_dense(scene), shared_windows=_shared_hint(scene))
             cs_coef = None
             if commonsense is not None:
                 from .commonsense import TripletBitmaps

@@ -217,6 +217,31 @@ def count_shared_windows(bb: np.ndarray, img_ptr) -> int:
     return total
 
 
+def window_entry_counts(bb: np.ndarray, img_ptr) -> np.ndarray:
+    """[64] number of pair-specific (X) entries per pooling window over all ordered pairs of every image: a window inside the
+    rectangles of c objects of an image is an X window of c*(c-1) ordered pairs."""
+    r = object_window_rects(bb)
+    out = np.zeros(64, dtype=np.int64)
+    wy, wx = np.divmod(np.arange(64), 8)
+    for b in range(len(img_ptr) - 1):
+        q = r[int(img_ptr[b]):int(img_ptr[b + 1])]
+        if len(q) < 2:
+            continue
+        inside = (wx[None] >= q[:, 0:1]) & (wx[None] < q[:, 1:2]) & (wy[None] >= q[:, 2:3]) & (wy[None] < q[:, 3:4])
+        c = inside.sum(0)
+        out += c * (c - 1)
+    return out
+
+
+def window_major_layout(entry_counts: np.ndarray, n_pseudo: int):
+    """Group offsets of the window-major row space (``csrc/kernels_shared.hip``): group w = n_pseudo per-object rows + its X entries,
+    padded to a multiple of 256.  Returns (goff [65] int32, tile_group [rows/256] int32)."""
+    size = (n_pseudo + np.asarray(entry_counts, dtype=np.int64) + 255) // 256 * 256
+    goff = np.concatenate([[0], np.cumsum(size)]).astype(np.int32)
+    tile_group = np.repeat(np.arange(64, dtype=np.int32), (size // 256).astype(np.int64))
+    return goff, tile_group
+
+
 def flatten_scene(cfg, batch, device) -> DeviceScene:
     """SceneBatch (reference data contract) -> DeviceScene with all ordered pairs in reference order.
     Host work is O(objects): concatenating the ragged annotation lists into one pinned staging buffer; one asynchronous
@@ -298,6 +323,7 @@ def flatten_scene(cfg, batch, device) -> DeviceScene:
                        obj_ptr=t["obj_ptr"], sub_list=t["sub_list"], obj_list=t["obj_list"], step_ptr=t["step_ptr"], bbox_raw=raw,
                        num_objects=n_list, n_pairs=P, n_steps=T, max_n=int(max_n), _stage=stage, _tables=tab,
                        shared_windows=count_shared_windows(bb, img_ptr) if (n_obj and F == 32) else None,
+                       window_entries=window_entry_counts(bb, img_ptr) if (n_obj and F == 32) else None,
                        _rel_src=getattr(batch, "relationships", None) if rel is not None else None)
 
 

@@ -30,6 +30,19 @@ def _edge_boxes(batch):
     return batch
 
 
+def _with_env(env, fn):
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        return fn()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+
+
 def _poison(eng):
     """NaN into every per-pair buffer the shared path writes only partly (the pair expansion next to the pair-specific windows,
     dz likewise): a read outside what was written shows up in the results instead of finding the previous run's values."""
@@ -46,15 +59,8 @@ def _poison(eng):
 
 
 def _with(flag, fn):
-    old = os.environ.get("SGC_SHARED_CONV3")
-    os.environ["SGC_SHARED_CONV3"] = flag
-    try:
-        return fn()
-    finally:
-        if old is None:
-            del os.environ["SGC_SHARED_CONV3"]
-        else:
-            os.environ["SGC_SHARED_CONV3"] = old
+    """conv3 shared on / off with fc1 as the one [pairs, 65536] GEMM (the bit-for-bit statements are about conv3)."""
+    return _with_env({"SGC_SHARED_CONV3": flag, "SGC_SHARED_FC1": "0"}, fn)
 
 
 @pytest.mark.parametrize("nobj,edge", [([9, 4, 12], True), ([36] * 3, False), ([64] * 2, True)])
@@ -105,19 +111,6 @@ def test_pair_subset_and_overlap_filtered_evaluation():
     assert torch.equal(a.relation, b.relation) and torch.equal(a.cand_conf, b.cand_conf) and torch.equal(a.cand_pred, b.cand_pred)
 
 
-def _with_env(env, fn):
-    old = {k: os.environ.get(k) for k in env}
-    os.environ.update(env)
-    try:
-        return fn()
-    finally:
-        for k, v in old.items():
-            if v is None:
-                del os.environ[k]
-            else:
-                os.environ[k] = v
-
-
 @pytest.mark.parametrize("nobj,edge,cfrac", [([20, 11, 16], True, 0.2), ([36] * 3, False, 0.03), ([1, 2, 5], True, 0.5)])
 def test_training_step_shared_forward_is_bit_identical_and_shared_backward_agrees(nobj, edge, cfrac):
     """Forward: what the backward reads (bf16 copy, routing codes) and the loss are bit-identical, and with the per-pair backward
@@ -140,10 +133,10 @@ def test_training_step_shared_forward_is_bit_identical_and_shared_backward_agree
         torch.cuda.synchronize()
         return (float(loss), eng.ws.bufs["y_bf"][:P * 65536].clone(), eng.ws.bufs["argmax"][:P * 65536].clone(),
                 {n: p.grad.clone() for n, p in model.named_parameters()})
-    l0, yb0, am0, g0 = _with_env({"SGC_SHARED_CONV3": "0"}, run)
-    l1, yb1, am1, g1 = _with_env({"SGC_SHARED_CONV3": "1", "SGC_SHARED_BWD": "0"}, run)
+    l0, yb0, am0, g0 = _with_env({"SGC_SHARED_CONV3": "0", "SGC_SHARED_FC1": "0"}, run)
+    l1, yb1, am1, g1 = _with_env({"SGC_SHARED_CONV3": "1", "SGC_SHARED_BWD": "0", "SGC_SHARED_FC1": "0"}, run)
     _poison(eng)
-    l2, yb2, am2, g2 = _with_env({"SGC_SHARED_CONV3": "1", "SGC_SHARED_BWD": "1"}, run)
+    l2, yb2, am2, g2 = _with_env({"SGC_SHARED_CONV3": "1", "SGC_SHARED_BWD": "1", "SGC_SHARED_FC1": "0"}, run)
     for n in g2:
         assert torch.isfinite(g2[n]).all(), n
     assert l0 == l1 == l2
@@ -162,3 +155,45 @@ def test_training_step_shared_forward_is_bit_identical_and_shared_backward_agree
         else:
             assert err <= tol, (n, err)
     print({k: "%.2e" % v for k, v in worst.items() if v > 0})
+
+
+@pytest.mark.parametrize("nobj,edge", [([9, 4, 12], True), ([36] * 3, False), ([64] * 2, True), ([1, 3], True)])
+def test_fc1_over_window_major_rows_matches_the_one_gemm_form(nobj, edge):
+    """fc1 as grouped GEMM + per-object prefix sums + per-pair assembly is the same sum in another order: f32 round-off before the
+    f16 rounding of h1, far inside the 1e-3 parity tolerance of the forward (which tests/test_forward_gpu.py checks against the
+    reference's goldens with this path on)."""
+    from scene_graph_commonsense_amd.pair_loop import evaluate_minibatch
+    from scene_graph_commonsense_amd.pairs import flatten_scene
+    from scene_graph_commonsense_amd.synthetic import HeadConfig, make_scene_batch
+    cfg = HeadConfig()
+    model = _model(cfg)
+    batch = make_scene_batch(cfg, nobj, seed=11)
+    if edge:
+        batch = _edge_boxes(batch)
+    sc = flatten_scene(cfg, batch, "cuda:0")
+    eng = model.refresh_weights()
+    P = sc.n_pairs
+
+    def run():
+        out = model.forward_pairs(sc)
+        torch.cuda.synchronize()
+        return out, eng.ws.bufs["h1"][:P * 4096].clone().float()
+    o0, h0 = _with_env({"SGC_SHARED_FC1": "0"}, run)
+    for name in ("h1", "owm", "fc1_S", "ywm"):
+        for ws in (eng.ws, eng.scratch):
+            if name in ws.bufs:
+                ws.bufs[name].view(torch.int16).fill_(0x7E00 if name in ("h1", "ywm") else -1)      # NaN bit patterns
+    o1, h1 = _with_env({"SGC_SHARED_FC1": "1"}, run)
+    assert torch.isfinite(h1).all()
+    scale = float(h0.abs().max())
+    assert float((h1 - h0).abs().max()) <= 2e-3 * scale, (float((h1 - h0).abs().max()), scale)     # one f16 ulp at the top of the range
+    assert float((h1 - h0).norm() / h0.norm().clamp(min=1e-30)) <= 2e-4
+    for a, b in ((o0.relation, o1.relation), (o0.connectivity, o1.connectivity), (o0.hidden, o1.hidden)):
+        assert float((a - b).abs().max()) <= 1e-3 * max(float(a.abs().max()), 1.0)
+    # pair subsets (overlap-filtered evaluation) take the read-back route for the per-window counts
+    b2 = _edge_boxes(make_scene_batch(cfg, [14, 9], seed=8, connect_frac=0.3))
+    ev = lambda: evaluate_minibatch(model, b2, overlap_filtering=True, skip_filtered=True)[1]
+    a, b = _with_env({"SGC_SHARED_FC1": "0"}, ev), _with_env({"SGC_SHARED_FC1": "1"}, ev)
+    fin = torch.isfinite(a.cand_conf)
+    assert torch.equal(fin, torch.isfinite(b.cand_conf))
+    assert float((a.cand_conf[fin] - b.cand_conf[fin]).abs().max()) <= 1e-3
