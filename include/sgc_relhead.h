@@ -83,7 +83,8 @@ int sgc_shared_windows_assemble(const int* bbox, const int* sub_idx, const int* 
  *                                    (I windows -> subject's row, J windows -> object's row); sub_ptr/sub_list, obj_ptr/obj_list =
  *                                    CSR lists of the pairs of every object in each role (sgc_scene_tables)
  *   sgc_windows_unpool               dy3x [4*entries_pad][1024]: ReLU + max-pool backward of the listed (X) windows, row 4e+q = pixel q
- *                                    of window gather[e]; rows of entries >= *gather_n are zero; bias_part [*n_parts <= 1024][1024]
+ *                                    of window gather[e]; rows of entries >= *gather_n are zero; bias_part [*n_parts <= 1024][1024];
+ *                                    the gradient row of entry e is dy[dest[e]] (window-major, shared fc1) or dy[gather[e]] (dest NULL)
  *   sgc_windows_im2col               zcol [4*entries_pad][9][512] = the 3x3 neighbourhoods of those pixels in z_pad_bf16
  *   sgc_windows_wgrad                conv3 weight-gradient slabs [splits][1024][9*512] of the X windows = dy3x^T * zcol
  *   sgc_windows_dgrad_cols           col [rows][9][512] = dy3x * w3col^T, w3col [(tap, c_in)][c_out] bf16
@@ -95,8 +96,8 @@ int sgc_shared_windows_assemble(const int* bbox, const int* sub_idx, const int* 
  *                                    sgc_shared_windows_count */
 int sgc_shared_windows_assemble_bwd(const int* bbox, const int* sub_idx, const int* obj_idx, const int* sub_ptr, const int* sub_list,
                                     const int* obj_ptr, const int* obj_list, int n_obj, const void* dy, void* dy_obj, void* stream);
-int sgc_windows_unpool(const void* dy, const unsigned char* argmax, const int* gather, const int* gather_n, int entries_pad, void* dy3x,
-                       float* bias_part, int* n_parts, void* stream);
+int sgc_windows_unpool(const void* dy, const unsigned char* argmax, const int* gather, const int* gather_n, const int* dest,
+                       int entries_pad, void* dy3x, float* bias_part, int* n_parts, void* stream);
 int sgc_windows_im2col(const void* z_pad_bf16, const int* gather, const int* gather_n, int entries_pad, void* zcol, void* stream);
 int sgc_windows_wgrad(const void* dy3x, const void* zcol, float* slabs, int rows, int splits, int* n_slabs, void* stream);
 int sgc_windows_dgrad_cols(const void* dy3x, const void* w3col, void* col, int rows, void* stream);
@@ -122,6 +123,20 @@ int sgc_fc1_integral(const float* owm, const int* goff, int n_pseudo, float* S, 
 int sgc_fc1_assemble(const float* S, const float* owm, const int* bbox, const int* sub_idx, const int* obj_idx, const int* count_incl,
                      const int* dest, int n_obj, const float* bias, int drop_enable, unsigned drop_seed, void* h1, int n_pairs,
                      void* stream);
+
+/* Backward of the shared fc1 (window-major rows; all bf16, f32 sums):
+ *   sgc_fc1_gsum           pseudo rows of gwm [rows][4096]: row goff[w] + role*n_obj + o = sum of dh1 over the pairs of object o in that
+ *                          role whose window w was a copy of o's row
+ *   sgc_fc1_xrows          X rows: gwm[dest[e]] = dh1[pair of entry e]; zeroes the padding rows [gend[g], goff[g+1]) of gwm and ywm_bf16
+ *   sgc_fc1_windows_dgrad  dywm [rows][1024] = gwm * (rows g*1024.. of w1pT [65536][4096])^T (per-object rows: gradient of the
+ *                          pseudo-pairs' conv3 output; X rows: of the entries')
+ *   sgc_fc1_windows_wgrad  dw [4096][65536] f32, column block g = gwm[group g]^T * ywm_bf16[group g] */
+int sgc_fc1_gsum(const void* dh1, const int* bbox, const int* sub_idx, const int* obj_idx, const int* sub_ptr, const int* sub_list,
+                 const int* obj_ptr, const int* obj_list, const int* goff, int n_obj, void* gwm, void* stream);
+int sgc_fc1_xrows(const void* dh1, const int* gather, const int* dest, int n_entries, const int* goff, const int* gend, void* gwm,
+                  void* ywm_bf16, void* stream);
+int sgc_fc1_windows_dgrad(const void* gwm, const void* w1pT, const int* tile_group, void* dywm, int rows, void* stream);
+int sgc_fc1_windows_wgrad(const void* gwm, const void* ywm_bf16, const int* goff, float* dw, int rows, void* stream);
 
 /* h1 [n_pairs][4096] f16 = dropout(relu(y[n_pairs][K] * w1p[4096][K]^T + b))   (model.py:148-149; columns of w1p in (window, channel) order) */
 int sgc_fc1_relu(const void* y, const void* w1p, const float* b, void* h1, int n_pairs, int K, int drop_enable, unsigned drop_seed, void* stream);

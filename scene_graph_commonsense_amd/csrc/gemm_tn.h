@@ -25,6 +25,8 @@ struct TnParams {
     int tiles_m, tiles_n, ktiles_per_split, splits;
     int xcd_map;                 // conv3 wgrad only: XCD-aware tile assignment (see kernel)
     int xcd_patch;               // ping-pong block: per-XCD 4x8 tile patches (tile count per split divisible by 8)
+    const int* goff;             // ping-pong block, grouped form: block -> (group g, tile); the contraction runs over rows goff[g] .. goff[g+1]
+                                 // (multiples of 64) and the result goes to columns g*N .. of C (no split-K, splits = number of groups)
 };
 
 template <int ELEM, int BMODE, int ACONV, int WR, int WC, int TM, int TN>
@@ -229,10 +231,11 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(const TnParams p) {
         else supertile_map(blockIdx.x - split * tiles, p.tiles_m, p.tiles_n, tm, tn);
     }
     const int m0 = tm * BM, n0 = tn * BN;
-    const int kt_begin = split * p.ktiles_per_split;
+    int kt_begin = split * p.ktiles_per_split;
     int kt_end = kt_begin + p.ktiles_per_split;
     const int nk_total = p.K >> 6;
     if (kt_end > nk_total) kt_end = nk_total;
+    if (p.goff) { kt_begin = p.goff[split] >> 6; kt_end = p.goff[split + 1] >> 6; }      // grouped: "split" is the group
     const int nk = kt_end - kt_begin;
 
     // ---- staging: one instruction = one k block (4 rows) x 8 sub-blocks of a half tile; wave w owns k blocks 2w, 2w+1
@@ -346,7 +349,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(const TnParams p) {
     for (; it < nk; ++it) tile(it, it & 1, std::false_type{});
     if (wr == 0) __builtin_amdgcn_s_barrier();
 
-    float* C = p.C + (long)split * p.slab_stride;
+    float* C = p.C + (p.goff ? (long)split * p.N : (long)split * p.slab_stride);
     const int hh = lane >> 5, cl = lane & 31;
 #pragma unroll
     for (int i = 0; i < 4; ++i)

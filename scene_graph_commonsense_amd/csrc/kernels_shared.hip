@@ -172,7 +172,8 @@ __global__ __launch_bounds__(256) void shared_assemble_bwd_kernel(const int* __r
 // bias_part[block][c] = the block's share of sum_e dy[..][c] over live routes (conv3 bias gradient).
 __global__ __launch_bounds__(256) void windows_unpool_kernel(const u16* __restrict__ dy, const unsigned char* __restrict__ am,
                                                              const int* __restrict__ gather, const int* __restrict__ gather_n,
-                                                             int entries_pad, u16* __restrict__ dy3x, float* __restrict__ bias_part) {
+                                                             const int* __restrict__ dest, int entries_pad, u16* __restrict__ dy3x,
+                                                             float* __restrict__ bias_part) {
     __shared__ float red[4][1024];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int E = *gather_n;
@@ -185,9 +186,10 @@ __global__ __launch_bounds__(256) void windows_unpool_kernel(const u16* __restri
         for (int q = 0; q < 4; ++q) { o[q][0] = make_uint4(0, 0, 0, 0); o[q][1] = make_uint4(0, 0, 0, 0); }
         if (e < E) {
             const long row = gather[e];
+            const long drow = dest ? (long)dest[e] : row;       // window-major gradient rows (shared fc1) or pair-major
             uint4 v[2];
-            v[0] = *reinterpret_cast<const uint4*>(dy + row * 1024 + lane * 16);
-            v[1] = *reinterpret_cast<const uint4*>(dy + row * 1024 + lane * 16 + 8);
+            v[0] = *reinterpret_cast<const uint4*>(dy + drow * 1024 + lane * 16);
+            v[1] = *reinterpret_cast<const uint4*>(dy + drow * 1024 + lane * 16 + 8);
             const uint4 cd = *reinterpret_cast<const uint4*>(am + row * 1024 + lane * 16);
             const u16* vh = reinterpret_cast<const u16*>(v);
             const unsigned char* ch = reinterpret_cast<const unsigned char*>(&cd);
@@ -454,6 +456,100 @@ __global__ __launch_bounds__(256) void fc1_assemble_kernel(const float* __restri
     dst[1] = out[1];
 }
 
+// ---- fc1 backward over the window-major rows
+// 64-bit mask of the pooling windows inside a rectangle (bit wy*8 + wx)
+__device__ __forceinline__ unsigned long long rect_mask(const WRect& r) {
+    if (r.x1 <= r.x0) return 0ull;
+    const unsigned long long row = ((1ull << r.x1) - (1ull << r.x0)) & 0xffull;
+    unsigned long long m = 0ull;
+    for (int y = r.y0; y < r.y1; ++y) m |= row << (8 * y);
+    return m;
+}
+
+// Gradient of the per-object rows (transpose of the assembly): G[(role, o)][w] = sum of dh1 over the pairs of o whose window w was
+// a copy of o's row - role 0: all windows outside the partner's rectangle; role 1: windows inside o's and outside the partner's.
+// One workgroup per (role, object, 256 channels); thread = one channel with the 64 window sums in registers; the pair ids and
+// window masks of the object's pairs are staged in LDS first so that the gradient rows stream without dependent look-ups.
+// Rows go to the window-major space: gwm[goff[w] + role*n_obj + o].
+__global__ __launch_bounds__(256) void fc1_gsum_kernel(const u16* __restrict__ dh, const int* __restrict__ bbox, const int* __restrict__ sub,
+                                                       const int* __restrict__ obj, const int* __restrict__ sub_ptr,
+                                                       const int* __restrict__ sub_list, const int* __restrict__ obj_ptr,
+                                                       const int* __restrict__ obj_list, const int* __restrict__ goff, int n_obj,
+                                                       u16* __restrict__ gwm) {
+    __shared__ int s_pair[256];
+    __shared__ unsigned long long s_mask[256];
+    const int chunk = blockIdx.x & 15;
+    const int ps = blockIdx.x >> 4;
+    const int role = ps >= n_obj ? 1 : 0, o = ps - role * n_obj;
+    const int c = chunk * 256 + threadIdx.x;
+    const int* ptr = role ? obj_ptr : sub_ptr;
+    const int* list = role ? obj_list : sub_list;
+    const int i0 = ptr[o], i1 = ptr[o + 1];
+    const unsigned long long own = rect_mask(object_windows(bbox + 4 * o));
+    float acc[64];
+#pragma unroll
+    for (int w = 0; w < 64; ++w) acc[w] = 0.f;
+    for (int base = i0; base < i1; base += 256) {
+        __syncthreads();
+        const int n = min(256, i1 - base);
+        if ((int)threadIdx.x < n) {
+            const int p = list[base + threadIdx.x];
+            const unsigned long long pm = rect_mask(object_windows(bbox + 4 * (role ? sub[p] : obj[p])));
+            s_pair[threadIdx.x] = p;
+            s_mask[threadIdx.x] = role ? (own & ~pm) : ~pm;
+        }
+        __syncthreads();
+        for (int k = 0; k < n; k += 4) {
+            float v[4];
+            unsigned long long m[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool ok = k + u < n;
+                m[u] = ok ? s_mask[k + u] : 0ull;
+                v[u] = ok ? bf16_bits_to_f32(dh[(long)s_pair[k + u] * 4096 + c]) : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const unsigned lo = (unsigned)m[u], hi = (unsigned)(m[u] >> 32);
+#pragma unroll
+                for (int w = 0; w < 32; ++w) {
+                    acc[w] += ((lo >> w) & 1u) ? v[u] : 0.f;
+                    acc[32 + w] += ((hi >> w) & 1u) ? v[u] : 0.f;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int w = 0; w < 64; ++w) gwm[((long)goff[w] + ps) * 4096 + c] = f32_to_bf16_bits(acc[w]);
+}
+
+// X rows of the window-major gradient: gwm[dest[e]] = dh1[pair of entry e]; and the padding rows of every group are zeroed in gwm
+// and in ywm_bf16 (they take part in the contraction of the weight gradient).
+__global__ __launch_bounds__(256) void fc1_xrows_kernel(const u16* __restrict__ dh, const int* __restrict__ gather, const int* __restrict__ dest,
+                                                        int n_entries, const int* __restrict__ goff, const int* __restrict__ gend,
+                                                        u16* __restrict__ gwm, u16* __restrict__ ywm_bf, long n_items) {
+    const int lane = threadIdx.x & 63;
+    for (long it = (long)blockIdx.x * 4 + (threadIdx.x >> 6); it < n_items; it += (long)gridDim.x * 4) {
+        if (it < n_entries) {
+            const long src = (long)(gather[it] >> 6) * 4096, dst = (long)dest[it] * 4096;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                *reinterpret_cast<uint4*>(gwm + dst + u * 512 + lane * 8) = *reinterpret_cast<const uint4*>(dh + src + u * 512 + lane * 8);
+        } else {
+            const long t = it - n_entries;                       // (group, padding slot 0..255)
+            const int g = (int)(t >> 8);
+            const long row = (long)gend[g] + (t & 255);
+            if (row < goff[g + 1]) {
+                const uint4 z = make_uint4(0, 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) *reinterpret_cast<uint4*>(gwm + row * 4096 + u * 512 + lane * 8) = z;
+                *reinterpret_cast<uint4*>(ywm_bf + row * 1024 + lane * 8) = z;
+                *reinterpret_cast<uint4*>(ywm_bf + row * 1024 + 512 + lane * 8) = z;
+            }
+        }
+    }
+}
+
 static inline int grid_cap(long items, long per_block, int cap) {
     long b = (items + per_block - 1) / per_block;
     if (b > cap) b = cap;
@@ -517,12 +613,12 @@ int sgc_shared_windows_assemble_bwd(const int* bbox, const int* sub_idx, const i
     return SGC_OK;
 }
 
-int sgc_windows_unpool(const void* dy, const unsigned char* argmax, const int* gather, const int* gather_n, int entries_pad, void* dy3x,
-                       float* bias_part, int* n_parts, void* stream) {
+int sgc_windows_unpool(const void* dy, const unsigned char* argmax, const int* gather, const int* gather_n, const int* dest,
+                       int entries_pad, void* dy3x, float* bias_part, int* n_parts, void* stream) {
     if (entries_pad <= 0) { if (n_parts) *n_parts = 0; return SGC_OK; }
     const int blocks = grid_cap(entries_pad, 4 * 8, 1024);
     if (n_parts) *n_parts = blocks;
-    SGC_LAUNCH(windows_unpool_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const u16*)dy, argmax, gather, gather_n,
+    SGC_LAUNCH(windows_unpool_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const u16*)dy, argmax, gather, gather_n, dest,
                entries_pad, (u16*)dy3x, bias_part);
     SGC_CHECK_LAUNCH();
     return SGC_OK;
@@ -615,6 +711,47 @@ int sgc_fc1_assemble(const float* S, const float* owm, const int* bbox, const in
     if (n_pairs <= 0) return SGC_OK;
     SGC_LAUNCH(fc1_assemble_kernel, dim3(n_pairs), dim3(256), 0, (hipStream_t)stream, S, owm, bbox, sub_idx, obj_idx, count_incl, dest,
                n_obj, bias, drop_enable, drop_seed, 2.f, (u16*)h1);
+    SGC_CHECK_LAUNCH();
+    return SGC_OK;
+}
+
+// ---- fc1 backward over the window-major rows
+int sgc_fc1_gsum(const void* dh1, const int* bbox, const int* sub_idx, const int* obj_idx, const int* sub_ptr, const int* sub_list,
+                 const int* obj_ptr, const int* obj_list, const int* goff, int n_obj, void* gwm, void* stream) {
+    if (n_obj <= 0) return SGC_OK;
+    SGC_LAUNCH(fc1_gsum_kernel, dim3((unsigned)(2 * n_obj * 16)), dim3(256), 0, (hipStream_t)stream, (const u16*)dh1, bbox, sub_idx, obj_idx,
+               sub_ptr, sub_list, obj_ptr, obj_list, goff, n_obj, (u16*)gwm);
+    SGC_CHECK_LAUNCH();
+    return SGC_OK;
+}
+int sgc_fc1_xrows(const void* dh1, const int* gather, const int* dest, int n_entries, const int* goff, const int* gend, void* gwm,
+                  void* ywm_bf16, void* stream) {
+    const long items = (long)n_entries + 64L * 256;
+    SGC_LAUNCH(fc1_xrows_kernel, dim3(grid_cap(items, 4, 262144)), dim3(256), 0, (hipStream_t)stream, (const u16*)dh1, gather, dest,
+               n_entries, goff, gend, (u16*)gwm, (u16*)ywm_bf16, items);
+    SGC_CHECK_LAUNCH();
+    return SGC_OK;
+}
+// dywm [rows][1024] bf16 = gwm [rows][4096] * (rows g*1024.. of w1pT [65536][4096])^T, g = tile_group[row / 256]
+int sgc_fc1_windows_dgrad(const void* gwm, const void* w1pT, const int* tile_group, void* dywm, int rows, void* stream) {
+    if (rows <= 0) return SGC_OK;
+    if (rows & 255) return SGC_ERR_ARG;
+    NtParams p{};
+    p.A = (const u16*)gwm; p.B = (const u16*)w1pT; p.C = dywm; p.M = rows; p.N = 1024; p.K = 4096;
+    p.lda = 4096; p.ldb = 4096; p.ldc = 1024; p.tile_group = tile_group; p.group_stride = 1024L * 4096;
+    p.epi_lds = 1;
+    return launch_gemm_nt_pp<ELEM_BF16, EPI_STORE>(p, (hipStream_t)stream);
+}
+// dw [4096][65536] f32 (columns in (window, channel) order): block g = gwm[group g]^T * ywm_bf16[group g]
+int sgc_fc1_windows_wgrad(const void* gwm, const void* ywm_bf16, const int* goff, float* dw, int rows, void* stream) {
+    if (rows <= 0) return SGC_OK;
+    TnParams p{};
+    p.A = (const u16*)gwm; p.B = (const u16*)ywm_bf16; p.C = dw; p.M = 4096; p.N = 1024; p.K = rows;
+    p.lda = 4096; p.ldb = 1024; p.ldc = 65536; p.goff = goff;
+    p.tiles_m = 16; p.tiles_n = 4; p.ktiles_per_split = 0; p.splits = 64; p.xcd_map = 0; p.xcd_patch = 1;
+    auto kern = gemm_tn_pp_kernel<ELEM_BF16, BMODE_PLAIN, 0>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 16384);
+    SGC_LAUNCH(kern, dim3(64 * 64), dim3(512), 8 * 16384, (hipStream_t)stream, p);
     SGC_CHECK_LAUNCH();
     return SGC_OK;
 }

@@ -368,7 +368,9 @@ class RelHeadEngine:
         base = torch.from_numpy(goff[:64].astype(np.int64) + n2 - cex).to(dev)
         dest = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
         dest[order] = (base[skeys] + torch.arange(E, device=dev)).int()
-        return dict(goff=goff_d, goff_host=goff, tile_group=torch.from_numpy(tile_group).to(dev), dest=dest, rows=int(goff[64]), E=E, n2=n2)
+        gend = torch.from_numpy((goff[:64].astype(np.int64) + n2 + np.asarray(counts, dtype=np.int64)).astype(np.int32)).to(dev)
+        return dict(goff=goff_d, goff_host=goff, gend=gend, tile_group=torch.from_numpy(tile_group).to(dev), dest=dest, rows=int(goff[64]),
+                    E=E, n2=n2)
 
     def fc1_shared(self, wm, ywm, bbox, sub_idx, obj_idx, incl, P, n_obj, h1, dropout, seed):
         """fc1 + ReLU (+ dropout) from the window-major rows: grouped GEMM, per-object 2-D prefix sums, per-pair assembly."""
@@ -607,16 +609,27 @@ class RelHeadEngine:
             Workspace._zero(y_bf[P * 65536:])
         am = ws.get("argmax", P * 65536, torch.uint8)
         ctx.shared = None
-        if share:
+        wm = None
+        h1 = ws.get("h1", Ppad * 4096, torch.float16)
+        if narrow and shared_fc1_enabled():
+            # fc1 over window-major rows: y and its bf16 copy exist only as the rows fc1 multiplies (per-object rows + X entries)
+            wm = self.window_major_rows(plan, P, 2 * ctx.n_obj)
+            ywm = sc.get("ywm", wm["rows"] * 1024, torch.float16)
+            ywm_bf = ws.get("ywm_bf", wm["rows"] * 1024, torch.bfloat16)
+            ctx.shared = self.conv3_shared(plan, z, ctx.uv[0], ctx.uv[1], bbox, obj_img, sub_idx, obj_idx, P, ywm, am, ywm_bf,
+                                           keep=(z_bf[P * 18 * 18 * 512:], amz[P * 256 * 256:]), wm=wm)
+            ctx.shared["ywm_bf"] = ywm_bf
+            self.fc1_shared(wm, ywm, bbox, sub_idx, obj_idx, plan["incl"], P, ctx.n_obj, h1, dropout, seeds[0])
+        elif share:
             ctx.shared = self.conv3_shared(plan, z, ctx.uv[0], ctx.uv[1], bbox, obj_img, sub_idx, obj_idx, P, y, am, y_bf,
                                            keep=(z_bf[P * 18 * 18 * 512:], amz[P * 256 * 256:]))
         else:
             self._timed("conv3_fwd", lambda: _lib.check(lib.sgc_conv3_relu_pool(_lib.ptr(z), _lib.ptr(self.w["w3r"]), _lib.ptr(self.w["b3"]), _lib.ptr(y), _lib.ptr(am),
                                                _lib.ptr(y_bf), P, self._st()), "sgc_conv3_relu_pool"))
         ctx.y_bf = y_bf
-        h1 = ws.get("h1", Ppad * 4096, torch.float16)
-        self._timed("fc1_fwd", lambda: _lib.check(lib.sgc_fc1_relu(_lib.ptr(y), _lib.ptr(self.w["w1p"]), _lib.ptr(self.w["bf1"]), _lib.ptr(h1), P, 65536,
-                                    int(dropout), ctypes.c_uint(seeds[0]), self._st()), "sgc_fc1_relu"))
+        if wm is None:
+            self._timed("fc1_fwd", lambda: _lib.check(lib.sgc_fc1_relu(_lib.ptr(y), _lib.ptr(self.w["w1p"]), _lib.ptr(self.w["bf1"]), _lib.ptr(h1), P, 65536,
+                                        int(dropout), ctypes.c_uint(seeds[0]), self._st()), "sgc_fc1_relu"))
         p = ws.get("p", Ppad * 512, torch.float32)
         self._timed("fc2_fwd", lambda: _lib.check(lib.sgc_fc2_labels_relu(_lib.ptr(h1), _lib.ptr(self.w["w2m"]), _lib.ptr(self.w["bf2"]), _lib.ptr(ctx.lsub),
                                            _lib.ptr(ctx.lobj), _lib.ptr(sub_idx), _lib.ptr(obj_idx), _lib.ptr(p), P, int(dropout),
@@ -726,7 +739,33 @@ class RelHeadEngine:
                    "sgc_fc2_dgrad"))
 
         # ---- fc1
-        with side():
+        wm = ctx.shared.get("wm") if getattr(ctx, "shared", None) is not None else None
+        if wm is not None:
+            # window-major rows (csrc/kernels_shared.hip): per-object sums of dh1 + one copy of dh1 per X entry, then grouped GEMMs
+            sh = ctx.shared
+            gwm = ws.get("gwm", wm["rows"] * 4096, torch.bfloat16)
+            self._timed("fc1_bwd_rows", lambda: (
+                _lib.check(lib.sgc_fc1_gsum(_lib.ptr(dh1), _lib.ptr(ctx.bbox), _lib.ptr(ctx.sub_idx), _lib.ptr(ctx.obj_idx), _lib.ptr(sub_csr[0]),
+                                            _lib.ptr(sub_csr[1]), _lib.ptr(obj_csr[0]), _lib.ptr(obj_csr[1]), _lib.ptr(wm["goff"]), n_obj,
+                                            _lib.ptr(gwm), st()), "sgc_fc1_gsum"),
+                _lib.check(lib.sgc_fc1_xrows(_lib.ptr(dh1), _lib.ptr(sh["gather"]), _lib.ptr(wm["dest"]), wm["E"], _lib.ptr(wm["goff"]),
+                                             _lib.ptr(wm["gend"]), _lib.ptr(gwm), _lib.ptr(sh["ywm_bf"]), st()), "sgc_fc1_xrows")))
+            with side():
+                dW1p = ws.get("dW1p", 4096 * 65536, torch.float32)
+                self._timed("fc1_wgrad", lambda: _lib.check(lib.sgc_fc1_windows_wgrad(_lib.ptr(gwm), _lib.ptr(sh["ywm_bf"]), _lib.ptr(wm["goff"]),
+                                                                                      _lib.ptr(dW1p), wm["rows"], st()), "sgc_fc1_windows_wgrad"))
+                gfc1 = torch.empty(4096, 65536, dtype=torch.float32, device=dev)
+                _lib.check(lib.sgc_transpose_cast(_lib.ptr(dW1p), _lib.ptr(gfc1), 2, 4096, 16, _c_long(65536), _c_long(64), _c_long(1024),
+                                                  _c_long(65536), _c_long(4096), _c_long(64), st()), "sgc_transpose_cast")
+                grads["fc1.weight"] = gfc1
+                if grad_hook is not None:
+                    grad_hook("fc1.weight", grads["fc1.weight"])
+                grads["fc1.bias"] = self._colsum(dh1, Ppad, 4096)
+            dy = ws.get("dywm", wm["rows"] * 1024, torch.bfloat16)
+            self._timed("fc1_dgrad", lambda: _lib.check(lib.sgc_fc1_windows_dgrad(_lib.ptr(gwm), _lib.ptr(w["w1pT"]), _lib.ptr(wm["tile_group"]),
+                                                                                  _lib.ptr(dy), wm["rows"], st()), "sgc_fc1_windows_dgrad"))
+        else:
+          with side():
             y_bf = ctx.y_bf
             dW1p = ws.get("dW1p", 4096 * 65536, torch.float32)
             self._timed("fc1_wgrad", lambda: _lib.check(lib.sgc_fc1_wgrad(_lib.ptr(dh1), _lib.ptr(y_bf), _lib.ptr(dW1p), Ppad, 65536, st()), "sgc_fc1_wgrad"))
@@ -738,8 +777,8 @@ class RelHeadEngine:
             if grad_hook is not None:          # largest gradient (97 % of the bytes) is ready first: overlap its all-reduce
                 grad_hook("fc1.weight", grads["fc1.weight"])
             grads["fc1.bias"] = self._colsum(dh1, Ppad, 4096)
-        dy = ws.get("dy", Ppad * 65536, torch.bfloat16)
-        self._timed("fc1_dgrad", lambda: _lib.check(lib.sgc_fc1_dgrad(_lib.ptr(dh1), _lib.ptr(w["w1pT"]), _lib.ptr(dy), P, 65536, st()), "sgc_fc1_dgrad"))
+          dy = ws.get("dy", Ppad * 65536, torch.bfloat16)
+          self._timed("fc1_dgrad", lambda: _lib.check(lib.sgc_fc1_dgrad(_lib.ptr(dh1), _lib.ptr(w["w1pT"]), _lib.ptr(dy), P, 65536, st()), "sgc_fc1_dgrad"))
 
         # ---- conv3
         nparts = ctypes.c_int(0)
@@ -861,9 +900,17 @@ class RelHeadEngine:
         dz_tail = dz[P * 256 * 512:]
         # ---- copies: per-object sums, then the pseudo-pairs' ordinary backward
         dy_ps = ws.get("dy_ps", n2 * 65536, torch.bfloat16)
-        self._timed("conv3_bwd_assemble", lambda: _lib.check(lib.sgc_shared_windows_assemble_bwd(
-            _lib.ptr(ctx.bbox), _lib.ptr(ctx.sub_idx), _lib.ptr(ctx.obj_idx), _lib.ptr(sub_csr[0]), _lib.ptr(sub_csr[1]), _lib.ptr(obj_csr[0]),
-            _lib.ptr(obj_csr[1]), n_obj, _lib.ptr(dy), _lib.ptr(dy_ps), st()), "sgc_shared_windows_assemble_bwd"))
+        wm = sh.get("wm")
+        dest = None
+        if wm is not None:
+            # ``dy`` is the window-major gradient of the shared fc1: the per-object rows are already sums; bring them to pair-major order
+            idx = (wm["goff"][:64].long()[None, :] + torch.arange(n2, device=self.device)[:, None]).reshape(-1)
+            torch.index_select(dy.view(-1, 1024), 0, idx, out=dy_ps.view(-1, 1024))
+            dest = wm["dest"]
+        else:
+            self._timed("conv3_bwd_assemble", lambda: _lib.check(lib.sgc_shared_windows_assemble_bwd(
+                _lib.ptr(ctx.bbox), _lib.ptr(ctx.sub_idx), _lib.ptr(ctx.obj_idx), _lib.ptr(sub_csr[0]), _lib.ptr(sub_csr[1]), _lib.ptr(obj_csr[0]),
+                _lib.ptr(obj_csr[1]), n_obj, _lib.ptr(dy), _lib.ptr(dy_ps), st()), "sgc_shared_windows_assemble_bwd"))
         bpart = ws.get("b3_part", 2048 * 1024, torch.float32)
         bpart_x = ws.get("b3_part_x", 1024 * 1024, torch.float32)
         pack_a = ws.get("w3_pack_a", n2 * 4 * 1024 * 64, torch.uint8)
@@ -874,8 +921,8 @@ class RelHeadEngine:
         # ---- pair-specific windows: compact un-pool
         dy3x = ws.get("dy3x", max(Epad, 16) * 4 * 1024, torch.bfloat16)
         self._timed("unpool_windows", lambda: _lib.check(lib.sgc_windows_unpool(
-            _lib.ptr(dy), _lib.ptr(ctx.am), _lib.ptr(gather), _lib.ptr(gn), Epad, _lib.ptr(dy3x), _lib.ptr(bpart_x), ctypes.byref(nparts_x), st()),
-            "sgc_windows_unpool"))
+            _lib.ptr(dy), _lib.ptr(ctx.am), _lib.ptr(gather), _lib.ptr(gn), _lib.ptr(dest), Epad, _lib.ptr(dy3x), _lib.ptr(bpart_x),
+            ctypes.byref(nparts_x), st()), "sgc_windows_unpool"))
         with side():
             gb = self._slab_sum(bpart, 1024, nparts.value)
             if nparts_x.value:

@@ -155,6 +155,22 @@ def test_training_step_shared_forward_is_bit_identical_and_shared_backward_agree
         else:
             assert err <= tol, (n, err)
     print({k: "%.2e" % v for k, v in worst.items() if v > 0})
+    # ---- the whole shipped default: fc1 over window-major rows as well.  h1 differs by f32 round-off before its f16 rounding, so
+    # a few ReLU / dropout-scaled values move by one f16 ulp and every gradient sees that; nothing is bit-equal any more
+    _poison(eng)
+    for name in ("gwm", "dywm", "ywm_bf"):
+        for ws in (eng.ws, eng.scratch):
+            if name in ws.bufs:
+                ws.bufs[name].view(torch.int16).fill_(0x7FC0)
+    l3, _, _, g3 = _with_env({"SGC_SHARED_CONV3": "1", "SGC_SHARED_BWD": "1", "SGC_SHARED_FC1": "1"}, run)
+    assert abs(l3 - l0) <= 2e-5 * abs(l0), (l3, l0)
+    worst3 = {}
+    for n in g0:
+        assert torch.isfinite(g3[n]).all(), n
+        ref = g0[n].double()
+        worst3[n] = float((g3[n].double() - ref).norm() / ref.norm().clamp(min=1e-30))
+        assert worst3[n] <= 8e-3, (n, worst3[n])
+    print("fc1 shared:", {k: "%.2e" % v for k, v in worst3.items()})
 
 
 @pytest.mark.parametrize("nobj,edge", [([9, 4, 12], True), ([36] * 3, False), ([64] * 2, True), ([1, 3], True)])
