@@ -29,11 +29,11 @@ sys.path.insert(0, REPO)
 
 MFMA_PEAK_TFLOPS = 2500.0      # dense bf16/f16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
-# fc1 forward: f16 NT GEMM 32256 x 4096 x 65536, bias + ReLU + dropout epilogue (template <ELEM, EPI, ABL>).  With conv3 computed
-# over shared windows (csrc/kernels_shared.hip) the three fc1 GEMMs are the largest launches of the step; conv3's own launches are
-# reported in kernels_ms (conv3_fwd_objects / conv3_fwd_windows / ...).
-DOMINANT_KERNEL = ("gemm_nt_pp_kernel<0, 2, 0>",)
-PMC_TAGS = ("r02_shared",)                                      # newest committed counter passes first
+# conv3 forward over the pair-specific windows: f16 implicit 3x3 GEMM whose rows are gathered from the window list, ReLU + max-pool
+# epilogue (gemm_nt_kernel<ELEM, AMODE_CONV_GATHER, EPI_POOL, 2, 4, 4, 2>).  With conv3 AND fc1 computed over shared windows
+# (csrc/kernels_shared.hip) it is the longest launch of the step; the others are in kernels_ms.
+DOMINANT_KERNEL = ("gemm_nt_kernel<0, 2, 3, 2, 4, 4, 2, 0>",)
+PMC_TAGS = ("r02_final2",)                                      # newest committed counter passes first
 
 
 def parse_args(argv=None):
@@ -258,24 +258,30 @@ def run_rank(args):
         flops = {"conv3_fwd": 2.0 * P * 256 * 1024 * 4608, "conv3_dgrad": 2.0 * P * 256 * 512 * 9216,
                  "conv3_wgrad": 2.0 * P * 256 * 1024 * 4608, "fc1_fwd": 2.0 * P * 65536 * 4096,
                  "fc1_dgrad": 2.0 * P * 65536 * 4096, "fc1_wgrad": 2.0 * P * 65536 * 4096}
-        dom = "fc1_fwd"
+        dom = "conv3_fwd_windows"
         two_streams = os.environ.get("SGC_BWD_STREAMS", "1") != "0" and not args.forward_only
         fwd_only = ("conv2_fwd", "expand_dense", "expand", "expand_train", "conv3_fwd", "conv3_fwd_objects", "conv3_fwd_windows",
-                    "conv3_fwd_assemble", "fc1_fwd", "fc2_fwd")
+                    "conv3_fwd_assemble", "fc1_fwd", "fc1_fwd_windows", "fc1_fwd_integral", "fc1_fwd_assemble", "fc2_fwd")
         xw = getattr(eng, "_xw", None)
-        if xw is not None:                         # conv3 over shared windows: flops of what is actually computed
+        n_x = 0
+        if xw is not None:                         # conv3 / fc1 over shared windows: flops of what is actually computed
             n_x = int(xw[1][-1])
+            n_ps = 2 * args.objects * args.images
             flops["conv3_fwd_windows"] = 2.0 * n_x * 4 * 1024 * 4608
-            flops["conv3_fwd_objects"] = 2.0 * (2 * args.objects * args.images) * 256 * 1024 * 4608
+            flops["conv3_fwd_objects"] = 2.0 * n_ps * 256 * 1024 * 4608
+            flops["conv3_dgrad_windows"] = flops["conv3_wgrad_windows"] = flops["conv3_fwd_windows"]
+            flops["fc1_fwd_windows"] = 2.0 * (n_x + 64 * n_ps) * 1024 * 4096          # padding rows not counted
+            flops["fc1_dgrad"] = flops["fc1_wgrad"] = flops["fc1_fwd_windows"]
         roof = None
         if dom in kern and kern[dom] > 0:
             ach = flops[dom] / (kern[dom] * 1e-3) / 1e12
             traffic, tag = pmc_traffic() if P == 32256 else (None, None)
-            roof = {"bound": "mfma", "kernel": "gemm_nt_pp_kernel<f16,bias+relu+dropout> (sgc_fc1_relu, %d x 4096 x 65536)" % P,
+            roof = {"bound": "mfma", "kernel": "gemm_nt_kernel<f16,conv-gather,relu+pool> (sgc_conv3_relu_pool_windows_wm: %d windows x 4 pixels "
+                                               "x 1024 x 4608 of the %d per-pair windows; the rest is shared per object)" % (n_x, P * 64),
                     "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                     "traffic_note": "bytes/launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from profiles/%s_pmc_{f,w}.csv "
-                                    "(separate rocprofv3 --pmc passes at this workload); algorithmic 5.0e9 (y f16 4.2 + weights 0.54 + h1 0.26)" % tag,
+                                    "(separate rocprofv3 --pmc passes at this workload); algorithmic ~2.9e9 (z next to the windows 1.7 + outputs 1.2 + weights 0.01)" % tag,
                     "ms_per_launch": round(kern[dom], 3)}
         out = {
             "metric": "ordered object-pairs/sec (relation head fwd+bwd), batch=%d, N=%d" % (args.images, args.objects)
@@ -290,8 +296,8 @@ def run_rank(args):
             "loss": None if loss is None else float(loss), "loss_first_step": first_loss,
             "roofline": roof,
             "shared_windows": None if xw is None else {"pair_specific": n_x, "of": P * 64, "fraction": round(n_x / max(P * 64, 1), 4),
-                                                       "note": "conv3 runs per pair only on these pooling windows; the rest is computed "
-                                                               "once per object (csrc/kernels_shared.hip), results bit-identical"},
+                                                       "note": "conv3 and fc1 run per pair only on these pooling windows; the rest is computed "
+                                                               "once per object (csrc/kernels_shared.hip)"},
             "kernels_ms": {k: round(v, 3) for k, v in sorted(kern.items()) if k in fwd_only or not two_streams},
             "kernels_tflops": {k: round(flops[k] / (kern[k] * 1e-3) / 1e12, 1) for k in kern
                                if k in flops and kern[k] > 0 and (k in fwd_only or not two_streams)},

@@ -35,12 +35,56 @@ def run_train_gpu(cfg, sd, batch, dropout=False, seeds=(0, 0), keep_ctx=False):
 def device_routes(ctx):
     """The routing decisions the device's backward follows, in the oracle's layouts (CPU tensors, one row per ordered pair):
     pool2 [P,512,16,16] / pool3 [P,1024,8,8] window codes (dy*2+dx, 4 = killed by the ReLU), relu1 [P,4096] / relu2 [P,512]
-    pass masks (an element the dropout removed reads as "not passed": the injected dropout mask zeroes it anyway)."""
+    pass masks (an element the dropout removed reads as "not passed": the injected dropout mask zeroes it anyway).
+    With conv3 / fc1 over shared windows (``csrc/kernels_shared.hip``) a pair's own codes exist only next to its pair-specific
+    windows; everywhere else its gradient flows through the pseudo-pair (subject, background) or (background, object), whose
+    codes are what the reference's graph has there too (identical inputs), so the full per-pair tables are put together from them."""
     P = ctx.P
-    amz = ctx.amz[:P * 256 * 256].view(P, 256, 256).cpu()                       # [pair][window][channel pair]: two 4-bit codes
-    codes = torch.stack((amz & 15, amz >> 4), dim=3).reshape(P, 256, 512)       # channel 2k low nibble, 2k+1 high
+    sh = getattr(ctx, "shared", None)
+    unpack = lambda a: torch.stack((a & 15, a >> 4), dim=3).reshape(a.shape[0], 256, 512)      # channel 2k low nibble, 2k+1 high
+    if sh is None:
+        codes = unpack(ctx.amz[:P * 256 * 256].view(P, 256, 256).cpu())
+        am3 = ctx.am[:P * 65536].view(P, 64, 1024).cpu()
+    else:
+        from scene_graph_commonsense_amd.pairs import object_window_rects
+        n_obj, n2 = ctx.n_obj, sh["n2"]
+        allc = unpack(ctx.amz[:(P + n2) * 256 * 256].view(P + n2, 256, 256).cpu())
+        real, pseudo = allc[:P], allc[P:]
+        bb = ctx.bbox.cpu().numpy()
+        sub, obj = ctx.sub_idx.cpu().numpy(), ctx.obj_idx.cpu().numpy()
+        pr = sh["pixrect"].cpu().numpy()
+        R = object_window_rects(bb)
+        # D16_o: the 16-grid pixels where object o's conv2 half differs from the background's (box, +-1 on the 32-grid, /2)
+        d16 = np.zeros((len(bb), 16, 16), dtype=bool)
+        for o, (x0, x1, y0, y1) in enumerate(bb):
+            x0, x1, y0, y1 = max(x0, 0), min(x1, 32), max(y0, 0), min(y1, 32)
+            if x1 > x0 and y1 > y0:
+                lx, hx, ly, hy = max(x0 - 1, 0), min(x1 + 1, 32), max(y0 - 1, 0), min(y1 + 1, 32)
+                d16[o, ly >> 1:(hy + 1) >> 1, lx >> 1:(hx + 1) >> 1] = True
+        am_real = ctx.am[:P * 65536].view(P, 64, 1024).cpu()
+        am_ps = sh["am_ps"][:n2 * 65536].view(n2, 64, 1024).cpu()
+        codes = torch.empty(P, 256, 512, dtype=real.dtype)
+        am3 = torch.empty(P, 64, 1024, dtype=am_real.dtype)
+        wy, wx = np.divmod(np.arange(64), 8)
+        for p in range(P):
+            i, j = int(sub[p]), int(obj[p])
+            r = int(pr[p])
+            own = np.zeros((16, 16), dtype=bool)
+            own[r & 31:(r >> 5) & 31, (r >> 10) & 31:(r >> 15) & 31] = True
+            assert not (d16[i] & d16[j] & ~own).any()                 # pair-specific pixels lie inside what the pair computed itself
+            from_j = torch.from_numpy((~own & d16[j]).reshape(256))
+            from_i = torch.from_numpy((~own & ~d16[j]).reshape(256))
+            codes[p] = real[p]
+            codes[p][from_i] = pseudo[i][from_i]
+            codes[p][from_j] = pseudo[n_obj + j][from_j]
+            in_i = (wx >= R[i, 0]) & (wx < R[i, 1]) & (wy >= R[i, 2]) & (wy < R[i, 3])
+            in_j = (wx >= R[j, 0]) & (wx < R[j, 1]) & (wy >= R[j, 2]) & (wy < R[j, 3])
+            am3[p] = am_real[p]
+            am3[p][torch.from_numpy(~in_j)] = am_ps[i][torch.from_numpy(~in_j)]
+            sel = torch.from_numpy(in_j & ~in_i)
+            am3[p][sel] = am_ps[n_obj + j][sel]
     pool2 = codes.permute(0, 2, 1).reshape(P, 512, 16, 16).contiguous()
-    pool3 = ctx.am[:P * 65536].view(P, 64, 1024).cpu().permute(0, 2, 1).reshape(P, 1024, 8, 8).contiguous()
+    pool3 = am3.permute(0, 2, 1).reshape(P, 1024, 8, 8).contiguous()
     relu1 = (ctx.h1[:P * 4096].view(P, 4096) != 0).float().cpu()
     relu2 = (ctx.p[:P * 512].view(P, 512) != 0).float().cpu()
     return dict(pool2=pool2, pool3=pool3, relu1=relu1, relu2=relu2)
