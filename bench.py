@@ -30,10 +30,11 @@ sys.path.insert(0, REPO)
 MFMA_PEAK_TFLOPS = 2500.0      # dense bf16/f16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
 # conv3 forward over the pair-specific windows: f16 implicit 3x3 GEMM whose rows are gathered from the window list, ReLU + max-pool
-# epilogue (gemm_nt_kernel<ELEM, AMODE_CONV_GATHER, EPI_POOL, 2, 4, 4, 2>).  With conv3 AND fc1 computed over shared windows
-# (csrc/kernels_shared.hip) it is the longest launch of the step; the others are in kernels_ms.
-DOMINANT_KERNEL = ("gemm_nt_kernel<0, 2, 3, 2, 4, 4, 2, 0>",)
-PMC_TAGS = ("r02_final2",)                                      # newest committed counter passes first
+# epilogue (gemm_nt_pp_kernel<ELEM, EPI_POOL, ABL, ACG = 1>: the ping-pong block with gathered conv rows).  With conv3 AND fc1
+# computed over shared windows (csrc/kernels_shared.hip) the three GEMMs over those windows are the longest launches of the step
+# (forward / data gradient / weight gradient, 7.4 / 7.9 / 8.3 ms); the forward one is reported here, the others are in kernels_ms.
+DOMINANT_KERNEL = ("gemm_nt_pp_kernel<0, 3, 0, 1>",)
+PMC_TAGS = ("r02_final3",)                                      # newest committed counter passes first
 
 
 def parse_args(argv=None):
@@ -276,7 +277,7 @@ def run_rank(args):
         if dom in kern and kern[dom] > 0:
             ach = flops[dom] / (kern[dom] * 1e-3) / 1e12
             traffic, tag = pmc_traffic() if P == 32256 else (None, None)
-            roof = {"bound": "mfma", "kernel": "gemm_nt_kernel<f16,conv-gather,relu+pool> (sgc_conv3_relu_pool_windows_wm: %d windows x 4 pixels "
+            roof = {"bound": "mfma", "kernel": "gemm_nt_pp_kernel<f16,relu+pool,conv-gather> (sgc_conv3_relu_pool_windows_wm: %d windows x 4 pixels "
                                                "x 1024 x 4608 of the %d per-pair windows; the rest is shared per object)" % (n_x, P * 64),
                     "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,

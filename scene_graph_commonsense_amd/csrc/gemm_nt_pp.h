@@ -79,7 +79,11 @@ __device__ __forceinline__ bool xcd_patch_map_aligned(int id, int tiles_m, int t
 }
 
 // ABL (tools/gemm_microbench.py only): 0 normal, 1 no global loads inside the K loop.
-template <int ELEM, int EPI, int ABL = 0>
+// ACG = 1: the A operand is the implicit 3x3 convolution over a LIST of 2x2 windows of 16x16 maps (AMODE_CONV_GATHER of gemm_nt.h:
+// row m = pixel m&3 of window gather[m>>2] = image*64 + window, *gather_n entries, p.M only bounds the launch).  The rows of one
+// tile come from a few consecutive images (the list is sorted), so their byte offsets from the tile's first image fit the 32-bit
+// per-lane offset of the buffer load; the K step (64-channel chunk, tap) is a wave-uniform byte offset.
+template <int ELEM, int EPI, int ABL = 0, int ACG = 0>
 __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(const NtParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int HT = 16384;                        // half-tile bytes; slot = parity*4 + kind, kind 0 A0, 1 B0, 2 B1, 3 A1
@@ -93,10 +97,17 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(const NtParams p) {
         xcd_patch_map(blockIdx.x, p.tiles_m, p.tiles_n, tm, tn);
     }
     const int m0 = tm * 256, n0 = tn * 256;
+    int Mlim = p.M;
+    long img0 = 0;
+    if constexpr (ACG) {
+        Mlim = min(p.M, 4 * *p.gather_n);
+        if (m0 >= Mlim) return;                      // the grid is sized for the bound (uniform exit, before any barrier)
+        img0 = p.gather[m0 >> 2] >> 6;
+    }
 
     // ---- staging sources: wave w writes LDS rows (2w+q)*8 .. +7 of every half tile (q = 0,1), 8 lanes per 128-B row
     const int lrow = lane >> 3, cpos = lane & 7;
-    const u16* const a_blk = p.A + (long)m0 * p.lda;
+    const u16* const a_blk = ACG ? p.A + img0 * (324L * p.Cin) : p.A + (long)m0 * p.lda;
     const u16* const b_blk = p.B + (long)n0 * p.ldb + (p.tile_group ? (long)p.tile_group[tm] * p.group_stride : 0L);
     int voff[4][2];                                  // byte offsets from a_blk / b_blk
 #pragma unroll
@@ -106,8 +117,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(const NtParams p) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             int m = (r >> 6) * 128 + h * 64 + (r & 63);
-            if (m0 + m > p.M - 1) m = p.M - 1 - m0;
-            voff[h ? 3 : 0][q] = (int)((m * p.lda + chunk) * 2);
+            if (m0 + m > Mlim - 1) m = Mlim - 1 - m0;
+            if constexpr (ACG) {
+                const int mg = m0 + m;
+                const int mv = p.gather[mg >> 2] * 4 + (mg & 3);
+                voff[h ? 3 : 0][q] = (int)((conv_row_base(mv, 4, p.Cin) - img0 * (324L * p.Cin) + chunk) * 2);
+            } else {
+                voff[h ? 3 : 0][q] = (int)((m * p.lda + chunk) * 2);
+            }
             const int n = (r >> 5) * 64 + h * 32 + (r & 31);
             voff[1 + h][q] = (int)((n * p.ldb + chunk) * 2);
         }
@@ -116,8 +133,16 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(const NtParams p) {
         if (ABL == 1 && t > 1) return;
         char* base = smem + (((t & 1) << 2) + kind) * HT + wid * 2048;
         const u16* g = (kind == 0 || kind == 3) ? a_blk : b_blk;
-        buf_load_lds16(g, voff[kind][0], t << 7, base);
-        buf_load_lds16(g, voff[kind][1], t << 7, base + 1024);
+        int soff = t << 7;
+        if constexpr (ACG) {
+            if (kind == 0 || kind == 3) {            // K tile t = (64-channel chunk t/9, tap t%9) of the padded 18x18 map
+                const int cc = t / 9, tap = t - cc * 9;
+                const int ky = tap / 3, kx = tap - 3 * ky;
+                soff = ((ky * 18 + kx) * p.Cin + (cc << 6)) * 2;
+            }
+        }
+        buf_load_lds16(g, voff[kind][0], soff, base);
+        buf_load_lds16(g, voff[kind][1], soff, base + 1024);
     };
 
     // ---- fragment reads (row swizzle (row>>1)&7 only depends on lane&31: half tiles start at multiples of 32 rows)
@@ -196,7 +221,23 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(const NtParams p) {
     if constexpr (EPI == EPI_STORE) {
         if (p.epi_lds) { nt_epilogue_store16<ELEM>(p, acc, m0, n0, wr, wc, lane, wid, smem); return; }
     }
-    nt_epilogue<ELEM, EPI, 4, 2>(p, acc, m0, n0, wr, wc, lane);
+    if constexpr (ACG) nt_epilogue<ELEM, EPI, 4, 2, true>(p, acc, m0, n0, wr, wc, lane, Mlim);
+    else nt_epilogue<ELEM, EPI, 4, 2>(p, acc, m0, n0, wr, wc, lane);
+}
+
+// conv3 over a window list with the ping-pong block (csrc/kernels_shared.hip): rows = 4 x max_entries, N = 1024, K = 9 x 512
+template <int ELEM, int EPI>
+static int launch_gemm_nt_pp_conv_gather(NtParams p, hipStream_t stream) {
+    constexpr int LDS = 8 * 16384;
+    if (p.lgS != 4 || (p.Cin & 63) || p.K != 9 * p.Cin || (p.N & 255)) return SGC_ERR_ARG;
+    p.tiles_m = (p.M + 255) / 256;
+    p.tiles_n = p.N / 256;
+    p.patch_aligned = 0;
+    auto kern = gemm_nt_pp_kernel<ELEM, EPI, 0, 1>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    SGC_LAUNCH(kern, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(512), LDS, stream, p);
+    SGC_CHECK_LAUNCH();
+    return SGC_OK;
 }
 
 template <int ELEM, int EPI, int ABL = 0>

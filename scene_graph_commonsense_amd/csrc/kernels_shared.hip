@@ -586,6 +586,9 @@ int sgc_conv3_relu_pool_windows(const void* z_pad, const void* w3r, const float*
     p.A = (const u16*)z_pad; p.B = (const u16*)w3r; p.C = y; p.M = max_entries * 4; p.N = 1024; p.K = 9 * 512;
     p.ldb = 9 * 512; p.ldc = 1024; p.lgS = 4; p.Cin = 512; p.bias = b3; p.argmax = argmax; p.C2 = (u16*)y_bf16;
     p.gather = gather; p.gather_n = gather_n;
+    static int pp = -1;               // SGC_GATHER_PP=0: the 2-stage block (A/B hook)
+    if (pp < 0) { const char* e = getenv("SGC_GATHER_PP"); pp = e ? atoi(e) : 1; }
+    if (pp) return launch_gemm_nt_pp_conv_gather<ELEM_F16, EPI_POOL>(p, (hipStream_t)stream);
     return launch_gemm_nt_cfg<ELEM_F16, AMODE_CONV_GATHER, EPI_POOL, 2, 4, 4, 2>(p, (hipStream_t)stream);
 }
 
@@ -687,6 +690,9 @@ int sgc_conv3_relu_pool_windows_wm(const void* z_pad, const void* w3r, const flo
     p.A = (const u16*)z_pad; p.B = (const u16*)w3r; p.C = ywm; p.M = max_entries * 4; p.N = 1024; p.K = 9 * 512;
     p.ldb = 9 * 512; p.ldc = 1024; p.lgS = 4; p.Cin = 512; p.bias = b3; p.argmax = argmax; p.C2 = (u16*)ywm_bf16;
     p.gather = gather; p.gather_n = gather_n; p.dest = dest;
+    static int pp = -1;               // SGC_GATHER_PP=0: the 2-stage block (A/B hook)
+    if (pp < 0) { const char* e = getenv("SGC_GATHER_PP"); pp = e ? atoi(e) : 1; }
+    if (pp) return launch_gemm_nt_pp_conv_gather<ELEM_F16, EPI_POOL>(p, (hipStream_t)stream);
     return launch_gemm_nt_cfg<ELEM_F16, AMODE_CONV_GATHER, EPI_POOL, 2, 4, 4, 2>(p, (hipStream_t)stream);
 }
 // owm [rows][4096] f32 = ywm [rows][1024] f16 * w1p[:, g*1024 .. +1024]^T, g = tile_group[row / 256]  (rows a multiple of 256)

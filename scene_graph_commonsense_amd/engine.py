@@ -131,9 +131,17 @@ def shared_fc1_enabled() -> bool:
     return os.environ.get("SGC_SHARED_FC1", "1") != "0"
 
 
-def shared_conv3_enabled() -> bool:
-    """``SGC_SHARED_CONV3=0`` computes conv3 for every window of every pair (A/B hook; default: per-object sharing on)."""
-    return os.environ.get("SGC_SHARED_CONV3", "1") != "0"
+def shared_conv3_enabled(hint=None, n_pairs=0) -> bool:
+    """``SGC_SHARED_CONV3=0`` computes conv3 for every window of every pair (A/B hook; default: per-object sharing on).
+    ``hint`` (the host's count of pair-specific windows, ``DeviceScene.shared_windows``): when more than half of all windows are
+    pair-specific (most boxes cover most of the image) the per-pair kernels are used - the column buffers of the shared backward
+    grow with that count (9.2 KB per window pixel, twice) and the saving shrinks to nothing near 75 %."""
+    if os.environ.get("SGC_SHARED_CONV3", "1") == "0":
+        return False
+    n = hint[0] if isinstance(hint, tuple) else hint
+    if n is not None and n_pairs > 0 and n > float(os.environ.get("SGC_SHARED_MAX_FRACTION", "0.5")) * 64 * n_pairs:
+        return False
+    return True
 
 
 class RelHeadEngine:
@@ -489,7 +497,7 @@ class RelHeadEngine:
         pairs and scatter the results into full-size outputs; the other pairs get confidence -inf (exactly what the overlap filter
         gives them in the evaluator, ``evaluator.py:131-134``), prediction 0, zero log-probs and hidden vectors."""
         a_img = self.image_maps(image_feature, image_depth)
-        share = shared_conv3_enabled()
+        share = shared_conv3_enabled(shared_windows, int(sub_idx.shape[0]))
         uv = self.object_halves(a_img, obj_img, bbox, with_bg=share)
         shared = (bbox, obj_img, shared_windows) if share else None
         lsub, lobj = self.label_vectors(cats, super_mh)
@@ -590,7 +598,7 @@ class RelHeadEngine:
             x_s = self._x
             a_o = self.image_maps(role_inputs[1], None, roles=(1,), tag="o")
             ctx.a_img, ctx.x = {0: a_s[0], 1: a_o[1]}, (x_s, self._x)
-        share = role_inputs is None and shared_conv3_enabled()     # per-step calls: every crop is one full-size box, nothing is shared
+        share = role_inputs is None and shared_conv3_enabled(shared_windows, P)   # per-step calls: every crop is one full-size box, nothing is shared
         ctx.uv = self.object_halves(ctx.a_img, obj_img, bbox, with_bg=share)
         ctx.lsub, lobj_same = self.label_vectors(ctx.cats[0], ctx.super_mh[0])
         ctx.lobj = lobj_same if role_inputs is None else self.label_vectors(ctx.cats[1], ctx.super_mh[1])[1]

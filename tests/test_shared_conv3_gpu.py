@@ -11,6 +11,13 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _always_shared(monkeypatch):
+    """The edge-case boxes of these tests (full-image boxes next to tiny ones) make most windows pair-specific; the engine would
+    switch such a scene to the per-pair kernels (``shared_conv3_enabled``).  Here the shared path is the subject."""
+    monkeypatch.setenv("SGC_SHARED_MAX_FRACTION", "2")
+
+
 def _model(cfg, seed=1):
     from scene_graph_commonsense_amd.model import BayesianRelationClassifier
     from scene_graph_commonsense_amd.synthetic import make_state_dict
@@ -213,3 +220,36 @@ def test_fc1_over_window_major_rows_matches_the_one_gemm_form(nobj, edge):
     fin = torch.isfinite(a.cand_conf)
     assert torch.equal(fin, torch.isfinite(b.cand_conf))
     assert float((a.cand_conf[fin] - b.cand_conf[fin]).abs().max()) <= 1e-3
+
+
+def test_scenes_that_are_mostly_pair_specific_use_the_per_pair_kernels(monkeypatch):
+    """Every box = the whole image: nothing can be shared, the column buffers of the shared backward would be at their largest.
+    The host's window count sends the step to the per-pair kernels; the results are the per-pair results."""
+    from scene_graph_commonsense_amd.pairs import flatten_scene
+    from scene_graph_commonsense_amd.synthetic import HeadConfig, make_scene_batch
+    monkeypatch.delenv("SGC_SHARED_MAX_FRACTION")
+    cfg = HeadConfig()
+    model = _model(cfg)
+    batch = make_scene_batch(cfg, [6, 5], seed=4, connect_frac=0.3)
+    for b in batch.bbox:
+        b[:] = torch.tensor([0, 32, 0, 32], dtype=b.dtype)
+    sc = flatten_scene(cfg, batch, "cuda:0")
+    assert sc.shared_windows == sc.n_pairs * 64
+    eng = model.refresh_weights(backward=True)
+
+    def run():
+        model.zero_grad(set_to_none=True)
+        loss = model.training_step(sc)
+        torch.cuda.synchronize()
+        return float(loss), {n: p.grad.clone() for n, p in model.named_parameters()}, model.last_ctx_shared
+    model.last_ctx_shared = None
+    import scene_graph_commonsense_amd.engine as E
+    seen = []
+    orig = E.RelHeadEngine.conv3_shared
+    monkeypatch.setattr(E.RelHeadEngine, "conv3_shared", lambda self, *a, **k: (seen.append(1), orig(self, *a, **k))[1])
+    l1, g1, _ = run()
+    assert not seen                                            # the shared path was not taken
+    l0, g0, _ = _with_env({"SGC_SHARED_CONV3": "0"}, run)
+    assert l0 == l1
+    for n in g0:
+        assert torch.equal(g0[n], g1[n]), n
