@@ -215,24 +215,28 @@ __global__ __launch_bounds__(256) void windows_unpool_kernel(const u16* __restri
         bias_part[(long)blockIdx.x * 1024 + c] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
 }
 
-// zcol[4e + q][tap][512] = z_pad_bf16[pair][y + ky][x + kx][:]: the rows of the weight-gradient GEMM's second operand
+// zcol[4e + q][tap][512] = z_pad_bf16[pair][y + ky][x + kx][:]: the rows of the weight-gradient GEMM's second operand.
+// One wavefront per row: its nine 1 KiB neighbourhood rows are requested before the first is stored.
 __global__ __launch_bounds__(256) void windows_im2col_kernel(const u16* __restrict__ zbf, const int* __restrict__ gather,
-                                                             const int* __restrict__ gather_n, long n_items, u16* __restrict__ zcol) {
+                                                             const int* __restrict__ gather_n, long n_rows, u16* __restrict__ zcol) {
     const int lane = threadIdx.x & 63;
     const int E = *gather_n;
-    for (long it = (long)blockIdx.x * 4 + (threadIdx.x >> 6); it < n_items; it += (long)gridDim.x * 4) {
-        const long row = it / 9;
-        const int tap = (int)(it - row * 9);
+    for (long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6); row < n_rows; row += (long)gridDim.x * 4) {
         const int e = (int)(row >> 2), q = (int)(row & 3);
-        uint4 v = make_uint4(0, 0, 0, 0);
+        uint4 v[9];
         if (e < E) {
             const int g = gather[e];
             const int pair = g >> 6, w = g & 63;
             const int y = 2 * (w >> 3) + (q >> 1), x = 2 * (w & 7) + (q & 1);
-            const int ky = tap / 3, kx = tap - 3 * ky;
-            v = *reinterpret_cast<const uint4*>(zbf + (((long)pair * 18 + y + ky) * 18 + x + kx) * 512 + lane * 8);
+            const u16* src = zbf + (((long)pair * 18 + y) * 18 + x) * 512 + lane * 8;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) v[tap] = *reinterpret_cast<const uint4*>(src + ((tap / 3) * 18 + (tap % 3)) * 512);
+        } else {
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) v[tap] = make_uint4(0, 0, 0, 0);
         }
-        *reinterpret_cast<uint4*>(zcol + it * 512 + lane * 8) = v;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) *reinterpret_cast<uint4*>(zcol + (row * 9 + tap) * 512 + lane * 8) = v[tap];
     }
 }
 
@@ -629,9 +633,9 @@ int sgc_windows_unpool(const void* dy, const unsigned char* argmax, const int* g
 
 int sgc_windows_im2col(const void* z_pad_bf16, const int* gather, const int* gather_n, int entries_pad, void* zcol, void* stream) {
     if (entries_pad <= 0) return SGC_OK;
-    const long items = (long)entries_pad * 4 * 9;
-    SGC_LAUNCH(windows_im2col_kernel, dim3(grid_cap(items, 4 * 4, 262144)), dim3(256), 0, (hipStream_t)stream, (const u16*)z_pad_bf16,
-               gather, gather_n, items, (u16*)zcol);
+    const long rows = (long)entries_pad * 4;
+    SGC_LAUNCH(windows_im2col_kernel, dim3(grid_cap(rows, 4, 262144)), dim3(256), 0, (hipStream_t)stream, (const u16*)z_pad_bf16,
+               gather, gather_n, rows, (u16*)zcol);
     SGC_CHECK_LAUNCH();
     return SGC_OK;
 }
