@@ -106,7 +106,10 @@ def _detr_outputs(detr, image2, rank):
     if hasattr(detr, "detect"):
         out = detr.detect(images)
     else:
-        from utils import nested_tensor_from_tensor_list            # host repository helper
+        try:
+            from utils import nested_tensor_from_tensor_list        # host repository helper
+        except Exception:
+            from .detr import nested_tensor_from_tensor_list
         out = detr(nested_tensor_from_tensor_list(images))
     return out["pred_logits"], out["pred_boxes"]
 

@@ -81,7 +81,10 @@ def build_feature_encoder(args, rank):
         return enc
     if enc == "precomputed":
         return PrecomputedFeatures()
-    from utils import build_detr101                      # host repository: DETR-101 backbone + encoder (needs its weights)
+    try:
+        from utils import build_detr101                  # host repository: torch.hub DETR-101 (needs the network once, and its weights)
+    except Exception:
+        from .detr import build_detr101                  # stand-alone: the same architecture and state-dict names, no hub (detr.py)
     return build_detr101(args).to(rank).eval()
 
 

@@ -17,15 +17,19 @@ import torch.nn.functional as F
 
 def process_image_features(args, images, detr, rank):
     """``[B,256,32,32]`` encoder features of a minibatch (``train_utils.py:9-18``).  ``detr`` is either the reference's DDP-wrapped
-    DETR-101 (``utils.build_detr101``; its backbone / input_proj / transformer.encoder are called as the reference does) or any
+    DETR-101 (``utils.build_detr101``) or this package's ``detr.build_detr101`` (its backbone / input_proj / transformer.encoder are
+    called as the reference does) or any
     callable mapping the stacked images to the feature map (precomputed features: pass ``lambda x: x``)."""
     images = torch.stack(list(images)).to(rank)
     core = getattr(detr, "module", detr)
     if not hasattr(core, "backbone"):
         feats = core(images)
     else:
-        from utils import nested_tensor_from_tensor_list              # the host repository's own helper (not on the hot path)
-        maps, pos = core.backbone(nested_tensor_from_tensor_list(images))
+        try:
+            from utils import nested_tensor_from_tensor_list          # the host repository's own helper (not on the hot path)
+        except Exception:
+            from .detr import nested_tensor_from_tensor_list          # stand-alone: the local restatement (detr.py)
+        maps, pos = core.backbone(nested_tensor_from_tensor_list(list(images)))
         src, mask = maps[-1].decompose()
         tokens = core.input_proj(src).flatten(2).permute(2, 0, 1)
         feats = core.transformer.encoder(tokens, src_key_padding_mask=mask.flatten(1), pos=pos[-1].flatten(2).permute(2, 0, 1))
