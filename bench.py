@@ -296,6 +296,9 @@ def run_rank(args):
                        "parallelism": "dp%d" % world},
             "loss": None if loss is None else float(loss), "loss_first_step": first_loss,
             "roofline": roof,
+            # SURVEY 8d priced the path at 2.996 (fwd) / 8.99 (fwd+bwd) GFLOP per ordered pair, taking conv3 / fc1 per pair as
+            # irreducible; with the shared windows most of that is no longer executed, so this is an equivalence, not a rate
+            "survey_equivalent_tflops": round(value / max(world, 1) * (2.996e9 if args.forward_only else 8.99e9) / 1e12, 1),
             "shared_windows": None if xw is None else {"pair_specific": n_x, "of": P * 64, "fraction": round(n_x / max(P * 64, 1), 4),
                                                        "note": "conv3 and fc1 run per pair only on these pooling windows; the rest is computed "
                                                                "once per object (csrc/kernels_shared.hip)"},
