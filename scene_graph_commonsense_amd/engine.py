@@ -446,24 +446,23 @@ class RelHeadEngine:
         self.expand(U, V, sub_idx, obj_idx, P, z, dense=dense, pixrect=None if plan is None else plan["pixrect"])
         am = ws.get("argmax", P * 65536, torch.uint8) if keep_argmax else None
         h1 = ws.get("h1", Ppad * 4096, torch.float16)
-        wm = None
         if shared is not None and shared_fc1_enabled():
+            # conv3 and fc1 over shared windows: the rows fc1 multiplies are written window-major, y [P, 65536] never exists
             n_obj = int(shared[1].shape[0])
             wm = self.window_major_rows(plan, P, 2 * n_obj)
             ywm = ws.get("ywm", wm["rows"] * 1024, torch.float16)
             self.conv3_shared(plan, z, U, V, shared[0], shared[1], sub_idx, obj_idx, P, ywm, am, None, wm=wm)
             self.fc1_shared(wm, ywm, shared[0], sub_idx, obj_idx, plan["incl"], P, n_obj, h1, train, seeds[0])
-        y = ws.get("y", Ppad * 65536, torch.float16) if wm is None else None
-        if wm is not None:
-            pass
-        elif shared is not None:
-            self.conv3_shared(plan, z, U, V, shared[0], shared[1], sub_idx, obj_idx, P, y, am, None)
         else:
-            self._timed("conv3_fwd", lambda: _lib.check(lib.sgc_conv3_relu_pool(_lib.ptr(z), _lib.ptr(self.w["w3r"]), _lib.ptr(self.w["b3"]), _lib.ptr(y),
-                                               _lib.ptr(am), _lib.ptr(None), P, self._st()), "sgc_conv3_relu_pool"))
-        if wm is None:
+            y = ws.get("y", Ppad * 65536, torch.float16)
+            if shared is not None:
+                self.conv3_shared(plan, z, U, V, shared[0], shared[1], sub_idx, obj_idx, P, y, am, None)
+            else:
+                self._timed("conv3_fwd", lambda: _lib.check(lib.sgc_conv3_relu_pool(_lib.ptr(z), _lib.ptr(self.w["w3r"]), _lib.ptr(self.w["b3"]),
+                                                                                   _lib.ptr(y), _lib.ptr(am), _lib.ptr(None), P, self._st()),
+                                                            "sgc_conv3_relu_pool"))
             self._timed("fc1_fwd", lambda: _lib.check(lib.sgc_fc1_relu(_lib.ptr(y), _lib.ptr(self.w["w1p"]), _lib.ptr(self.w["bf1"]), _lib.ptr(h1), P, 65536,
-                                        int(train), ctypes.c_uint(seeds[0]), self._st()), "sgc_fc1_relu"))
+                                                                       int(train), ctypes.c_uint(seeds[0]), self._st()), "sgc_fc1_relu"))
         p = ws.get("p", Ppad * 512, torch.float32)
         self._timed("fc2_fwd", lambda: _lib.check(lib.sgc_fc2_labels_relu(_lib.ptr(h1), _lib.ptr(self.w["w2m"]), _lib.ptr(self.w["bf2"]), _lib.ptr(lsub),
                                            _lib.ptr(lobj), _lib.ptr(sub_idx), _lib.ptr(obj_idx), _lib.ptr(p), P,
@@ -611,38 +610,37 @@ class RelHeadEngine:
         narrow = share and os.environ.get("SGC_SHARED_BWD", "1") != "0"
         self.expand(ctx.uv[0], ctx.uv[1], sub_idx, obj_idx, P, z, z_bf, amz, dense=dense, pixrect=plan["pixrect"] if narrow else None)
         ctx.z_bf = z_bf
-        y = sc.get("y", Ppad * 65536, torch.float16)
-        y_bf = ws.get("y_bf", Ppad * 65536, torch.bfloat16)         # bf16 copy for the fc1 weight gradient, written by the same epilogue
-        if Ppad > P:
-            Workspace._zero(y_bf[P * 65536:])
-        am = ws.get("argmax", P * 65536, torch.uint8)
-        ctx.shared = None
-        wm = None
+        am = ws.get("argmax", P * 65536, torch.uint8)               # conv3 routing codes (shared path: only the rows of X windows)
         h1 = ws.get("h1", Ppad * 4096, torch.float16)
+        tails = (z_bf[P * 18 * 18 * 512:], amz[P * 256 * 256:])
+        ctx.shared, ctx.y, ctx.y_bf = None, None, None
         if narrow and shared_fc1_enabled():
-            # fc1 over window-major rows: y and its bf16 copy exist only as the rows fc1 multiplies (per-object rows + X entries)
+            # conv3 and fc1 over shared windows: y and its bf16 copy exist only as the window-major rows fc1 multiplies
             wm = self.window_major_rows(plan, P, 2 * ctx.n_obj)
             ywm = sc.get("ywm", wm["rows"] * 1024, torch.float16)
             ywm_bf = ws.get("ywm_bf", wm["rows"] * 1024, torch.bfloat16)
-            ctx.shared = self.conv3_shared(plan, z, ctx.uv[0], ctx.uv[1], bbox, obj_img, sub_idx, obj_idx, P, ywm, am, ywm_bf,
-                                           keep=(z_bf[P * 18 * 18 * 512:], amz[P * 256 * 256:]), wm=wm)
+            ctx.shared = self.conv3_shared(plan, z, ctx.uv[0], ctx.uv[1], bbox, obj_img, sub_idx, obj_idx, P, ywm, am, ywm_bf, keep=tails, wm=wm)
             ctx.shared["ywm_bf"] = ywm_bf
             self.fc1_shared(wm, ywm, bbox, sub_idx, obj_idx, plan["incl"], P, ctx.n_obj, h1, dropout, seeds[0])
-        elif share:
-            ctx.shared = self.conv3_shared(plan, z, ctx.uv[0], ctx.uv[1], bbox, obj_img, sub_idx, obj_idx, P, y, am, y_bf,
-                                           keep=(z_bf[P * 18 * 18 * 512:], amz[P * 256 * 256:]))
         else:
-            self._timed("conv3_fwd", lambda: _lib.check(lib.sgc_conv3_relu_pool(_lib.ptr(z), _lib.ptr(self.w["w3r"]), _lib.ptr(self.w["b3"]), _lib.ptr(y), _lib.ptr(am),
-                                               _lib.ptr(y_bf), P, self._st()), "sgc_conv3_relu_pool"))
-        ctx.y_bf = y_bf
-        if wm is None:
+            y = sc.get("y", Ppad * 65536, torch.float16)
+            y_bf = ws.get("y_bf", Ppad * 65536, torch.bfloat16)     # bf16 copy for the fc1 weight gradient, written by the same epilogue
+            if Ppad > P:
+                Workspace._zero(y_bf[P * 65536:])
+            if share:
+                ctx.shared = self.conv3_shared(plan, z, ctx.uv[0], ctx.uv[1], bbox, obj_img, sub_idx, obj_idx, P, y, am, y_bf, keep=tails)
+            else:
+                self._timed("conv3_fwd", lambda: _lib.check(lib.sgc_conv3_relu_pool(_lib.ptr(z), _lib.ptr(self.w["w3r"]), _lib.ptr(self.w["b3"]),
+                                                                                   _lib.ptr(y), _lib.ptr(am), _lib.ptr(y_bf), P, self._st()),
+                                                            "sgc_conv3_relu_pool"))
             self._timed("fc1_fwd", lambda: _lib.check(lib.sgc_fc1_relu(_lib.ptr(y), _lib.ptr(self.w["w1p"]), _lib.ptr(self.w["bf1"]), _lib.ptr(h1), P, 65536,
-                                        int(dropout), ctypes.c_uint(seeds[0]), self._st()), "sgc_fc1_relu"))
+                                                                       int(dropout), ctypes.c_uint(seeds[0]), self._st()), "sgc_fc1_relu"))
+            ctx.y, ctx.y_bf = y, y_bf
         p = ws.get("p", Ppad * 512, torch.float32)
         self._timed("fc2_fwd", lambda: _lib.check(lib.sgc_fc2_labels_relu(_lib.ptr(h1), _lib.ptr(self.w["w2m"]), _lib.ptr(self.w["bf2"]), _lib.ptr(ctx.lsub),
                                            _lib.ptr(ctx.lobj), _lib.ptr(sub_idx), _lib.ptr(obj_idx), _lib.ptr(p), P, int(dropout),
                                            ctypes.c_uint(seeds[1]), self._st()), "sgc_fc2_labels_relu"))
-        ctx.z, ctx.amz, ctx.y, ctx.am, ctx.h1, ctx.p = z, amz, y, am, h1, p
+        ctx.z, ctx.amz, ctx.am, ctx.h1, ctx.p = z, amz, am, h1, p
         ctx.out = self.head(p, P)
         return ctx
 
@@ -747,46 +745,10 @@ class RelHeadEngine:
                    "sgc_fc2_dgrad"))
 
         # ---- fc1
-        wm = ctx.shared.get("wm") if getattr(ctx, "shared", None) is not None else None
-        if wm is not None:
-            # window-major rows (csrc/kernels_shared.hip): per-object sums of dh1 + one copy of dh1 per X entry, then grouped GEMMs
-            sh = ctx.shared
-            gwm = ws.get("gwm", wm["rows"] * 4096, torch.bfloat16)
-            self._timed("fc1_bwd_rows", lambda: (
-                _lib.check(lib.sgc_fc1_gsum(_lib.ptr(dh1), _lib.ptr(ctx.bbox), _lib.ptr(ctx.sub_idx), _lib.ptr(ctx.obj_idx), _lib.ptr(sub_csr[0]),
-                                            _lib.ptr(sub_csr[1]), _lib.ptr(obj_csr[0]), _lib.ptr(obj_csr[1]), _lib.ptr(wm["goff"]), n_obj,
-                                            _lib.ptr(gwm), st()), "sgc_fc1_gsum"),
-                _lib.check(lib.sgc_fc1_xrows(_lib.ptr(dh1), _lib.ptr(sh["gather"]), _lib.ptr(wm["dest"]), wm["E"], _lib.ptr(wm["goff"]),
-                                             _lib.ptr(wm["gend"]), _lib.ptr(gwm), _lib.ptr(sh["ywm_bf"]), st()), "sgc_fc1_xrows")))
-            with side():
-                dW1p = ws.get("dW1p", 4096 * 65536, torch.float32)
-                self._timed("fc1_wgrad", lambda: _lib.check(lib.sgc_fc1_windows_wgrad(_lib.ptr(gwm), _lib.ptr(sh["ywm_bf"]), _lib.ptr(wm["goff"]),
-                                                                                      _lib.ptr(dW1p), wm["rows"], st()), "sgc_fc1_windows_wgrad"))
-                gfc1 = torch.empty(4096, 65536, dtype=torch.float32, device=dev)
-                _lib.check(lib.sgc_transpose_cast(_lib.ptr(dW1p), _lib.ptr(gfc1), 2, 4096, 16, _c_long(65536), _c_long(64), _c_long(1024),
-                                                  _c_long(65536), _c_long(4096), _c_long(64), st()), "sgc_transpose_cast")
-                grads["fc1.weight"] = gfc1
-                if grad_hook is not None:
-                    grad_hook("fc1.weight", grads["fc1.weight"])
-                grads["fc1.bias"] = self._colsum(dh1, Ppad, 4096)
-            dy = ws.get("dywm", wm["rows"] * 1024, torch.bfloat16)
-            self._timed("fc1_dgrad", lambda: _lib.check(lib.sgc_fc1_windows_dgrad(_lib.ptr(gwm), _lib.ptr(w["w1pT"]), _lib.ptr(wm["tile_group"]),
-                                                                                  _lib.ptr(dy), wm["rows"], st()), "sgc_fc1_windows_dgrad"))
+        if getattr(ctx, "shared", None) is not None and ctx.shared.get("wm") is not None:
+            dy = self._fc1_backward_rows(ctx, dh1, sub_csr, obj_csr, side, grads, grad_hook)
         else:
-          with side():
-            y_bf = ctx.y_bf
-            dW1p = ws.get("dW1p", 4096 * 65536, torch.float32)
-            self._timed("fc1_wgrad", lambda: _lib.check(lib.sgc_fc1_wgrad(_lib.ptr(dh1), _lib.ptr(y_bf), _lib.ptr(dW1p), Ppad, 65536, st()), "sgc_fc1_wgrad"))
-            # back to the reference column order (c*64 + window): 64x64 tile transposes, f32 -> f32
-            gfc1 = torch.empty(4096, 65536, dtype=torch.float32, device=dev)
-            _lib.check(lib.sgc_transpose_cast(_lib.ptr(dW1p), _lib.ptr(gfc1), 2, 4096, 16, _c_long(65536), _c_long(64), _c_long(1024),
-                                              _c_long(65536), _c_long(4096), _c_long(64), st()), "sgc_transpose_cast")
-            grads["fc1.weight"] = gfc1
-            if grad_hook is not None:          # largest gradient (97 % of the bytes) is ready first: overlap its all-reduce
-                grad_hook("fc1.weight", grads["fc1.weight"])
-            grads["fc1.bias"] = self._colsum(dh1, Ppad, 4096)
-          dy = ws.get("dy", Ppad * 65536, torch.bfloat16)
-          self._timed("fc1_dgrad", lambda: _lib.check(lib.sgc_fc1_dgrad(_lib.ptr(dh1), _lib.ptr(w["w1pT"]), _lib.ptr(dy), P, 65536, st()), "sgc_fc1_dgrad"))
+            dy = self._fc1_backward_pairs(ctx, dh1, side, grads, grad_hook)
 
         # ---- conv3
         nparts = ctypes.c_int(0)
@@ -847,6 +809,51 @@ class RelHeadEngine:
             grads["conv2_1.weight"] = gc2
         side.join()                              # the caller's stream continues only after every gradient is complete
         return loss, grads
+
+    def _fc1_finish_wgrad(self, dW1p, dh1, Ppad, grads, grad_hook):
+        """dW1p [4096][(window, channel)] -> the reference's column order (channel*64 + window), bias gradient, early all-reduce hook."""
+        lib, dev, st = self.lib, self.device, self._st
+        gfc1 = torch.empty(4096, 65536, dtype=torch.float32, device=dev)
+        _lib.check(lib.sgc_transpose_cast(_lib.ptr(dW1p), _lib.ptr(gfc1), 2, 4096, 16, _c_long(65536), _c_long(64), _c_long(1024),
+                                          _c_long(65536), _c_long(4096), _c_long(64), st()), "sgc_transpose_cast")
+        grads["fc1.weight"] = gfc1
+        if grad_hook is not None:              # largest gradient (97 % of the bytes) is ready first: overlap its all-reduce
+            grad_hook("fc1.weight", grads["fc1.weight"])
+        grads["fc1.bias"] = self._colsum(dh1, Ppad, 4096)
+
+    def _fc1_backward_pairs(self, ctx, dh1, side, grads, grad_hook):
+        """fc1 backward as two [pairs, 65536] GEMMs; returns dy [Ppad*64, 1024] (pair-major pooled gradient)."""
+        lib, w, ws, st, P, Ppad = self.lib, self.w, self.scratch, self._st, ctx.P, ctx.Ppad
+        with side():
+            dW1p = ws.get("dW1p", 4096 * 65536, torch.float32)
+            self._timed("fc1_wgrad", lambda: _lib.check(lib.sgc_fc1_wgrad(_lib.ptr(dh1), _lib.ptr(ctx.y_bf), _lib.ptr(dW1p), Ppad, 65536, st()),
+                                                        "sgc_fc1_wgrad"))
+            self._fc1_finish_wgrad(dW1p, dh1, Ppad, grads, grad_hook)
+        dy = ws.get("dy", Ppad * 65536, torch.bfloat16)
+        self._timed("fc1_dgrad", lambda: _lib.check(lib.sgc_fc1_dgrad(_lib.ptr(dh1), _lib.ptr(w["w1pT"]), _lib.ptr(dy), P, 65536, st()), "sgc_fc1_dgrad"))
+        return dy
+
+    def _fc1_backward_rows(self, ctx, dh1, sub_csr, obj_csr, side, grads, grad_hook):
+        """fc1 backward over the window-major rows (``csrc/kernels_shared.hip``): per-object sums of dh1 + one copy of dh1 per X entry,
+        then the grouped weight- and data-gradient GEMMs; returns dywm [rows, 1024] (window-major pooled gradient)."""
+        lib, w, ws, st, sh = self.lib, self.w, self.scratch, self._st, ctx.shared
+        wm = sh["wm"]
+        gwm = ws.get("gwm", wm["rows"] * 4096, torch.bfloat16)
+        self._timed("fc1_bwd_rows", lambda: (
+            _lib.check(lib.sgc_fc1_gsum(_lib.ptr(dh1), _lib.ptr(ctx.bbox), _lib.ptr(ctx.sub_idx), _lib.ptr(ctx.obj_idx), _lib.ptr(sub_csr[0]),
+                                        _lib.ptr(sub_csr[1]), _lib.ptr(obj_csr[0]), _lib.ptr(obj_csr[1]), _lib.ptr(wm["goff"]), ctx.n_obj,
+                                        _lib.ptr(gwm), st()), "sgc_fc1_gsum"),
+            _lib.check(lib.sgc_fc1_xrows(_lib.ptr(dh1), _lib.ptr(sh["gather"]), _lib.ptr(wm["dest"]), wm["E"], _lib.ptr(wm["goff"]),
+                                         _lib.ptr(wm["gend"]), _lib.ptr(gwm), _lib.ptr(sh["ywm_bf"]), st()), "sgc_fc1_xrows")))
+        with side():
+            dW1p = ws.get("dW1p", 4096 * 65536, torch.float32)
+            self._timed("fc1_wgrad", lambda: _lib.check(lib.sgc_fc1_windows_wgrad(_lib.ptr(gwm), _lib.ptr(sh["ywm_bf"]), _lib.ptr(wm["goff"]),
+                                                                                  _lib.ptr(dW1p), wm["rows"], st()), "sgc_fc1_windows_wgrad"))
+            self._fc1_finish_wgrad(dW1p, dh1, ctx.Ppad, grads, grad_hook)
+        dy = ws.get("dywm", wm["rows"] * 1024, torch.bfloat16)
+        self._timed("fc1_dgrad", lambda: _lib.check(lib.sgc_fc1_windows_dgrad(_lib.ptr(gwm), _lib.ptr(w["w1pT"]), _lib.ptr(wm["tile_group"]),
+                                                                              _lib.ptr(dy), wm["rows"], st()), "sgc_fc1_windows_dgrad"))
+        return dy
 
     def _conv3_backward_pairs(self, ctx, dy, side, sl, grads):
         """conv3 backward over every window of every pair (no per-object sharing): bias + weight gradient, returns dz."""
