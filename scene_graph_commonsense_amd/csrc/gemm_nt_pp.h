@@ -232,10 +232,12 @@ static int launch_gemm_nt_pp_conv_gather(NtParams p, hipStream_t stream) {
     if (p.lgS != 4 || (p.Cin & 63) || p.K != 9 * p.Cin || (p.N & 255)) return SGC_ERR_ARG;
     p.tiles_m = (p.M + 255) / 256;
     p.tiles_n = p.N / 256;
-    p.patch_aligned = 0;
+    static int al = -1;               // SGC_ACG_ALIGNED=1: grid padded to whole per-XCD patches (A/B hook)
+    if (al < 0) { const char* e = getenv("SGC_ACG_ALIGNED"); al = e ? atoi(e) : 0; }
+    p.patch_aligned = al;
     auto kern = gemm_nt_pp_kernel<ELEM, EPI, 0, 1>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    SGC_LAUNCH(kern, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(512), LDS, stream, p);
+    SGC_LAUNCH(kern, dim3((unsigned)(al ? xcd_patch_grid(p.tiles_m, p.tiles_n) : p.tiles_m * p.tiles_n)), dim3(512), LDS, stream, p);
     SGC_CHECK_LAUNCH();
     return SGC_OK;
 }

@@ -384,7 +384,10 @@ static int launch_gemm_tn_pp(TnParams p, int splits, int* slabs_out, hipStream_t
         p.xcd_map = (xm && BMODE == BMODE_CONV && p.tiles_m == 4 && p.tiles_n == 18) ? 1 : 0;
         static int xp = -1;          // SGC_TN_PATCH=0: 16x16 super-tiles instead of per-XCD 4x8 patches (A/B hook)
         if (xp < 0) { const char* e = getenv("SGC_TN_PATCH"); xp = e ? atoi(e) : 1; }
-        p.xcd_patch = (xp && !p.xcd_map && ((p.tiles_m * p.tiles_n) & 7) == 0) ? 1 : 0;
+        // per-XCD 4(M) x 8(N) patches need M tiles to share: with 4 M tiles (weight gradient over the pair-specific windows, 4 x 18
+        // tiles x 7 splits) a patch is a whole tile column block and the 9 tiles an XCD gets per split straddle two of them - the
+        // 16 x 16 super-tile walk measured 7.61 vs 8.48 ms there (alternated twice in one box); grids with >= 8 M tiles keep the patches
+        p.xcd_patch = (xp && !p.xcd_map && ((p.tiles_m * p.tiles_n) & 7) == 0 && p.tiles_m >= 8) ? 1 : 0;
     }
     SGC_LAUNCH(kern, dim3((unsigned)(p.tiles_m * p.tiles_n * splits)), dim3(512), LDS, stream, p);
     SGC_CHECK_LAUNCH();
