@@ -1,0 +1,151 @@
+"""The individual entry points of csrc/kernels_shared.hip against numpy / torch restatements on random inputs (the path as a whole
+is checked in tests/test_shared_conv3_gpu.py): window plan, packed pixel rectangles, un-pool of listed windows, im2col / col2im of
+the column forms, prefix sums and the per-object gradient sums of the shared fc1."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _lib():
+    from scene_graph_commonsense_amd import _lib as L
+    return L, L.load()
+
+
+def _boxes(rng, n):
+    x0, y0 = rng.integers(0, 30, n), rng.integers(0, 30, n)
+    b = np.stack([x0, x0 + rng.integers(1, 33 - x0), y0, y0 + rng.integers(1, 33 - y0)], axis=1)
+    b[0] = [0, 32, 0, 32]
+    b[1] = [7, 7, 3, 9]                                     # empty box
+    return b.astype(np.int32)
+
+
+def _plan(rng, n=9):
+    """boxes, all ordered pairs, device plan (count / incl / gather / pixrect) + the numpy rectangles."""
+    from scene_graph_commonsense_amd.pairs import object_window_rects
+    L, lib = _lib()
+    bb = _boxes(rng, n)
+    sub, obj = np.array([(i, j) for i in range(n) for j in range(n) if i != j], dtype=np.int32).T
+    P = len(sub)
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    bb_d, sub_d, obj_d = d(bb), d(sub), d(obj)
+    cnt = torch.empty(P, dtype=torch.int32, device=DEV)
+    pix = torch.empty(P, dtype=torch.int32, device=DEV)
+    L.check(lib.sgc_shared_windows_count(L.ptr(bb_d), L.ptr(sub_d), L.ptr(obj_d), P, L.ptr(cnt), L.ptr(pix), L.stream_ptr()), "count")
+    incl = torch.cumsum(cnt, 0, dtype=torch.int32)
+    gather = torch.full((P * 64,), -1, dtype=torch.int32, device=DEV)
+    L.check(lib.sgc_shared_windows_fill(L.ptr(bb_d), L.ptr(sub_d), L.ptr(obj_d), P, L.ptr(incl), L.ptr(gather), L.stream_ptr()), "fill")
+    R = object_window_rects(bb)
+    return dict(bb=bb, sub=sub, obj=obj, P=P, bb_d=bb_d, sub_d=sub_d, obj_d=obj_d, cnt=cnt, incl=incl, gather=gather, pix=pix, R=R)
+
+
+def test_window_plan_and_pixel_rectangles():
+    pl = _plan(np.random.default_rng(0))
+    R, want_g, want_pix = pl["R"], [], []
+    for p, (i, j) in enumerate(zip(pl["sub"], pl["obj"])):
+        x0, x1, y0, y1 = max(R[i, 0], R[j, 0]), min(R[i, 1], R[j, 1]), max(R[i, 2], R[j, 2]), min(R[i, 3], R[j, 3])
+        if x1 <= x0 or y1 <= y0:
+            want_pix.append(0)
+            continue
+        want_g += [p * 64 + wy * 8 + wx for wy in range(y0, y1) for wx in range(x0, x1)]
+        want_pix.append(max(2 * y0 - 1, 0) | (min(2 * y1 + 1, 16) << 5) | (max(2 * x0 - 1, 0) << 10) | (min(2 * x1 + 1, 16) << 15))
+    E = int(pl["incl"][-1])
+    assert E == len(want_g) and pl["gather"][:E].cpu().tolist() == want_g and int(pl["gather"][E]) == -1
+    assert pl["pix"].cpu().tolist() == want_pix
+
+
+def test_unpool_im2col_col2im_of_the_listed_windows():
+    L, lib = _lib()
+    rng = np.random.default_rng(1)
+    pl = _plan(rng, n=6)
+    P, E = pl["P"], int(pl["incl"][-1])
+    Epad = (E + 15) // 16 * 16
+    g = pl["gather"][:E].long()
+    gn = pl["incl"][P - 1:]
+    # ---- un-pool: dy3x[4e+q][c] = (code == q) ? dy[gather[e]][c] : 0, zero rows behind the list, bias partials over live routes
+    dy = torch.randn(P * 64, 1024, device=DEV).bfloat16()
+    am = torch.randint(0, 5, (P * 64, 1024), device=DEV, dtype=torch.uint8)
+    dy3x = torch.full((Epad * 4, 1024), float("nan"), device=DEV).bfloat16()
+    bpart = torch.zeros(1024, 1024, device=DEV)
+    nparts = ctypes.c_int(0)
+    L.check(lib.sgc_windows_unpool(L.ptr(dy), L.ptr(am), L.ptr(pl["gather"]), L.ptr(gn), None, Epad, L.ptr(dy3x), L.ptr(bpart), ctypes.byref(nparts),
+                                   L.stream_ptr()), "unpool")
+    want = torch.zeros(Epad, 4, 1024, device=DEV)
+    for q in range(4):
+        want[:E, q] = torch.where(am[g] == q, dy[g].float(), torch.zeros((), device=DEV))
+    assert torch.equal(dy3x.float().view(Epad, 4, 1024), want)
+    live = torch.where(am[g] < 4, dy[g].float(), torch.zeros((), device=DEV)).sum(0)
+    assert torch.allclose(bpart[:nparts.value].sum(0), live, atol=1e-3, rtol=1e-4)
+    # ---- im2col: zcol[4e+q][tap] = z[pair][y+ky][x+kx]
+    z = torch.randn(P, 18, 18, 512, device=DEV).bfloat16()
+    zcol = torch.full((Epad * 4, 9, 512), float("nan"), device=DEV).bfloat16()
+    L.check(lib.sgc_windows_im2col(L.ptr(z), L.ptr(pl["gather"]), L.ptr(gn), Epad, L.ptr(zcol), L.stream_ptr()), "im2col")
+    pair, w = (g >> 6), (g & 63)
+    for q in range(4):
+        y, x = 2 * (w >> 3) + (q >> 1), 2 * (w & 7) + (q & 1)
+        for tap in range(9):
+            assert torch.equal(zcol.view(Epad, 4, 9, 512)[:E, q, tap], z[pair, y + tap // 3, x + tap % 3])
+    if Epad > E:
+        assert float(zcol.view(Epad, 4, 9, 512)[E:].float().abs().max()) == 0.0          # padding entries are zero rows
+    # ---- col2im: dz[pair][pixel] = sum over taps of col[row of (pixel - tap + 1)][tap], only inside the pair's pixel rectangle
+    col = torch.randn(Epad * 4, 9, 512, device=DEV).bfloat16()
+    dz = torch.full((P * 256, 512), float("nan"), device=DEV).bfloat16()
+    L.check(lib.sgc_windows_col2im(L.ptr(col), L.ptr(pl["bb_d"]), L.ptr(pl["sub_d"]), L.ptr(pl["obj_d"]), L.ptr(pl["incl"]), P, L.ptr(dz),
+                                   L.stream_ptr()), "col2im")
+    acc = torch.zeros(P, 18, 18, 512, device=DEV)                 # padded scatter form
+    colf = col.float().view(Epad, 4, 9, 512)
+    for q in range(4):
+        y, x = 2 * (w >> 3) + (q >> 1), 2 * (w & 7) + (q & 1)
+        for tap in range(9):
+            acc.index_put_((pair, y + tap // 3, x + tap % 3), colf[:E, q, tap], accumulate=True)
+    pix = pl["pix"].cpu().numpy()
+    dzv = dz.float().view(P, 256, 512)
+    for p in range(P):
+        r = int(pix[p])
+        Y0, Y1, X0, X1 = r & 31, (r >> 5) & 31, (r >> 10) & 31, (r >> 15) & 31
+        for Y in range(16):
+            for X in range(16):
+                m3 = 4 * ((Y >> 1) * 8 + (X >> 1)) + (Y & 1) * 2 + (X & 1)
+                if Y0 <= Y < Y1 and X0 <= X < X1:
+                    assert torch.allclose(dzv[p, m3], acc[p, Y + 1, X + 1], atol=0.07, rtol=2e-2)       # bf16 output of up to 9 terms
+                else:
+                    assert torch.isnan(dzv[p, m3]).all()                                             # never written
+
+
+def test_fc1_prefix_sums_and_per_object_gradient_sums():
+    from scene_graph_commonsense_amd.pairs import window_major_layout
+    L, lib = _lib()
+    rng = np.random.default_rng(2)
+    pl = _plan(rng, n=7)
+    n_obj, P, n2 = 7, pl["P"], 14
+    goff, _ = window_major_layout(np.zeros(64, dtype=np.int64), n2)
+    goff_d = torch.from_numpy(goff).to(DEV)
+    rows = int(goff[64])
+    owm = torch.randn(rows, 4096, device=DEV)
+    S = torch.full((n2, 9, 9, 4096), float("nan"), device=DEV)
+    L.check(lib.sgc_fc1_integral(L.ptr(owm), L.ptr(goff_d), n2, L.ptr(S), L.stream_ptr()), "integral")
+    T = torch.stack([owm[int(goff[w]):int(goff[w]) + n2] for w in range(64)], dim=1).view(n2, 8, 8, 4096)
+    want = torch.zeros(n2, 9, 9, 4096, device=DEV)
+    want[:, 1:, 1:] = T.cumsum(1).cumsum(2)
+    assert torch.allclose(S, want, atol=1e-4, rtol=1e-5)
+    # ---- per-object sums of dh1: role 0 = windows outside the partner's rectangle, role 1 = inside the own, outside the partner's
+    from scene_graph_commonsense_amd.engine import csr_by
+    dh = torch.randn(P, 4096, device=DEV).bfloat16()
+    sp, sl = (torch.from_numpy(a).to(DEV) for a in csr_by(pl["sub"], n_obj))
+    op, ol = (torch.from_numpy(a).to(DEV) for a in csr_by(pl["obj"], n_obj))
+    gwm = torch.zeros(rows, 4096, device=DEV).bfloat16()
+    L.check(lib.sgc_fc1_gsum(L.ptr(dh), L.ptr(pl["bb_d"]), L.ptr(pl["sub_d"]), L.ptr(pl["obj_d"]), L.ptr(sp), L.ptr(sl), L.ptr(op), L.ptr(ol),
+                             L.ptr(goff_d), n_obj, L.ptr(gwm), L.stream_ptr()), "gsum")
+    R = pl["R"]
+    wy, wx = np.divmod(np.arange(64), 8)
+    ins = lambda o: (wx >= R[o, 0]) & (wx < R[o, 1]) & (wy >= R[o, 2]) & (wy < R[o, 3])
+    want = torch.zeros(2, n_obj, 64, 4096, device=DEV)
+    for p, (i, j) in enumerate(zip(pl["sub"], pl["obj"])):
+        want[0, i][torch.from_numpy(~ins(j)).to(DEV)] += dh[p].float()
+        want[1, j][torch.from_numpy(ins(j) & ~ins(i)).to(DEV)] += dh[p].float()
+    got = torch.stack([gwm[int(goff[w]):int(goff[w]) + n2].float() for w in range(64)], dim=1).view(2, n_obj, 64, 4096)
+    assert torch.allclose(got, want, atol=0.05, rtol=1e-2)                 # bf16 output of sums of up to 6 terms
