@@ -22,6 +22,9 @@ def process_image_features(args, images, detr, rank):
     callable mapping the stacked images to the feature map (precomputed features: pass ``lambda x: x``)."""
     images = torch.stack(list(images)).to(rank)
     core = getattr(detr, "module", detr)
+    half = args["models"].get("feature_encoder_dtype")         # "bf16": the frozen extractor under bf16 autocast (detr.DETR.encode); default f32 as the reference
+    if half in ("bf16", "bfloat16") and hasattr(core, "encode"):
+        return core.encode(images, feature_size=args["models"]["feature_size"], autocast=torch.bfloat16)
     if not hasattr(core, "backbone"):
         feats = core(images)
     else:
