@@ -92,8 +92,9 @@ int sgc_shared_windows_assemble(const int* bbox, const int* sub_idx, const int* 
  *                                    windows (the other rows of a real pair's dz are never written nor read)
  *   sgc_pair_contract_windows        sgc_pair_contract over those rows + the pseudo-pairs (pair index n_real_pairs + o for (o, bg),
  *                                    n_real_pairs + n_obj + o for (bg, o)); dU_pad has n_obj + n_img objects, object n_obj + b = the
- *                                    background of image b (objects img_ptr[b] .. img_ptr[b+1]); pixel_rect from
- *                                    sgc_shared_windows_count */
+ *                                    background of image b (objects img_ptr[b] .. img_ptr[b+1]); pixel_rect [n_real_pairs + 2*n_obj
+ *                                    (+ n_img)]: sgc_shared_windows_count for the real pairs, the whole map (16 << 5 | 16 << 15) or
+ *                                    sgc_shared_objects_count for the pseudo-pairs */
 int sgc_shared_windows_assemble_bwd(const int* bbox, const int* sub_idx, const int* obj_idx, const int* sub_ptr, const int* sub_list,
                                     const int* obj_ptr, const int* obj_list, int n_obj, const void* dy, void* dy_obj, void* stream);
 int sgc_windows_unpool(const void* dy, const unsigned char* argmax, const int* gather, const int* gather_n, const int* dest,
@@ -104,7 +105,24 @@ int sgc_windows_dgrad_cols(const void* dy3x, const void* w3col, void* col, int r
 int sgc_windows_col2im(const void* col, const int* bbox, const int* sub_idx, const int* obj_idx, const int* count_incl, int n_pairs,
                        void* dz, void* stream);
 int sgc_pair_contract_windows(const void* dz, const unsigned char* amz, const int* ptr, const int* list, const int* pixel_rect,
-                              const int* img_ptr, int role, int n_real_pairs, int n_obj, int n_img, void* dU_pad, void* stream);
+                              const int* img_ptr, int role, int n_real_pairs, int n_obj, int n_img, int bg_maps, void* dU_pad, void* stream);
+/* Second level of the same sharing: a per-object map equals the all-background map outside R_o, so a pseudo-pair is computed only
+ * on the windows of R_o - appended to the window list as entries of the "pair" n_real_pairs + ps (ps = role*n_obj + o) - and takes the
+ * rest from the background map of its image (pair n_real_pairs + 2*n_obj + image).  pixel_rect of sgc_pair_contract_windows then has
+ * n_real_pairs + 2*n_obj + n_img entries (pseudo-pairs: around R_o; background maps: everything) and bg_maps = 1.
+ *   sgc_shared_objects_count      count[ps] = |R_o|, pixel_rect[ps] (arrays offset to the pseudo-pairs)
+ *   sgc_shared_objects_fill       their entries of the window list (count_incl = inclusive prefix over real pairs + pseudo-pairs)
+ *   sgc_shared_objects_fill_rows  window-major rows (and pair-major routing rows) of the pseudo-pairs outside R_o = copies of the
+ *                                 background maps y_bg [n_img*64][1024]
+ *   sgc_shared_objects_bg_grad    dy_bg [n_img*64][1024] = the sum of the gradient rows of those copies
+ *   sgc_windows_col2im_objects    sgc_windows_col2im for the pseudo-pairs' entries */
+int sgc_shared_objects_count(const int* bbox, int n_obj, int* count, int* pixel_rect, void* stream);
+int sgc_shared_objects_fill(const int* bbox, int n_obj, int n_real_pairs, const int* count_incl, int* gather, void* stream);
+int sgc_shared_objects_fill_rows(const int* bbox, const int* obj_img, int n_obj, const int* goff, const void* y_bg, const void* y_bg_bf16,
+                                 const unsigned char* argmax_bg, void* ywm, void* ywm_bf16, unsigned char* argmax_ps, void* stream);
+int sgc_shared_objects_bg_grad(const int* bbox, const int* img_ptr, int n_obj, int n_img, const int* goff, const void* dywm, void* dy_bg,
+                               void* stream);
+int sgc_windows_col2im_objects(const void* col, const int* bbox, int n_obj, int n_real_pairs, const int* count_incl, void* dz, void* stream);
 
 /* fc1 over shared windows (csrc/kernels_shared.hip; model.py:148-149).  fc1 is a sum over conv3's 64 pooling windows and the I / J
  * windows of a pair are copies of per-object rows, so every row fc1 multiplies lives in one WINDOW-MAJOR row space: group w =

@@ -33,6 +33,8 @@ __device__ __forceinline__ WRect object_windows(const int* __restrict__ b) {
     return r;
 }
 
+__device__ __forceinline__ bool in_rect(const WRect& r, int wx, int wy) { return wx >= r.x0 && wx < r.x1 && wy >= r.y0 && wy < r.y1; }
+
 __device__ __forceinline__ WRect pair_windows(const WRect& a, const WRect& b) {
     WRect r{max(a.x0, b.x0), min(a.x1, b.x1), max(a.y0, b.y0), min(a.y1, b.y1)};
     if (r.x1 <= r.x0 || r.y1 <= r.y0) r = WRect{0, 0, 0, 0};
@@ -54,6 +56,83 @@ __global__ __launch_bounds__(256) void shared_count_kernel(const int* __restrict
     const WRect x = pair_windows(object_windows(bbox + 4 * sub[p]), object_windows(bbox + 4 * obj[p]));
     count[p] = (x.x1 - x.x0) * (x.y1 - x.y0);
     if (pixrect) pixrect[p] = pack_pixel_rect(x);
+}
+
+// Second level of sharing: the per-object maps themselves equal the all-background map outside R_o, so a pseudo-pair (o, bg) /
+// (bg, o) needs conv3 only on the windows of R_o; they are appended to the window list as entries of the "pair" n_real + ps.
+//   count[ps] = |R_o|, pixrect[ps] = the pixels within one pixel of R_o   (o = ps mod n_obj; arrays already offset to the pseudo-pairs)
+__global__ __launch_bounds__(256) void shared_count_objects_kernel(const int* __restrict__ bbox, int n_obj, int* __restrict__ count,
+                                                                   int* __restrict__ pixrect) {
+    const int ps = blockIdx.x * 256 + threadIdx.x;
+    if (ps >= 2 * n_obj) return;
+    const WRect r = object_windows(bbox + 4 * (ps >= n_obj ? ps - n_obj : ps));
+    count[ps] = (r.x1 - r.x0) * (r.y1 - r.y0);
+    pixrect[ps] = pack_pixel_rect(r);
+}
+
+__global__ __launch_bounds__(256) void shared_fill_objects_kernel(const int* __restrict__ bbox, int n_obj, int n_real,
+                                                                  const int* __restrict__ incl, int* __restrict__ gather) {
+    const int ps = blockIdx.x * 256 + threadIdx.x;
+    if (ps >= 2 * n_obj) return;
+    const WRect r = object_windows(bbox + 4 * (ps >= n_obj ? ps - n_obj : ps));
+    const int pair = n_real + ps;
+    int e = pair ? incl[pair - 1] : 0;
+    for (int wy = r.y0; wy < r.y1; ++wy)
+        for (int wx = r.x0; wx < r.x1; ++wx) gather[e++] = pair * 64 + wy * 8 + wx;
+}
+
+// Rows of the pseudo-pairs outside R_o: copies of the background map of the object's image (y_bg [n_img*64][1024] etc.), written to
+// the window-major row goff[w] + ps (y, bf16 copy) and to the pair-major routing row (n_real + ps)*64 + w.
+__global__ __launch_bounds__(256) void shared_fill_object_rows_kernel(const int* __restrict__ bbox, const int* __restrict__ obj_img,
+                                                                      int n_obj, const int* __restrict__ goff,
+                                                                      const uint4* __restrict__ y_bg, const uint4* __restrict__ ybf_bg,
+                                                                      const uint4* __restrict__ am_bg, uint4* __restrict__ ywm,
+                                                                      uint4* __restrict__ ywm_bf, uint4* __restrict__ am_ps, long n_rows) {
+    const int lane = threadIdx.x & 63;
+    for (long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6); row < n_rows; row += (long)gridDim.x * 4) {
+        const int ps = (int)(row >> 6), w = (int)(row & 63);
+        const int o = ps >= n_obj ? ps - n_obj : ps;
+        if (in_rect(object_windows(bbox + 4 * o), w & 7, w >> 3)) continue;         // computed for the object (window-list entry)
+        const long src = (long)obj_img[o] * 64 + w, dst = (long)goff[w] + ps;
+        ywm[dst * 128 + lane] = y_bg[src * 128 + lane];
+        ywm[dst * 128 + 64 + lane] = y_bg[src * 128 + 64 + lane];
+        if (ywm_bf) {
+            ywm_bf[dst * 128 + lane] = ybf_bg[src * 128 + lane];
+            ywm_bf[dst * 128 + 64 + lane] = ybf_bg[src * 128 + 64 + lane];
+        }
+        if (am_ps) am_ps[row * 64 + lane] = am_bg[src * 64 + lane];
+    }
+}
+
+// Transpose of that copy: dy_bg[b*64 + w] = sum over the pseudo-pairs ps of image b with w outside R_o of dywm[goff[w] + ps]
+__global__ __launch_bounds__(256) void shared_bg_grad_kernel(const int* __restrict__ bbox, const int* __restrict__ img_ptr, int n_obj,
+                                                             const int* __restrict__ goff, const u16* __restrict__ dywm,
+                                                             u16* __restrict__ dy_bg, long n_items) {
+    const int lane = threadIdx.x & 63;
+    for (long it = (long)blockIdx.x * 4 + (threadIdx.x >> 6); it < n_items; it += (long)gridDim.x * 4) {
+        const int b = (int)(it >> 6), w = (int)(it & 63);
+        float acc[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+        for (int role = 0; role < 2; ++role)
+            for (int o = img_ptr[b]; o < img_ptr[b + 1]; ++o) {
+                if (in_rect(object_windows(bbox + 4 * o), w & 7, w >> 3)) continue;
+                const u16* r = dywm + ((long)goff[w] + role * n_obj + o) * 1024 + lane * 8;
+                const uint4 a = *reinterpret_cast<const uint4*>(r), c = *reinterpret_cast<const uint4*>(r + 512);
+                const u16* ah = reinterpret_cast<const u16*>(&a);
+                const u16* ch = reinterpret_cast<const u16*>(&c);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { acc[k] += bf16_bits_to_f32(ah[k]); acc[8 + k] += bf16_bits_to_f32(ch[k]); }
+            }
+        uint4 oa, ob;
+        u16* oah = reinterpret_cast<u16*>(&oa);
+        u16* obh = reinterpret_cast<u16*>(&ob);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { oah[k] = f32_to_bf16_bits(acc[k]); obh[k] = f32_to_bf16_bits(acc[8 + k]); }
+        u16* dst = dy_bg + it * 1024 + lane * 8;
+        *reinterpret_cast<uint4*>(dst) = oa;
+        *reinterpret_cast<uint4*>(dst + 512) = ob;
+    }
 }
 
 // gather[e] = pair * 64 + window for the X windows of every pair, pairs in list order, windows row-major
@@ -101,8 +180,6 @@ __global__ __launch_bounds__(256) void shared_assemble_kernel(const int* __restr
     }
 }
 
-
-__device__ __forceinline__ bool in_rect(const WRect& r, int wx, int wy) { return wx >= r.x0 && wx < r.x1 && wy >= r.y0 && wy < r.y1; }
 
 // ------------------------------------------------------------------------------------------------ backward
 // Transpose of the assembly: the gradient of a per-object row is the sum of the gradients of its copies.
@@ -243,13 +320,10 @@ __global__ __launch_bounds__(256) void windows_im2col_kernel(const u16* __restri
 // dz[pair][pixel] = sum over the taps of col[row of the source pixel][tap]: the scatter half of the transposed convolution, written
 // as a gather so that every dz row has one writer.  Only the pixels within one pixel of the pair's X windows exist; one workgroup
 // per pair.
-__global__ __launch_bounds__(256) void windows_col2im_kernel(const u16* __restrict__ col, const int* __restrict__ bbox,
-                                                             const int* __restrict__ sub, const int* __restrict__ obj,
-                                                             const int* __restrict__ incl, u16* __restrict__ dz) {
-    const int p = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const WRect x = pair_windows(object_windows(bbox + 4 * sub[p]), object_windows(bbox + 4 * obj[p]));
+__device__ __forceinline__ void col2im_rect(const u16* __restrict__ col, const WRect& x, int off, long p, u16* __restrict__ dz) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (x.x1 <= x.x0) return;
-    const int off = p ? incl[p - 1] : 0, wdt = x.x1 - x.x0;
+    const int wdt = x.x1 - x.x0;
     const int Y0 = max(2 * x.y0 - 1, 0), Y1 = min(2 * x.y1 + 1, 16), X0 = max(2 * x.x0 - 1, 0), X1 = min(2 * x.x1 + 1, 16);
     const int nx = X1 - X0, n = (Y1 - Y0) * nx;
     for (int t = wv; t < n; t += 4) {
@@ -274,8 +348,24 @@ __global__ __launch_bounds__(256) void windows_col2im_kernel(const u16* __restri
 #pragma unroll
         for (int k = 0; k < 8; ++k) oh[k] = f32_to_bf16_bits(acc[k]);
         const int m3 = 4 * ((y >> 1) * 8 + (xx >> 1)) + (y & 1) * 2 + (xx & 1);
-        *reinterpret_cast<uint4*>(dz + ((long)p * 256 + m3) * 512 + lane * 8) = ov;
+        *reinterpret_cast<uint4*>(dz + (p * 256 + m3) * 512 + lane * 8) = ov;
     }
+}
+
+__global__ __launch_bounds__(256) void windows_col2im_kernel(const u16* __restrict__ col, const int* __restrict__ bbox,
+                                                             const int* __restrict__ sub, const int* __restrict__ obj,
+                                                             const int* __restrict__ incl, u16* __restrict__ dz) {
+    const int p = blockIdx.x;
+    const WRect x = pair_windows(object_windows(bbox + 4 * sub[p]), object_windows(bbox + 4 * obj[p]));
+    col2im_rect(col, x, p ? incl[p - 1] : 0, p, dz);
+}
+
+// the same for the window-list entries of the pseudo-pairs (pair index n_real + ps, windows R_o)
+__global__ __launch_bounds__(256) void windows_col2im_objects_kernel(const u16* __restrict__ col, const int* __restrict__ bbox, int n_obj,
+                                                                     int n_real, const int* __restrict__ incl, u16* __restrict__ dz) {
+    const int ps = blockIdx.x, pair = n_real + ps;
+    const WRect x = object_windows(bbox + 4 * (ps >= n_obj ? ps - n_obj : ps));
+    col2im_rect(col, x, pair ? incl[pair - 1] : 0, pair, dz);
 }
 
 // Pair contraction (csrc/kernels_bwd.hip:pair_contract_kernel) for the shared-window backward: a real pair contributes to pixel
@@ -285,7 +375,8 @@ __global__ __launch_bounds__(256) void windows_col2im_kernel(const u16* __restri
 __global__ __launch_bounds__(256) void pair_contract_windows_kernel(const u16* __restrict__ dz, const unsigned char* __restrict__ amz,
                                                                     const int* __restrict__ ptr, const int* __restrict__ list,
                                                                     const int* __restrict__ pixrect, const int* __restrict__ img_ptr,
-                                                                    int role, int n_real, int n_obj, u16* __restrict__ dU, long n_items) {
+                                                                    int role, int n_real, int n_obj, int bg_maps, u16* __restrict__ dU,
+                                                                    long n_items) {
     const int lane = threadIdx.x & 63;
     for (long it = (long)blockIdx.x * 4 + (threadIdx.x >> 6); it < n_items; it += (long)gridDim.x * 4) {
         const int o = (int)(it >> 8), W = (int)(it & 255);
@@ -325,8 +416,8 @@ __global__ __launch_bounds__(256) void pair_contract_windows_kernel(const u16* _
                 int pk = 0;
                 bool ok = false;
                 if (i < i1) {
-                    if (real) { pk = list[i]; ok = in_pixel_rect(pixrect[pk], Y, X); }
-                    else { pk = n_real + (role ? i : n_obj + i); ok = true; }
+                    pk = real ? list[i] : n_real + (role ? i : n_obj + i);
+                    ok = in_pixel_rect(pixrect[pk], Y, X);                  // pixrect covers real pairs, pseudo-pairs and background maps
                 }
                 unsigned long long m = __ballot(ok);
                 while (m) {
@@ -348,9 +439,14 @@ __global__ __launch_bounds__(256) void pair_contract_windows_kernel(const u16* _
             scan(ptr[o], ptr[o + 1], true);
             long vp[4];
             vp[0] = (long)n_real + (role ? n_obj + o : o);
-            add4(vp, 1);
+            if (in_pixel_rect(pixrect[vp[0]], Y, X)) add4(vp, 1);
         } else {
             scan(img_ptr[o - n_obj], img_ptr[o - n_obj + 1], false);
+            if (bg_maps) {                                                  // the all-background map of this image: pair (bg_b, bg_b)
+                long vp[4];
+                vp[0] = (long)n_real + 2 * n_obj + (o - n_obj);
+                add4(vp, 1);
+            }
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -668,11 +764,12 @@ int sgc_windows_col2im(const void* col, const int* bbox, const int* sub_idx, con
 }
 
 int sgc_pair_contract_windows(const void* dz, const unsigned char* amz, const int* ptr, const int* list, const int* pixel_rect,
-                              const int* img_ptr, int role, int n_real_pairs, int n_obj, int n_img, void* dU_pad, void* stream) {
+                              const int* img_ptr, int role, int n_real_pairs, int n_obj, int n_img, int bg_maps, void* dU_pad,
+                              void* stream) {
     if (n_obj <= 0) return SGC_OK;
     const long items = (long)(n_obj + n_img) * 256;
     SGC_LAUNCH(pair_contract_windows_kernel, dim3(grid_cap(items, 4, 262144)), dim3(256), 0, (hipStream_t)stream, (const u16*)dz, amz,
-               ptr, list, pixel_rect, img_ptr, role, n_real_pairs, n_obj, (u16*)dU_pad, items);
+               ptr, list, pixel_rect, img_ptr, role, n_real_pairs, n_obj, bg_maps, (u16*)dU_pad, items);
     SGC_CHECK_LAUNCH();
     return SGC_OK;
 }
@@ -762,6 +859,47 @@ int sgc_fc1_windows_wgrad(const void* gwm, const void* ywm_bf16, const int* goff
     auto kern = gemm_tn_pp_kernel<ELEM_BF16, BMODE_PLAIN, 0>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 16384);
     SGC_LAUNCH(kern, dim3(64 * 64), dim3(512), 8 * 16384, (hipStream_t)stream, p);
+    SGC_CHECK_LAUNCH();
+    return SGC_OK;
+}
+
+// ---- second level: pseudo-pairs restricted to the windows of R_o (entries of pair n_real + ps), the rest from per-image background maps
+int sgc_shared_objects_count(const int* bbox, int n_obj, int* count, int* pixel_rect, void* stream) {
+    if (n_obj <= 0) return SGC_OK;
+    SGC_LAUNCH(shared_count_objects_kernel, dim3((2 * n_obj + 255) / 256), dim3(256), 0, (hipStream_t)stream, bbox, n_obj, count, pixel_rect);
+    SGC_CHECK_LAUNCH();
+    return SGC_OK;
+}
+int sgc_shared_objects_fill(const int* bbox, int n_obj, int n_real_pairs, const int* count_incl, int* gather, void* stream) {
+    if (n_obj <= 0) return SGC_OK;
+    SGC_LAUNCH(shared_fill_objects_kernel, dim3((2 * n_obj + 255) / 256), dim3(256), 0, (hipStream_t)stream, bbox, n_obj, n_real_pairs,
+               count_incl, gather);
+    SGC_CHECK_LAUNCH();
+    return SGC_OK;
+}
+int sgc_shared_objects_fill_rows(const int* bbox, const int* obj_img, int n_obj, const int* goff, const void* y_bg, const void* y_bg_bf16,
+                                 const unsigned char* argmax_bg, void* ywm, void* ywm_bf16, unsigned char* argmax_ps, void* stream) {
+    if (n_obj <= 0) return SGC_OK;
+    if ((ywm_bf16 && !y_bg_bf16) || (argmax_ps && !argmax_bg)) return SGC_ERR_ARG;
+    const long rows = 2L * n_obj * 64;
+    SGC_LAUNCH(shared_fill_object_rows_kernel, dim3(grid_cap(rows, 4, 131072)), dim3(256), 0, (hipStream_t)stream, bbox, obj_img, n_obj, goff,
+               (const uint4*)y_bg, (const uint4*)y_bg_bf16, (const uint4*)argmax_bg, (uint4*)ywm, (uint4*)ywm_bf16, (uint4*)argmax_ps, rows);
+    SGC_CHECK_LAUNCH();
+    return SGC_OK;
+}
+int sgc_shared_objects_bg_grad(const int* bbox, const int* img_ptr, int n_obj, int n_img, const int* goff, const void* dywm, void* dy_bg,
+                               void* stream) {
+    if (n_img <= 0) return SGC_OK;
+    const long items = (long)n_img * 64;
+    SGC_LAUNCH(shared_bg_grad_kernel, dim3(grid_cap(items, 4, 65536)), dim3(256), 0, (hipStream_t)stream, bbox, img_ptr, n_obj, goff,
+               (const u16*)dywm, (u16*)dy_bg, items);
+    SGC_CHECK_LAUNCH();
+    return SGC_OK;
+}
+int sgc_windows_col2im_objects(const void* col, const int* bbox, int n_obj, int n_real_pairs, const int* count_incl, void* dz, void* stream) {
+    if (n_obj <= 0) return SGC_OK;
+    SGC_LAUNCH(windows_col2im_objects_kernel, dim3(2 * n_obj), dim3(256), 0, (hipStream_t)stream, (const u16*)col, bbox, n_obj, n_real_pairs,
+               count_incl, (u16*)dz);
     SGC_CHECK_LAUNCH();
     return SGC_OK;
 }

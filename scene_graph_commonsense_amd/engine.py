@@ -131,6 +131,12 @@ def shared_fc1_enabled() -> bool:
     return os.environ.get("SGC_SHARED_FC1", "1") != "0"
 
 
+def shared_objects_enabled() -> bool:
+    """``SGC_SHARED_OBJECTS=0``: every pseudo-pair (object, background) is a full conv3 map (A/B hook; default: second level - only the
+    windows of the object's rectangle, the rest from the image's all-background map)."""
+    return os.environ.get("SGC_SHARED_OBJECTS", "1") != "0"
+
+
 def shared_conv3_enabled(hint=None, n_pairs=0) -> bool:
     """``SGC_SHARED_CONV3=0`` computes conv3 for every window of every pair (A/B hook; default: per-object sharing on).
     ``hint`` (the host's count of pair-specific windows, ``DeviceScene.shared_windows``): when more than half of all windows are
@@ -138,7 +144,7 @@ def shared_conv3_enabled(hint=None, n_pairs=0) -> bool:
     grow with that count (9.2 KB per window pixel, twice) and the saving shrinks to nothing near 75 %."""
     if os.environ.get("SGC_SHARED_CONV3", "1") == "0":
         return False
-    n = hint[0] if isinstance(hint, tuple) else hint
+    n = hint.get("windows") if isinstance(hint, dict) else hint
     if n is not None and n_pairs > 0 and n > float(os.environ.get("SGC_SHARED_MAX_FRACTION", "0.5")) * 64 * n_pairs:
         return False
     return True
@@ -331,34 +337,54 @@ class RelHeadEngine:
                 _lib.ptr(U), _lib.ptr(V), _lib.ptr(sub_idx), _lib.ptr(obj_idx), _lib.ptr(z), _lib.ptr(z_bf), _lib.ptr(amz), P,
                 self._st()), "sgc_pair_expand_train"))
 
-    def shared_plan(self, bbox, sub_idx, obj_idx, P, bound=None, keep=False):
-        """The pair-specific (X) windows of a pair list (``csrc/kernels_shared.hip``): ``gather`` [E] = pair*64 + window in pair
-        order, ``incl`` [P] inclusive prefix counts, ``pixrect`` [P] the packed pixel rectangle around each pair's X windows, and
-        ``entries`` = E when the host knows it (``bound`` from ``DeviceScene.shared_windows``; with ``keep`` - training, where the
-        backward's GEMMs need exact sizes - one sync reads it back otherwise).  ``keep``: the lists live in buffers this engine owns."""
+    FULL_PIXRECT = (16 << 5) | (16 << 15)          # packed pixel rectangle covering the whole 16x16 map
+
+    def shared_plan(self, bbox, sub_idx, obj_idx, P, bound=None, keep=False, n_obj=0, n_img=0, objects=False):
+        """The window list of a pair list (``csrc/kernels_shared.hip``).  Pair index space: [P real pairs][2*n_obj pseudo-pairs
+        (o, bg), (bg, o)][n_img all-background maps].  ``gather`` = pair*64 + window of every listed window (the X windows of the
+        real pairs and - second level, ``objects`` - the windows R_o of the pseudo-pairs), ``incl`` inclusive prefix counts over
+        the pair index space, ``pixrect`` the packed pixel rectangle in which a pair's z / routing codes / dz exist (whole map for
+        pseudo-pairs without the second level and for the background maps).  ``bound`` = what the host knows
+        (``model._shared_hint``): then nothing is read back; with ``keep`` (training: the backward's GEMMs need exact sizes) one
+        sync reads the counts otherwise.  ``keep``: the lists live in buffers this engine owns."""
         lib = self.lib
-        window_entries = None
-        if isinstance(bound, tuple):
-            bound, window_entries = bound
+        hint = bound if isinstance(bound, dict) else ({"windows": bound} if bound is not None else {})
         own = self.ws if keep else self.scratch
-        cnt = self.scratch.get("xw_count", P, torch.int32)
-        pixrect = own.get("xw_pixrect", P, torch.int32)
+        n2 = 2 * n_obj
+        Pt = P + n2 + n_img
+        cnt = self.scratch.get("xw_count", Pt, torch.int32)
+        pixrect = own.get("xw_pixrect", Pt, torch.int32)
         _lib.check(lib.sgc_shared_windows_count(_lib.ptr(bbox), _lib.ptr(sub_idx), _lib.ptr(obj_idx), P, _lib.ptr(cnt), _lib.ptr(pixrect),
                                                 self._st()), "sgc_shared_windows_count")
+        if Pt > P:
+            cnt[P:].zero_()
+            pixrect[P:].fill_(self.FULL_PIXRECT)
+            if objects:
+                _lib.check(lib.sgc_shared_objects_count(_lib.ptr(bbox), n_obj, _lib.ptr(cnt[P:]), _lib.ptr(pixrect[P:]), self._st()),
+                           "sgc_shared_objects_count")
         incl = torch.cumsum(cnt, 0, dtype=torch.int32)
-        gather = own.get("xw_gather", P * 64, torch.int32)
+        gather = own.get("xw_gather", (P + (n2 if objects else 0)) * 64, torch.int32)
         _lib.check(lib.sgc_shared_windows_fill(_lib.ptr(bbox), _lib.ptr(sub_idx), _lib.ptr(obj_idx), P, _lib.ptr(incl), _lib.ptr(gather),
                                                self._st()), "sgc_shared_windows_fill")
-        if bound is None and keep:
-            bound = int(incl[P - 1])
-        exact = bound is not None
-        bound = P * 64 if bound is None else max(0, min(int(bound), P * 64))
-        self._xw = (gather, incl)
-        return dict(gather=gather, incl=incl, pixrect=pixrect, bound=bound, entries=bound if exact else None, window_entries=window_entries)
+        if objects:
+            _lib.check(lib.sgc_shared_objects_fill(_lib.ptr(bbox), n_obj, P, _lib.ptr(incl), _lib.ptr(gather), self._st()), "sgc_shared_objects_fill")
+        e_real, e_obj = hint.get("windows"), (hint.get("object_windows") if objects else 0)
+        if (e_real is None or e_obj is None) and keep:
+            e_real = int(incl[P - 1]) if P else 0
+            e_obj = int(incl[Pt - 1]) - e_real
+        exact = e_real is not None and e_obj is not None
+        total = (e_real + e_obj) if exact else (P + (n2 if objects else 0)) * 64
+        if not exact and e_real is not None:
+            total = min(total, int(e_real) + n2 * 64)
+        self._xw = (gather, incl[:P] if P else incl)
+        return dict(gather=gather, incl=incl, n_total=incl[Pt - 1:], pixrect=pixrect, bound=total, entries=total if exact else None,
+                    entries_real=e_real if exact else None, window_entries=hint.get("per_window"), objects=objects, P=P, n_obj=n_obj,
+                    n_img=n_img)
 
     def window_major_rows(self, plan, P, n2):
         """Window-major row space of the shared fc1 (``csrc/kernels_shared.hip``): device group offsets, tile -> group table and the
-        row ``dest[e]`` of every X entry.  Per-window entry counts come from the host when it knows them (full scenes,
+        row ``dest[e]`` of every listed window (X entries behind the per-object rows of their group; a pseudo-pair's own windows
+        ARE per-object rows).  Per-window entry counts come from the host when it knows them (full scenes,
         ``DeviceScene.window_entries``); a pair subset costs one read-back."""
         from .pairs import window_major_layout
         dev = self.device
@@ -374,11 +400,17 @@ class RelHeadEngine:
         keys = (gather[:E] & 63).long()
         skeys, order = torch.sort(keys, stable=True)
         base = torch.from_numpy(goff[:64].astype(np.int64) + n2 - cex).to(dev)
-        dest = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
+        Et = E
+        if plan.get("objects"):
+            Et = plan["entries"] if plan["entries"] is not None else int(plan["n_total"][0])
+        dest = torch.empty(max(Et, 1), dtype=torch.int32, device=dev)
         dest[order] = (base[skeys] + torch.arange(E, device=dev)).int()
+        if Et > E:                                   # the pseudo-pairs' own windows: row goff[w] + ps
+            code = gather[E:Et].long()
+            dest[E:Et] = (goff_d[:64].long()[code & 63] + (code >> 6) - P).int()
         gend = torch.from_numpy((goff[:64].astype(np.int64) + n2 + np.asarray(counts, dtype=np.int64)).astype(np.int32)).to(dev)
         return dict(goff=goff_d, goff_host=goff, gend=gend, tile_group=torch.from_numpy(tile_group).to(dev), dest=dest, rows=int(goff[64]),
-                    E=E, n2=n2)
+                    E=E, E_total=Et, n2=n2)
 
     def fc1_shared(self, wm, ywm, bbox, sub_idx, obj_idx, incl, P, n_obj, h1, dropout, seed):
         """fc1 + ReLU (+ dropout) from the window-major rows: grouped GEMM, per-object 2-D prefix sums, per-pair assembly."""
@@ -396,59 +428,91 @@ class RelHeadEngine:
     def conv3_shared(self, plan, z, U, V, bbox, obj_img, sub_idx, obj_idx, P, y, am, y_bf, keep=None, wm=None):
         """conv3 + ReLU + pool with the per-object part computed once per object (``csrc/kernels_shared.hip``): U / V hold
         n_obj + n_img objects, the last n_img the empty-box backgrounds of the images; ``plan`` from ``shared_plan``.
-        ``keep=(z_bf_tail, amz_tail)`` (training): the pseudo-pairs' bf16 expansion and routing codes go there; returns what the
-        backward needs."""
+        ``z`` [P + 2 n_obj (+ n_img)] padded maps: the real pairs' expansion is there already, the pseudo-pairs' (and background
+        maps') is written here; ``keep=(z_bf, amz)`` (training): same-shaped bf16 copy and routing codes for the backward.
+        ``wm`` (``window_major_rows``): ``y`` / ``y_bf`` are the window-major buffers of the shared fc1 and nothing is assembled
+        per pair; with ``plan['objects']`` the pseudo-pairs are computed on their own windows only (second level).
+        Returns what the backward needs."""
         lib, sc = self.lib, self.scratch
         own = self.ws if keep is not None else sc
-        n_obj = int(obj_img.shape[0])
+        n_obj, n_img = int(obj_img.shape[0]), plan["n_img"]
         n2 = 2 * n_obj
+        objects = bool(plan["objects"]) and wm is not None
         ar = torch.arange(n_obj, dtype=torch.int32, device=self.device)
         bg = obj_img.to(torch.int32) + n_obj                                     # every object's background = its image's
-        ps = (n_obj, torch.cat([ar, bg]).contiguous(), torch.cat([bg, ar]).contiguous())
-        z_ps = sc.get("z_ps", n2 * 18 * 18 * 512, torch.float16)                 # created zeroed: the halo stays zero
+        ps_sub, ps_obj = torch.cat([ar, bg]), torch.cat([bg, ar])
+        if objects:                                                              # + the all-background map of every image
+            bgs = torch.arange(n_obj, n_obj + n_img, dtype=torch.int32, device=self.device)
+            ps_sub, ps_obj = torch.cat([ps_sub, bgs]), torch.cat([ps_obj, bgs])
+        n_tail = int(ps_sub.shape[0])
+        zt = z[P * 18 * 18 * 512:]
         if keep is None:
-            _lib.check(lib.sgc_pair_expand(_lib.ptr(U), _lib.ptr(V), _lib.ptr(ps[1]), _lib.ptr(ps[2]), _lib.ptr(z_ps), n2, ELEM_F16, self._st()),
+            _lib.check(lib.sgc_pair_expand(_lib.ptr(U), _lib.ptr(V), _lib.ptr(ps_sub), _lib.ptr(ps_obj), _lib.ptr(zt), n_tail, ELEM_F16, self._st()),
                        "sgc_pair_expand")
         else:
-            _lib.check(lib.sgc_pair_expand_train(_lib.ptr(U), _lib.ptr(V), _lib.ptr(ps[1]), _lib.ptr(ps[2]), _lib.ptr(z_ps), _lib.ptr(keep[0]),
-                                                 _lib.ptr(keep[1]), n2, self._st()), "sgc_pair_expand_train")
-        am_ps = own.get("am_ps", n2 * 65536, torch.uint8) if am is not None else None
+            _lib.check(lib.sgc_pair_expand_train(_lib.ptr(U), _lib.ptr(V), _lib.ptr(ps_sub), _lib.ptr(ps_obj), _lib.ptr(zt),
+                                                 _lib.ptr(keep[0][P * 18 * 18 * 512:]), _lib.ptr(keep[1][P * 256 * 256:]), n_tail, self._st()),
+                       "sgc_pair_expand_train")
         gather, incl = plan["gather"], plan["incl"]
+        out = dict(plan, n2=n2, wm=wm)
         if wm is not None:
-            # window-major rows for the shared fc1: ``y`` / ``y_bf`` ARE the window-major buffers, nothing is assembled per pair
-            self._timed("conv3_fwd_objects", lambda: _lib.check(lib.sgc_conv3_relu_pool_wm(
-                _lib.ptr(z_ps), _lib.ptr(self.w["w3r"]), _lib.ptr(self.w["b3"]), _lib.ptr(wm["goff"]), _lib.ptr(y), _lib.ptr(am_ps), _lib.ptr(y_bf),
-                n2, self._st()), "sgc_conv3_relu_pool_wm"))
+            am_ps = am[P * 65536:] if am is not None else None                   # routing codes of the pseudo-pairs: behind the real pairs'
+            if objects:
+                # second level: the pseudo-pairs' windows R_o are entries of the window list; the other rows are the background maps'
+                zb = zt[n2 * 18 * 18 * 512:]
+                y_bg = sc.get("y_bg", n_img * 65536, torch.float16)
+                ybf_bg = sc.get("ybf_bg", n_img * 65536, torch.bfloat16) if y_bf is not None else None
+                am_bg = own.get("am_bg", n_img * 65536, torch.uint8) if am is not None else None
+                self._timed("conv3_fwd_objects", lambda: _lib.check(lib.sgc_conv3_relu_pool(
+                    _lib.ptr(zb), _lib.ptr(self.w["w3r"]), _lib.ptr(self.w["b3"]), _lib.ptr(y_bg), _lib.ptr(am_bg), _lib.ptr(ybf_bg), n_img,
+                    self._st()), "sgc_conv3_relu_pool"))
+                _lib.check(lib.sgc_shared_objects_fill_rows(_lib.ptr(bbox), _lib.ptr(obj_img), n_obj, _lib.ptr(wm["goff"]), _lib.ptr(y_bg),
+                                                            _lib.ptr(ybf_bg), _lib.ptr(am_bg), _lib.ptr(y), _lib.ptr(y_bf), _lib.ptr(am_ps),
+                                                            self._st()), "sgc_shared_objects_fill_rows")
+                out["am_bg"] = am_bg
+            else:
+                self._timed("conv3_fwd_objects", lambda: _lib.check(lib.sgc_conv3_relu_pool_wm(
+                    _lib.ptr(zt), _lib.ptr(self.w["w3r"]), _lib.ptr(self.w["b3"]), _lib.ptr(wm["goff"]), _lib.ptr(y), _lib.ptr(am_ps), _lib.ptr(y_bf),
+                    n2, self._st()), "sgc_conv3_relu_pool_wm"))
             self._timed("conv3_fwd_windows", lambda: _lib.check(lib.sgc_conv3_relu_pool_windows_wm(
-                _lib.ptr(z), _lib.ptr(self.w["w3r"]), _lib.ptr(self.w["b3"]), _lib.ptr(gather), _lib.ptr(incl[P - 1:]), _lib.ptr(wm["dest"]),
+                _lib.ptr(z), _lib.ptr(self.w["w3r"]), _lib.ptr(self.w["b3"]), _lib.ptr(gather), _lib.ptr(plan["n_total"]), _lib.ptr(wm["dest"]),
                 plan["bound"], _lib.ptr(y), _lib.ptr(am), _lib.ptr(y_bf), self._st()), "sgc_conv3_relu_pool_windows_wm"))
-            return dict(plan, am_ps=am_ps, n2=n2, wm=wm)
+            out["am_ps"] = am_ps
+            return out
+        am_ps = own.get("am_ps", n2 * 65536, torch.uint8) if am is not None else None
         y_ps = sc.get("y_ps", n2 * 65536, torch.float16)
         ybf_ps = sc.get("ybf_ps", n2 * 65536, torch.bfloat16) if y_bf is not None else None
         self._timed("conv3_fwd_objects", lambda: _lib.check(lib.sgc_conv3_relu_pool(
-            _lib.ptr(z_ps), _lib.ptr(self.w["w3r"]), _lib.ptr(self.w["b3"]), _lib.ptr(y_ps), _lib.ptr(am_ps), _lib.ptr(ybf_ps), n2,
+            _lib.ptr(zt), _lib.ptr(self.w["w3r"]), _lib.ptr(self.w["b3"]), _lib.ptr(y_ps), _lib.ptr(am_ps), _lib.ptr(ybf_ps), n2,
             self._st()), "sgc_conv3_relu_pool"))
         self._timed("conv3_fwd_windows", lambda: _lib.check(lib.sgc_conv3_relu_pool_windows(
-            _lib.ptr(z), _lib.ptr(self.w["w3r"]), _lib.ptr(self.w["b3"]), _lib.ptr(gather), _lib.ptr(incl[P - 1:]), plan["bound"], _lib.ptr(y),
+            _lib.ptr(z), _lib.ptr(self.w["w3r"]), _lib.ptr(self.w["b3"]), _lib.ptr(gather), _lib.ptr(plan["n_total"]), plan["bound"], _lib.ptr(y),
             _lib.ptr(am), _lib.ptr(y_bf), self._st()), "sgc_conv3_relu_pool_windows"))
         self._timed("conv3_fwd_assemble", lambda: _lib.check(lib.sgc_shared_windows_assemble(
             _lib.ptr(bbox), _lib.ptr(sub_idx), _lib.ptr(obj_idx), P, n_obj, _lib.ptr(y_ps), _lib.ptr(am_ps), _lib.ptr(ybf_ps),
             _lib.ptr(y), _lib.ptr(am), _lib.ptr(y_bf), self._st()), "sgc_shared_windows_assemble"))
-        return dict(plan, am_ps=am_ps, n2=n2)
+        out["am_ps"] = am_ps
+        return out
 
     def pair_trunk(self, U, V, sub_idx, obj_idx, lsub, lobj, train=False, seeds=(0, 0), keep_argmax=False,
                    iou_mask=None, dense=None, shared=None) -> PairOutputs:
         lib, ws, cfg = self.lib, self.ws, self.cfg
         P = int(sub_idx.shape[0])
         Ppad = (P + 63) // 64 * 64
-        z = ws.get("z_pad", P * 18 * 18 * 512, torch.float16)      # border stays zero: only interiors are written
-        plan = self.shared_plan(shared[0], sub_idx, obj_idx, P, shared[2]) if shared is not None else None
-        self.expand(U, V, sub_idx, obj_idx, P, z, dense=dense, pixrect=None if plan is None else plan["pixrect"])
-        am = ws.get("argmax", P * 65536, torch.uint8) if keep_argmax else None
-        h1 = ws.get("h1", Ppad * 4096, torch.float16)
-        if shared is not None and shared_fc1_enabled():
-            # conv3 and fc1 over shared windows: the rows fc1 multiplies are written window-major, y [P, 65536] never exists
+        plan, Pt = None, P
+        if shared is not None:
             n_obj = int(shared[1].shape[0])
+            n_img = int(U.numel()) // (1024 * 512) - n_obj                 # the background objects behind the real ones
+            wm_mode = shared_fc1_enabled()
+            plan = self.shared_plan(shared[0], sub_idx, obj_idx, P, shared[2], n_obj=n_obj, n_img=n_img,
+                                    objects=wm_mode and shared_objects_enabled())
+            Pt = P + 2 * n_obj + n_img
+        z = ws.get("z_pad", Pt * 18 * 18 * 512, torch.float16)     # border stays zero: only interiors are written
+        self.expand(U, V, sub_idx, obj_idx, P, z, dense=dense, pixrect=None if plan is None else plan["pixrect"])
+        am = ws.get("argmax", Pt * 65536, torch.uint8) if keep_argmax else None
+        h1 = ws.get("h1", Ppad * 4096, torch.float16)
+        if shared is not None and wm_mode:
+            # conv3 and fc1 over shared windows: the rows fc1 multiplies are written window-major, y [P, 65536] never exists
             wm = self.window_major_rows(plan, P, 2 * n_obj)
             ywm = ws.get("ywm", wm["rows"] * 1024, torch.float16)
             self.conv3_shared(plan, z, U, V, shared[0], shared[1], sub_idx, obj_idx, P, ywm, am, None, wm=wm)
@@ -520,8 +584,9 @@ class RelHeadEngine:
             ok = pid >= 0
             pc = pid.clamp(min=0).long()
             dense_s = (img_ptr, torch.where(ok & sel[pc], rank[pc], torch.full_like(pid, -1)).contiguous(), max_n)
-        if shared is not None and isinstance(shared[2], tuple):
-            shared = (shared[0], shared[1], shared[2][0])        # the per-window counts describe the full pair list, not a subset
+        if shared is not None and isinstance(shared[2], dict):
+            # the counts describe the full pair list: for a subset only the object part stays exact, the rest is an upper bound
+            shared = (shared[0], shared[1], None)
         out = self.pair_trunk(uv[0], uv[1], sub_idx[idx].contiguous(), obj_idx[idx].contiguous(), lsub, lobj, train, seeds, keep_argmax,
                               None if iou_mask is None else iou_mask[idx].contiguous(), dense_s, shared)
         full.relation[idx] = out.relation
@@ -601,25 +666,26 @@ class RelHeadEngine:
         ctx.uv = self.object_halves(ctx.a_img, obj_img, bbox, with_bg=share)
         ctx.lsub, lobj_same = self.label_vectors(ctx.cats[0], ctx.super_mh[0])
         ctx.lobj = lobj_same if role_inputs is None else self.label_vectors(ctx.cats[1], ctx.super_mh[1])[1]
-        z = sc.get("z_pad", P * 18 * 18 * 512, torch.float16)
-        Pt = P + (2 * ctx.n_obj if share else 0)                     # the pseudo-pairs (object, background) live behind the real pairs
-        z_bf = ws.get("z_pad_bf", Pt * 18 * 18 * 512, torch.bfloat16)
-        amz = ws.get("amz", Pt * 256 * 256, torch.uint8)             # two 4-bit routing codes per byte
-        plan = self.shared_plan(bbox, sub_idx, obj_idx, P, shared_windows, keep=True) if share else None
         # the per-pair backward (SGC_SHARED_BWD=0, A/B hook) reads every pixel of z / amz; the shared one only those next to X windows
         narrow = share and os.environ.get("SGC_SHARED_BWD", "1") != "0"
+        wm_mode = narrow and shared_fc1_enabled()
+        plan = self.shared_plan(bbox, sub_idx, obj_idx, P, shared_windows, keep=True, n_obj=ctx.n_obj, n_img=ctx.n_img,
+                                objects=wm_mode and shared_objects_enabled()) if share else None
+        Pt = P + (2 * ctx.n_obj + ctx.n_img if share else 0)         # pseudo-pairs and background maps live behind the real pairs
+        z = sc.get("z_pad", Pt * 18 * 18 * 512, torch.float16)
+        z_bf = ws.get("z_pad_bf", Pt * 18 * 18 * 512, torch.bfloat16)
+        amz = ws.get("amz", Pt * 256 * 256, torch.uint8)             # two 4-bit routing codes per byte
         self.expand(ctx.uv[0], ctx.uv[1], sub_idx, obj_idx, P, z, z_bf, amz, dense=dense, pixrect=plan["pixrect"] if narrow else None)
         ctx.z_bf = z_bf
-        am = ws.get("argmax", P * 65536, torch.uint8)               # conv3 routing codes (shared path: only the rows of X windows)
+        am = ws.get("argmax", Pt * 65536, torch.uint8)              # conv3 routing codes (shared path: only the rows of listed windows)
         h1 = ws.get("h1", Ppad * 4096, torch.float16)
-        tails = (z_bf[P * 18 * 18 * 512:], amz[P * 256 * 256:])
         ctx.shared, ctx.y, ctx.y_bf = None, None, None
-        if narrow and shared_fc1_enabled():
+        if wm_mode:
             # conv3 and fc1 over shared windows: y and its bf16 copy exist only as the window-major rows fc1 multiplies
             wm = self.window_major_rows(plan, P, 2 * ctx.n_obj)
             ywm = sc.get("ywm", wm["rows"] * 1024, torch.float16)
             ywm_bf = ws.get("ywm_bf", wm["rows"] * 1024, torch.bfloat16)
-            ctx.shared = self.conv3_shared(plan, z, ctx.uv[0], ctx.uv[1], bbox, obj_img, sub_idx, obj_idx, P, ywm, am, ywm_bf, keep=tails, wm=wm)
+            ctx.shared = self.conv3_shared(plan, z, ctx.uv[0], ctx.uv[1], bbox, obj_img, sub_idx, obj_idx, P, ywm, am, ywm_bf, keep=(z_bf, amz), wm=wm)
             ctx.shared["ywm_bf"] = ywm_bf
             self.fc1_shared(wm, ywm, bbox, sub_idx, obj_idx, plan["incl"], P, ctx.n_obj, h1, dropout, seeds[0])
         else:
@@ -628,7 +694,7 @@ class RelHeadEngine:
             if Ppad > P:
                 Workspace._zero(y_bf[P * 65536:])
             if share:
-                ctx.shared = self.conv3_shared(plan, z, ctx.uv[0], ctx.uv[1], bbox, obj_img, sub_idx, obj_idx, P, y, am, y_bf, keep=tails)
+                ctx.shared = self.conv3_shared(plan, z, ctx.uv[0], ctx.uv[1], bbox, obj_img, sub_idx, obj_idx, P, y, am, y_bf, keep=(z_bf, amz))
             else:
                 self._timed("conv3_fwd", lambda: _lib.check(lib.sgc_conv3_relu_pool(_lib.ptr(z), _lib.ptr(self.w["w3r"]), _lib.ptr(self.w["b3"]),
                                                                                    _lib.ptr(y), _lib.ptr(am), _lib.ptr(y_bf), P, self._st()),
@@ -755,7 +821,7 @@ class RelHeadEngine:
         shared = ctx.shared if (getattr(ctx, "shared", None) is not None and os.environ.get("SGC_SHARED_BWD", "1") != "0") else None
         n_objx = n_obj + (n_img if shared is not None else 0)      # the images' background objects take part in the conv2 backward
         if shared is not None:
-            dz = self._conv3_backward_shared(ctx, shared, dy, sub_csr, obj_csr, side, sl, grads)
+            dz = self._conv3_backward_shared(ctx, shared, dy, sub_csr, obj_csr, img_ptr, side, sl, grads)
         else:
             dz = self._conv3_backward_pairs(ctx, dy, side, sl, grads)
 
@@ -766,7 +832,8 @@ class RelHeadEngine:
             if shared is not None:
                 self._timed("contract", lambda: _lib.check(lib.sgc_pair_contract_windows(
                     _lib.ptr(dz), _lib.ptr(ctx.amz), _lib.ptr(csr[0]), _lib.ptr(csr[1]), _lib.ptr(shared["pixrect"]), _lib.ptr(img_ptr),
-                    r, P, n_obj, n_img, _lib.ptr(dU), st()), "sgc_pair_contract_windows"))
+                    r, P, n_obj, n_img, int(bool(shared.get("objects")) and shared.get("wm") is not None), _lib.ptr(dU), st()),
+                    "sgc_pair_contract_windows"))
             else:
                 self._timed("contract", lambda: _lib.check(lib.sgc_pair_contract(_lib.ptr(dz), _lib.ptr(ctx.amz), _lib.ptr(csr[0]), _lib.ptr(csr[1]), _lib.ptr(dU), n_obj, st()),
                            "sgc_pair_contract"))
@@ -898,42 +965,52 @@ class RelHeadEngine:
             self._timed("conv3_dgrad", lambda: _lib.check(lib.sgc_conv3_dgrad(_lib.ptr(dy3), _lib.ptr(w["wd3"]), _lib.ptr(dz), P, st()), "sgc_conv3_dgrad"))
         return dz
 
-    def _conv3_backward_shared(self, ctx, sh, dy, sub_csr, obj_csr, side, sl, grads):
-        """Backward of ``conv3_shared`` (autodiff of that graph): the gradient rows of copied windows are summed per object and go
-        through the ordinary conv3 backward of the 2*n_obj pseudo-pairs; the pair-specific windows go through a compact column
-        form (un-pool -> [rows,1024]; weight gradient = rows^T x im2col(z); data gradient = rows x W^T -> col2im).  Returns dz
-        [(P + 2 n_obj) * 256, 512]: pseudo-pairs behind the real pairs, a real pair's rows exist only next to its X windows."""
-        lib, w, ws, st, P, n_obj = self.lib, self.w, self.scratch, self._st, ctx.P, ctx.n_obj
-        n2 = sh["n2"]
+    def _conv3_backward_shared(self, ctx, sh, dy, sub_csr, obj_csr, img_ptr, side, sl, grads):
+        """Backward of ``conv3_shared`` (autodiff of that graph).  Per-object part: the gradient rows of copied windows, summed per
+        object (by the shared fc1's data gradient, or by ``sgc_shared_windows_assemble_bwd`` from a pair-major ``dy``), go through
+        the ordinary conv3 backward of whole maps - the 2*n_obj pseudo-pairs, or with the second level only the n_img background
+        maps, the pseudo-pairs' own windows being window-list entries like the X windows.  Listed windows: compact column form
+        (un-pool -> [rows,1024]; weight gradient = rows^T x im2col(z); data gradient = rows x W^T -> col2im).
+        Returns dz [(P + 2 n_obj + n_img) * 256, 512]: a pair's rows exist only inside its pixel rectangle (``plan['pixrect']``)."""
+        lib, w, ws, st, P, n_obj, n_img = self.lib, self.w, self.scratch, self._st, ctx.P, ctx.n_obj, ctx.n_img
+        n2, wm, objects = sh["n2"], sh.get("wm"), bool(sh.get("objects")) and sh.get("wm") is not None
         E = sh["entries"]
         Epad = (E + 15) // 16 * 16                                   # 4 rows per entry: the GEMMs want a multiple of 64 rows
         slabs_n, slabs_x, nparts, nparts_x = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
-        gather, gn = sh["gather"], sh["incl"][P - 1:]
-        am_tail = sh["am_ps"]
-        z_bf, z_bf_tail = ctx.z_bf, ctx.z_bf[P * 18 * 18 * 512:]
-        dz = ws.get("dz", (P + n2) * 256 * 512, torch.bfloat16)
-        dz_tail = dz[P * 256 * 512:]
-        # ---- copies: per-object sums, then the pseudo-pairs' ordinary backward
-        dy_ps = ws.get("dy_ps", n2 * 65536, torch.bfloat16)
-        wm = sh.get("wm")
-        dest = None
-        if wm is not None:
-            # ``dy`` is the window-major gradient of the shared fc1: the per-object rows are already sums; bring them to pair-major order
-            idx = (wm["goff"][:64].long()[None, :] + torch.arange(n2, device=self.device)[:, None]).reshape(-1)
-            torch.index_select(dy.view(-1, 1024), 0, idx, out=dy_ps.view(-1, 1024))
-            dest = wm["dest"]
+        gather, gn = sh["gather"], sh["n_total"]
+        z_bf = ctx.z_bf
+        Pt = P + n2 + n_img
+        dz = ws.get("dz", Pt * 256 * 512, torch.bfloat16)
+        # ---- whole maps: the pseudo-pairs (first level) or the background maps (second level), gradient = sums of copied rows
+        if objects:
+            n_maps, map0 = n_img, P + n2
+            dy_maps = ws.get("dy_bg", n_img * 65536, torch.bfloat16)
+            _lib.check(lib.sgc_shared_objects_bg_grad(_lib.ptr(ctx.bbox), _lib.ptr(img_ptr), n_obj, n_img, _lib.ptr(wm["goff"]), _lib.ptr(dy),
+                                                      _lib.ptr(dy_maps), st()), "sgc_shared_objects_bg_grad")
+            am_maps = sh["am_bg"]
         else:
-            self._timed("conv3_bwd_assemble", lambda: _lib.check(lib.sgc_shared_windows_assemble_bwd(
-                _lib.ptr(ctx.bbox), _lib.ptr(ctx.sub_idx), _lib.ptr(ctx.obj_idx), _lib.ptr(sub_csr[0]), _lib.ptr(sub_csr[1]), _lib.ptr(obj_csr[0]),
-                _lib.ptr(obj_csr[1]), n_obj, _lib.ptr(dy), _lib.ptr(dy_ps), st()), "sgc_shared_windows_assemble_bwd"))
+            n_maps, map0 = n2, P
+            dy_maps = ws.get("dy_ps", n2 * 65536, torch.bfloat16)
+            if wm is not None:
+                # ``dy`` is the window-major gradient of the shared fc1: the per-object rows are already sums; bring them to pair-major order
+                idx = (wm["goff"][:64].long()[None, :] + torch.arange(n2, device=self.device)[:, None]).reshape(-1)
+                torch.index_select(dy.view(-1, 1024), 0, idx, out=dy_maps.view(-1, 1024))
+            else:
+                self._timed("conv3_bwd_assemble", lambda: _lib.check(lib.sgc_shared_windows_assemble_bwd(
+                    _lib.ptr(ctx.bbox), _lib.ptr(ctx.sub_idx), _lib.ptr(ctx.obj_idx), _lib.ptr(sub_csr[0]), _lib.ptr(sub_csr[1]), _lib.ptr(obj_csr[0]),
+                    _lib.ptr(obj_csr[1]), n_obj, _lib.ptr(dy), _lib.ptr(dy_maps), st()), "sgc_shared_windows_assemble_bwd"))
+            am_maps = sh["am_ps"]
+        dest = wm["dest"] if wm is not None else None
+        z_bf_maps = z_bf[map0 * 18 * 18 * 512:]
+        dz_maps = dz[map0 * 256 * 512:]
         bpart = ws.get("b3_part", 2048 * 1024, torch.float32)
         bpart_x = ws.get("b3_part_x", 1024 * 1024, torch.float32)
-        pack_a = ws.get("w3_pack_a", n2 * 4 * 1024 * 64, torch.uint8)
-        pack_i = ws.get("w3_pack_i", n2 * 4 * 1024 * 8, torch.uint8)
+        pack_a = ws.get("w3_pack_a", n_maps * 4 * 1024 * 64, torch.uint8)
+        pack_i = ws.get("w3_pack_i", n_maps * 4 * 1024 * 8, torch.uint8)
         self._timed("unpool_objects", lambda: _lib.check(lib.sgc_unpool_relu_bwd_pack(
-            _lib.ptr(dy_ps), _lib.ptr(am_tail), None, _lib.ptr(bpart), ctypes.byref(nparts), _lib.ptr(pack_a), _lib.ptr(pack_i), n2, st()),
+            _lib.ptr(dy_maps), _lib.ptr(am_maps), None, _lib.ptr(bpart), ctypes.byref(nparts), _lib.ptr(pack_a), _lib.ptr(pack_i), n_maps, st()),
             "sgc_unpool_relu_bwd_pack"))
-        # ---- pair-specific windows: compact un-pool
+        # ---- listed windows: compact un-pool
         dy3x = ws.get("dy3x", max(Epad, 16) * 4 * 1024, torch.bfloat16)
         self._timed("unpool_windows", lambda: _lib.check(lib.sgc_windows_unpool(
             _lib.ptr(dy), _lib.ptr(ctx.am), _lib.ptr(gather), _lib.ptr(gn), _lib.ptr(dest), Epad, _lib.ptr(dy3x), _lib.ptr(bpart_x),
@@ -944,7 +1021,7 @@ class RelHeadEngine:
                 gb = gb + self._slab_sum(bpart_x, 1024, nparts_x.value)
             grads["conv3_1.bias"] = gb
             self._timed("conv3_wgrad_objects", lambda: _lib.check(lib.sgc_conv3_wgrad_sparse(
-                None, None, _lib.ptr(z_bf_tail), _lib.ptr(pack_a), _lib.ptr(pack_i), _lib.ptr(sl), n2, 0, ctypes.byref(slabs_n), st()),
+                None, None, _lib.ptr(z_bf_maps), _lib.ptr(pack_a), _lib.ptr(pack_i), _lib.ptr(sl), n_maps, 0, ctypes.byref(slabs_n), st()),
                 "sgc_conv3_wgrad_sparse"))
             if Epad:
                 zcol = ws.get("zcol", Epad * 4 * 9 * 512, torch.bfloat16)
@@ -957,14 +1034,16 @@ class RelHeadEngine:
             grads["conv3_1.weight"] = dW3r.view(1024, 3, 3, 512).permute(0, 3, 1, 2).contiguous()
         # ---- data gradients
         self._timed("conv3_dgrad_objects", lambda: _lib.check(lib.sgc_conv3_dgrad_pooled(
-            _lib.ptr(dy_ps), _lib.ptr(am_tail), _lib.ptr(w["wd3"]), _lib.ptr(dz_tail), n2, st()), "sgc_conv3_dgrad_pooled"))
+            _lib.ptr(dy_maps), _lib.ptr(am_maps), _lib.ptr(w["wd3"]), _lib.ptr(dz_maps), n_maps, st()), "sgc_conv3_dgrad_pooled"))
         if Epad:
             col = ws.get("xcol", Epad * 4 * 9 * 512, torch.bfloat16)
             self._timed("conv3_dgrad_windows", lambda: _lib.check(lib.sgc_windows_dgrad_cols(_lib.ptr(dy3x), _lib.ptr(w["w3col"]), _lib.ptr(col), Epad * 4, st()),
                                                                   "sgc_windows_dgrad_cols"))
-            self._timed("col2im_windows", lambda: _lib.check(lib.sgc_windows_col2im(
-                _lib.ptr(col), _lib.ptr(ctx.bbox), _lib.ptr(ctx.sub_idx), _lib.ptr(ctx.obj_idx), _lib.ptr(sh["incl"]), P, _lib.ptr(dz), st()),
-                "sgc_windows_col2im"))
+            self._timed("col2im_windows", lambda: (
+                _lib.check(lib.sgc_windows_col2im(_lib.ptr(col), _lib.ptr(ctx.bbox), _lib.ptr(ctx.sub_idx), _lib.ptr(ctx.obj_idx), _lib.ptr(sh["incl"]),
+                                                  P, _lib.ptr(dz), st()), "sgc_windows_col2im"),
+                _lib.check(lib.sgc_windows_col2im_objects(_lib.ptr(col), _lib.ptr(ctx.bbox), n_obj, P, _lib.ptr(sh["incl"]), _lib.ptr(dz), st()),
+                           "sgc_windows_col2im_objects") if objects else None))
         return dz
 
     # ------------------------------------------------------------------ two-stream backward

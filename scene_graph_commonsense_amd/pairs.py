@@ -217,6 +217,13 @@ def count_shared_windows(bb: np.ndarray, img_ptr) -> int:
     return total
 
 
+def count_object_windows(bb: np.ndarray) -> int:
+    """Windows of the pseudo-pairs (o, background) and (background, o) that are computed per object (second level of sharing):
+    2 * sum |R_o|."""
+    r = object_window_rects(bb)
+    return int(2 * ((r[:, 1] - r[:, 0]) * (r[:, 3] - r[:, 2])).sum())
+
+
 def window_entry_counts(bb: np.ndarray, img_ptr) -> np.ndarray:
     """[64] number of pair-specific (X) entries per pooling window over all ordered pairs of every image: a window inside the
     rectangles of c objects of an image is an X window of c*(c-1) ordered pairs."""
@@ -324,6 +331,7 @@ def flatten_scene(cfg, batch, device) -> DeviceScene:
                        num_objects=n_list, n_pairs=P, n_steps=T, max_n=int(max_n), _stage=stage, _tables=tab,
                        shared_windows=count_shared_windows(bb, img_ptr) if (n_obj and F == 32) else None,
                        window_entries=window_entry_counts(bb, img_ptr) if (n_obj and F == 32) else None,
+                       object_windows=count_object_windows(bb) if (n_obj and F == 32) else None,
                        _rel_src=getattr(batch, "relationships", None) if rel is not None else None)
 
 

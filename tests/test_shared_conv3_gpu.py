@@ -178,6 +178,14 @@ def test_training_step_shared_forward_is_bit_identical_and_shared_backward_agree
         worst3[n] = float((g3[n].double() - ref).norm() / ref.norm().clamp(min=1e-30))
         assert worst3[n] <= 8e-3, (n, worst3[n])
     print("fc1 shared:", {k: "%.2e" % v for k, v in worst3.items()})
+    # ---- without the second level (every pseudo-pair a whole conv3 map): identical forward, gradients to bf16 round-off
+    _poison(eng)
+    l4, _, _, g4 = _with_env({"SGC_SHARED_CONV3": "1", "SGC_SHARED_BWD": "1", "SGC_SHARED_FC1": "1", "SGC_SHARED_OBJECTS": "0"}, run)
+    assert l4 == l3
+    for n in g3:
+        assert torch.isfinite(g4[n]).all(), n
+        e = float((g4[n].double() - g3[n].double()).norm() / g3[n].double().norm().clamp(min=1e-30))
+        assert e <= 6e-3, (n, e)
 
 
 @pytest.mark.parametrize("nobj,edge", [([9, 4, 12], True), ([36] * 3, False), ([64] * 2, True), ([1, 3], True)])
@@ -208,6 +216,9 @@ def test_fc1_over_window_major_rows_matches_the_one_gemm_form(nobj, edge):
                 ws.bufs[name].view(torch.int16).fill_(0x7E00 if name in ("h1", "ywm") else -1)      # NaN bit patterns
     o1, h1 = _with_env({"SGC_SHARED_FC1": "1"}, run)
     assert torch.isfinite(h1).all()
+    # second level (pseudo-pairs computed on their own windows only, the rest from the images' background maps): the same bits
+    o2, h2 = _with_env({"SGC_SHARED_FC1": "1", "SGC_SHARED_OBJECTS": "0"}, run)
+    assert torch.equal(h1, h2) and torch.equal(o1.relation, o2.relation) and torch.equal(o1.cand_pred, o2.cand_pred)
     scale = float(h0.abs().max())
     assert float((h1 - h0).abs().max()) <= 2e-3 * scale, (float((h1 - h0).abs().max()), scale)     # one f16 ulp at the top of the range
     assert float((h1 - h0).norm() / h0.norm().clamp(min=1e-30)) <= 2e-4
