@@ -34,7 +34,7 @@ HBM_PEAK_GBS = 8000.0
 # computed over shared windows (csrc/kernels_shared.hip) the three GEMMs over those windows are the longest launches of the step
 # (forward / data gradient / weight gradient, 7.4 / 7.9 / 8.3 ms); the forward one is reported here, the others are in kernels_ms.
 DOMINANT_KERNEL = ("gemm_nt_pp_kernel<0, 3, 0, 1>",)
-PMC_TAGS = ("r02_final4", "r02_final3")                                      # newest committed counter passes first
+PMC_TAGS = ("r02_final5", "r02_final4")                                      # newest committed counter passes first
 
 
 def parse_args(argv=None):
@@ -95,6 +95,12 @@ def launch_ranks(args, argv):
 
 
 # ------------------------------------------------------------------------------------------------ measurement helpers
+def state_plan_total(eng):
+    """Length of the window list of the last step (X windows of the real pairs + the windows the pseudo-pairs compute themselves)."""
+    t = getattr(eng, "_xw_total", None)
+    return None if t is None else int(t[0])
+
+
 def pmc_traffic():
     """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (separate FETCH_SIZE
     and WRITE_SIZE runs, profiles/rNN_final_pmc_{f,w}.csv).  FETCH_SIZE is doubled: gfx950 counts 128-B requests of
@@ -264,12 +270,13 @@ def run_rank(args):
         fwd_only = ("conv2_fwd", "expand_dense", "expand", "expand_train", "conv3_fwd", "conv3_fwd_objects", "conv3_fwd_windows",
                     "conv3_fwd_assemble", "fc1_fwd", "fc1_fwd_windows", "fc1_fwd_integral", "fc1_fwd_assemble", "fc2_fwd")
         xw = getattr(eng, "_xw", None)
-        n_x = 0
+        n_x = n_list = 0
         if xw is not None:                         # conv3 / fc1 over shared windows: flops of what is actually computed
             n_x = int(xw[1][-1])
             n_ps = 2 * args.objects * args.images
-            flops["conv3_fwd_windows"] = 2.0 * n_x * 4 * 1024 * 4608
-            flops["conv3_fwd_objects"] = 2.0 * n_ps * 256 * 1024 * 4608
+            n_list = int(state_plan_total(eng)) if state_plan_total(eng) else n_x      # X windows + the pseudo-pairs' own windows
+            flops["conv3_fwd_windows"] = 2.0 * n_list * 4 * 1024 * 4608
+            flops["conv3_fwd_objects"] = 2.0 * (args.images if n_list > n_x else n_ps) * 256 * 1024 * 4608
             flops["conv3_dgrad_windows"] = flops["conv3_wgrad_windows"] = flops["conv3_fwd_windows"]
             flops["fc1_fwd_windows"] = 2.0 * (n_x + 64 * n_ps) * 1024 * 4096          # padding rows not counted
             flops["fc1_dgrad"] = flops["fc1_wgrad"] = flops["fc1_fwd_windows"]
@@ -278,7 +285,8 @@ def run_rank(args):
             ach = flops[dom] / (kern[dom] * 1e-3) / 1e12
             traffic, tag = pmc_traffic() if P == 32256 else (None, None)
             roof = {"bound": "mfma", "kernel": "gemm_nt_pp_kernel<f16,relu+pool,conv-gather> (sgc_conv3_relu_pool_windows_wm: %d windows x 4 pixels "
-                                               "x 1024 x 4608 of the %d per-pair windows; the rest is shared per object)" % (n_x, P * 64),
+                                               "x 1024 x 4608: the pair-specific windows of the %d per-pair windows + the per-object windows; the "
+                                               "rest is shared)" % (n_list, P * 64),
                     "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                     "traffic_note": "bytes/launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from profiles/%s_pmc_{f,w}.csv "

@@ -377,6 +377,7 @@ class RelHeadEngine:
         if not exact and e_real is not None:
             total = min(total, int(e_real) + n2 * 64)
         self._xw = (gather, incl[:P] if P else incl)
+        self._xw_total = incl[Pt - 1:]
         return dict(gather=gather, incl=incl, n_total=incl[Pt - 1:], pixrect=pixrect, bound=total, entries=total if exact else None,
                     entries_real=e_real if exact else None, window_entries=hint.get("per_window"), objects=objects, P=P, n_obj=n_obj,
                     n_img=n_img)
