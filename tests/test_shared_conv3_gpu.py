@@ -30,7 +30,8 @@ def _model(cfg, seed=1):
 def _edge_boxes(batch):
     """Overwrite the first boxes of every image with the edge cases."""
     special = torch.tensor([[0, 32, 0, 32], [5, 6, 7, 8], [0, 3, 0, 2], [29, 32, 30, 32], [10, 10, 4, 9], [12, 20, 12, 20],
-                            [12, 20, 12, 20], [0, 32, 15, 17], [3, 4, 0, 32]])
+                            [12, 20, 12, 20], [0, 32, 15, 17], [3, 4, 0, 32], [-4, 6, -2, 9], [30, 40, 28, 36], [9, 3, 5, 8]])
+    # the last three: negative starts (Python slice semantics: counted from the end), stops beyond the grid, a reversed (empty) box
     for b in batch.bbox:
         k = min(len(special), b.shape[0])
         b[:k] = special[:k].to(b.dtype)
