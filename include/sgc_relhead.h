@@ -101,6 +101,10 @@ int sgc_windows_unpool(const void* dy, const unsigned char* argmax, const int* g
                        int entries_pad, void* dy3x, float* bias_part, int* n_parts, void* stream);
 int sgc_windows_im2col(const void* z_pad_bf16, const int* gather, const int* gather_n, int entries_pad, void* zcol, void* stream);
 int sgc_windows_wgrad(const void* dy3x, const void* zcol, float* slabs, int rows, int splits, int* n_slabs, void* stream);
+/* ... without the im2col buffer: the rows of the second operand are gathered from z_pad_bf16 through the window list; gather must hold
+ * valid windows of fully written maps for all rows/4 entries (the rows of dy3x behind the list are zero) */
+int sgc_windows_wgrad_gather(const void* dy3x, const void* z_pad_bf16, const int* gather, float* slabs, int rows, int splits, int* n_slabs,
+                             void* stream);
 int sgc_windows_dgrad_cols(const void* dy3x, const void* w3col, void* col, int rows, void* stream);
 int sgc_windows_col2im(const void* col, const int* bbox, const int* sub_idx, const int* obj_idx, const int* count_incl, int n_pairs,
                        void* dz, void* stream);

@@ -13,7 +13,7 @@
 #include "common.h"
 #include "gemm_nt.h"
 
-enum { BMODE_PLAIN = 0, BMODE_CONV = 1 };
+enum { BMODE_PLAIN = 0, BMODE_CONV = 1, BMODE_GATHER = 2 };   // GATHER (ping-pong block only): conv rows from a window list, see TnParams::gather
 
 struct TnParams {
     const u16* A; const u16* B; float* C;
@@ -25,6 +25,10 @@ struct TnParams {
     int tiles_m, tiles_n, ktiles_per_split, splits;
     int xcd_map;                 // conv3 wgrad only: XCD-aware tile assignment (see kernel)
     int xcd_patch;               // ping-pong block: per-XCD 4x8 tile patches (tile count per split divisible by 8)
+    const int* gather;           // BMODE_GATHER: contraction row r = pixel r&3 of window gather[r>>2] = image*64 + window of 16x16 maps
+                                 // [img][18][18][Cin] (csrc/kernels_shared.hip): the conv weight gradient over LISTED windows with no
+                                 // im2col buffer.  A k block of 4 rows is one window, so the row base is wave-uniform (scalar load
+                                 // of the list entry) and only the pixel / tap / column part is per lane.
     const int* goff;             // ping-pong block, grouped form: block -> (group g, tile); the contraction runs over rows goff[g] .. goff[g+1]
                                  // (multiples of 64) and the result goes to columns g*N .. of C (no split-K, splits = number of groups)
 };
@@ -259,6 +263,12 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(const TnParams p) {
                 const int tap = tap_raw > 8 ? 8 : tap_raw;
                 const int ky = tap / 3, kx = tap - 3 * ky;
                 b = conv_row_base(kl, p.lgS, p.Cin) + (long)(ky * ((1 << p.lgS) + 2) + kx) * p.Cin + (col - tap_raw * p.Cin);
+            } else if constexpr (BMODE == BMODE_GATHER) {
+                const int tap_raw = col / p.Cin;
+                const int tap = tap_raw > 8 ? 8 : tap_raw;
+                const int ky = tap / 3, kx = tap - 3 * ky;
+                // pixel kr of the window + tap + column; the window's own offset is added per K tile (stage)
+                b = (long)(((kr >> 1) + ky) * 18 + (kr & 1) + kx) * p.Cin + (col - tap_raw * p.Cin);
             } else {
                 b = (long)kl * p.ldb + col;
             }
@@ -275,7 +285,19 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(const TnParams p) {
             g = p.A + toff;                          // wave-uniform: goes into the buffer descriptor
         } else {
             if constexpr (BMODE == BMODE_CONV) toff = conv_row_base(kt * 64, p.lgS, p.Cin); else toff = (long)kt * 64 * p.ldb;
-            g = p.B + toff;
+            g = p.B + toff;                          // (BMODE_GATHER: replaced below by the window's own base)
+        }
+        if constexpr (BMODE == BMODE_GATHER) {
+            if (kind == 1 || kind == 2) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int code = __builtin_amdgcn_readfirstlane(p.gather[__builtin_amdgcn_readfirstlane(kt * 16 + wid * 2 + q)]);
+                    const int W = code & 63;
+                    const u16* gq = p.B + ((long)((code >> 6) * 18 + 2 * (W >> 3)) * 18 + 2 * (W & 7)) * p.Cin;
+                    buf_load_lds16(gq, voff[kind][q], 0, base + q * 1024);
+                }
+                return;
+            }
         }
         buf_load_lds16(g, voff[kind][0], 0, base);
         buf_load_lds16(g, voff[kind][1], 0, base + 1024);

@@ -904,4 +904,18 @@ int sgc_windows_col2im_objects(const void* col, const int* bbox, int n_obj, int 
     return SGC_OK;
 }
 
+// The same weight gradient without the im2col buffer: the second operand's rows are gathered from z_pad_bf16 by the window list
+// (gemm_tn_pp_kernel<BMODE_GATHER>).  gather must hold VALID windows for all rows / 4 entries (pad behind the list with any
+// window of a fully written map: the matching rows of dy3x are zero).
+int sgc_windows_wgrad_gather(const void* dy3x, const void* z_pad_bf16, const int* gather, float* slabs, int rows, int splits, int* n_slabs,
+                             void* stream) {
+    if (rows <= 0) { if (n_slabs) *n_slabs = 0; return SGC_OK; }
+    if (rows & 63) return SGC_ERR_ARG;
+    TnParams p{};
+    p.A = (const u16*)dy3x; p.B = (const u16*)z_pad_bf16; p.C = slabs; p.M = 1024; p.N = 9 * 512; p.K = rows;
+    p.lda = 1024; p.ldc = 9 * 512; p.slab_stride = 1024L * 9 * 512; p.lgS = 4; p.Cin = 512; p.gather = gather;
+    if (splits <= 0) splits = tn_auto_splits(4 * 18, rows >> 6);
+    return launch_gemm_tn_pp<ELEM_BF16, BMODE_GATHER, 0>(p, splits, n_slabs, (hipStream_t)stream);
+}
+
 }  // extern "C"
