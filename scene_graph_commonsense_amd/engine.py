@@ -1043,7 +1043,8 @@ class RelHeadEngine:
                 slx = sl[slabs_n.value * 1024 * 4608:]
                 if os.environ.get("SGC_WGRAD_GATHER", "0") != "0":
                     # A/B hook, off: rows of z gathered by the window list inside the GEMM block (no im2col buffer).  Measured 11.0 ms
-                    # against 8.3 + 2.3 ms for im2col + plain GEMM (the per-window scalar look-up sits in front of every staging step).
+                    # against 8.3 + 2.3 ms for im2col + plain GEMM; looking the windows up one K tile ahead made it 12.0 ms - it is the nine
+                    # shifted re-reads of the z rows by different N tiles, not the look-up latency, that costs.
                     # The entries behind the list (their dy3x rows are zero) must name a fully written map: the first pseudo-pair's
                     if Epad > E:
                         gather[E:Epad] = P * 64
