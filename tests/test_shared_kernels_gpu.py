@@ -149,3 +149,63 @@ def test_fc1_prefix_sums_and_per_object_gradient_sums():
         want[1, j][torch.from_numpy(ins(j) & ~ins(i)).to(DEV)] += dh[p].float()
     got = torch.stack([gwm[int(goff[w]):int(goff[w]) + n2].float() for w in range(64)], dim=1).view(2, n_obj, 64, 4096)
     assert torch.allclose(got, want, atol=0.05, rtol=1e-2)                 # bf16 output of sums of up to 6 terms
+
+
+def test_second_level_rows_and_their_gradient():
+    """sgc_shared_objects_fill_rows copies the background map's rows to the pseudo-pairs' window-major rows outside R_o (and nowhere
+    else); sgc_shared_objects_bg_grad is its transpose; sgc_shared_objects_count / _fill list exactly the windows of R_o."""
+    from scene_graph_commonsense_amd.pairs import count_object_windows, window_major_layout
+    L, lib = _lib()
+    rng = np.random.default_rng(3)
+    n_obj, n_img = 7, 2
+    pl = _plan(rng, n=n_obj)
+    R, bb_d = pl["R"], pl["bb_d"]
+    obj_img = torch.tensor([0, 0, 0, 1, 1, 1, 1], dtype=torch.int32, device=DEV)
+    img_ptr = torch.tensor([0, 3, 7], dtype=torch.int32, device=DEV)
+    n2 = 2 * n_obj
+    goff, _ = window_major_layout(np.zeros(64, dtype=np.int64), n2)
+    goff_d = torch.from_numpy(goff).to(DEV)
+    rows = int(goff[64])
+    wy, wx = np.divmod(np.arange(64), 8)
+    ins = lambda o: (wx >= R[o, 0]) & (wx < R[o, 1]) & (wy >= R[o, 2]) & (wy < R[o, 3])
+    # ---- plan of the pseudo-pairs
+    cnt = torch.zeros(n2, dtype=torch.int32, device=DEV)
+    pix = torch.zeros(n2, dtype=torch.int32, device=DEV)
+    L.check(lib.sgc_shared_objects_count(L.ptr(bb_d), n_obj, L.ptr(cnt), L.ptr(pix), L.stream_ptr()), "count")
+    assert cnt.cpu().tolist() == [int(ins(o % n_obj).sum()) for o in range(n2)] and int(cnt.sum()) == count_object_windows(pl["bb"])
+    P = 5                                                       # pretend five real pairs without X windows in front
+    incl = torch.cumsum(torch.cat([torch.zeros(P, dtype=torch.int32, device=DEV), cnt]), 0, dtype=torch.int32)
+    gather = torch.full((int(incl[-1]) + 3,), -1, dtype=torch.int32, device=DEV)
+    L.check(lib.sgc_shared_objects_fill(L.ptr(bb_d), n_obj, P, L.ptr(incl), L.ptr(gather), L.stream_ptr()), "fill")
+    want = [(P + ps) * 64 + int(w) for ps in range(n2) for w in np.nonzero(ins(ps % n_obj))[0]]
+    assert gather[:len(want)].cpu().tolist() == want and int(gather[len(want)]) == -1
+    # ---- rows
+    y_bg = torch.randn(n_img * 64, 1024, device=DEV).half()
+    ybf_bg = y_bg.bfloat16()
+    am_bg = torch.randint(0, 5, (n_img * 64, 1024), device=DEV, dtype=torch.uint8)
+    ywm = torch.full((rows, 1024), -7.0, device=DEV).half()
+    ywm_bf = torch.full((rows, 1024), -7.0, device=DEV).bfloat16()
+    am_ps = torch.full((n2 * 64, 1024), 9, device=DEV, dtype=torch.uint8)
+    L.check(lib.sgc_shared_objects_fill_rows(L.ptr(bb_d), L.ptr(obj_img), n_obj, L.ptr(goff_d), L.ptr(y_bg), L.ptr(ybf_bg), L.ptr(am_bg),
+                                             L.ptr(ywm), L.ptr(ywm_bf), L.ptr(am_ps), L.stream_ptr()), "fill_rows")
+    for ps in range(n2):
+        o = ps % n_obj
+        for w in range(64):
+            row = int(goff[w]) + ps
+            if ins(o)[w]:
+                assert float(ywm[row, 0]) == -7.0 and int(am_ps[ps * 64 + w, 0]) == 9          # left for the window-list entry
+            else:
+                src = int(obj_img[o]) * 64 + w
+                assert torch.equal(ywm[row], y_bg[src]) and torch.equal(ywm_bf[row], ybf_bg[src]) and torch.equal(am_ps[ps * 64 + w], am_bg[src])
+    # ---- gradient of the copies
+    dywm = torch.randn(rows, 1024, device=DEV).bfloat16()
+    dy_bg = torch.zeros(n_img * 64, 1024, device=DEV).bfloat16()
+    L.check(lib.sgc_shared_objects_bg_grad(L.ptr(bb_d), L.ptr(img_ptr), n_obj, n_img, L.ptr(goff_d), L.ptr(dywm), L.ptr(dy_bg), L.stream_ptr()),
+            "bg_grad")
+    want = torch.zeros(n_img * 64, 1024, device=DEV)
+    for ps in range(n2):
+        o = ps % n_obj
+        for w in range(64):
+            if not ins(o)[w]:
+                want[int(obj_img[o]) * 64 + w] += dywm[int(goff[w]) + ps].float()
+    assert torch.allclose(dy_bg.float(), want, atol=0.05, rtol=1e-2)
