@@ -1,5 +1,6 @@
-// conv3 over SHARED windows: the part of conv3_1 -> ReLU -> 2x2 max-pool (reference model.py:145-147) that is the same for
-// every pair with the same subject (or the same object) is computed once per object instead of once per pair.
+// conv3 and fc1 over SHARED windows: the part of conv3_1 -> ReLU -> 2x2 max-pool -> fc1 (reference model.py:145-149) that is the
+// same for every pair with the same subject (or the same object) is computed once per object instead of once per pair, and the part
+// that is the same for every object of an image once per image.
 //
 // Why it is exact.  Object o's masked map is tanh(conv1(features)) inside its box and the constant tanh(b1) outside
 // (train_test.py:194-195 multiplies by the box mask before conv1_1/conv1_2).  So the conv2 half V_o equals V_bg - the half of
@@ -9,8 +10,14 @@
 // conv3's pooling windows (`object_windows`).  For the pair (i, j) a window is
 //   I : outside R_j                 -> y_ij[w] = y of the pseudo-pair (i, bg)[w]     (identical inputs, identical arithmetic)
 //   J : inside R_j, outside R_i     -> y_ij[w] = y of the pseudo-pair (bg, j)[w]
-//   X : inside R_i and R_j          -> computed for the pair (`gemm_nt_kernel<AMODE_CONV_GATHER>` over the list of X windows)
-// On the benchmark's boxes 11.5 % of the windows are X (13 % on VG-like box statistics, tools/background_sparsity.py).
+//   X : inside R_i and R_j          -> computed for the pair
+// and, one level up, a pseudo-pair (o, bg) equals the all-background map (bg, bg) outside R_o.  What is computed per window is the
+// WINDOW LIST: the X windows of the real pairs and the windows R_o of the pseudo-pairs (gemm_nt_pp_kernel<ACG> forward; un-pool,
+// im2col, column GEMMs, col2im backward); whole conv3 maps remain only for the n_img background maps.  On the benchmark's boxes
+// 11.5 % of the windows are X (13 % on VG-like box statistics, tools/background_sparsity.py).
+// fc1 is a sum over the 64 windows and runs over the same rows in a window-major row space (see "fc1 over shared windows" below).
+// tests: tests/test_shared_identity_cpu.py (the identity on the reference's literal graph, float64), tests/test_shared_conv3_gpu.py
+// (bit-identity of the forward, gradients), tests/test_shared_kernels_gpu.py (every entry point against numpy / torch).
 #include "gemm_tn.h"
 
 struct WRect { int x0, x1, y0, y1; };                  // half-open on the 8x8 window grid; x1 <= x0: empty
