@@ -36,14 +36,6 @@ def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
 
 
-def _newest_dep() -> float:
-    t = 0.0
-    for root in (CSRC, os.path.join(os.path.dirname(HERE), "include")):
-        for f in os.listdir(root):
-            t = max(t, os.path.getmtime(os.path.join(root, f)))
-    return t
-
-
 def lib_path() -> str:
     return os.path.join(LIBDIR, LIBNAME)
 
@@ -73,34 +65,72 @@ def is_stale() -> bool:
         return f.read().strip() != source_hash()
 
 
-def _compile(src: str) -> str:
-    obj = os.path.join(OBJDIR, os.path.basename(src)[:-4] + ".o")
-    if os.path.exists(obj) and os.path.getmtime(obj) >= _newest_dep():
+def _headers_hash() -> str:
+    """Hash of the flags and of every header a translation unit may include (csrc/*.h, include/*.h)."""
+    import hashlib
+    h = hashlib.sha1(" ".join(f for f in FLAGS if f.startswith("-") and f != "-I").encode())
+    for root in (CSRC, os.path.join(os.path.dirname(HERE), "include")):
+        for f in sorted(os.listdir(root)):
+            if f.endswith(".h"):
+                h.update(f.encode())
+                with open(os.path.join(root, f), "rb") as fh:
+                    h.update(fh.read())
+    return h.hexdigest()
+
+
+def _compile(src: str, hdr_hash: str) -> str:
+    """One object per (source content, headers, flags): the object's name carries that hash, so a changed flag (``SGC_EXPERIMENTS``)
+    or header can never be satisfied by an object compiled under another one; older objects of the same source are removed."""
+    import hashlib
+    base = os.path.basename(src)[:-4]
+    with open(src, "rb") as fh:
+        key = hashlib.sha1(hdr_hash.encode() + fh.read()).hexdigest()[:12]
+    obj = os.path.join(OBJDIR, "%s.%s.o" % (base, key))
+    for f in os.listdir(OBJDIR):
+        if f.startswith(base + ".") and f.endswith(".o") and f != os.path.basename(obj):
+            os.remove(os.path.join(OBJDIR, f))
+    if os.path.exists(obj):
         return obj
-    cmd = [hipcc()] + FLAGS + ["-c", src, "-o", obj]
+    tmp = obj + ".tmp%d" % os.getpid()
+    cmd = [hipcc()] + FLAGS + ["-c", src, "-o", tmp]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
+        if os.path.exists(tmp):
+            os.remove(tmp)
         raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
+    os.replace(tmp, obj)
     return obj
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
+    """Compile and link under an exclusive file lock (several ranks may find the library stale at once: one builds, the others
+    wait and then see a fresh stamp); the library and its stamp are moved into place atomically."""
+    import fcntl
     os.makedirs(OBJDIR, exist_ok=True)
     out = lib_path()
-    if not force and not is_stale():
-        return out
-    if force or not os.path.exists(_stamp_path()):
-        for f in os.listdir(OBJDIR):
-            os.remove(os.path.join(OBJDIR, f))
-    srcs = sources()
-    with cf.ThreadPoolExecutor(max_workers=min(6, len(srcs))) as ex:
-        objs = list(ex.map(_compile, srcs))
-    cmd = [hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", out] + objs
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    if r.returncode != 0:
-        raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
-    with open(_stamp_path(), "w") as f:
-        f.write(source_hash())
+    with open(os.path.join(LIBDIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not is_stale():
+                return out
+            if force:
+                for f in os.listdir(OBJDIR):
+                    os.remove(os.path.join(OBJDIR, f))
+            srcs = sources()
+            hh = _headers_hash()
+            with cf.ThreadPoolExecutor(max_workers=min(6, len(srcs))) as ex:
+                objs = list(ex.map(lambda s_: _compile(s_, hh), srcs))
+            tmp = out + ".tmp%d" % os.getpid()
+            cmd = [hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", tmp] + objs
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+            os.replace(tmp, out)
+            with open(_stamp_path() + ".tmp", "w") as f:
+                f.write(source_hash())
+            os.replace(_stamp_path() + ".tmp", _stamp_path())
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     if verbose:
         print("built", out)
     return out

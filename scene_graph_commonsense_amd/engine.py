@@ -801,8 +801,12 @@ class RelHeadEngine:
             h1_bf = self._to_bf16("h1_bf", ctx.h1, Ppad * 4096)
             self._timed("fc2_wgrad", lambda: _lib.check(lib.sgc_fc2_wgrad(_lib.ptr(dpre), _lib.ptr(h1_bf), _lib.ptr(sl), Ppad, 32, ctypes.byref(slabs_n), st()),
                        "sgc_fc2_wgrad"))
-            gfc2 = torch.empty_like(w["fc2_full"])                       # every column is written: main block + label columns
+            gfc2 = torch.empty_like(w["fc2_full"])                       # main block + label columns are written below
             ld2 = int(gfc2.shape[1])
+            use_mh = ctx.super_mh[0] is not None and cfg.dataset == "vg"
+            n_lab = 2 * cfg.num_classes + (2 * cfg.num_super_classes if use_mh else 0)
+            if 4096 + n_lab < ld2:                                       # VG model without super-categories: nothing writes the
+                gfc2[:, 4096 + n_lab:].zero_()                           # multi-hot columns - their gradient is zero, not garbage
             _lib.check(lib.sgc_slab_sum_ld(_lib.ptr(sl), _lib.ptr(gfc2), 512, 4096, _c_long(ld2), slabs_n.value, st()), "sgc_slab_sum_ld")
             dls = torch.empty(n_obj, 512, dtype=torch.float32, device=dev)
             dlo = torch.empty(n_obj, 512, dtype=torch.float32, device=dev)
@@ -810,7 +814,6 @@ class RelHeadEngine:
                        "sgc_segment_sum_rows")
             _lib.check(lib.sgc_segment_sum_rows(_lib.ptr(dpre), _lib.ptr(obj_csr[0]), _lib.ptr(obj_csr[1]), _lib.ptr(dlo), n_obj, 512, st()),
                        "sgc_segment_sum_rows")
-            use_mh = ctx.super_mh[0] is not None and cfg.dataset == "vg"
             mh_s, mh_o = (ctx.super_mh if use_mh else (None, None))
             cats_s, cats_o = (c if c.dtype == torch.int64 else c.long() for c in ctx.cats)
             _lib.check(lib.sgc_label_grads(_lib.ptr(dls), _lib.ptr(dlo), _lib.ptr(cats_s), _lib.ptr(cats_o), _lib.ptr(mh_s), _lib.ptr(mh_o),

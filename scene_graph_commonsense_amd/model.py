@@ -19,7 +19,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from .engine import PairOutputs, RelHeadEngine, csr_by
+from .engine import PairOutputs, RelHeadEngine
 from .pairs import DeviceScene, pair_targets_fast, super_multihot
 from .synthetic import HeadConfig, predicate_counts
 
@@ -36,6 +36,14 @@ def _dense(scene):
     if getattr(scene, "pid", None) is None or scene.max_n <= 0:
         return None
     return (scene.img_ptr, scene.pid, scene.max_n)
+
+
+def _csr_by_device(index: torch.Tensor, n: int):
+    """Device form of ``engine.csr_by``: (ptr [n+1], list) int32 of the positions grouped by object id, stable (sums run in list order)."""
+    idx = index.long()
+    order = torch.argsort(idx, stable=True)
+    ptr = torch.searchsorted(idx[order].contiguous(), torch.arange(n + 1, device=index.device))
+    return ptr.to(torch.int32).contiguous(), order.to(torch.int32).contiguous()
 
 
 def strip_ddp_prefix(state_dict: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
@@ -189,6 +197,18 @@ class _RelationBase(nn.Module):
         dev = eng.device
         P = scene.n_pairs
         if P == 0:                                 # no image with two objects: nothing to score, zero loss and gradients
+            if reducer is not None and reducer.world > 1:
+                # the other ranks reduce this step's gradients: take part in the same collectives, in the same order, with
+                # zeros (a rank that skipped them would pair its NEXT step's all-reduce with the peers' current one)
+                zeros = {n: torch.zeros_like(p) for n, p in self.named_parameters()}
+                if "fc1.weight" in zeros:
+                    reducer.hook("fc1.weight", zeros["fc1.weight"])
+                reducer.finish_grads(zeros)
+                for n, p in self.named_parameters():
+                    if p.grad is None:
+                        p.grad = zeros[n]
+                    else:
+                        p.grad.add_(zeros[n])
             for p in self.parameters():
                 if p.grad is None:
                     p.grad = torch.zeros_like(p)
@@ -234,10 +254,10 @@ class _RelationBase(nn.Module):
             extra = None
             loss_c = None
             if image_feature_aug is not None:
-                directed_h = directed_d.cpu().numpy().astype(np.int64)     # the contrastive branch gathers the connected pairs on the host
-                conn_idx = np.nonzero(directed_h >= 0)[0]
-            if image_feature_aug is not None and len(conn_idx) > 0:
-                extra = self._contrast_forward(eng, scene, image_feature_aug, conn_idx, directed_h, ctx, lambda_contrast)
+                # connected pairs selected on the device; the only host synchronisation is their count (the augmented trunk's sizes)
+                conn_idx = torch.nonzero(directed_d >= 0).flatten()
+            if image_feature_aug is not None and int(conn_idx.numel()) > 0:
+                extra = self._contrast_forward(eng, scene, image_feature_aug, conn_idx, directed_d, ctx, lambda_contrast)
                 loss_c, dp_main = extra["loss"], extra["dp_main"]
             loss, grads = eng.train_backward(ctx, coefs_d, sub_csr, obj_csr, img_ptr,
                                              grad_hook=grad_hook if extra is None else None, dp_extra=dp_main,
@@ -276,8 +296,8 @@ class _RelationBase(nn.Module):
             self._engine_aug = RelHeadEngine(self.head_config(), dev)
         eng_a = self._engine_aug
         eng_a.w, eng_a.T, eng_a.head_rows = eng.w, eng.T, eng.head_rows          # shared weights, own workspace
-        M = len(conn_idx)
-        cidx = torch.from_numpy(conn_idx).to(dev)
+        M = int(conn_idx.numel())
+        cidx = conn_idx
         sub_a = scene.sub_idx[cidx].contiguous()
         obj_a = scene.obj_idx[cidx].contiguous()
         ctx_a = eng_a.train_forward(image_feature_aug.to(dev, torch.float32).contiguous(), scene.image_depth, scene.obj_img,
@@ -285,17 +305,16 @@ class _RelationBase(nn.Module):
                                     seeds=self._next_seeds() if self.training else (0, 0), dropout=self.training)
         P = scene.n_pairs
         feats = torch.cat((ctx.p[:P * 512].view(P, 512)[cidx], ctx_a.p[:M * 512].view(M, 512)), dim=0).contiguous()
-        labels = torch.from_numpy(directed[conn_idx].astype(np.int32)).to(dev)
+        labels = directed[cidx].to(torch.int32).contiguous()
         lam2 = float(lambda_contrast) * float(lambda_contrast)
         loss_c, dF = eng.supcon_loss(feats, labels, grad_scale=lam2)
         dp_main = torch.zeros(P, 512, dtype=torch.float32, device=dev)
         dp_main[cidx] = dF[:M]
         n_obj = int(scene.obj_img.shape[0])
-        pidx = scene.pidx
         zeros = torch.zeros(M, dtype=torch.float32, device=dev)
         coefs = (torch.full((M,), -1, dtype=torch.int32, device=dev), zeros, zeros, zeros, zeros)
-        sub_csr = tuple(torch.from_numpy(a).to(dev) for a in csr_by(pidx.sub[conn_idx], n_obj))
-        obj_csr = tuple(torch.from_numpy(a).to(dev) for a in csr_by(pidx.obj[conn_idx], n_obj))
+        sub_csr = _csr_by_device(sub_a, n_obj)
+        obj_csr = _csr_by_device(obj_a, n_obj)
         return dict(engine=eng_a, ctx=ctx_a, loss=loss_c, dp_main=dp_main, dp_aug=dF[M:].contiguous(), coefs=coefs,
                     sub_csr=sub_csr, obj_csr=obj_csr)
 

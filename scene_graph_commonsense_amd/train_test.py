@@ -180,9 +180,17 @@ def load_checkpoint(model, args, epoch, cs_mode, rank):
     raise FileNotFoundError("no checkpoint at %s (or %s)" % checkpoint_name(args, epoch, cs_mode))
 
 
+class EmptyMinibatch(Exception):
+    """The dataloader tuple holds no sample (all dropped): the only condition under which a step is skipped.  Errors of the
+    feature encoder are NOT caught - a rank that swallowed one would skip the step's collectives."""
+
+
 def _to_batch(args, data, detr, rank, with_aug):
     """The dataloader tuple (``dataloader.py:163-165``) -> ``SceneBatch`` (+ augmented-view features)."""
-    images, images_aug, image_depth, categories, super_categories, bbox, relationships, subj_or_obj, annot_path = data[:9]
+    try:
+        images, images_aug, image_depth, categories, super_categories, bbox, relationships, subj_or_obj, annot_path = data[:9]
+    except (ValueError, IndexError):
+        raise EmptyMinibatch()               # every sample was dropped by the loader: the collate gave an empty tuple
     with torch.no_grad():
         image_feature = process_image_features(args, images, detr, rank)
         feature_aug = process_image_features(args, images_aug, detr, rank) if (with_aug and images_aug[0] is not None) else None
@@ -268,7 +276,7 @@ def training(gpu, args, train_subset, test_subset):
         for batch_count, data in enumerate(train_loader):
             try:
                 batch, feature_aug, annot_path = _to_batch(args, data, detr, rank, with_aug=True)
-            except (ValueError, IndexError):
+            except EmptyMinibatch:
                 continue                                     # a minibatch whose samples were all dropped by the loader
             Recall.load_annotation_paths(annot_path)
             # the reference rescales lr inside its graph_iter loop and steps once per minibatch: the value in force at
@@ -286,7 +294,9 @@ def training(gpu, args, train_subset, test_subset):
             if relation_classifier.last_connectivity_stats is not None:
                 stats += relation_classifier.last_connectivity_stats
             last = batch_count + 1 == len(train_loader)
-            if batch_count % T["eval_freq"] == 0 or last:
+            if (batch_count % T["eval_freq"] == 0 or last) and relation_classifier.last_outputs is None:
+                pass                                         # no image of this minibatch had two objects: nothing to rank
+            elif batch_count % T["eval_freq"] == 0 or last:
                 # evaluator feed with the training-mode outputs of this step, no overlap filter (iou_mask all ones, train_test.py:209)
                 feed_evaluators(relation_classifier, relation_classifier.last_scene, relation_classifier.last_outputs, Recall,
                                 Recall_top3 if args["models"]["hierarchical_pred"] else None, overlap=None)
@@ -301,14 +311,20 @@ def training(gpu, args, train_subset, test_subset):
                 Recall.clear_data()
             if rank == 0 and writer is not None:
                 writer.add_scalar("train/running_losses", float(running_losses), batch_count + len(train_loader) * epoch)
-            if batch_count % T["print_freq"] == 0 or last:
+            if (batch_count % T["print_freq"] == 0 or last) and recall is not None:
                 s = stats.tolist()
                 record_train(args, record, rank, epoch, batch_count, optimizer.param_groups[0]["lr"], recall_top3, recall, mean_recall_top3,
                              mean_recall, recall_zs, mean_recall_zs, running_losses, running_losses, running_contrast,
                              torch.zeros(()), torch.zeros(()), torch.tensor(float(s[4])), s[1], s[0], torch.tensor(float(s[3])), s[2],
                              wmap_rel, wmap_phrase)
+            if batch_count % T["print_freq"] == 0 or last:
                 dist.barrier()
-            running_losses.zero_(); running_contrast.zero_(); stats.zero_()
+            # the reference resets the losses, connectivity_precision, num_connected and num_not_connected every minibatch and lets
+            # connectivity_recall and num_connected_pred run on (train_test.py:308-309): same here, so the logged ratios agree.
+            # (Per-term running losses are not kept apart on the fused path: the total is logged as running_loss_relationship,
+            # connectivity and commonsense as 0.)
+            running_losses.zero_(); running_contrast.zero_()
+            stats[0] = 0; stats[1] = 0; stats[3] = 0
         if rank == 0:
             path = checkpoint_name(args, epoch, cs_mode)[0]
             print("Saving model to %s..." % path)
@@ -344,7 +360,7 @@ def testing(args, detr, relation_classifier, test_loader, test_record, epoch, ra
                 break
             try:
                 batch, _, _ = _to_batch(args, data, detr, rank, with_aug=False)
-            except (ValueError, IndexError):
+            except EmptyMinibatch:
                 continue
             last = batch_count + 1 == len(test_loader)
             feed = batch_count % T["eval_freq_test"] == 0 or last
