@@ -51,6 +51,9 @@ def parse_args(argv=None):
     ap.add_argument("--torch-sgd", action="store_true", help="torch.optim.SGD instead of the one-pass optim.FusedSGD (same update)")
     ap.add_argument("--dataset", default="vg", choices=["vg", "oiv6"], help="oiv6 = 601 classes, (4,2,24) head, no super-classes")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL)")
+    ap.add_argument("--no-sensitivity", action="store_true", help="skip the three short box-size sensitivity runs (N=1 only)")
+    ap.add_argument("--box-scale", type=float, default=1.0,
+                    help="scale every box about its centre (clipped to the image); >= 100 = every box is the full image")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / rendezvous / reduction plumbing only, no GPU work (the CPU test of the N-rank launch uses it with gloo)")
     return ap.parse_args(argv)
@@ -117,6 +120,44 @@ def pmc_traffic():
         if len(vals) == 2:
             return int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024), tag
     return None, None
+
+
+def scale_boxes(batch, factor):
+    """Boxes of a synthetic minibatch scaled about their centres and clipped to the 32x32 grid (>= 100: the whole image).  The
+    reference's cost does not depend on the boxes (``model.py:138-150`` runs every pixel of every pair); this implementation's does
+    - the pair-specific share of conv3 / fc1 grows with the overlap of the per-object window rectangles - hence the sweep."""
+    import torch
+    out = []
+    for bb in batch.bbox:
+        b = bb.double()
+        if factor >= 100:
+            nb = torch.tensor([0, 32, 0, 32], dtype=torch.float64).repeat(b.shape[0], 1)
+        else:
+            cx, cy = (b[:, 0] + b[:, 1]) / 2, (b[:, 2] + b[:, 3]) / 2
+            hw, hh = (b[:, 1] - b[:, 0]) * factor / 2, (b[:, 3] - b[:, 2]) * factor / 2
+            nb = torch.stack([torch.floor(cx - hw), torch.ceil(cx + hw), torch.floor(cy - hh), torch.ceil(cy + hh)], 1).clamp(0, 32)
+        out.append(nb.to(bb.dtype))
+    batch.bbox = out
+    return batch
+
+
+def executed_flops(P, n_img, n_obj, n_x, n_list, shared, forward_only=False):
+    """Matrix flops one step really executes (2 x multiply-adds of every GEMM launch, padding rows not counted): what
+    ``roofline.step_frac`` divides by the step time.  ``shared``: conv3 / fc1 over shared windows (csrc/kernels_shared.hip) - the
+    per-pair GEMMs run over the ``n_list`` listed windows (``n_x`` of them pair-specific) and whole conv3 maps remain only for the
+    background maps; otherwise every pair is a whole map.  Passes: forward, data gradient, weight gradient (conv1: no data gradient)."""
+    passes = 1 if forward_only else 3
+    n_objx = n_obj + (n_img if shared else 0)
+    f = {"conv1": 2 * (2.0 * n_img * 1024 * 257 * 128) * (1 if forward_only else 2),
+         "conv2": 2 * (2.0 * n_objx * 1024 * 1152 * 512) * passes,
+         "fc2": 2.0 * P * 4096 * 512 * passes}
+    if shared:
+        f["conv3"] = (2.0 * n_list * 4 * 1024 * 4608 + 2.0 * n_img * 256 * 1024 * 4608) * passes
+        f["fc1"] = 2.0 * (n_x + 64 * 2 * n_obj) * 1024 * 4096 * passes
+    else:
+        f["conv3"] = 2.0 * P * 256 * 1024 * 4608 * passes
+        f["fc1"] = 2.0 * P * 65536 * 4096 * passes
+    return f
 
 
 def cpu_baseline(cfg, sd, budget_s=20.0):
@@ -203,65 +244,100 @@ def run_rank(args):
     model.load_state_dict(sd)
     model.train()
     batch = make_scene_batch(cfg, [args.objects] * args.images, seed=1000 + rank, connect_frac=0.02)
+    if args.box_scale != 1.0:
+        scale_boxes(batch, args.box_scale)
     # inputs resident in HBM when the timed region starts (the DETR features are produced on the GPU upstream); the ragged
     # annotation lists stay host-side Python objects exactly as the reference's dataloader hands them over
     batch.image_feature = batch.image_feature.to(dev)
     batch.image_depth = batch.image_depth.to(dev)
-    scene0 = flatten_scene(cfg, batch, dev)
-    P = scene0.n_pairs
-    # SGD as in the reference (momentum 0.9, wd 1e-4, lr 1e-5 at its largest case N=20, i.e. T=380 direction-steps).
-    # The running-sum loss quirk scales the gradient with T^2, so the learning rate is scaled by (380/T)^2 to keep
-    # the update as stable as the reference's at N=64 (T=4032): otherwise the weights diverge within three steps and
-    # the timed kernels would run on inf/NaN data (data-dependent clocks, meaningless ReLU masks).
-    T = scene0.n_steps
-    lr = 1e-5 * min(1.0, (380.0 / max(T, 1)) ** 2)
     if args.torch_sgd:
-        opt = torch.optim.SGD(model.parameters(), lr=lr, momentum=0.9, weight_decay=1e-4)
+        opt = torch.optim.SGD(model.parameters(), lr=1e-5, momentum=0.9, weight_decay=1e-4)
     else:                                    # same update in one pass over (grad, weight, momentum buffer): optim.FusedSGD
         from scene_graph_commonsense_amd.optim import FusedSGD
-        opt = FusedSGD(model.parameters(), lr=lr, momentum=0.9, weight_decay=1e-4)
+        opt = FusedSGD(model.parameters(), lr=1e-5, momentum=0.9, weight_decay=1e-4)
     reducer = sgd_dist.GradReducer(world)
     eng = model.engine()
-    eng.timers = {}
-
-    def step():
-        if args.forward_only:
-            model.forward_pairs(scene0 if args.cached_scene else flatten_scene(cfg, batch, dev))
-            return None
-        return train_minibatch(model, batch, opt, reducer=reducer, scene=scene0 if args.cached_scene else None)
 
     def barrier():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    first_loss = None
-    for _ in range(args.warmup):
-        l0 = step()
-        if first_loss is None and l0 is not None:
-            first_loss = float(l0)
-    eng.timers = {}
-    barrier()
-    t0 = time.time()
-    loss = None
-    for _ in range(args.steps):
-        loss = step()
-    barrier()
-    dt = time.time() - t0
-    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    def measure(batch, steps, warmup):
+        """W untimed + K timed steps on ``batch`` (barrier + device synchronisation on both sides); this rank's wall time and
+        what the engine did."""
+        scene0 = flatten_scene(cfg, batch, dev)
+        # SGD as in the reference (momentum 0.9, wd 1e-4, lr 1e-5 at its largest case N=20, i.e. T=380 direction-steps).
+        # The running-sum loss quirk scales the gradient with T^2, so the learning rate is scaled by (380/T)^2 to keep
+        # the update as stable as the reference's at N=64 (T=4032): otherwise the weights diverge within three steps and
+        # the timed kernels would run on inf/NaN data (data-dependent clocks, meaningless ReLU masks).
+        opt.param_groups[0]["lr"] = 1e-5 * min(1.0, (380.0 / max(scene0.n_steps, 1)) ** 2)
+
+        def step():
+            if args.forward_only:
+                model.forward_pairs(scene0 if args.cached_scene else flatten_scene(cfg, batch, dev))
+                return None
+            return train_minibatch(model, batch, opt, reducer=reducer, scene=scene0 if args.cached_scene else None)
+
+        eng.timers = {}
+        eng._xw = None
+        first_loss = None
+        for _ in range(warmup):
+            l0 = step()
+            if first_loss is None and l0 is not None:
+                first_loss = float(l0)
+        eng.timers = {}
+        torch.cuda.reset_peak_memory_stats(dev)
+        barrier()
+        t0 = time.time()
+        loss = None
+        for _ in range(steps):
+            loss = step()
+        barrier()
+        dt = time.time() - t0
+        kern = {name: float(np.mean([a.elapsed_time(b) for a, b in evs])) for name, evs in eng.timers.items()}
+        xw = getattr(eng, "_xw", None)
+        n_x = int(xw[1][-1]) if xw is not None else 0
+        n_list = (int(state_plan_total(eng)) if state_plan_total(eng) else n_x) if xw is not None else 0
+        return dict(dt=dt, loss=None if loss is None else float(loss), first_loss=first_loss, kern=kern, P=scene0.n_pairs,
+                    shared=xw is not None, n_x=n_x, n_list=n_list, n_obj=int(scene0.obj_img.shape[0]),
+                    peak_gb=torch.cuda.max_memory_allocated(dev) / 1e9)
+
+    m = measure(batch, args.steps, args.warmup)
+    P, loss, first_loss, kern = m["P"], m["loss"], m["first_loss"], m["kern"]
+    t = torch.tensor([m["dt"]], device=dev, dtype=torch.float64)
+    rank_ms = torch.zeros(world, device=dev, dtype=torch.float64)
+    rank_ms[rank] = m["dt"] / args.steps * 1e3
     ranks = torch.ones(1, device=dev)
     if world > 1:
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         torch.distributed.all_reduce(ranks, op=torch.distributed.ReduceOp.SUM)
+        torch.distributed.all_reduce(rank_ms, op=torch.distributed.ReduceOp.SUM)
     dt = float(t.item())
     assert int(ranks.item()) == args.gpus, "ranks that took part in the timed region != --gpus"
+
+    # ---- box-size sensitivity (N=1): the same step on scaled boxes - the pair-specific share of conv3 / fc1, hence the step time
+    # and the workspace, depend on how much the objects' window rectangles overlap; the reference's cost does not
+    sensitivity = None
+    if world == 1 and not args.no_sensitivity and not args.forward_only and args.box_scale == 1.0:
+        sensitivity = []
+        for label, factor in (("boxes x1.5", 1.5), ("boxes x2.5", 2.5), ("every box = full image", 100.0)):
+            eng.ws.bufs.clear()                       # the workspace only grows: start every point from an empty one
+            model._weights_version = None
+            torch.cuda.empty_cache()
+            b2 = scale_boxes(make_scene_batch(cfg, [args.objects] * args.images, seed=1000 + rank, connect_frac=0.02), factor)
+            b2.image_feature, b2.image_depth = batch.image_feature, batch.image_depth
+            r = measure(b2, 2, 1)
+            fl = executed_flops(r["P"], args.images, r["n_obj"], r["n_x"], r["n_list"], r["shared"])
+            sensitivity.append({"boxes": label, "pair_specific_fraction": round(r["n_x"] / max(64 * r["P"], 1), 4) if r["shared"] else 1.0,
+                                "path": "shared windows" if r["shared"] else "per-pair kernels (more than SGC_SHARED_MAX_FRACTION of the windows pair-specific)",
+                                "ms_per_step": round(r["dt"] / 2 * 1e3, 2), "pairs_per_s": round(r["P"] * 2 / r["dt"], 1),
+                                "peak_memory_gb": round(r["peak_gb"], 1),
+                                "step_frac": round(sum(fl.values()) / (r["dt"] / 2) / 1e12 / MFMA_PEAK_TFLOPS, 4)})
 
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = P * world * args.steps / dt
-        kern = {}
-        for name, evs in eng.timers.items():
-            kern[name] = float(np.mean([a.elapsed_time(b) for a, b in evs]))
         flops = {"conv3_fwd": 2.0 * P * 256 * 1024 * 4608, "conv3_dgrad": 2.0 * P * 256 * 512 * 9216,
                  "conv3_wgrad": 2.0 * P * 256 * 1024 * 4608, "fc1_fwd": 2.0 * P * 65536 * 4096,
                  "fc1_dgrad": 2.0 * P * 65536 * 4096, "fc1_wgrad": 2.0 * P * 65536 * 4096}
@@ -269,12 +345,10 @@ def run_rank(args):
         two_streams = os.environ.get("SGC_BWD_STREAMS", "1") != "0" and not args.forward_only
         fwd_only = ("conv2_fwd", "expand_dense", "expand", "expand_train", "conv3_fwd", "conv3_fwd_objects", "conv3_fwd_windows",
                     "conv3_fwd_assemble", "fc1_fwd", "fc1_fwd_windows", "fc1_fwd_integral", "fc1_fwd_assemble", "fc2_fwd")
-        xw = getattr(eng, "_xw", None)
-        n_x = n_list = 0
+        xw = True if m["shared"] else None
+        n_x, n_list = m["n_x"], m["n_list"]          # X windows; X windows + the pseudo-pairs' own windows
         if xw is not None:                         # conv3 / fc1 over shared windows: flops of what is actually computed
-            n_x = int(xw[1][-1])
             n_ps = 2 * args.objects * args.images
-            n_list = int(state_plan_total(eng)) if state_plan_total(eng) else n_x      # X windows + the pseudo-pairs' own windows
             flops["conv3_fwd_windows"] = 2.0 * n_list * 4 * 1024 * 4608
             flops["conv3_fwd_objects"] = 2.0 * (args.images if n_list > n_x else n_ps) * 256 * 1024 * 4608
             flops["conv3_dgrad_windows"] = flops["conv3_wgrad_windows"] = flops["conv3_fwd_windows"]
@@ -292,6 +366,11 @@ def run_rank(args):
                     "traffic_note": "bytes/launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from profiles/%s_pmc_{f,w}.csv "
                                     "(separate rocprofv3 --pmc passes at this workload); algorithmic ~2.9e9 (z next to the windows 1.7 + outputs 1.2 + weights 0.01)" % tag,
                     "ms_per_launch": round(kern[dom], 3)}
+        ex = executed_flops(P, args.images, m["n_obj"], n_x, n_list, m["shared"], args.forward_only)
+        if roof is not None:
+            # whole-step efficiency on EXECUTED matrix flops (the per-pair form SURVEY 8d prices is mostly not executed any more)
+            roof["step_frac"] = round(sum(ex.values()) / (dt / args.steps) / 1e12 / MFMA_PEAK_TFLOPS, 4)
+            roof["step_executed_tflop"] = {k: round(v / 1e12, 2) for k, v in ex.items()}
         out = {
             "metric": "ordered object-pairs/sec (relation head fwd+bwd), batch=%d, N=%d" % (args.images, args.objects)
                       if not args.forward_only else "ordered object-pairs/sec (relation head forward only)",
@@ -314,7 +393,12 @@ def run_rank(args):
             "kernels_tflops": {k: round(flops[k] / (kern[k] * 1e-3) / 1e12, 1) for k in kern
                                if k in flops and kern[k] > 0 and (k in fwd_only or not two_streams)},
             "backward_streams": 2 if two_streams else 1,
+            "peak_memory_gb": round(m["peak_gb"], 1),
+            "ranks_seen": int(ranks.item()), "rank_ms_per_step": [round(float(x), 2) for x in rank_ms.tolist()],
+            "sensitivity": sensitivity,
         }
+        if getattr(reducer, "exposed_ms", None):
+            out["exposed_comm_ms"] = round(float(np.mean(reducer.exposed_ms[-args.steps:])), 3)
         if two_streams:
             out["kernels_note"] = ("backward launches run on two streams and overlap: their HIP-event durations are not kernel times and "
                                    "are omitted (SGC_BWD_STREAMS=0 for single-stream per-kernel numbers, as in profiles/)")

@@ -249,7 +249,8 @@ def run_pair_loop(sd: Dict[str, Tensor], batch, cfg, mode: str = "eval", evaluat
 
     ``call_hook(t, b)`` (tests only): for the t-th classifier call (0-based, direction-steps in loop order, b rows) returns a
     dict with any of ``drop1`` [b,4096] / ``drop2`` [b,512] (dropout masks of ``model.py:120-121,149,175`` injected instead
-    of drawn - how the training-mode device path is compared) and ``routes`` (see ``conv_trunk``).
+    of drawn - how the training-mode device path is compared), ``routes`` (see ``conv_trunk``) and ``routes_aug`` (the same for
+    the augmented view of the contrastive branch; only the rows of connected pairs matter).
 
     mode 'eval' mirrors ``testing()`` (overlap filter on, steps with no overlapping image skipped),
     mode 'train' mirrors ``training()`` (iou_mask all ones, loss with the running-sum quirk; dropout
@@ -333,9 +334,11 @@ def run_pair_loop(sd: Dict[str, Tensor], batch, cfg, mode: str = "eval", evaluat
                     losses = losses + run_rel + lambda_connectivity * run_conn + lambda_commonsense * run_cs
                     if contrast and len(connected) > 0:
                         hsa, hoa = (h_graph_aug, h_edge_aug) if first else (h_edge_aug, h_graph_aug)
-                        h_aug = conv_trunk(sd, hsa, hoa)
+                        ra = inj.get("routes_aug")          # test hook: the device's routing of the augmented trunk (rows of this call)
+                        h_aug = conv_trunk(sd, hsa, hoa, routes=ra)
                         hca = concat_labels(h_aug, cs, co, ss, so, cfg.num_classes, cfg.num_super_classes)
-                        hidden_aug = F.relu(F.linear(hca, sd["fc2.weight"], sd["fc2.bias"]))
+                        pa = F.linear(hca, sd["fc2.weight"], sd["fc2.bias"])
+                        hidden_aug = F.relu(pa) if ra is None else pa * ra["relu2"]
                         for idx in connected:
                             bi = int(keep[idx])
                             hid_acc[bi].append(torch.stack((hidden[idx], hidden_aug[idx])))

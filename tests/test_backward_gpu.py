@@ -23,6 +23,16 @@ def _tol(name):
     return HEAD_TOL if name.split('.')[0] in ('fc3', 'fc3_1', 'fc3_2', 'fc3_3', 'fc4', 'fc5') else GRAD_TOL
 
 
+# The reference's goldens hold 509 strided samples of every gradient: an un-routed comparison like the whole-tensor one, same bound
+# (round 2 allowed twice that).  What pins the arithmetic of the contrastive / commonsense steps are the ROUTED comparisons below.
+SAMPLE_TOL = _tol
+ROUTED_TOL = 5e-3        # tests/test_training_mode_gpu.py: head, fc2, fc1, conv3 with the device's routes injected; 7e-3 below conv3
+
+
+def _routed_tol(name):
+    return 7e-3 if name.split(".")[0] in ("conv2_1", "conv1_1", "conv1_2") else ROUTED_TOL
+
+
 def run_train(cfg, sd, batch, dropout=False):
     from scene_graph_commonsense_amd.engine import RelHeadEngine, csr_by, loss_coefficients
     from scene_graph_commonsense_amd.pairs import flatten_scene, pair_targets
@@ -91,7 +101,7 @@ def test_backward_matches_reference_fingerprints(name):
         assert abs(float(flat.double().norm()) - ref_l2) <= _tol(k) * ref_l2, (k, float(flat.norm()), ref_l2)
         samp, ref = flat[::stride][:509].double().numpy(), gold["grad_sample__" + key].astype(np.float64)
         err = np.linalg.norm(samp - ref) / max(np.linalg.norm(ref), 1e-30)
-        assert err <= 2 * _tol(k), (k, err)
+        assert err <= SAMPLE_TOL(k), (k, err)
 
 
 def _aug_features(batch, seed):
@@ -153,7 +163,7 @@ def test_contrastive_training_step_matches_reference(name):
         assert abs(float(flat.double().norm()) - ref_l2) <= _tol(n) * ref_l2, (n, float(flat.norm()), ref_l2)
         samp, ref = flat[::stride][:509].double().numpy(), gold["gradc_sample__" + key].astype(np.float64)
         err = np.linalg.norm(samp - ref) / max(np.linalg.norm(ref), 1e-30)
-        assert err <= 2 * _tol(n), (n, err)
+        assert err <= SAMPLE_TOL(n), (n, err)
 
 
 def test_train_cs_step_matches_reference():
@@ -184,7 +194,7 @@ def test_train_cs_step_matches_reference():
         assert abs(float(flat.double().norm()) - ref_l2) <= _tol(n) * ref_l2, (n, float(flat.norm()), ref_l2)
         samp, ref = flat[::stride][:509].double().numpy(), gold["gradcs_sample__" + key].astype(np.float64)
         err = np.linalg.norm(samp - ref) / max(np.linalg.norm(ref), 1e-30)
-        assert err <= 2 * _tol(n), (n, err)
+        assert err <= SAMPLE_TOL(n), (n, err)
 
 
 def test_commonsense_penalty_alone_matches_oracle():
@@ -264,3 +274,54 @@ def test_fused_sgd_matches_torch_sgd():
         for a, b in zip(ref, mine):
             assert (a - b).abs().max().item() <= 3e-7 * max(1.0, a.abs().max().item())
             assert (o_ref.state[a]["momentum_buffer"] - o_mine.state[b]["momentum_buffer"]).abs().max().item() <= 1e-6
+
+
+@pytest.mark.parametrize("name", ["vg_full_hit", "vg_full"])
+def test_contrastive_step_with_device_routes_is_arithmetic_exact(name):
+    """The contrastive training step against the ORACLE with the device's routing injected in both trunks (main view: every pair;
+    augmented view: the connected pairs): loss, contrastive term and every parameter gradient at the routed bounds."""
+    from scene_graph_commonsense_amd.model import BayesianRelationClassifier
+    from scene_graph_commonsense_amd.pairs import flatten_scene
+    from tests.golden_cases import CASES
+    from tests.train_case import fro, routed_model_step
+    cfg, sd, batch, _ = load_case(name)
+    model = BayesianRelationClassifier(cfg.args()).cuda()
+    model.load_state_dict(sd)
+    model.eval()
+    sc = flatten_scene(cfg, batch, "cuda:0")
+    aug = _aug_features(batch, CASES[name][2])
+    loss, grads, ref_loss, ref_grads, out = routed_model_step(model, sc, batch, aug=aug)
+    lc, ref_lc = float(model.last_contrast_loss), float(out["loss_contrast"])
+    print(name, "routed contrastive", lc, ref_lc, "total", loss, ref_loss)
+    assert abs(lc - ref_lc) <= 2e-3 * max(1.0, abs(ref_lc))
+    assert abs(loss - ref_loss) <= 2e-3 * abs(ref_loss)
+    errs = {k: fro(grads[k], ref_grads[k]) for k in ref_grads}
+    print({k: "%.1e" % v for k, v in errs.items()})
+    for k, e in errs.items():
+        assert e <= _routed_tol(k), (k, e)
+
+
+def test_train_cs_step_with_device_routes_is_arithmetic_exact():
+    """The train_cs step (commonsense penalty on top of the hierarchical loss) against the oracle with the device's routes."""
+    import os
+    from scene_graph_commonsense_amd.model import BayesianRelationClassifier
+    from scene_graph_commonsense_amd.pairs import flatten_scene
+    from tests.golden_cases import GOLDEN
+    from tests.train_case import fro, routed_model_step
+    fx = os.path.join(GOLDEN, "ref_fixtures") + os.sep
+    aligned = torch.load(fx + "commonsense_aligned_triplets.pt")
+    violated = torch.load(fx + "commonsense_violated_triplets.pt")
+    cfg, sd, batch, _ = load_case("vg_full_hit")
+    model = BayesianRelationClassifier(cfg.args()).cuda()
+    model.load_state_dict(sd)
+    model.eval()
+    sc = flatten_scene(cfg, batch, "cuda:0")
+    loss, grads, ref_loss, ref_grads, _ = routed_model_step(
+        model, sc, batch, step_kw=dict(commonsense=(list(aligned.keys()), list(violated.keys()))),
+        oracle_kw=dict(commonsense=(aligned, violated)))
+    print("routed train_cs loss", loss, ref_loss)
+    assert abs(loss - ref_loss) <= 2e-3 * abs(ref_loss)
+    errs = {k: fro(grads[k], ref_grads[k]) for k in ref_grads}
+    print({k: "%.1e" % v for k, v in errs.items()})
+    for k, e in errs.items():
+        assert e <= _routed_tol(k), (k, e)

@@ -29,6 +29,14 @@ def test_bench_single_rank_line():
     roof = out["roofline"]
     assert roof["bound"] == "mfma" and 0 < roof["frac"] < 1 and roof["ms_per_launch"] < out["ms_per_step"]
     assert out["loss"] == out["loss"]          # finite, not NaN
+    # whole-step efficiency on executed flops, and the box-size sensitivity sweep of the default invocation
+    assert 0 < roof["step_frac"] < roof["frac"] + 0.2 and roof["step_frac"] < 1
+    assert out["ranks_seen"] == 1 and len(out["rank_ms_per_step"]) == 1 and out["peak_memory_gb"] > 1
+    sens = out["sensitivity"]
+    assert [s["boxes"] for s in sens] == ["boxes x1.5", "boxes x2.5", "every box = full image"]
+    fr = [out["shared_windows"]["fraction"]] + [s["pair_specific_fraction"] for s in sens]
+    assert fr == sorted(fr) and fr[-1] == 1.0 and sens[-1]["path"].startswith("per-pair")
+    assert all(s["ms_per_step"] > 0 and s["peak_memory_gb"] > 1 for s in sens)
 
 
 def test_bench_refuses_a_world_size_that_is_not_gpus():

@@ -1,0 +1,108 @@
+"""Multi-step TRAINING trajectory of the device path against the f32 oracle (VERDICT r2 task 1a).
+
+What ``bench.py`` times is forward + loss + backward + SGD with f16 forward activations and **bf16 gradient tensors**.  The
+single-step tests bound the gradient error (2-5e-2 un-routed, 5-7e-3 with the device's routes injected); this test shows where
+that leaves TRAINING: K optimisation steps through the product entry points (``pair_loop.train_minibatch`` ->
+``model.training_step`` -> ``optim.FusedSGD``; ``model.train()``, dropout on) against K steps of the CPU oracle in f32 with
+``torch.optim.SGD`` (momentum 0.9, weight decay 1e-4 - ``train_test.py:100``), the oracle drawing the SAME dropout masks
+(``synthetic.dropout_keep_mask`` replicates the kernels' counter hash; seeds follow ``model._next_seeds``).
+
+Bars: the loss curves agree within 1e-2 relative at EVERY step, and the weight update of every parameter tensor (w_k+1 - w_k,
+i.e. lr x momentum buffer) has cosine >= 0.99 with the oracle's at every step, its norm within 5 %.  At the reference's learning
+rate 1e-5 (``config.yaml:51``) the running-sum loss already falls by tens of percent over the K steps on these cases (asserted:
+the run must train, otherwise nothing is tested).
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests.golden_cases import load_case
+
+pytestmark = pytest.mark.gpu
+
+K = 10
+MOMENTUM, WEIGHT_DECAY = 0.9, 1e-4
+LR = {"vg_full": 1e-5, "oiv6_full": 1e-5}      # the reference's learning rate (config.yaml:51): -35 % / -18 % loss in 6 oracle steps
+
+
+def _seeds(dropout_seed, step):
+    return ((dropout_seed * 2654435761 + 2 * step) & 0xFFFFFFFF, (dropout_seed * 2654435761 + 2 * step + 1) & 0xFFFFFFFF)
+
+
+@pytest.mark.parametrize("name", ["vg_full", "oiv6_full"])
+def test_training_trajectory_matches_f32_oracle(name):
+    from oracle import relhead_oracle as O
+    from scene_graph_commonsense_amd.model import BayesianRelationClassifier
+    from scene_graph_commonsense_amd.optim import FusedSGD
+    from scene_graph_commonsense_amd.pair_loop import train_minibatch
+    from scene_graph_commonsense_amd.pairs import enumerate_pairs
+    from scene_graph_commonsense_amd.synthetic import dropout_keep_mask, predicate_counts
+    cfg, sd, batch, _ = load_case(name)
+    lr = LR[name]
+
+    # ---- device: the product path
+    model = BayesianRelationClassifier(cfg.args(), num_classes=cfg.num_classes, num_super_classes=cfg.num_super_classes,
+                                       num_geometric=cfg.num_geometric, num_possessive=cfg.num_possessive,
+                                       num_semantic=cfg.num_semantic).cuda()
+    model.load_state_dict(sd)
+    model.train()
+    assert model._step == 0
+    opt = FusedSGD(model.parameters(), lr=lr, momentum=MOMENTUM, weight_decay=WEIGHT_DECAY)
+    names = [n for n, _ in model.named_parameters()]
+    dev_losses, dev_updates = [], []
+    prev = {n: p.detach().clone() for n, p in model.named_parameters()}
+    for k in range(K):
+        loss = train_minibatch(model, batch, opt)
+        dev_losses.append(float(loss))
+        upd = {}
+        for n, p in model.named_parameters():
+            upd[n] = (p.detach() - prev[n]).double().flatten().cpu() if p.numel() <= (1 << 22) else (p.detach() - prev[n])
+            prev[n].copy_(p.detach())
+        # large tensors (fc1.weight: 268 M elements) are reduced on the device against the oracle's update below
+        dev_updates.append(upd)
+    torch.cuda.synchronize()
+    assert model._step == K
+
+    # ---- oracle: f32 on the CPU, same dropout masks
+    nobj = [int(b.shape[0]) for b in batch.bbox]
+    pidx = enumerate_pairs(nobj)
+    start = np.concatenate([[0], np.cumsum(pidx.call_sizes)])
+    sdr = {k_: v.clone().requires_grad_(True) for k_, v in sd.items()}
+    ref_opt = torch.optim.SGD([sdr[n] for n in names], lr=lr, momentum=MOMENTUM, weight_decay=WEIGHT_DECAY)
+    weights = O.class_weights(predicate_counts(cfg))
+    ref_losses, worst_cos = [], {n: 1.0 for n in names}
+    for k in range(K):
+        s1, s2 = _seeds(model.dropout_seed, k + 1)
+
+        def hook(t, b, s1=s1, s2=s2):
+            r0 = int(start[t])
+            return dict(drop1=torch.from_numpy(dropout_keep_mask(s1, b, 4096, r0)).float() * 2,
+                        drop2=torch.from_numpy(dropout_keep_mask(s2, b, 512, r0)).float() * 2)
+
+        before = {n: sdr[n].detach().clone() for n in names}
+        out = O.run_pair_loop(sdr, batch, cfg, mode="train", weights=weights, call_hook=hook)
+        ref_opt.zero_grad(set_to_none=True)
+        out["losses"].backward()
+        ref_opt.step()
+        ref_losses.append(float(out["losses"].detach()))
+        for n in names:
+            r = (sdr[n].detach() - before[n])
+            d = dev_updates[k][n]
+            if d.is_cuda:
+                r = r.cuda()
+                dot, na, nb = float((d.double() * r.double()).sum()), float(d.double().norm()), float(r.double().norm())
+            else:
+                r = r.double().flatten()
+                dot, na, nb = float(d @ r), float(d.norm()), float(r.norm())
+            cos = dot / max(na * nb, 1e-300)
+            worst_cos[n] = min(worst_cos[n], cos)
+            assert abs(na - nb) <= 5e-2 * nb, (k, n, na, nb)
+        dev_updates[k] = None
+        print("step %d loss device %.4f oracle %.4f" % (k + 1, dev_losses[k], ref_losses[k]))
+    print({n: "%.4f" % c for n, c in worst_cos.items()})
+    for k in range(K):
+        assert abs(dev_losses[k] - ref_losses[k]) <= 1e-2 * abs(ref_losses[k]), (k, dev_losses[k], ref_losses[k])
+    for n, c in worst_cos.items():
+        assert c >= 0.99, (n, c)
+    # the run must have trained: the (dropout-noisy) loss of the last three steps lies well below that of the first three
+    assert np.mean(ref_losses[-3:]) <= 0.9 * np.mean(ref_losses[:3]), ref_losses
