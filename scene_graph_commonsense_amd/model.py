@@ -177,11 +177,31 @@ class _RelationBase(nn.Module):
         return ((self.dropout_seed * 2654435761 + 2 * self._step) & 0xFFFFFFFF,
                 (self.dropout_seed * 2654435761 + 2 * self._step + 1) & 0xFFFFFFFF)
 
+    def _class_weight_device(self, class_weight, dev):
+        """[R] f32 device tensor of the class weights of the relation NLL (default 1 - count / total, ``train_test.py:105-117``)."""
+        if class_weight is None:
+            counts = predicate_counts(self.head_config()).numpy()
+            class_weight = 1 - counts / counts.sum()
+        cw = np.ascontiguousarray(class_weight, dtype=np.float32)
+        if getattr(self, "_cw_cache", None) is None or self._cw_cache[0].shape != cw.shape or not np.array_equal(self._cw_cache[0], cw) \
+                or self._cw_cache[1].device != dev:
+            self._cw_cache = (cw.copy(), torch.from_numpy(cw.copy()).to(dev))
+        return self._cw_cache[1]
+
+    def minibatch_loss_coefficients(self, scene: DeviceScene, class_weight=None, lambda_connectivity: float = 0.1,
+                                    lambda_not_connected: float = 1.0):
+        """(tgt, a, b, c, y) per ordered pair of ``scene`` (``engine.loss_coefficients``) on the device."""
+        eng = self.refresh_weights(backward=True)
+        if scene.directed is None:
+            raise ValueError("the scene carries no relation targets")
+        return eng.loss_coefficients_device(scene.step_ptr, scene.n_steps, scene.directed, self._class_weight_device(class_weight, eng.device),
+                                            lambda_connectivity, lambda_not_connected)
+
     def training_step(self, scene: DeviceScene, relationships=None, subj_or_obj=None, directed: Optional[np.ndarray] = None,
                       lambda_connectivity: float = 0.1, lambda_not_connected: float = 1.0, class_weight=None,
                       grad_hook=None, reducer=None, image_feature_aug: Optional[torch.Tensor] = None, lambda_contrast: float = 1.0,
                       commonsense=None, lambda_commonsense: float = 1.0, lambda_cs_weak: float = 0.1,
-                      lambda_cs_strong: float = 10.0):
+                      lambda_cs_strong: float = 10.0, loss_coefs=None, grads_out: Optional[Dict[str, torch.Tensor]] = None):
         """Forward + loss + backward over all ordered pairs; gradients land in ``param.grad`` (accumulating like
         autograd).  Loss follows ``train_test.py:189-258`` / ``train_utils.py:64-157`` (hierarchical NLL, BCE on
         connectivity, running-sum step weights).  With ``image_feature_aug`` (DETR features of the colour-jittered view,
@@ -189,13 +209,21 @@ class _RelationBase(nn.Module):
         is run ONLY for the connected pairs (the only ones the loss reads; the reference runs it for every pair).
         ``commonsense=(aligned_keys, violated_keys)`` adds the train_cs penalty of ``train_utils.py:36-62``.
         ``reducer`` (``distributed.GradReducer``): the step's gradients are mean-reduced across ranks before they are
-        accumulated into ``param.grad`` (the fc1 weight gradient is handed to RCCL as soon as it is enqueued)."""
+        accumulated into ``param.grad`` (the fc1 weight gradient is handed to RCCL as soon as it is enqueued).
+        ``loss_coefs`` / ``grads_out`` serve the image-group chunking of ``pair_loop.train_minibatch``: the per-pair loss
+        coefficients of THIS scene's pairs taken from the whole minibatch's (per-step means and running-sum weights couple the
+        images of a minibatch, the gradients are additive over images once the coefficients are fixed), and a dict the step's
+        gradients are summed into instead of ``param.grad`` (no reduction here: the caller reduces the sum once)."""
         if reducer is not None:
             grad_hook = reducer.hook
         cfg = self.head_config()
         eng = self.refresh_weights(backward=True)
         dev = eng.device
         P = scene.n_pairs
+        if P == 0 and grads_out is not None:       # an image group without pairs adds nothing to the minibatch's gradient sum
+            self.last_outputs = None
+            self.last_connectivity_stats = None
+            return torch.zeros((), device=dev)
         if P == 0:                                 # no image with two objects: nothing to score, zero loss and gradients
             if reducer is not None and reducer.world > 1:
                 # the other ranks reduce this step's gradients: take part in the same collectives, in the same order, with
@@ -217,7 +245,9 @@ class _RelationBase(nn.Module):
             return torch.zeros((), device=dev)
         # directed target per pair on the device: an explicit array wins, else what flatten_scene derived from the batch's
         # relationships / subj_or_obj lists (sgc_scene_tables), else derive it from the lists given here
-        if directed is not None:
+        if torch.is_tensor(directed):
+            directed_d = directed.to(dev, torch.int32).contiguous()
+        elif directed is not None:
             directed_d = torch.from_numpy(np.ascontiguousarray(directed, dtype=np.int32)).to(dev)
         elif scene.directed is not None and (relationships is None or relationships is scene._rel_src):
             directed_d = scene.directed
@@ -226,15 +256,15 @@ class _RelationBase(nn.Module):
         else:
             raise ValueError("training_step needs relation targets: build the scene from a batch with relationships / subj_or_obj, "
                              "or pass them (or a directed array) here")
-        if class_weight is None:
-            counts = predicate_counts(cfg).numpy()
-            class_weight = 1 - counts / counts.sum()
-        cw = np.ascontiguousarray(class_weight, dtype=np.float32)
-        if getattr(self, "_cw_cache", None) is None or self._cw_cache[0].shape != cw.shape or not np.array_equal(self._cw_cache[0], cw) \
-                or self._cw_cache[1].device != dev:
-            self._cw_cache = (cw.copy(), torch.from_numpy(cw.copy()).to(dev))
-        coefs_d = eng.loss_coefficients_device(scene.step_ptr, scene.n_steps, directed_d, self._cw_cache[1], lambda_connectivity,
-                                               lambda_not_connected)
+        cw_d = self._class_weight_device(class_weight, dev)
+        if loss_coefs is not None:
+            if image_feature_aug is not None or commonsense is not None:
+                raise NotImplementedError("externally supplied loss coefficients (image-group chunking) cover the hierarchical / "
+                                          "connectivity loss only: the contrastive and commonsense terms couple all pairs of a minibatch")
+            coefs_d = tuple(c.contiguous() for c in loss_coefs)
+        else:
+            coefs_d = eng.loss_coefficients_device(scene.step_ptr, scene.n_steps, directed_d, cw_d, lambda_connectivity,
+                                                   lambda_not_connected)
         sub_csr, obj_csr, img_ptr = scene.sub_csr, scene.obj_csr, scene.img_ptr
         with torch.no_grad():
             ctx = eng.train_forward(scene.image_feature, scene.image_depth, scene.obj_img, scene.bbox, scene.cats,
@@ -273,14 +303,22 @@ class _RelationBase(nn.Module):
                 if not bool(torch.isnan(loss_c)):
                     loss = loss + lambda_contrast * lambda_contrast * loss_c      # lambda applied twice (train_test.py:270-273)
                 self.last_contrast_loss = loss_c
-            if reducer is not None:
-                reducer.finish_grads(grads)
-            for name, p in self.named_parameters():
-                g = grads[name].view_as(p)
-                if p.grad is None:
-                    p.grad = g if g.is_contiguous() else g.contiguous()
-                else:
-                    p.grad.add_(g)
+            if grads_out is not None:
+                for name, p in self.named_parameters():
+                    g = grads[name].view_as(p)
+                    if name in grads_out:
+                        grads_out[name].add_(g)
+                    else:
+                        grads_out[name] = g.clone()          # the engine reuses its gradient buffers in the next group's pass
+            else:
+                if reducer is not None:
+                    reducer.finish_grads(grads)
+                for name, p in self.named_parameters():
+                    g = grads[name].view_as(p)
+                    if p.grad is None:
+                        p.grad = g if g.is_contiguous() else g.contiguous()
+                    else:
+                        p.grad.add_(g)
             # connectivity statistics of train_one_direction (train_utils.py:66-87) summed over the minibatch: a [5] device
             # tensor (not connected, connected, predicted connected, precision numerator, recall numerator), no host sync
             raw_d = scene.raw_target if (directed is None and scene.raw_target is not None) else directed_d

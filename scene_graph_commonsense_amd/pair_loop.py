@@ -17,6 +17,121 @@ from . import _lib
 from .pairs import DeviceScene, flatten_scene, match_target_sgd, pair_targets_fast
 
 
+# ------------------------------------------------------------------------------------------------ image-group chunking
+# A minibatch is scored in ONE fused pass whose workspace grows with its ordered pairs (~2.3 MB per pair in training at
+# 11 % pair-specific windows).  The reference's per-step loop handles any object count (``evaluate.py:375-444``: up to 2 x 100
+# predicted objects per image, 16 images), so a minibatch that does not fit is cut into consecutive IMAGE GROUPS that run back to
+# back: images are independent in the forward, the evaluator is fed in the reference's candidate order across groups from the
+# scattered outputs, and in training the per-pair loss coefficients are computed for the WHOLE minibatch first (its per-step means
+# and running-sum weights couple the images) so that the groups' gradients simply add (tests/test_configs_gpu.py: additivity).
+# Bytes per pair / per pair-specific window / per object, measured with tools/mem_report.py (+15 % margin in ``plan_image_groups``):
+_COST = {
+    # (per pair, per X window, per pair on the per-pair kernels, per object)
+    True: (1.25e6, 0.125e6, 2.7e6, 8.0e6),          # training: z f16 + bf16 + routing codes + dz, column forms of the backward
+    False: (0.40e6, 0.03e6, 0.60e6, 3.0e6),         # evaluation: z f16, window-major rows, f32 fc1 products
+}
+
+
+def slice_batch(batch, a: int, b: int):
+    """Images [a, b) of a ``SceneBatch`` (views; the per-image lists are shared)."""
+    from .synthetic import SceneBatch
+    pick = lambda x: None if x is None else list(x[a:b])
+    return SceneBatch(batch.image_feature[a:b], batch.image_depth[a:b], pick(batch.bbox), pick(batch.categories),
+                      pick(batch.super_categories), pick(getattr(batch, "relationships", None)), pick(getattr(batch, "subj_or_obj", None)),
+                      [int(x.shape[0]) for x in batch.bbox[a:b]])
+
+
+def default_workspace_budget(model) -> int:
+    """70 % of what this process could allocate right now: free HBM + the allocator's cached blocks + the engine's own workspace
+    (it is reused)."""
+    dev = next(model.parameters()).device
+    free, _ = torch.cuda.mem_get_info(dev)
+    cached = torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
+    eng = getattr(model, "_engine", None)
+    own = eng.ws.nbytes() if eng is not None else 0
+    return int(0.7 * (free + cached + own))
+
+
+def image_workspace_bytes(cfg, bbox, train: bool) -> float:
+    """Estimated workspace of one image's pairs in a fused pass (``bbox``: its [n,4] boxes as given)."""
+    from .engine import shared_conv3_enabled
+    from .pairs import count_shared_windows, normalise_boxes
+    n = int(bbox.shape[0])
+    pairs = n * (n - 1)
+    per_pair, per_win, per_pair_full, per_obj = _COST[bool(train)]
+    if pairs == 0:
+        return per_obj * n
+    xw = None
+    if cfg.feature_size == 32:
+        bb = normalise_boxes(torch.as_tensor(bbox).detach().cpu(), cfg.feature_size)
+        xw = count_shared_windows(bb, [0, n])
+    if xw is not None and shared_conv3_enabled(xw, pairs):
+        return per_pair * pairs + per_win * xw + per_obj * n
+    return per_pair_full * pairs + per_obj * n
+
+
+def plan_image_groups(cfg, batch, train: bool, budget_bytes: float):
+    """Consecutive image ranges [(a, b), ...] whose estimated workspace (+15 %) stays within ``budget_bytes``; an image that
+    exceeds the budget on its own is a group of one (its pairs cannot be split: loss and ranking are per image)."""
+    n = [int(b.shape[0]) for b in batch.bbox]
+    if 1.15 * sum(_COST[bool(train)][2] * k * (k - 1) + _COST[bool(train)][3] * k for k in n) <= budget_bytes:
+        return [(0, len(n))]                        # fits even on the per-pair kernels: no need to count windows (the usual case)
+    cost = [1.15 * image_workspace_bytes(cfg, b, train) for b in batch.bbox]
+    groups, a, acc = [], 0, 0.0
+    for k, c in enumerate(cost):
+        if k > a and acc + c > budget_bytes:
+            groups.append((a, k))
+            a, acc = k, 0.0
+        acc += c
+    groups.append((a, len(cost)))
+    return groups
+
+
+def _budget(model, workspace_budget):
+    if workspace_budget is not None:
+        return float(workspace_budget)
+    b = getattr(model, "workspace_budget_bytes", None)
+    if b is not None:
+        return float(b)
+    if getattr(model, "_auto_budget", None) is None:     # measured once per model: the planner runs every step
+        model._auto_budget = float(default_workspace_budget(model))
+    return model._auto_budget
+
+
+def _group_rows(scene: DeviceScene, a: int, b: int) -> torch.Tensor:
+    """Pairs of the images [a, b) in the whole minibatch's pair order = the pair order of the group's own scene (restricting
+    ``keep_in_batch`` to a subset of images keeps their relative order)."""
+    img = scene.image
+    return torch.nonzero((img >= a) & (img < b)).flatten()
+
+
+def forward_pairs_chunked(model, cfg, batch, scene: DeviceScene, groups, iou: Optional[torch.Tensor], select: Optional[torch.Tensor]):
+    """``model.forward_pairs`` over image groups; the groups' rows are scattered into full-size outputs in the minibatch's pair order."""
+    from .engine import PairOutputs
+    dev = scene.bbox.device
+    P = scene.n_pairs
+    nc = 3 if cfg.hierarchical else 1
+    full = PairOutputs(torch.zeros(P, cfg.num_relations, device=dev), torch.zeros(P, 3, device=dev) if cfg.hierarchical else None,
+                       torch.zeros(P, device=dev), torch.zeros(P, 512, device=dev), torch.full((P, nc), -float("inf"), device=dev),
+                       torch.zeros(P, nc, dtype=torch.int32, device=dev))
+    for a, b in groups:
+        rows = _group_rows(scene, a, b)
+        if rows.numel() == 0:
+            continue
+        sub = flatten_scene(cfg, slice_batch(batch, a, b), dev)
+        assert sub.n_pairs == int(rows.numel())
+        out = model.forward_pairs(sub, iou_mask=None if iou is None else iou[rows].contiguous(),
+                                  select=None if select is None else select[rows].contiguous())
+        full.relation[rows] = out.relation
+        if full.super_relation is not None:
+            full.super_relation[rows] = out.super_relation
+        full.connectivity[rows] = out.connectivity
+        full.hidden[rows] = out.hidden
+        full.cand_conf[rows] = out.cand_conf
+        full.cand_pred[rows] = out.cand_pred
+    return full
+
+
 def overlap_mask(scene: DeviceScene) -> torch.Tensor:
     """[P] uint8: the pair's two boxes share a grid cell (``train_test.py:403-408``)."""
     lib = _lib.load()
@@ -87,14 +202,16 @@ def feed_evaluators(model, scene: DeviceScene, out, evaluator=None, evaluator_to
 
 
 def evaluate_minibatch(model, batch, evaluator=None, evaluator_top3=None, overlap_filtering: bool = True,
-                       scene: Optional[DeviceScene] = None, skip_filtered: bool = False):
+                       scene: Optional[DeviceScene] = None, skip_filtered: bool = False, workspace_budget: Optional[float] = None):
     """Returns (scene, outputs, included[P] bool numpy, directed targets numpy).
     ``skip_filtered=True`` runs the per-pair trunk only for the pairs that pass the overlap filter (about 40 % of the ordered pairs
     on the synthetic boxes) in every image that has at least top-K such pairs: Recall@K is unchanged (a filtered pair's
     confidence is -inf either way, ``evaluator.py:131-134``, and cannot reach the top K there); ``outputs`` of the skipped pairs
     are zeros.  The reference cannot skip them: its batched per-step call always scores the whole batch.
     ``model.last_connectivity_stats`` holds the counters of ``evaluate_one_direction`` (``train_utils.py:176-184``) summed over the
-    kept steps ([5] int64 device tensor; None with ``skip_filtered``)."""
+    kept steps ([5] int64 device tensor; None with ``skip_filtered``).
+    ``workspace_budget`` (bytes; default ``model.workspace_budget_bytes`` or 70 % of the free HBM): a minibatch whose fused pass
+    would need more is scored in consecutive image groups (``plan_image_groups``) - same outputs, same evaluator feed."""
     cfg = model.head_config()
     dev = next(model.parameters()).device
     if scene is None:
@@ -103,7 +220,12 @@ def evaluate_minibatch(model, batch, evaluator=None, evaluator_top3=None, overla
     select = None
     if skip_filtered and overlap_filtering:
         select = _unfiltered_selection(scene, iou, (evaluator, evaluator_top3))
-    out = model.forward_pairs(scene, iou_mask=iou, select=select)
+    groups = plan_image_groups(cfg, batch, False, _budget(model, workspace_budget))
+    if len(groups) > 1:
+        out = forward_pairs_chunked(model, cfg, batch, scene, groups, iou, select)
+    else:
+        out = model.forward_pairs(scene, iou_mask=iou, select=select)
+    model.last_image_groups = groups
     directed_d = scene.directed
     if directed_d is None:
         directed_d = torch.from_numpy(pair_targets_fast(batch.relationships, batch.subj_or_obj, scene.pidx).astype(np.int32)).to(dev)
@@ -116,7 +238,8 @@ def evaluate_minibatch(model, batch, evaluator=None, evaluator_top3=None, overla
 
 
 def evaluate_sgdet_minibatch(model, image_feature, image_depth, categories_pred, cat_pred_confidence, bbox_pred, evaluator,
-                             sub2super=None, targets=None, overlap_filtering: bool = True, skip_filtered: bool = False):
+                             sub2super=None, targets=None, overlap_filtering: bool = True, skip_filtered: bool = False,
+                             workspace_budget: Optional[float] = None):
     """SGDET evaluation of one minibatch (``evaluate.py:375-444``): every ordered pair of the PREDICTED objects of each image
     (per-image lists as returned by ``object_frontend.DetrFrontEnd.sgdet``: categories, category confidences, boxes
     (x0,x1,y0,y1) on the grid, one entry per image of ``image_feature``), overlap filter, evaluator fed in the reference's
@@ -139,7 +262,12 @@ def evaluate_sgdet_minibatch(model, image_feature, image_depth, categories_pred,
     scene = flatten_scene(cfg, batch, dev)
     iou = overlap_mask(scene) if overlap_filtering else None
     select = _unfiltered_selection(scene, iou, (evaluator,)) if (skip_filtered and overlap_filtering) else None
-    out = model.forward_pairs(scene, iou_mask=iou, select=select)
+    groups = plan_image_groups(cfg, batch, False, _budget(model, workspace_budget))       # 16 images x 100+ detections: image groups
+    if len(groups) > 1:
+        out = forward_pairs_chunked(model, cfg, batch, scene, groups, iou, select)
+    else:
+        out = model.forward_pairs(scene, iou_mask=iou, select=select)
+    model.last_image_groups = groups
     included, any_overlap = _step_filter(scene, iou)
     sel = torch.nonzero(included).flatten()
     sub, obj = scene.sub_idx.long()[sel], scene.obj_idx.long()[sel]
@@ -156,16 +284,78 @@ def evaluate_sgdet_minibatch(model, image_feature, image_depth, categories_pred,
     return scene, out, included.cpu().numpy()
 
 
-def train_minibatch(model, batch, optimizer=None, reducer=None, scene: Optional[DeviceScene] = None, **loss_kw):
-    """One optimisation step over all ordered pairs of the minibatch; returns the loss tensor."""
+def train_minibatch(model, batch, optimizer=None, reducer=None, scene: Optional[DeviceScene] = None,
+                    workspace_budget: Optional[float] = None, **loss_kw):
+    """One optimisation step over all ordered pairs of the minibatch; returns the loss tensor.
+    A minibatch whose fused pass would exceed ``workspace_budget`` (bytes; default ``model.workspace_budget_bytes`` or 70 % of
+    the free HBM) is run in consecutive image groups: whole-minibatch loss coefficients first, then forward + backward per group
+    with its rows of them, the gradients summed and reduced across ranks once.  Equal to the one-pass step up to f32 summation
+    order (dropout masks differ: the keep bit is indexed by a pair's position within its pass)."""
     cfg = model.head_config()
     dev = next(model.parameters()).device
-    if scene is None:
-        scene = flatten_scene(cfg, batch, dev)
     if optimizer is not None:
         optimizer.zero_grad(set_to_none=True)
-    loss = model.training_step(scene, batch.relationships, batch.subj_or_obj, reducer=reducer, **loss_kw)
+    groups = plan_image_groups(cfg, batch, True, _budget(model, workspace_budget))
+    model.last_image_groups = groups
+    if scene is None:
+        scene = flatten_scene(cfg, batch, dev)
+    if len(groups) == 1:
+        loss = model.training_step(scene, batch.relationships, batch.subj_or_obj, reducer=reducer, **loss_kw)
+    else:
+        loss = _train_image_groups(model, cfg, batch, scene, groups, reducer, loss_kw)
     model.last_scene = scene
     if optimizer is not None:
         optimizer.step()
+    return loss
+
+
+def _train_image_groups(model, cfg, batch, scene: DeviceScene, groups, reducer, loss_kw):
+    from .engine import PairOutputs
+    dev = scene.bbox.device
+    kw = dict(loss_kw)
+    if kw.get("image_feature_aug") is not None or kw.get("commonsense") is not None:
+        raise NotImplementedError("this minibatch needs %d image groups (workspace budget); the contrastive and commonsense terms couple "
+                                  "all pairs of a minibatch and are not chunked - lower the batch size or raise the budget" % len(groups))
+    for k_ in ("image_feature_aug", "commonsense", "lambda_contrast", "lambda_commonsense", "lambda_cs_weak", "lambda_cs_strong"):
+        kw.pop(k_, None)
+    coefs = model.minibatch_loss_coefficients(scene, kw.pop("class_weight", None), kw.pop("lambda_connectivity", 0.1),
+                                              kw.pop("lambda_not_connected", 1.0))
+    P = scene.n_pairs
+    nc = 3 if cfg.hierarchical else 1
+    full = PairOutputs(torch.zeros(P, cfg.num_relations, device=dev), torch.zeros(P, 3, device=dev) if cfg.hierarchical else None,
+                       torch.zeros(P, device=dev), torch.zeros(P, 512, device=dev), torch.zeros(P, nc, device=dev),
+                       torch.zeros(P, nc, dtype=torch.int32, device=dev))
+    acc, stats = {}, torch.zeros(5, dtype=torch.int64, device=dev)
+    loss = torch.zeros((), device=dev)
+    for a, b in groups:
+        rows = _group_rows(scene, a, b)
+        if rows.numel() == 0:
+            continue
+        sub_b = slice_batch(batch, a, b)
+        sub = flatten_scene(cfg, sub_b, dev)
+        assert sub.n_pairs == int(rows.numel())
+        loss = loss + model.training_step(sub, sub_b.relationships, sub_b.subj_or_obj, loss_coefs=tuple(c[rows] for c in coefs),
+                                          grads_out=acc, **kw)
+        out = model.last_outputs
+        full.relation[rows] = out.relation
+        if full.super_relation is not None:
+            full.super_relation[rows] = out.super_relation
+        full.connectivity[rows] = out.connectivity
+        full.hidden[rows] = out.hidden
+        full.cand_conf[rows] = out.cand_conf
+        full.cand_pred[rows] = out.cand_pred
+        if model.last_connectivity_stats is not None:
+            stats += model.last_connectivity_stats
+    # the minibatch's gradient = the sum over its image groups: mean-reduce it across ranks once, then accumulate like autograd
+    if reducer is not None:
+        if "fc1.weight" in acc:
+            reducer.hook("fc1.weight", acc["fc1.weight"])
+        reducer.finish_grads(acc)
+    for name, p in model.named_parameters():
+        g = acc[name].view_as(p)
+        if p.grad is None:
+            p.grad = g if g.is_contiguous() else g.contiguous()
+        else:
+            p.grad.add_(g)
+    model.last_outputs, model.last_connectivity_stats = full, stats
     return loss

@@ -423,3 +423,31 @@ def test_object_window_rects_match_a_brute_force_influence_propagation():
                 if i != j:
                     total += max(0, min(q[i, 1], q[j, 1]) - max(q[i, 0], q[j, 0])) * max(0, min(q[i, 3], q[j, 3]) - max(q[i, 2], q[j, 2]))
     assert total == PR.count_shared_windows(bb, img_ptr)
+
+
+def test_image_group_planner_covers_every_image_within_the_budget():
+    """``pair_loop.plan_image_groups`` (host logic of the automatic chunking): consecutive ranges that cover every image once,
+    each within the budget unless it is a single image, one group when everything fits, estimates that grow with the overlap
+    of the boxes and fall back to the per-pair cost when most windows are pair-specific."""
+    from scene_graph_commonsense_amd.pair_loop import _COST, image_workspace_bytes, plan_image_groups, slice_batch
+    from scene_graph_commonsense_amd.synthetic import HeadConfig, make_scene_batch
+    cfg = HeadConfig()
+    nobj = [64, 3, 40, 40, 1, 64, 20, 20, 20, 64]
+    batch = make_scene_batch(cfg, nobj, seed=9)
+    for train in (True, False):
+        cost = [1.15 * image_workspace_bytes(cfg, b, train) for b in batch.bbox]
+        assert plan_image_groups(cfg, batch, train, 1e15) == [(0, len(nobj))]
+        for budget in (sum(cost) / 2.5, max(cost) * 1.01, max(cost) / 3):
+            groups = plan_image_groups(cfg, batch, train, budget)
+            assert groups[0][0] == 0 and groups[-1][1] == len(nobj) and all(a[1] == b[0] for a, b in zip(groups, groups[1:]))
+            assert len(groups) >= 2
+            for a, b in groups:
+                assert b > a and (b - a == 1 or sum(cost[a:b]) <= budget)
+                assert a == 0 or sum(cost[groups[[g[0] for g in groups].index(a) - 1][0]:a]) + cost[a] > budget   # greedy: the previous group was full
+    # boxes: disjoint small boxes are cheaper than full-image boxes, which are priced on the per-pair kernels
+    small = torch.tensor([[k % 8 * 4, k % 8 * 4 + 2, k // 8 * 4, k // 8 * 4 + 2] for k in range(40)], dtype=torch.int32)
+    full = torch.tensor([[0, 32, 0, 32]] * 40, dtype=torch.int32)
+    c_small, c_full = image_workspace_bytes(cfg, small, True), image_workspace_bytes(cfg, full, True)
+    assert c_full == _COST[True][2] * 40 * 39 + _COST[True][3] * 40 and c_small < 0.6 * c_full
+    sub = slice_batch(batch, 2, 5)
+    assert sub.num_objects == [40, 40, 1] and sub.image_feature.shape[0] == 3 and len(sub.relationships) == 3
