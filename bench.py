@@ -51,6 +51,8 @@ def parse_args(argv=None):
     ap.add_argument("--torch-sgd", action="store_true", help="torch.optim.SGD instead of the one-pass optim.FusedSGD (same update)")
     ap.add_argument("--dataset", default="vg", choices=["vg", "oiv6"], help="oiv6 = 601 classes, (4,2,24) head, no super-classes")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL)")
+    ap.add_argument("--dp-mode", default="sharded", choices=["sharded", "allreduce"],
+                    help="N > 1: reduce-scatter + sharded SGD + all-gather (distributed.ShardedSGD, default) or all-reduce + full SGD on every rank")
     ap.add_argument("--no-sensitivity", action="store_true", help="skip the three short box-size sensitivity runs (N=1 only)")
     ap.add_argument("--box-scale", type=float, default=1.0,
                     help="scale every box about its centre (clipped to the image); >= 100 = every box is the full image")
@@ -256,6 +258,9 @@ def run_rank(args):
         from scene_graph_commonsense_amd.optim import FusedSGD
         opt = FusedSGD(model.parameters(), lr=1e-5, momentum=0.9, weight_decay=1e-4)
     reducer = sgd_dist.GradReducer(world)
+    if world > 1 and args.dp_mode == "sharded" and not args.torch_sgd:
+        # one object is both: reduce-scatter of the gradients, SGD on this rank's shard, all-gather of the updated parameters
+        opt = reducer = sgd_dist.ShardedSGD(model.named_parameters(), world, rank, lr=1e-5, momentum=0.9, weight_decay=1e-4)
     eng = model.engine()
 
     def barrier():
@@ -289,6 +294,7 @@ def run_rank(args):
         eng.timers = {}
         torch.cuda.reset_peak_memory_stats(dev)
         barrier()
+        reducer.pop_exposed_ms()
         t0 = time.time()
         loss = None
         for _ in range(steps):
@@ -301,6 +307,7 @@ def run_rank(args):
         n_list = (int(state_plan_total(eng)) if state_plan_total(eng) else n_x) if xw is not None else 0
         return dict(dt=dt, loss=None if loss is None else float(loss), first_loss=first_loss, kern=kern, P=scene0.n_pairs,
                     shared=xw is not None, n_x=n_x, n_list=n_list, n_obj=int(scene0.obj_img.shape[0]),
+                    exposed_ms=reducer.pop_exposed_ms() / max(steps, 1),
                     peak_gb=torch.cuda.max_memory_allocated(dev) / 1e9)
 
     m = measure(batch, args.steps, args.warmup)
@@ -397,8 +404,9 @@ def run_rank(args):
             "ranks_seen": int(ranks.item()), "rank_ms_per_step": [round(float(x), 2) for x in rank_ms.tolist()],
             "sensitivity": sensitivity,
         }
-        if getattr(reducer, "exposed_ms", None):
-            out["exposed_comm_ms"] = round(float(np.mean(reducer.exposed_ms[-args.steps:])), 3)
+        if world > 1:
+            out["dp_mode"] = args.dp_mode if not args.torch_sgd else "allreduce"
+            out["exposed_comm_ms"] = round(m["exposed_ms"], 3)      # rank 0: time its compute stream waited for collectives, per step
         if two_streams:
             out["kernels_note"] = ("backward launches run on two streams and overlap: their HIP-event durations are not kernel times and "
                                    "are omitted (SGC_BWD_STREAMS=0 for single-stream per-kernel numbers, as in profiles/)")

@@ -46,6 +46,7 @@ class GradReducer:
         self.early = set(early)
         self.pending: List = []          # (work handle, tensor) of the early reductions in flight
         self.done = set()
+        self.exposed_events: List = []   # (start, end) event pairs around the waits on the compute stream
 
     def hook(self, name: str, grad: torch.Tensor):
         if self.world <= 1 or name not in self.early or name in self.done:
@@ -55,10 +56,24 @@ class GradReducer:
 
     def _drain(self):
         for work, g in self.pending:
+            timed = g.is_cuda
+            if timed:
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
             work.wait()                  # orders the compute stream after RCCL's: later kernels see the reduced tensor
+            if timed:
+                b.record()
+                self.exposed_events.append((a, b))
             g.div_(self.world)
         self.pending.clear()
         self.done.clear()
+
+    def pop_exposed_ms(self) -> float:
+        """Milliseconds the compute stream waited for the early all-reduces since the last call (after a device synchronise).  The
+        flat bucket of the small tensors is a synchronous collective on top of that (34 MB)."""
+        t = sum(a.elapsed_time(b) for a, b in self.exposed_events)
+        self.exposed_events = []
+        return float(t)
 
     def _flat(self, tensors: List[torch.Tensor]):
         if not tensors:
@@ -92,3 +107,233 @@ def allreduce_counters(values: torch.Tensor) -> torch.Tensor:
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(values, op=dist.ReduceOp.SUM)
     return values
+
+
+# ------------------------------------------------------------------------------------------------ sharded data parallelism
+def _hip_sgd_update(p, g, m, lr, momentum, weight_decay, first):
+    """One-pass SGD-momentum update of a contiguous f32 slice through the HIP kernel (``sgc_sgd_momentum_step``); GPU only."""
+    import ctypes
+    from . import _lib
+    if not p.is_cuda:
+        raise RuntimeError("ShardedSGD updates parameters with the HIP kernel: GPU tensors only (no CPU fallback)")
+    f = ctypes.c_float
+    _lib.check(_lib.load().sgc_sgd_momentum_step(_lib.ptr(p), _lib.ptr(g), _lib.ptr(m), ctypes.c_long(p.numel()), f(lr), f(momentum),
+                                                 f(weight_decay), int(first), _lib.stream_ptr()), "sgc_sgd_momentum_step")
+
+
+class _Piece:
+    """One shard this rank owns: ``length`` elements at ``offset`` of a flat f32 buffer (a big parameter's storage or the small
+    parameters' bucket), with its momentum buffer and the step's (accumulated) mean gradient."""
+    __slots__ = ("key", "offset", "length", "bucket_off", "bucket_len", "mom", "acc", "first")
+
+    def __init__(self, key, offset, length, bucket_off, bucket_len):
+        self.key, self.offset, self.length, self.bucket_off, self.bucket_len = key, offset, length, bucket_off, bucket_len
+        self.mom, self.acc, self.first = None, None, True
+
+
+class ShardedSGD:
+    """Gradient reducer AND optimizer of the data-parallel relation head: reduce-scatter of the f32 gradients, SGD-momentum on
+    the shard this rank owns, all-gather of the updated f32 parameters (the reference: DDP all-reduce + a full
+    ``torch.optim.SGD`` step on every rank, ``train_test.py:72-80,100,276``).
+
+    Against all-reduce + full update (``GradReducer`` + ``optim.FusedSGD``, still available: ``bench.py --dp-mode allreduce``)
+    the wire bytes are the same (a ring all-reduce IS a reduce-scatter + an all-gather) but (a) the optimizer pass touches 1/W
+    of the parameters and the momentum buffer is 1/W of 1.1 GB per rank, (b) the two halves are separate collectives: the
+    reduce-scatter overlaps the rest of the backward exactly like the all-reduce did, and the all-gather of a row block starts
+    as soon as that block's shard is updated (asynchronous collectives on RCCL's stream, waited for once at the end of
+    ``step``).  ``fc1.weight`` (97 % of the bytes) is cut into ``buckets`` row blocks that are reduce-scattered / gathered as
+    separate collectives, so the optimizer works on the first block while the last is on the wire.  The f32 master parameters
+    stay REPLICATED and bit-identical on every rank (checkpoints, ``state_dict`` and the 16-bit re-cast work as before).
+    Not done: gathering 16-bit compute copies instead of f32 (halves the all-gather, but every rank would hold stale masters
+    outside its shard), and deferring the wait for fc1's gather until the next forward reaches fc1 (~12 ms later).
+
+    Interface: ``hook`` / ``finish_grads`` (what ``model.training_step(reducer=...)`` calls; ``owns_grads`` tells it not to
+    write ``param.grad`` - no rank holds the full mean gradient), ``zero_grad`` / ``step`` / ``param_groups`` (what the training
+    loops call on an optimizer).  Gradient accumulation over several ``finish_grads`` sums MEAN gradient shards.  Update rule =
+    ``torch.optim.SGD(lr, momentum, weight_decay)`` (dampening 0, no Nesterov), the kernel of ``optim.FusedSGD``."""
+
+    owns_grads = True
+
+    def __init__(self, named_params, world: int = 1, rank: int = 0, lr: float = 1e-3, momentum: float = 0.0, weight_decay: float = 0.0,
+                 big=("fc1.weight",), buckets: int = 8, update_fn=None, group=None):
+        self.named = [(n, p) for n, p in named_params]
+        self.world, self.rank, self.group = int(world), int(rank), group
+        self.param_groups = [dict(lr=lr, momentum=momentum, weight_decay=weight_decay, params=[p for _, p in self.named])]
+        self.update = update_fn or _hip_sgd_update
+        self.big = [n for n, p in self.named if n in set(big) and p.numel() % (self.world * 4) == 0]
+        self.small = [(n, p) for n, p in self.named if n not in self.big]
+        self.pieces: Dict[str, List[_Piece]] = {}
+        W = self.world
+        for n, p in self.named:
+            if n not in self.big:
+                continue
+            if not p.is_contiguous():
+                raise RuntimeError("ShardedSGD needs contiguous parameters")
+            nb = max(1, int(buckets))
+            while nb > 1 and p.numel() % (nb * W * 4) != 0:
+                nb //= 2
+            bl = p.numel() // nb
+            self.pieces[n] = [_Piece(n, k * bl + self.rank * (bl // W), bl // W, k * bl, bl) for k in range(nb)]
+        self.small_numel = sum(p.numel() for _, p in self.small)
+        self.small_pad = (self.small_numel + 4 * W - 1) // (4 * W) * (4 * W)
+        sl = self.small_pad // W
+        self.pieces["__small__"] = [_Piece("__small__", self.rank * sl, sl, 0, self.small_pad)] if self.small else []
+        self.pending: List = []            # (work, shard tensor, piece) reduce-scatters in flight
+        self.hooked = set()
+        self.gathers: List = []            # (work, keep-alive) all-gathers in flight
+        self._small_flat = None
+        self._keep: List = []
+        self.exposed_events: List = []     # (start, end) event pairs around every wait on the compute stream
+        self._native_rs = None
+
+    # ------------------------------------------------------------------ collectives
+    def _reduce_scatter(self, out, inp, async_op):
+        """out = this rank's 1/W of sum over ranks of inp.  Backends without a native reduce-scatter for this tensor type (gloo
+        with GPU tensors in the one-GPU tests) fall back to all-reduce + slice: same values."""
+        if self.world == 1:
+            out.copy_(inp)
+            return None
+        if self._native_rs is not False:
+            try:
+                w = dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+                self._native_rs = True
+                return w
+            except (RuntimeError, NotImplementedError):
+                if self._native_rs:
+                    raise
+                self._native_rs = False
+        tmp = inp.clone()
+        dist.all_reduce(tmp, op=dist.ReduceOp.SUM, group=self.group)
+        n = out.numel()
+        out.copy_(tmp[self.rank * n:(self.rank + 1) * n])
+        return None
+
+    def _wait(self, work):
+        if work is None:
+            return
+        if torch.cuda.is_available() and torch.cuda.is_initialized():
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            work.wait()
+            b.record()
+            self.exposed_events.append((a, b))
+        else:
+            work.wait()
+
+    def pop_exposed_ms(self) -> float:
+        """Milliseconds the compute stream spent waiting for collectives since the last call (call after a device synchronise)."""
+        t = sum(a.elapsed_time(b) for a, b in self.exposed_events)
+        self.exposed_events = []
+        return float(t)
+
+    # ------------------------------------------------------------------ reducer half
+    def hook(self, name: str, grad: torch.Tensor):
+        """Called by the backward when a big gradient has been enqueued: reduce-scatter its row blocks asynchronously."""
+        if name not in self.pieces or name in self.hooked or name == "__small__":
+            return
+        g = grad.reshape(-1)
+        for pc in self.pieces[name]:
+            if self.world == 1:
+                self.pending.append((None, g[pc.offset:pc.offset + pc.length], pc))
+                continue
+            out = torch.empty(pc.length, dtype=g.dtype, device=g.device)
+            w = self._reduce_scatter(out, g[pc.bucket_off:pc.bucket_off + pc.bucket_len], async_op=True)
+            self.pending.append((w, out, pc))
+        self._keep.append(grad)                                   # the collective reads the gradient until it is waited for
+        self.hooked.add(name)
+
+    def finish_grads(self, grads: Dict[str, torch.Tensor]):
+        """Reduce-scatter everything of this step that ``hook`` has not taken, wait, and add the MEAN shards to the accumulators."""
+        for n in self.big:
+            if n not in self.hooked:
+                self.hook(n, grads[n] if grads[n].is_contiguous() else grads[n].contiguous())
+        if self.small:
+            dev, dt = grads[self.small[0][0]].device, grads[self.small[0][0]].dtype
+            flat = torch.zeros(self.small_pad, dtype=dt, device=dev)
+            off = 0
+            for n, p in self.small:
+                flat[off:off + p.numel()].copy_(grads[n].reshape(-1))
+                off += p.numel()
+            pc = self.pieces["__small__"][0]
+            out = torch.empty(pc.length, dtype=dt, device=dev)
+            self._reduce_scatter(out, flat, async_op=False)
+            self.pending.append((None, out, pc))
+        inv = 1.0 / self.world
+        for work, shard, pc in self.pending:
+            self._wait(work)
+            if pc.acc is None:        # world 1: the shard is a view of the engine's gradient buffer (reused next step) - own it
+                pc.acc = shard.clone() if self.world == 1 else shard.mul_(inv)
+            else:
+                pc.acc.add_(shard, alpha=inv)
+        self.pending.clear()
+        self.hooked.clear()
+        self._keep = []
+
+    # ------------------------------------------------------------------ optimizer half
+    def zero_grad(self, set_to_none: bool = True):
+        for pcs in self.pieces.values():
+            for pc in pcs:
+                pc.acc = None
+        for _, p in self.named:
+            p.grad = None
+
+    def wait_gathers(self):
+        """Block the compute stream until every parameter all-gather of the last ``step`` has landed (called before the weights
+        are read: ``model.refresh_weights``)."""
+        for work, _ in self.gathers:
+            self._wait(work)
+        self.gathers.clear()
+        if self._small_flat is not None:
+            off = 0
+            with torch.no_grad():
+                for n, p in self.small:
+                    p.view(-1).copy_(self._small_flat[off:off + p.numel()])
+                    off += p.numel()
+            self._small_flat = None
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        if closure is not None:
+            raise NotImplementedError("closures are not supported")
+        self.wait_gathers()
+        g0 = self.param_groups[0]
+        lr, mom, wd = float(g0["lr"]), float(g0["momentum"]), float(g0["weight_decay"])
+        named = dict(self.named)
+        nccl = self.world > 1 and dist.get_backend(self.group) == "nccl"
+        # ---- big parameters: update this rank's piece of every row block in place, gather the block
+        for n in self.big:
+            flat = named[n].view(-1)
+            for pc in self.pieces[n]:
+                if pc.acc is None:
+                    continue
+                mine = flat[pc.offset:pc.offset + pc.length]
+                if pc.mom is None:
+                    pc.mom = torch.empty_like(mine)
+                self.update(mine, pc.acc, pc.mom, lr, mom, wd, pc.first)
+                pc.first = False
+                if self.world > 1:
+                    src = mine if nccl else mine.clone()          # NCCL's in-place all-gather: input = output + rank * count
+                    w = dist.all_gather_into_tensor(flat[pc.bucket_off:pc.bucket_off + pc.bucket_len], src, group=self.group, async_op=True)
+                    self.gathers.append((w, src))
+        # ---- small parameters: one flat bucket
+        if self.small and self.pieces["__small__"][0].acc is not None:
+            pc = self.pieces["__small__"][0]
+            dev = pc.acc.device
+            flat = torch.zeros(self.small_pad, dtype=pc.acc.dtype, device=dev)
+            off = 0
+            for n, p in self.small:
+                flat[off:off + p.numel()].copy_(p.view(-1))
+                off += p.numel()
+            mine = flat[pc.offset:pc.offset + pc.length]
+            if pc.mom is None:
+                pc.mom = torch.empty_like(mine)
+            self.update(mine, pc.acc, pc.mom, lr, mom, wd, pc.first)
+            pc.first = False
+            if self.world > 1:
+                src = mine.clone()
+                self.gathers.append((dist.all_gather_into_tensor(flat, src, group=self.group, async_op=True), src))
+            self._small_flat = flat
+        for _, p in self.named:               # parameters change behind autograd's back: version-based caches must notice
+            torch.autograd.graph.increment_version(p)
+        self.wait_gathers()                   # the classifier re-derives its 16-bit copies right after: gathers must have landed
+        return None

@@ -231,15 +231,17 @@ class _RelationBase(nn.Module):
                 zeros = {n: torch.zeros_like(p) for n, p in self.named_parameters()}
                 if "fc1.weight" in zeros:
                     reducer.hook("fc1.weight", zeros["fc1.weight"])
-                reducer.finish_grads(zeros)
-                for n, p in self.named_parameters():
+                reducer.finish_grads(zeros)           # "zeros" now holds the mean of the OTHER ranks' gradients: apply it like they do
+                if not getattr(reducer, "owns_grads", False):
+                    for n, p in self.named_parameters():
+                        if p.grad is None:
+                            p.grad = zeros[n]
+                        else:
+                            p.grad.add_(zeros[n])
+            if not getattr(reducer, "owns_grads", False):
+                for p in self.parameters():
                     if p.grad is None:
-                        p.grad = zeros[n]
-                    else:
-                        p.grad.add_(zeros[n])
-            for p in self.parameters():
-                if p.grad is None:
-                    p.grad = torch.zeros_like(p)
+                        p.grad = torch.zeros_like(p)
             self.last_outputs = None
             self.last_connectivity_stats = None
             return torch.zeros((), device=dev)
@@ -313,12 +315,13 @@ class _RelationBase(nn.Module):
             else:
                 if reducer is not None:
                     reducer.finish_grads(grads)
-                for name, p in self.named_parameters():
-                    g = grads[name].view_as(p)
-                    if p.grad is None:
-                        p.grad = g if g.is_contiguous() else g.contiguous()
-                    else:
-                        p.grad.add_(g)
+                if not getattr(reducer, "owns_grads", False):      # a sharded reducer keeps the mean gradient shards itself
+                    for name, p in self.named_parameters():
+                        g = grads[name].view_as(p)
+                        if p.grad is None:
+                            p.grad = g if g.is_contiguous() else g.contiguous()
+                        else:
+                            p.grad.add_(g)
             # connectivity statistics of train_one_direction (train_utils.py:66-87) summed over the minibatch: a [5] device
             # tensor (not connected, connected, predicted connected, precision numerator, recall numerator), no host sync
             raw_d = scene.raw_target if (directed is None and scene.raw_target is not None) else directed_d

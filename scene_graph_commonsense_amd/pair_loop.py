@@ -351,11 +351,12 @@ def _train_image_groups(model, cfg, batch, scene: DeviceScene, groups, reducer, 
         if "fc1.weight" in acc:
             reducer.hook("fc1.weight", acc["fc1.weight"])
         reducer.finish_grads(acc)
-    for name, p in model.named_parameters():
-        g = acc[name].view_as(p)
-        if p.grad is None:
-            p.grad = g if g.is_contiguous() else g.contiguous()
-        else:
-            p.grad.add_(g)
+    if not getattr(reducer, "owns_grads", False):
+        for name, p in model.named_parameters():
+            g = acc[name].view_as(p)
+            if p.grad is None:
+                p.grad = g if g.is_contiguous() else g.contiguous()
+            else:
+                p.grad.add_(g)
     model.last_outputs, model.last_connectivity_stats = full, stats
     return loss

@@ -26,7 +26,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from .distributed import GradReducer
+from .distributed import GradReducer, ShardedSGD
 from .evaluator import Evaluator, Evaluator_Top3
 from .model import BayesianRelationClassifier, FlatRelationClassifier, strip_ddp_prefix
 from .optim import FusedSGD
@@ -252,11 +252,16 @@ def training(gpu, args, train_subset, test_subset):
     if rank == 0:
         print(f"Total number of parameters in the model: {sum(p.numel() for p in relation_classifier.parameters())}")
 
-    optimizer = FusedSGD(relation_classifier.parameters(), lr=T["learning_rate"], momentum=0.9, weight_decay=T["weight_decay"])
+    if world_size > 1 and T.get("dp_mode", "sharded") == "sharded":
+        # reduce-scatter of the gradients + SGD on this rank's shard + all-gather of the parameters: reducer and optimizer in one
+        optimizer = reducer = ShardedSGD(relation_classifier.named_parameters(), world_size, rank, lr=T["learning_rate"], momentum=0.9,
+                                         weight_decay=T["weight_decay"])
+    else:
+        optimizer = FusedSGD(relation_classifier.parameters(), lr=T["learning_rate"], momentum=0.9, weight_decay=T["weight_decay"])
+        reducer = GradReducer(world_size)
     relation_classifier.train()
     original_lr = optimizer.param_groups[0]["lr"]
     class_weight = _class_weight(args)
-    reducer = GradReducer(world_size)
     commonsense = _commonsense_keys(args)
     record_train = _host("record_train_results", _record_train)
 

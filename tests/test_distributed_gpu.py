@@ -61,3 +61,71 @@ def test_two_ranks_mean_gradients_on_one_gpu():
     [p.join(120) for p in procs]
     for rank, worst in res:
         assert worst <= 1e-5, (rank, worst)
+
+
+def _sharded_worker(rank, world, port, q):
+    """Two steps (the second accumulates two backward passes) with ``ShardedSGD`` as reducer + optimizer on the real HIP path, against
+    the all-reduce path (``GradReducer`` + ``FusedSGD``) started from the same weights on the same images: same parameters."""
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    from scene_graph_commonsense_amd import distributed as D
+    from scene_graph_commonsense_amd.model import BayesianRelationClassifier
+    from scene_graph_commonsense_amd.optim import FusedSGD
+    from scene_graph_commonsense_amd.pair_loop import train_minibatch
+    from scene_graph_commonsense_amd.synthetic import HeadConfig, make_scene_batch, make_state_dict
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg = HeadConfig()
+    sd = make_state_dict(cfg, seed=5, head_gain=4.0)
+    batch = make_scene_batch(cfg, (3, 2), seed=100 + rank, connect_frac=0.6)
+    models = []
+    for mode in ("allreduce", "sharded"):
+        model = BayesianRelationClassifier(cfg.args()).cuda()
+        model.load_state_dict(sd)
+        model.eval()                                                               # dropout off: both modes see the same step
+        if mode == "sharded":
+            opt = red = D.ShardedSGD(model.named_parameters(), world, rank, lr=1e-5, momentum=0.9, weight_decay=1e-4)
+        else:
+            opt, red = FusedSGD(model.parameters(), lr=1e-5, momentum=0.9, weight_decay=1e-4), D.GradReducer(world)
+        train_minibatch(model, batch, opt, reducer=red)                            # step 1
+        opt.zero_grad(set_to_none=True)                                            # step 2: two backward passes, one update
+        model.training_step(model.last_scene, batch.relationships, batch.subj_or_obj, reducer=red)
+        model.training_step(model.last_scene, batch.relationships, batch.subj_or_obj, reducer=red)
+        opt.step()
+        torch.cuda.synchronize()
+        models.append(model)
+        if mode == "sharded":
+            mom = sum(pc.mom.numel() for pcs in opt.pieces.values() for pc in pcs if pc.mom is not None)
+    worst = 0.0
+    moved = 0.0
+    for (n, a), (_, b) in zip(models[0].named_parameters(), models[1].named_parameters()):
+        worst = max(worst, float((a.detach() - b.detach()).abs().max() / a.detach().abs().max().clamp(min=1e-30)))
+        moved = max(moved, float((a.detach() - sd[n].cuda()).abs().max()))
+    # replicas agree bit for bit across ranks
+    same = True
+    for n, p in models[1].named_parameters():
+        if p.numel() > (1 << 22):
+            continue
+        other = [torch.empty_like(p.detach()) for _ in range(world)]
+        dist.all_gather(other, p.detach().contiguous())
+        same = same and torch.equal(other[0], other[1])
+    total = sum(p.numel() for p in models[1].parameters())
+    q.put((rank, worst, moved, same, mom, total))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_sharded_sgd_equals_allreduce_path_on_one_gpu():
+    import socket
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = sorted(q.get(timeout=900) for _ in range(2))
+    [p.join(120) for p in procs]
+    for rank, worst, moved, same, mom, total in res:
+        assert moved > 0 and worst <= 1e-6, (rank, worst, moved)                   # same update (f32 fma / summation order only)
+        assert same and mom <= total // 2 + 64

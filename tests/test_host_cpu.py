@@ -451,3 +451,98 @@ def test_image_group_planner_covers_every_image_within_the_budget():
     assert c_full == _COST[True][2] * 40 * 39 + _COST[True][3] * 40 and c_small < 0.6 * c_full
     sub = slice_batch(batch, 2, 5)
     assert sub.num_objects == [40, 40, 1] and sub.image_feature.shape[0] == 3 and len(sub.relationships) == 3
+
+
+def _torch_sgd_update(p, g, m, lr, momentum, weight_decay, first):
+    """The update rule of torch.optim.SGD (dampening 0) on a flat slice - what sgc_sgd_momentum_step computes on the GPU; injected
+    into ShardedSGD on the CPU so that its partitioning / collective / accumulation logic can be tested without a GPU."""
+    d = g + weight_decay * p
+    if first:
+        m.copy_(d)
+    else:
+        m.mul_(momentum).add_(d)
+    p.sub_(lr * m)
+
+
+def _sharded_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from scene_graph_commonsense_amd import distributed as D
+    r, w, _ = D.init_from_env(backend="gloo")
+    g = torch.Generator().manual_seed(0)                       # same initial parameters on every rank
+    shapes = [("conv1_1.weight", (3, 5, 1, 1)), ("fc1.weight", (64, 128)), ("fc1.bias", (7,)), ("fc2.weight", (5, 13))]
+    params = [(n, torch.nn.Parameter(torch.randn(s, generator=g))) for n, s in shapes]
+    ref = [(n, torch.nn.Parameter(p.detach().clone())) for n, p in params]
+    ref_opt = torch.optim.SGD([p for _, p in ref], lr=0.05, momentum=0.9, weight_decay=1e-3)
+    opt = D.ShardedSGD(params, w, r, lr=0.05, momentum=0.9, weight_decay=1e-3, buckets=4, update_fn=_torch_sgd_update)
+    assert len(opt.pieces["fc1.weight"]) == 4 and opt.pieces["fc1.weight"][1].length == 64 * 128 // 4 // w
+    assert opt.small_pad % (4 * w) == 0 and opt.small_pad >= 15 + 7 + 65
+    worst = 0.0
+    for step in range(4):
+        # every rank's own gradients (what its images give); the reference applies their MEAN with a plain torch SGD
+        gr = [torch.Generator().manual_seed(100 * step + k) for k in range(w)]
+        all_g = [{n: torch.randn(p.shape, generator=gr[k]) for n, p in params} for k in range(w)]
+        accumulate = step == 2                                # step 2 accumulates two backward passes before stepping
+        opt.zero_grad()
+        mine = {n: t.clone() for n, t in all_g[r].items()}
+        if step % 2 == 0:
+            opt.hook("fc1.weight", mine["fc1.weight"])        # early hand-over, as the backward does
+        mine["fc2.weight"] = mine["fc2.weight"].t().contiguous().t()      # a non-contiguous gradient (conv weights come out of a permute)
+        opt.finish_grads(mine)
+        assert not opt.pending and all(p.grad is None for _, p in params)
+        if accumulate:
+            opt.finish_grads({n: 0.5 * t for n, t in all_g[r].items()})
+        for n, p in ref:
+            p.grad = sum(all_g[k][n] for k in range(w)) / w * (1.5 if accumulate else 1.0)
+        if step == 3:
+            opt.param_groups[0]["lr"] = ref_opt.param_groups[0]["lr"] = 0.01
+        v0 = [p._version for _, p in params]
+        opt.step(); ref_opt.step()
+        assert all(p._version > v for (_, p), v in zip(params, v0))
+        for (n, p), (_, q_) in zip(params, ref):
+            worst = max(worst, float((p.detach() - q_.detach()).abs().max()))
+    # the momentum state is sharded: this rank holds 1/world of every bucket
+    mom = sum(pc.mom.numel() for pcs in opt.pieces.values() for pc in pcs)
+    total = sum(p.numel() for _, p in params)
+    q.put((rank, worst, mom, total, [p.detach().numpy().copy() for _, p in params]))     # numpy: no shared-memory handles
+    dist.destroy_process_group()
+
+
+def test_sharded_sgd_reduce_scatter_update_all_gather_gloo_world2():
+    """distributed.ShardedSGD under gloo, world 2: four steps (early hook or not, gradient accumulation, lr change) leave EVERY
+    rank with the parameters a single torch.optim.SGD gets from the mean gradients; optimizer state is 1/world per rank."""
+    import socket
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = sorted((q.get(timeout=180) for _ in range(2)), key=lambda t: t[0])
+    [p.join(60) for p in procs]
+    for rank, worst, mom, total, _ in res:
+        assert worst <= 1e-6, worst
+        assert mom <= total // 2 + 8
+    for a, b in zip(res[0][4], res[1][4]):
+        assert np.array_equal(a, b)                                        # replicas stay bit-identical
+
+
+def test_sharded_sgd_world1_is_plain_sgd():
+    from scene_graph_commonsense_amd import distributed as D
+    g = torch.Generator().manual_seed(3)
+    params = [("fc1.weight", torch.nn.Parameter(torch.randn(16, 32, generator=g))), ("fc4.bias", torch.nn.Parameter(torch.randn(1, generator=g)))]
+    ref = [torch.nn.Parameter(p.detach().clone()) for _, p in params]
+    ro = torch.optim.SGD(ref, lr=0.1, momentum=0.9, weight_decay=1e-4)
+    opt = D.ShardedSGD(params, 1, 0, lr=0.1, momentum=0.9, weight_decay=1e-4, update_fn=_torch_sgd_update)
+    for step in range(3):
+        gs = {n: torch.randn(p.shape, generator=g) for n, p in params}
+        opt.zero_grad()
+        opt.hook("fc1.weight", gs["fc1.weight"])
+        opt.finish_grads(gs)
+        for q_, (n, _) in zip(ref, params):
+            q_.grad = gs[n].clone()
+        opt.step(); ro.step()
+    for (_, p), q_ in zip(params, ref):
+        assert float((p.detach() - q_.detach()).abs().max()) <= 1e-6
