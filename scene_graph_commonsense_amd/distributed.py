@@ -208,6 +208,25 @@ class ShardedSGD:
         out.copy_(tmp[self.rank * n:(self.rank + 1) * n])
         return None
 
+    def _all_gather(self, out, src):
+        """out (flat, W x src.numel()) = the ranks' ``src`` in rank order; returns a work handle or None when already complete.
+        Same fallback rule as ``_reduce_scatter`` (list form of all-gather + copies)."""
+        if getattr(self, "_native_ag", None) is not False:
+            try:
+                w = dist.all_gather_into_tensor(out, src, group=self.group, async_op=True)
+                self._native_ag = True
+                return w
+            except (RuntimeError, NotImplementedError):
+                if getattr(self, "_native_ag", None):
+                    raise
+                self._native_ag = False
+        parts = [torch.empty_like(src) for _ in range(self.world)]
+        dist.all_gather(parts, src.contiguous(), group=self.group)
+        n = src.numel()
+        for k, t in enumerate(parts):
+            out[k * n:(k + 1) * n].copy_(t)
+        return None
+
     def _wait(self, work):
         if work is None:
             return
@@ -313,8 +332,7 @@ class ShardedSGD:
                 pc.first = False
                 if self.world > 1:
                     src = mine if nccl else mine.clone()          # NCCL's in-place all-gather: input = output + rank * count
-                    w = dist.all_gather_into_tensor(flat[pc.bucket_off:pc.bucket_off + pc.bucket_len], src, group=self.group, async_op=True)
-                    self.gathers.append((w, src))
+                    self.gathers.append((self._all_gather(flat[pc.bucket_off:pc.bucket_off + pc.bucket_len], src), src))
         # ---- small parameters: one flat bucket
         if self.small and self.pieces["__small__"][0].acc is not None:
             pc = self.pieces["__small__"][0]
@@ -331,7 +349,7 @@ class ShardedSGD:
             pc.first = False
             if self.world > 1:
                 src = mine.clone()
-                self.gathers.append((dist.all_gather_into_tensor(flat, src, group=self.group, async_op=True), src))
+                self.gathers.append((self._all_gather(flat, src), src))
             self._small_flat = flat
         for _, p in self.named:               # parameters change behind autograd's back: version-based caches must notice
             torch.autograd.graph.increment_version(p)
