@@ -53,6 +53,8 @@ def parse_args(argv=None):
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL)")
     ap.add_argument("--dp-mode", default="sharded", choices=["sharded", "allreduce"],
                     help="N > 1: reduce-scatter + sharded SGD + all-gather (distributed.ShardedSGD, default) or all-reduce + full SGD on every rank")
+    ap.add_argument("--streams", type=int, default=None,
+                    help="image-group lanes on concurrent HIP streams inside one step (pair_loop.train_minibatch; default: the model's setting)")
     ap.add_argument("--no-sensitivity", action="store_true", help="skip the three short box-size sensitivity runs (N=1 only)")
     ap.add_argument("--box-scale", type=float, default=1.0,
                     help="scale every box about its centre (clipped to the image); >= 100 = every box is the full image")
@@ -282,7 +284,7 @@ def run_rank(args):
             if args.forward_only:
                 model.forward_pairs(scene0 if args.cached_scene else flatten_scene(cfg, batch, dev))
                 return None
-            return train_minibatch(model, batch, opt, reducer=reducer, scene=scene0 if args.cached_scene else None)
+            return train_minibatch(model, batch, opt, reducer=reducer, scene=scene0 if args.cached_scene else None, streams=args.streams)
 
         eng.timers = {}
         eng._xw = None
@@ -400,6 +402,7 @@ def run_rank(args):
             "kernels_tflops": {k: round(flops[k] / (kern[k] * 1e-3) / 1e12, 1) for k in kern
                                if k in flops and kern[k] > 0 and (k in fwd_only or not two_streams)},
             "backward_streams": 2 if two_streams else 1,
+            "image_group_lanes": len(getattr(model, "last_image_groups", None) or [1]) if not args.forward_only else 1,
             "peak_memory_gb": round(m["peak_gb"], 1),
             "ranks_seen": int(ranks.item()), "rank_ms_per_step": [round(float(x), 2) for x in rank_ms.tolist()],
             "sensitivity": sensitivity,

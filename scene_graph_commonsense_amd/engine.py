@@ -175,6 +175,7 @@ class RelHeadEngine:
         c.cfg, c.device, c.lib, c.w, c.T, c.timers = self.cfg, self.device, self.lib, self.w, self.T, None
         c.head_rows = getattr(self, "head_rows", None)
         c.ws, c.scratch = Workspace(self.device), self.scratch
+        c._side_stream = getattr(self, "_side_stream", None)
         return c
 
     def _timed(self, name, fn):
@@ -1089,9 +1090,9 @@ class RelHeadEngine:
             def __init__(self):
                 self.main = torch.cuda.current_stream(eng.device)
                 if enabled:
-                    if RelHeadEngine._side_streams.get(eng.device) is None:
-                        RelHeadEngine._side_streams[eng.device] = torch.cuda.Stream(device=eng.device)
-                    self.side = RelHeadEngine._side_streams[eng.device]
+                    if getattr(eng, "_side_stream", None) is None:       # one per engine: image groups on concurrent lanes keep apart
+                        eng._side_stream = torch.cuda.Stream(device=eng.device)
+                    self.side = eng._side_stream
                     ev = torch.cuda.Event()
                     ev.record(self.main)
                     self.side.wait_event(ev)         # the side stream's previous work may not overtake buffers reused by this step
@@ -1113,8 +1114,6 @@ class RelHeadEngine:
                     ev.record(self.side)
                     self.main.wait_event(ev)
         return Chain()
-
-    _side_streams: Dict = {}
 
 
     def commonsense_coefficients(self, ctx: "TrainContext", bitmaps, step: torch.Tensor, n_steps: int, scat: torch.Tensor,

@@ -154,6 +154,19 @@ class _RelationBase(nn.Module):
             self._weights_version = v
         return eng
 
+    def lane_engine(self, k: int) -> RelHeadEngine:
+        """Engine ``k`` of this module: 0 is the module's own, the others share its weights (the 16-bit copies are re-derived once,
+        by ``refresh_weights``) and own their workspace, so that image groups can be in flight on different streams."""
+        eng = self.refresh_weights(backward=True)
+        if k == 0:
+            return eng
+        lanes = self.__dict__.setdefault("_lane_engines", {})
+        if k not in lanes or lanes[k].device != eng.device:
+            lanes[k] = RelHeadEngine(self.head_config(), eng.device)
+        lane = lanes[k]
+        lane.w, lane.T, lane.head_rows = eng.w, eng.T, eng.head_rows
+        return lane
+
     # ------------------------------------------------------------------ fused path
     def forward_pairs(self, scene: DeviceScene, iou_mask: Optional[torch.Tensor] = None, select: Optional[torch.Tensor] = None) -> PairOutputs:
         """All ordered pairs of a minibatch in one pass (eval numerics unless ``self.training``).  ``select`` [P]: compute only
@@ -201,7 +214,8 @@ class _RelationBase(nn.Module):
                       lambda_connectivity: float = 0.1, lambda_not_connected: float = 1.0, class_weight=None,
                       grad_hook=None, reducer=None, image_feature_aug: Optional[torch.Tensor] = None, lambda_contrast: float = 1.0,
                       commonsense=None, lambda_commonsense: float = 1.0, lambda_cs_weak: float = 0.1,
-                      lambda_cs_strong: float = 10.0, loss_coefs=None, grads_out: Optional[Dict[str, torch.Tensor]] = None):
+                      lambda_cs_strong: float = 10.0, loss_coefs=None, grads_out: Optional[Dict[str, torch.Tensor]] = None,
+                      engine: Optional[RelHeadEngine] = None):
         """Forward + loss + backward over all ordered pairs; gradients land in ``param.grad`` (accumulating like
         autograd).  Loss follows ``train_test.py:189-258`` / ``train_utils.py:64-157`` (hierarchical NLL, BCE on
         connectivity, running-sum step weights).  With ``image_feature_aug`` (DETR features of the colour-jittered view,
@@ -213,11 +227,12 @@ class _RelationBase(nn.Module):
         ``loss_coefs`` / ``grads_out`` serve the image-group chunking of ``pair_loop.train_minibatch``: the per-pair loss
         coefficients of THIS scene's pairs taken from the whole minibatch's (per-step means and running-sum weights couple the
         images of a minibatch, the gradients are additive over images once the coefficients are fixed), and a dict the step's
-        gradients are summed into instead of ``param.grad`` (no reduction here: the caller reduces the sum once)."""
+        gradients are summed into instead of ``param.grad`` (no reduction here: the caller reduces the sum once).  ``engine``: run on
+        this engine (``lane_engine``: same weights, own workspace) instead of the module's - image groups on concurrent streams."""
         if reducer is not None:
             grad_hook = reducer.hook
         cfg = self.head_config()
-        eng = self.refresh_weights(backward=True)
+        eng = engine if engine is not None else self.refresh_weights(backward=True)
         dev = eng.device
         P = scene.n_pairs
         if P == 0 and grads_out is not None:       # an image group without pairs adds nothing to the minibatch's gradient sum

@@ -87,6 +87,22 @@ def plan_image_groups(cfg, batch, train: bool, budget_bytes: float):
     return groups
 
 
+def split_balanced(num_objects, k: int):
+    """At most ``k`` consecutive image ranges with about equal numbers of ordered pairs (lanes of the two-stream step)."""
+    pairs = np.asarray([n * (n - 1) for n in num_objects], dtype=np.float64)
+    total, B = float(pairs.sum()), len(pairs)
+    if k <= 1 or B < 2 or total == 0:
+        return [(0, B)]
+    cum = np.cumsum(pairs)
+    cuts = [0]
+    for j in range(1, k):
+        c = int(np.searchsorted(cum, total * j / k, side="left")) + 1
+        c = min(max(c, cuts[-1] + 1), B - (k - j))
+        cuts.append(c)
+    cuts.append(B)
+    return [(a, b) for a, b in zip(cuts, cuts[1:]) if b > a]
+
+
 def _budget(model, workspace_budget):
     if workspace_budget is not None:
         return float(workspace_budget)
@@ -285,31 +301,49 @@ def evaluate_sgdet_minibatch(model, image_feature, image_depth, categories_pred,
 
 
 def train_minibatch(model, batch, optimizer=None, reducer=None, scene: Optional[DeviceScene] = None,
-                    workspace_budget: Optional[float] = None, **loss_kw):
+                    workspace_budget: Optional[float] = None, streams: Optional[int] = None, **loss_kw):
     """One optimisation step over all ordered pairs of the minibatch; returns the loss tensor.
     A minibatch whose fused pass would exceed ``workspace_budget`` (bytes; default ``model.workspace_budget_bytes`` or 70 % of
     the free HBM) is run in consecutive image groups: whole-minibatch loss coefficients first, then forward + backward per group
     with its rows of them, the gradients summed and reduced across ranks once.  Equal to the one-pass step up to f32 summation
-    order (dropout masks differ: the keep bit is indexed by a pair's position within its pass)."""
+    order (dropout masks differ: the keep bit is indexed by a pair's position within its pass).
+    ``streams`` (default ``model.pipeline_streams`` or 1): image groups run on that many concurrent HIP streams, each with its own
+    engine workspace - the HBM-bound kernels of one group (expansion, contraction, im2col / col2im, fc1 assembly, ...) then share
+    the chip with the MFMA-bound GEMMs of the other instead of leaving the matrix cores idle; a minibatch that fits in one pass
+    is cut into ``streams`` balanced groups for that purpose.  Same arithmetic as the sequential groups."""
     cfg = model.head_config()
     dev = next(model.parameters()).device
     if optimizer is not None:
         optimizer.zero_grad(set_to_none=True)
+    lanes = int(streams if streams is not None else getattr(model, "pipeline_streams", 1) or 1)
+    chunk_free = loss_kw.get("image_feature_aug") is None and loss_kw.get("commonsense") is None
     groups = plan_image_groups(cfg, batch, True, _budget(model, workspace_budget))
+    if len(groups) == 1 and lanes > 1 and chunk_free:
+        groups = split_balanced([int(b.shape[0]) for b in batch.bbox], lanes)
     model.last_image_groups = groups
     if scene is None:
         scene = flatten_scene(cfg, batch, dev)
     if len(groups) == 1:
         loss = model.training_step(scene, batch.relationships, batch.subj_or_obj, reducer=reducer, **loss_kw)
     else:
-        loss = _train_image_groups(model, cfg, batch, scene, groups, reducer, loss_kw)
+        loss = _train_image_groups(model, cfg, batch, scene, groups, reducer, loss_kw, lanes=lanes)
     model.last_scene = scene
     if optimizer is not None:
         optimizer.step()
     return loss
 
 
-def _train_image_groups(model, cfg, batch, scene: DeviceScene, groups, reducer, loss_kw):
+_LANE_STREAMS = {}
+
+
+def _lane_stream(dev, k):
+    key = (torch.device(dev), k)
+    if key not in _LANE_STREAMS:
+        _LANE_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return _LANE_STREAMS[key]
+
+
+def _train_image_groups(model, cfg, batch, scene: DeviceScene, groups, reducer, loss_kw, lanes: int = 1):
     from .engine import PairOutputs
     dev = scene.bbox.device
     kw = dict(loss_kw)
@@ -325,27 +359,46 @@ def _train_image_groups(model, cfg, batch, scene: DeviceScene, groups, reducer, 
     full = PairOutputs(torch.zeros(P, cfg.num_relations, device=dev), torch.zeros(P, 3, device=dev) if cfg.hierarchical else None,
                        torch.zeros(P, device=dev), torch.zeros(P, 512, device=dev), torch.zeros(P, nc, device=dev),
                        torch.zeros(P, nc, dtype=torch.int32, device=dev))
-    acc, stats = {}, torch.zeros(5, dtype=torch.int64, device=dev)
-    loss = torch.zeros((), device=dev)
-    for a, b in groups:
-        rows = _group_rows(scene, a, b)
-        if rows.numel() == 0:
-            continue
-        sub_b = slice_batch(batch, a, b)
-        sub = flatten_scene(cfg, sub_b, dev)
-        assert sub.n_pairs == int(rows.numel())
-        loss = loss + model.training_step(sub, sub_b.relationships, sub_b.subj_or_obj, loss_coefs=tuple(c[rows] for c in coefs),
-                                          grads_out=acc, **kw)
-        out = model.last_outputs
-        full.relation[rows] = out.relation
-        if full.super_relation is not None:
-            full.super_relation[rows] = out.super_relation
-        full.connectivity[rows] = out.connectivity
-        full.hidden[rows] = out.hidden
-        full.cand_conf[rows] = out.cand_conf
-        full.cand_pred[rows] = out.cand_pred
-        if model.last_connectivity_stats is not None:
-            stats += model.last_connectivity_stats
+    lanes = max(1, min(int(lanes), len(groups)))
+    main = torch.cuda.current_stream(dev)
+    lane = [dict(stream=main if lanes == 1 else _lane_stream(dev, k), engine=model.lane_engine(k), acc={},
+                 stats=torch.zeros(5, dtype=torch.int64, device=dev), loss=torch.zeros((), device=dev)) for k in range(lanes)]
+    if lanes > 1:
+        for ln in lane:
+            ln["stream"].wait_stream(main)          # coefficients, weights and the full-size outputs are ready; last step's reads are done
+    for gi, (a, b) in enumerate(groups):
+        ln = lane[gi % lanes]
+        with torch.cuda.stream(ln["stream"]):
+            rows = _group_rows(scene, a, b)
+            if rows.numel() == 0:
+                continue
+            sub_b = slice_batch(batch, a, b)
+            sub = flatten_scene(cfg, sub_b, dev)
+            assert sub.n_pairs == int(rows.numel())
+            ln["loss"] = ln["loss"] + model.training_step(sub, sub_b.relationships, sub_b.subj_or_obj,
+                                                          loss_coefs=tuple(c[rows] for c in coefs), grads_out=ln["acc"],
+                                                          engine=ln["engine"], **kw)
+            out = model.last_outputs
+            full.relation[rows] = out.relation
+            if full.super_relation is not None:
+                full.super_relation[rows] = out.super_relation
+            full.connectivity[rows] = out.connectivity
+            full.hidden[rows] = out.hidden
+            full.cand_conf[rows] = out.cand_conf
+            full.cand_pred[rows] = out.cand_pred
+            if model.last_connectivity_stats is not None:
+                ln["stats"] += model.last_connectivity_stats
+    if lanes > 1:
+        for ln in lane:
+            main.wait_stream(ln["stream"])
+    acc, stats, loss = lane[0]["acc"], lane[0]["stats"], lane[0]["loss"]
+    for ln in lane[1:]:                               # lane sums -> the minibatch's sums (fixed order: deterministic)
+        for name, g in ln["acc"].items():
+            if name in acc:
+                acc[name].add_(g)
+            else:
+                acc[name] = g
+        stats, loss = stats + ln["stats"], loss + ln["loss"]
     # the minibatch's gradient = the sum over its image groups: mean-reduce it across ranks once, then accumulate like autograd
     if reducer is not None:
         if "fc1.weight" in acc:
