@@ -351,7 +351,8 @@ def run_rank(args):
                  "conv3_wgrad": 2.0 * P * 256 * 1024 * 4608, "fc1_fwd": 2.0 * P * 65536 * 4096,
                  "fc1_dgrad": 2.0 * P * 65536 * 4096, "fc1_wgrad": 2.0 * P * 65536 * 4096}
         dom = "conv3_fwd_windows"
-        two_streams = os.environ.get("SGC_BWD_STREAMS", "1") != "0" and not args.forward_only
+        from scene_graph_commonsense_amd.engine import TUNING
+        two_streams = TUNING.bwd_streams and not args.forward_only
         fwd_only = ("conv2_fwd", "expand_dense", "expand", "expand_train", "conv3_fwd", "conv3_fwd_objects", "conv3_fwd_windows",
                     "conv3_fwd_assemble", "fc1_fwd", "fc1_fwd_windows", "fc1_fwd_integral", "fc1_fwd_assemble", "fc2_fwd")
         xw = True if m["shared"] else None

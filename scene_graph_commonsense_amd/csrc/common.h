@@ -19,6 +19,39 @@ typedef unsigned short u16;
 
 enum { ELEM_F16 = 0, ELEM_BF16 = 1 };
 
+// Launch-time selections among kernel variants.  The product library uses the measured defaults below (profiles/README.md) and
+// reads NO environment variable; a library built with -DSGC_EXPERIMENTS (SGC_EXPERIMENTS=1 python -m ...build, for
+// tools/gemm_microbench.py / tools/hook_sweep.sh) reads the SGC_* variables ONCE, in a thread-safe function-local static, for A/B runs.
+struct SgcTuning {
+    int gemm_cfg = 0;        // SGC_GEMM_CFG: 1 = 128x128 block, 2 = 2-stage 256x256, 3 = 4-stage ring, 4 = halo conv (2-stage), 5 / 7 = ping-pong plain / halo
+    int gemm_ring = 0;       // SGC_GEMM_RING: 4-stage ring kernel
+    int gemm_pp = 1;         // SGC_GEMM_PP: ping-pong 256x256 loops (0: 2-stage)
+    int conv_halo = 1;       // SGC_CONV_HALO: halo-staged implicit 3x3 convolution (0: plain implicit GEMM)
+    int epi_lds = 1;         // SGC_EPI_LDS: 16-bit outputs transposed through LDS into 16-byte stores
+    int acg_aligned = 0;     // SGC_ACG_ALIGNED: gathered conv grid padded to whole per-XCD patches
+    int nt_aligned = -1;     // SGC_NT_ALIGNED: -1 = by grid size
+    int halo_walk = -1;      // SGC_HALO_WALK: -1 = by weight-tile size
+    int tn_xcd = 1;          // SGC_TN_XCD: XCD-aware assignment of the 4 x 18 conv weight-gradient tile grid
+    int tn_patch = 1;        // SGC_TN_PATCH: per-XCD 4x8 patches for TN grids with >= 8 M tiles
+    int gather_pp = 1;       // SGC_GATHER_PP: ping-pong block for the gathered conv3 forward
+};
+inline const SgcTuning& sgc_tuning() {
+    static const SgcTuning t = [] {
+        SgcTuning v;
+#ifdef SGC_EXPERIMENTS
+        auto rd = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
+        v.gemm_cfg = rd("SGC_GEMM_CFG", v.gemm_cfg);       v.gemm_ring = rd("SGC_GEMM_RING", v.gemm_ring);
+        v.gemm_pp = rd("SGC_GEMM_PP", v.gemm_pp);          v.conv_halo = rd("SGC_CONV_HALO", v.conv_halo);
+        v.epi_lds = rd("SGC_EPI_LDS", v.epi_lds);          v.acg_aligned = rd("SGC_ACG_ALIGNED", v.acg_aligned);
+        v.nt_aligned = rd("SGC_NT_ALIGNED", v.nt_aligned); v.halo_walk = rd("SGC_HALO_WALK", v.halo_walk);
+        v.tn_xcd = rd("SGC_TN_XCD", v.tn_xcd);             v.tn_patch = rd("SGC_TN_PATCH", v.tn_patch);
+        v.gather_pp = rd("SGC_GATHER_PP", v.gather_pp);
+#endif
+        return v;
+    }();
+    return t;
+}
+
 // f32 -> bf16, round to nearest even: gfx950 has the conversion in hardware (v_cvt_pk_bf16_f32, one VALU op per PAIR); the
 // integer emulation (NaN test + add + shift, ~6 ops per value) made the bf16 epilogues of the GEMM blocks VALU-bound
 // (128 values per lane: fc1 data gradient 13.3 -> see profiles/README.md).

@@ -331,19 +331,11 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void gemm_nt_kernel(const NtParams
 }
 
 #ifdef SGC_EXPERIMENTS
-inline int sgc_gemm_ring() {      // SGC_GEMM_RING=1 selects the 4-stage ring kernel (A/B hook; default off, see below)
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("SGC_GEMM_RING"); v = e ? atoi(e) : 0; }
-    return v;
-}
+inline int sgc_gemm_ring() { return sgc_tuning().gemm_ring; }      // 4-stage ring kernel (experiment; default off, see below)
 
 #endif
 
-inline int sgc_gemm_cfg() {       // test hook: SGC_GEMM_CFG=1 forces the 128x128 block, =2 the 2-stage 256x256 block, =3 the 4-stage ring, =4 the halo-staged conv (2-stage), =5 the ping-pong plain block, =7 the ping-pong halo conv
-    static int cfg = -1;
-    if (cfg < 0) { const char* e = getenv("SGC_GEMM_CFG"); cfg = e ? atoi(e) : 0; }
-    return cfg;
-}
+inline int sgc_gemm_cfg() { return sgc_tuning().gemm_cfg; }        // forced block configuration (experiments only), common.h
 
 template <int ELEM, int AMODE, int EPI, int WR, int WC, int TM, int TN, int ABL = 0>
 static int launch_gemm_nt_cfg(NtParams p, hipStream_t stream) {
@@ -624,17 +616,8 @@ static int launch_conv16_halo(NtParams p, hipStream_t stream) {
 #include "gemm_nt_pp1.h"
 #endif
 
-inline int sgc_gemm_pp() {        // SGC_GEMM_PP=0 falls back to the 2-stage 256x256 loops (A/B hook)
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("SGC_GEMM_PP"); v = e ? atoi(e) : 1; }
-    return v;
-}
-
-inline int sgc_conv_halo() {      // SGC_CONV_HALO=0 falls back to the plain implicit GEMM (A/B hook)
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("SGC_CONV_HALO"); v = e ? atoi(e) : 1; }
-    return v;
-}
+inline int sgc_gemm_pp() { return sgc_tuning().gemm_pp; }          // ping-pong 256x256 loops (0: the 2-stage loops)
+inline int sgc_conv_halo() { return sgc_tuning().conv_halo; }      // halo-staged implicit convolution (0: plain implicit GEMM)
 
 template <int ELEM, int AMODE, int EPI>
 static int launch_gemm_nt(NtParams p, hipStream_t stream) {
@@ -642,11 +625,7 @@ static int launch_gemm_nt(NtParams p, hipStream_t stream) {
     if ((p.K & 63) || (p.N & 127) || p.K <= 0) return SGC_ERR_ARG;
     if (AMODE == AMODE_CONV && ((p.Cin & 63) || p.K != 9 * p.Cin)) return SGC_ERR_ARG;
     const int cfg = sgc_gemm_cfg();
-    {
-        static int epi = -1;        // SGC_EPI_LDS=0 keeps the direct 2-byte stores (A/B hook)
-        if (epi < 0) { const char* e = getenv("SGC_EPI_LDS"); epi = e ? atoi(e) : 1; }
-        p.epi_lds = epi;
-    }
+    p.epi_lds = sgc_tuning().epi_lds;      // 0 keeps the direct 2-byte stores
     const bool big_ok = (p.N % 256) == 0;
     if constexpr (AMODE == AMODE_CONV && (EPI == EPI_POOL || EPI == EPI_STORE)) {
         if (p.lgS == 4 && big_ok && (p.M % 256) == 0 && (cfg == 4 || cfg == 7 || (cfg == 0 && sgc_conv_halo() && (long)p.M * p.N >= 256L * 256 * 256))) {

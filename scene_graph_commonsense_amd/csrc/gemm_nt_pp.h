@@ -232,8 +232,7 @@ static int launch_gemm_nt_pp_conv_gather(NtParams p, hipStream_t stream) {
     if (p.lgS != 4 || (p.Cin & 63) || p.K != 9 * p.Cin || (p.N & 255)) return SGC_ERR_ARG;
     p.tiles_m = (p.M + 255) / 256;
     p.tiles_n = p.N / 256;
-    static int al = -1;               // SGC_ACG_ALIGNED=1: grid padded to whole per-XCD patches (A/B hook)
-    if (al < 0) { const char* e = getenv("SGC_ACG_ALIGNED"); al = e ? atoi(e) : 0; }
+    const int al = sgc_tuning().acg_aligned;      // 1: grid padded to whole per-XCD patches
     p.patch_aligned = al;
     auto kern = gemm_nt_pp_kernel<ELEM, EPI, 0, 1>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -251,8 +250,7 @@ static int launch_gemm_nt_pp(NtParams p, hipStream_t stream) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     // whole patches per XCD only pay once every XCD has several of them; small grids keep the even spread of the contiguous walk
     const int grid_aligned = xcd_patch_grid(p.tiles_m, p.tiles_n);
-    static int al = -2;               // SGC_NT_ALIGNED=0/1 forces (A/B hook)
-    if (al == -2) { const char* e = getenv("SGC_NT_ALIGNED"); al = e ? atoi(e) : -1; }
+    const int al = sgc_tuning().nt_aligned;       // 0 / 1 forces, -1 = by grid size
     const int nb = p.tiles_m * p.tiles_n;
     // the contiguous walk is itself patch-aligned when every XCD's share is a multiple of 32 tiles (fc1 data gradient: 126 x 256
     // tiles, measured 1 % faster than the round-robin patches); otherwise pad, unless the grid is small or the padding > 10 %
@@ -593,9 +591,8 @@ static int launch_conv16_halo_pp(NtParams p, hipStream_t stream) {
         // 28.7e6 - 45.5e6 KiB from run to run.  Launch time is the same within box noise (round 2: 60.2 vs 59.6 ms in one
         // alternated pair, 60.8 / 61.2 vs 60.9 / 61.0 in another; profiles/r02_halo_walk_ab.txt, r02_hook_sweep.txt) - the launch
         // is power-bound, not traffic-bound - so the forward keeps the walk with the lower, stable traffic.  A larger weight tile
-        // (conv3 data gradient: 4.7 MiB) thrashes either way and takes walk 1.  SGC_HALO_WALK=0/1 forces.
-        static int hw = -2;
-        if (hw == -2) { const char* e = getenv("SGC_HALO_WALK"); hw = e ? atoi(e) : -1; }
+        // (conv3 data gradient: 4.7 MiB) thrashes either way and takes walk 1.  (SgcTuning::halo_walk forces, experiments only.)
+        const int hw = sgc_tuning().halo_walk;
         p.halo_walk = hw >= 0 ? hw : ((long)p.K * 512 > (3L << 20) ? 1 : 0);
     }
     if constexpr (ELEM == ELEM_BF16 && EPI == EPI_STORE) {

@@ -200,8 +200,7 @@ static int launch_gemm_tn_cfg(TnParams p, int splits, int* slabs_out, hipStream_
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     p.splits = splits;
     {
-        static int xm = -1;          // SGC_TN_XCD=0 disables the XCD-aware assignment of the 4 x 18 tile grid (A/B hook; measured -0.7 % time, 2.5x less fabric traffic)
-        if (xm < 0) { const char* e = getenv("SGC_TN_XCD"); xm = e ? atoi(e) : 1; }
+        const int xm = sgc_tuning().tn_xcd;      // XCD-aware assignment of the 4 x 18 tile grid (measured -0.7 % time, 2.5x less fabric traffic)
         p.xcd_map = (xm && BMODE == BMODE_CONV && p.tiles_m == 4 && p.tiles_n == 18) ? 1 : 0;
     }
     SGC_LAUNCH(kern, dim3((unsigned)(p.tiles_m * p.tiles_n * splits)), dim3(WR * WC * 64), LDS, stream, p);
@@ -401,11 +400,9 @@ static int launch_gemm_tn_pp(TnParams p, int splits, int* slabs_out, hipStream_t
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     p.splits = splits;
     {
-        static int xm = -1;
-        if (xm < 0) { const char* e = getenv("SGC_TN_XCD"); xm = e ? atoi(e) : 1; }
+        const int xm = sgc_tuning().tn_xcd;
         p.xcd_map = (xm && BMODE == BMODE_CONV && p.tiles_m == 4 && p.tiles_n == 18) ? 1 : 0;
-        static int xp = -1;          // SGC_TN_PATCH=0: 16x16 super-tiles instead of per-XCD 4x8 patches (A/B hook)
-        if (xp < 0) { const char* e = getenv("SGC_TN_PATCH"); xp = e ? atoi(e) : 1; }
+        const int xp = sgc_tuning().tn_patch;    // 0: 16x16 super-tiles instead of per-XCD 4x8 patches
         // per-XCD 4(M) x 8(N) patches need M tiles to share: with 4 M tiles (weight gradient over the pair-specific windows, 4 x 18
         // tiles x 7 splits) a patch is a whole tile column block and the 9 tiles an XCD gets per split straddle two of them - the
         // 16 x 16 super-tile walk measured 7.61 vs 8.48 ms there (alternated twice in one box); grids with >= 8 M tiles keep the patches

@@ -564,70 +564,78 @@ __global__ __launch_bounds__(256) void fc1_assemble_kernel(const float* __restri
 }
 
 // ---- fc1 backward over the window-major rows
-// 64-bit mask of the pooling windows inside a rectangle (bit wy*8 + wx)
-__device__ __forceinline__ unsigned long long rect_mask(const WRect& r) {
-    if (r.x1 <= r.x0) return 0ull;
-    const unsigned long long row = ((1ull << r.x1) - (1ull << r.x0)) & 0xffull;
-    unsigned long long m = 0ull;
-    for (int y = r.y0; y < r.y1; ++y) m |= row << (8 * y);
-    return m;
-}
-
 // Gradient of the per-object rows (transpose of the assembly): G[(role, o)][w] = sum of dh1 over the pairs of o whose window w was
 // a copy of o's row - role 0: all windows outside the partner's rectangle; role 1: windows inside o's and outside the partner's.
-// One workgroup per (role, object, 256 channels); thread = one channel with the 64 window sums in registers; the pair ids and
-// window masks of the object's pairs are staged in LDS first so that the gradient rows stream without dependent look-ups.
+// With T = sum of dh1 over the object's pairs and D[w] = sum over the pairs whose PARTNER rectangle holds w, that is
+//   role 0: G[w] = T - D[w]        role 1: G[w] = [w in R_o] (T - D[w])
+// and D is a sum of rectangle indicators: every pair adds its gradient row at the four corners of the partner's rectangle in a 9x9
+// difference array (+ - - +), one 2-D prefix sum at the end turns the array into D.  4 additions per pair and channel instead of
+// 64 masked ones (the first version: one thread per channel holding 64 window sums, 1.7 ms at 8 x 64 - VALU-bound).
+// One workgroup per (role, object, 128 channels); thread = one channel; the difference array lives in LDS ([81][128] f32, the
+// corner index is uniform over the workgroup: conflict-free), pair ids and corners are staged in LDS in batches of 128 and the
+// gradient values of 8 pairs are loaded before they are added.  f32 sums in pair-list order per corner: deterministic.
 // Rows go to the window-major space: gwm[goff[w] + role*n_obj + o].
-__global__ __launch_bounds__(256) void fc1_gsum_kernel(const u16* __restrict__ dh, const int* __restrict__ bbox, const int* __restrict__ sub,
+__global__ __launch_bounds__(128) void fc1_gsum_kernel(const u16* __restrict__ dh, const int* __restrict__ bbox, const int* __restrict__ sub,
                                                        const int* __restrict__ obj, const int* __restrict__ sub_ptr,
                                                        const int* __restrict__ sub_list, const int* __restrict__ obj_ptr,
                                                        const int* __restrict__ obj_list, const int* __restrict__ goff, int n_obj,
                                                        u16* __restrict__ gwm) {
-    __shared__ int s_pair[256];
-    __shared__ unsigned long long s_mask[256];
-    const int chunk = blockIdx.x & 15;
-    const int ps = blockIdx.x >> 4;
+    __shared__ float diff[81][128];
+    __shared__ int s_pair[128];
+    __shared__ int s_corner[128];                         // x0 | x1 << 4 | y0 << 8 | y1 << 12 of the partner's rectangle; 0 = empty
+    const int chunk = blockIdx.x & 31;
+    const int ps = blockIdx.x >> 5;
     const int role = ps >= n_obj ? 1 : 0, o = ps - role * n_obj;
-    const int c = chunk * 256 + threadIdx.x;
+    const int t = threadIdx.x, c = chunk * 128 + t;
     const int* ptr = role ? obj_ptr : sub_ptr;
     const int* list = role ? obj_list : sub_list;
     const int i0 = ptr[o], i1 = ptr[o + 1];
-    const unsigned long long own = rect_mask(object_windows(bbox + 4 * o));
-    float acc[64];
 #pragma unroll
-    for (int w = 0; w < 64; ++w) acc[w] = 0.f;
-    for (int base = i0; base < i1; base += 256) {
+    for (int k = 0; k < 81; ++k) diff[k][t] = 0.f;
+    float total = 0.f;
+    for (int base = i0; base < i1; base += 128) {
         __syncthreads();
-        const int n = min(256, i1 - base);
-        if ((int)threadIdx.x < n) {
-            const int p = list[base + threadIdx.x];
-            const unsigned long long pm = rect_mask(object_windows(bbox + 4 * (role ? sub[p] : obj[p])));
-            s_pair[threadIdx.x] = p;
-            s_mask[threadIdx.x] = role ? (own & ~pm) : ~pm;
+        const int n = min(128, i1 - base);
+        if (t < n) {
+            const int p = list[base + t];
+            const WRect r = object_windows(bbox + 4 * (role ? sub[p] : obj[p]));
+            s_pair[t] = p;
+            s_corner[t] = (r.x1 > r.x0) ? (r.x0 | (r.x1 << 4) | (r.y0 << 8) | (r.y1 << 12)) : 0;
         }
         __syncthreads();
-        for (int k = 0; k < n; k += 4) {
-            float v[4];
-            unsigned long long m[4];
+        for (int k = 0; k < n; k += 8) {
+            float v[8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const bool ok = k + u < n;
-                m[u] = ok ? s_mask[k + u] : 0ull;
-                v[u] = ok ? bf16_bits_to_f32(dh[(long)s_pair[k + u] * 4096 + c]) : 0.f;
-            }
+            for (int u = 0; u < 8; ++u) v[u] = (k + u < n) ? bf16_bits_to_f32(dh[(long)s_pair[k + u] * 4096 + c]) : 0.f;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const unsigned lo = (unsigned)m[u], hi = (unsigned)(m[u] >> 32);
-#pragma unroll
-                for (int w = 0; w < 32; ++w) {
-                    acc[w] += ((lo >> w) & 1u) ? v[u] : 0.f;
-                    acc[32 + w] += ((hi >> w) & 1u) ? v[u] : 0.f;
+            for (int u = 0; u < 8; ++u) {
+                if (k + u >= n) break;
+                total += v[u];
+                const int cr = s_corner[k + u];
+                if (cr) {
+                    const int x0 = cr & 15, x1 = (cr >> 4) & 15, y0 = (cr >> 8) & 15, y1 = (cr >> 12) & 15;
+                    diff[y0 * 9 + x0][t] += v[u];
+                    diff[y0 * 9 + x1][t] -= v[u];
+                    diff[y1 * 9 + x0][t] -= v[u];
+                    diff[y1 * 9 + x1][t] += v[u];
                 }
             }
         }
     }
+    const WRect own = object_windows(bbox + 4 * o);
+    float col[8];
 #pragma unroll
-    for (int w = 0; w < 64; ++w) gwm[((long)goff[w] + ps) * 4096 + c] = f32_to_bf16_bits(acc[w]);
+    for (int x = 0; x < 8; ++x) col[x] = 0.f;
+    for (int y = 0; y < 8; ++y) {
+        float run = 0.f;
+#pragma unroll
+        for (int x = 0; x < 8; ++x) {
+            run += diff[y * 9 + x][t];
+            col[x] += run;                                           // D[y][x]
+            const bool live = role == 0 || in_rect(own, x, y);
+            gwm[((long)goff[y * 8 + x] + ps) * 4096 + c] = f32_to_bf16_bits(live ? total - col[x] : 0.f);
+        }
+    }
 }
 
 // X rows of the window-major gradient: gwm[dest[e]] = dh1[pair of entry e]; and the padding rows of every group are zeroed in gwm
@@ -693,9 +701,7 @@ int sgc_conv3_relu_pool_windows(const void* z_pad, const void* w3r, const float*
     p.A = (const u16*)z_pad; p.B = (const u16*)w3r; p.C = y; p.M = max_entries * 4; p.N = 1024; p.K = 9 * 512;
     p.ldb = 9 * 512; p.ldc = 1024; p.lgS = 4; p.Cin = 512; p.bias = b3; p.argmax = argmax; p.C2 = (u16*)y_bf16;
     p.gather = gather; p.gather_n = gather_n;
-    static int pp = -1;               // SGC_GATHER_PP=0: the 2-stage block (A/B hook)
-    if (pp < 0) { const char* e = getenv("SGC_GATHER_PP"); pp = e ? atoi(e) : 1; }
-    if (pp) return launch_gemm_nt_pp_conv_gather<ELEM_F16, EPI_POOL>(p, (hipStream_t)stream);
+    if (sgc_tuning().gather_pp) return launch_gemm_nt_pp_conv_gather<ELEM_F16, EPI_POOL>(p, (hipStream_t)stream);
     return launch_gemm_nt_cfg<ELEM_F16, AMODE_CONV_GATHER, EPI_POOL, 2, 4, 4, 2>(p, (hipStream_t)stream);
 }
 
@@ -798,9 +804,7 @@ int sgc_conv3_relu_pool_windows_wm(const void* z_pad, const void* w3r, const flo
     p.A = (const u16*)z_pad; p.B = (const u16*)w3r; p.C = ywm; p.M = max_entries * 4; p.N = 1024; p.K = 9 * 512;
     p.ldb = 9 * 512; p.ldc = 1024; p.lgS = 4; p.Cin = 512; p.bias = b3; p.argmax = argmax; p.C2 = (u16*)ywm_bf16;
     p.gather = gather; p.gather_n = gather_n; p.dest = dest;
-    static int pp = -1;               // SGC_GATHER_PP=0: the 2-stage block (A/B hook)
-    if (pp < 0) { const char* e = getenv("SGC_GATHER_PP"); pp = e ? atoi(e) : 1; }
-    if (pp) return launch_gemm_nt_pp_conv_gather<ELEM_F16, EPI_POOL>(p, (hipStream_t)stream);
+    if (sgc_tuning().gather_pp) return launch_gemm_nt_pp_conv_gather<ELEM_F16, EPI_POOL>(p, (hipStream_t)stream);
     return launch_gemm_nt_cfg<ELEM_F16, AMODE_CONV_GATHER, EPI_POOL, 2, 4, 4, 2>(p, (hipStream_t)stream);
 }
 // owm [rows][4096] f32 = ywm [rows][1024] f16 * w1p[:, g*1024 .. +1024]^T, g = tile_group[row / 256]  (rows a multiple of 256)
@@ -833,7 +837,7 @@ int sgc_fc1_assemble(const float* S, const float* owm, const int* bbox, const in
 int sgc_fc1_gsum(const void* dh1, const int* bbox, const int* sub_idx, const int* obj_idx, const int* sub_ptr, const int* sub_list,
                  const int* obj_ptr, const int* obj_list, const int* goff, int n_obj, void* gwm, void* stream) {
     if (n_obj <= 0) return SGC_OK;
-    SGC_LAUNCH(fc1_gsum_kernel, dim3((unsigned)(2 * n_obj * 16)), dim3(256), 0, (hipStream_t)stream, (const u16*)dh1, bbox, sub_idx, obj_idx,
+    SGC_LAUNCH(fc1_gsum_kernel, dim3((unsigned)(2 * n_obj * 32)), dim3(128), 0, (hipStream_t)stream, (const u16*)dh1, bbox, sub_idx, obj_idx,
                sub_ptr, sub_list, obj_ptr, obj_list, goff, n_obj, (u16*)gwm);
     SGC_CHECK_LAUNCH();
     return SGC_OK;

@@ -11,6 +11,7 @@ identities are SURVEY §7.1:
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes
 import math
 import os
@@ -126,26 +127,71 @@ class TrainContext:
     pass
 
 
+@dataclass
+class Tuning:
+    """The switches of the product path, in ONE place, read once at import.  Defaults are the measured best.
+    Environment (four documented variables; tests and tools flip the fields directly, e.g. ``with engine.tuning(shared_fc1=False)``):
+
+      SGC_SHARED_LEVEL         0 per-pair kernels | 1 conv3 over shared windows | 2 + fc1 over the same windows | 3 (default) + the
+                               per-object maps shared with the image's background map (second level)
+      SGC_SHARED_BWD           0: per-pair backward under a shared forward (A/B of the backward alone)
+      SGC_SHARED_MAX_FRACTION  share of pair-specific windows above which a scene goes to the per-pair kernels (default 0.5:
+                               profiles/r03_box_sweep.txt - the step time crosses near 0.65 but the workspace reaches 170 GB at 0.5)
+      SGC_BWD_STREAMS          0: weight-gradient chain on the caller's stream (single-stream profiles, tools/collect_profiles.sh)
+    Decided and no longer switchable: sparse-MFMA conv3 weight gradient, un-pool fused into the conv3 data gradient, im2col + plain
+    GEMM (not the gathered TN block) for the weight gradient over the listed windows."""
+    shared_conv3: bool = True
+    shared_fc1: bool = True
+    shared_objects: bool = True
+    shared_bwd: bool = True
+    shared_max_fraction: float = 0.5
+    bwd_streams: bool = True
+
+    @classmethod
+    def from_env(cls):
+        lvl = int(os.environ.get("SGC_SHARED_LEVEL", "3"))
+        return cls(shared_conv3=lvl >= 1, shared_fc1=lvl >= 2, shared_objects=lvl >= 3,
+                   shared_bwd=os.environ.get("SGC_SHARED_BWD", "1") != "0",
+                   shared_max_fraction=float(os.environ.get("SGC_SHARED_MAX_FRACTION", "0.5")),
+                   bwd_streams=os.environ.get("SGC_BWD_STREAMS", "1") != "0")
+
+
+TUNING = Tuning.from_env()
+
+
+@contextlib.contextmanager
+def tuning(**overrides):
+    """Temporarily override fields of ``TUNING`` (tests, A/B tools)."""
+    old = {k: getattr(TUNING, k) for k in overrides}
+    for k, v in overrides.items():
+        setattr(TUNING, k, v)
+    try:
+        yield TUNING
+    finally:
+        for k, v in old.items():
+            setattr(TUNING, k, v)
+
+
 def shared_fc1_enabled() -> bool:
-    """``SGC_SHARED_FC1=0``: fc1 as one [pairs, 65536] GEMM over assembled rows (A/B hook; default: grouped window-major GEMM)."""
-    return os.environ.get("SGC_SHARED_FC1", "1") != "0"
+    """fc1 as a grouped window-major GEMM (``TUNING.shared_fc1``; off: one [pairs, 65536] GEMM over assembled rows)."""
+    return TUNING.shared_fc1
 
 
 def shared_objects_enabled() -> bool:
-    """``SGC_SHARED_OBJECTS=0``: every pseudo-pair (object, background) is a full conv3 map (A/B hook; default: second level - only the
-    windows of the object's rectangle, the rest from the image's all-background map)."""
-    return os.environ.get("SGC_SHARED_OBJECTS", "1") != "0"
+    """Second level (``TUNING.shared_objects``): a pseudo-pair (object, background) computes only the windows of the object's
+    rectangle, the rest comes from the image's all-background map (off: every pseudo-pair is a full conv3 map)."""
+    return TUNING.shared_objects
 
 
 def shared_conv3_enabled(hint=None, n_pairs=0) -> bool:
-    """``SGC_SHARED_CONV3=0`` computes conv3 for every window of every pair (A/B hook; default: per-object sharing on).
-    ``hint`` (the host's count of pair-specific windows, ``DeviceScene.shared_windows``): when more than half of all windows are
-    pair-specific (most boxes cover most of the image) the per-pair kernels are used - the column buffers of the shared backward
-    grow with that count (9.2 KB per window pixel, twice) and the saving shrinks to nothing near 75 %."""
-    if os.environ.get("SGC_SHARED_CONV3", "1") == "0":
+    """conv3 over shared windows (``TUNING.shared_conv3``).  ``hint`` (the host's count of pair-specific windows,
+    ``DeviceScene.shared_windows``): when more than ``TUNING.shared_max_fraction`` of all windows are pair-specific (most boxes
+    cover most of the image) the per-pair kernels are used - the column buffers of the shared backward grow with that count
+    (9.2 KB per window pixel, twice); measured: ``bench.py`` sensitivity sweep / profiles/r03_box_sweep.txt."""
+    if not TUNING.shared_conv3:
         return False
     n = hint.get("windows") if isinstance(hint, dict) else hint
-    if n is not None and n_pairs > 0 and n > float(os.environ.get("SGC_SHARED_MAX_FRACTION", "0.5")) * 64 * n_pairs:
+    if n is not None and n_pairs > 0 and n > TUNING.shared_max_fraction * 64 * n_pairs:
         return False
     return True
 
@@ -683,8 +729,8 @@ class RelHeadEngine:
         ctx.uv = self.object_halves(ctx.a_img, obj_img, bbox, with_bg=share)
         ctx.lsub, lobj_same = self.label_vectors(ctx.cats[0], ctx.super_mh[0])
         ctx.lobj = lobj_same if role_inputs is None else self.label_vectors(ctx.cats[1], ctx.super_mh[1])[1]
-        # the per-pair backward (SGC_SHARED_BWD=0, A/B hook) reads every pixel of z / amz; the shared one only those next to X windows
-        narrow = share and os.environ.get("SGC_SHARED_BWD", "1") != "0"
+        # the per-pair backward (TUNING.shared_bwd off, A/B) reads every pixel of z / amz; the shared one only those next to X windows
+        narrow = share and TUNING.shared_bwd
         wm_mode = narrow and shared_fc1_enabled()
         plan = self.shared_plan(bbox, sub_idx, obj_idx, P, shared_windows, keep=True, n_obj=ctx.n_obj, n_img=ctx.n_img,
                                 objects=wm_mode and shared_objects_enabled()) if share else None
@@ -838,7 +884,7 @@ class RelHeadEngine:
 
         # ---- conv3
         nparts = ctypes.c_int(0)
-        shared = ctx.shared if (getattr(ctx, "shared", None) is not None and os.environ.get("SGC_SHARED_BWD", "1") != "0") else None
+        shared = ctx.shared if (getattr(ctx, "shared", None) is not None and TUNING.shared_bwd) else None
         n_objx = n_obj + (n_img if shared is not None else 0)      # the images' background objects take part in the conv2 backward
         if shared is not None:
             dz = self._conv3_backward_shared(ctx, shared, dy, sub_csr, obj_csr, img_ptr, side, sl, grads)
@@ -943,46 +989,33 @@ class RelHeadEngine:
         return dy
 
     def _conv3_backward_pairs(self, ctx, dy, side, sl, grads):
-        """conv3 backward over every window of every pair (no per-object sharing): bias + weight gradient, returns dz."""
+        """conv3 backward over every window of every pair (no per-object sharing): bias + weight gradient, returns dz.
+        Weight gradient on the sparse matrix cores: the pooled gradient + the arg-max byte ARE the 2:4-compressed operand
+        (csrc/gemm_tn_sp.h; one pass over dy packs it and writes the bias partials).  Data gradient with the un-pool inside its
+        operand staging (sgc_conv3_dgrad_pooled): the 21 GB un-pooled tensor is neither written nor read.  (The dense weight
+        gradient / the two-pass un-pool, sgc_conv3_wgrad / sgc_unpool_relu_bwd / sgc_conv3_dgrad, remain in the C-ABI and are tested
+        against these in tests/test_gemm_gpu.py; the step no longer switches to them.)"""
         lib, w, ws, st, P = self.lib, self.w, self.scratch, self._st, ctx.P
         slabs_n = ctypes.c_int(0)
         bpart = ws.get("b3_part", 2048 * 1024, torch.float32)
         nparts = ctypes.c_int(0)
-        sparse_w3 = os.environ.get("SGC_W3_SPARSE", "1") != "0"
-        # the data gradient un-pools inside its operand staging (sgc_conv3_dgrad_pooled): the 21 GB un-pooled tensor is neither
-        # written nor read.  Needs the sparse weight gradient (the dense one reads the un-pooled tensor); SGC_DGRAD_POOLED=0 = A/B hook.
-        pooled_dgrad = sparse_w3 and os.environ.get("SGC_DGRAD_POOLED", "1") != "0"
-        dy3 = None if pooled_dgrad else ws.get("dy3_pad", P * 18 * 18 * 1024, torch.bfloat16)
         z_bf = ctx.z_bf
-        if sparse_w3:
-            # sparse matrix cores: the pooled gradient + the arg-max byte ARE the 2:4-compressed operand (csrc/gemm_tn_sp.h);
-            # one pass over dy writes the un-pooled gradient for the input-gradient GEMM, the bias partials and that operand
-            pack_a = ws.get("w3_pack_a", P * 4 * 1024 * 64, torch.uint8)
-            pack_i = ws.get("w3_pack_i", P * 4 * 1024 * 8, torch.uint8)
-            self._timed("unpool", lambda: _lib.check(lib.sgc_unpool_relu_bwd_pack(
-                _lib.ptr(dy), _lib.ptr(ctx.am), _lib.ptr(dy3), _lib.ptr(bpart), ctypes.byref(nparts), _lib.ptr(pack_a),
-                _lib.ptr(pack_i), P, st()), "sgc_unpool_relu_bwd_pack"))
-        else:
-            self._timed("unpool", lambda: _lib.check(lib.sgc_unpool_relu_bwd(_lib.ptr(dy), _lib.ptr(ctx.am), _lib.ptr(dy3), _lib.ptr(bpart), ctypes.byref(nparts), P, st()),
-                       "sgc_unpool_relu_bwd"))
+        pack_a = ws.get("w3_pack_a", P * 4 * 1024 * 64, torch.uint8)
+        pack_i = ws.get("w3_pack_i", P * 4 * 1024 * 8, torch.uint8)
+        self._timed("unpool", lambda: _lib.check(lib.sgc_unpool_relu_bwd_pack(
+            _lib.ptr(dy), _lib.ptr(ctx.am), None, _lib.ptr(bpart), ctypes.byref(nparts), _lib.ptr(pack_a),
+            _lib.ptr(pack_i), P, st()), "sgc_unpool_relu_bwd_pack"))
         n_b3 = nparts.value
         with side():
             grads["conv3_1.bias"] = self._slab_sum(bpart, 1024, n_b3)
-            if sparse_w3:
-                self._timed("conv3_wgrad", lambda: _lib.check(lib.sgc_conv3_wgrad_sparse(
-                    None, None, _lib.ptr(z_bf), _lib.ptr(pack_a), _lib.ptr(pack_i), _lib.ptr(sl), P, 0,
-                    ctypes.byref(slabs_n), st()), "sgc_conv3_wgrad_sparse"))
-            else:
-                self._timed("conv3_wgrad", lambda: _lib.check(lib.sgc_conv3_wgrad(_lib.ptr(dy3), _lib.ptr(z_bf), _lib.ptr(sl), P, 0, ctypes.byref(slabs_n), st()),
-                           "sgc_conv3_wgrad"))
+            self._timed("conv3_wgrad", lambda: _lib.check(lib.sgc_conv3_wgrad_sparse(
+                None, None, _lib.ptr(z_bf), _lib.ptr(pack_a), _lib.ptr(pack_i), _lib.ptr(sl), P, 0,
+                ctypes.byref(slabs_n), st()), "sgc_conv3_wgrad_sparse"))
             dW3r = self._slab_sum(sl, 1024 * 4608, slabs_n.value)
             grads["conv3_1.weight"] = dW3r.view(1024, 3, 3, 512).permute(0, 3, 1, 2).contiguous()
         dz = ws.get("dz", P * 256 * 512, torch.bfloat16)
-        if pooled_dgrad:
-            self._timed("conv3_dgrad", lambda: _lib.check(lib.sgc_conv3_dgrad_pooled(_lib.ptr(dy), _lib.ptr(ctx.am), _lib.ptr(w["wd3"]), _lib.ptr(dz), P, st()),
-                                                          "sgc_conv3_dgrad_pooled"))
-        else:
-            self._timed("conv3_dgrad", lambda: _lib.check(lib.sgc_conv3_dgrad(_lib.ptr(dy3), _lib.ptr(w["wd3"]), _lib.ptr(dz), P, st()), "sgc_conv3_dgrad"))
+        self._timed("conv3_dgrad", lambda: _lib.check(lib.sgc_conv3_dgrad_pooled(_lib.ptr(dy), _lib.ptr(ctx.am), _lib.ptr(w["wd3"]), _lib.ptr(dz), P, st()),
+                                                      "sgc_conv3_dgrad_pooled"))
         return dz
 
     def _conv3_backward_shared(self, ctx, sh, dy, sub_csr, obj_csr, img_ptr, side, sl, grads):
@@ -1045,22 +1078,14 @@ class RelHeadEngine:
                 "sgc_conv3_wgrad_sparse"))
             if Epad:
                 slx = sl[slabs_n.value * 1024 * 4608:]
-                if os.environ.get("SGC_WGRAD_GATHER", "0") != "0":
-                    # A/B hook, off: rows of z gathered by the window list inside the GEMM block (no im2col buffer).  Measured 11.0 ms
-                    # against 8.3 + 2.3 ms for im2col + plain GEMM; looking the windows up one K tile ahead made it 12.0 ms - it is the nine
-                    # shifted re-reads of the z rows by different N tiles, not the look-up latency, that costs.
-                    # The entries behind the list (their dy3x rows are zero) must name a fully written map: the first pseudo-pair's
-                    if Epad > E:
-                        gather[E:Epad] = P * 64
-                    self._timed("conv3_wgrad_windows", lambda: _lib.check(lib.sgc_windows_wgrad_gather(
-                        _lib.ptr(dy3x), _lib.ptr(z_bf), _lib.ptr(gather), _lib.ptr(slx), Epad * 4, 0, ctypes.byref(slabs_x), st()),
-                        "sgc_windows_wgrad_gather"))
-                else:
-                    zcol = ws.get("zcol", Epad * 4 * 9 * 512, torch.bfloat16)
-                    self._timed("im2col_windows", lambda: _lib.check(lib.sgc_windows_im2col(_lib.ptr(z_bf), _lib.ptr(gather), _lib.ptr(gn), Epad,
-                                                                                           _lib.ptr(zcol), st()), "sgc_windows_im2col"))
-                    self._timed("conv3_wgrad_windows", lambda: _lib.check(lib.sgc_windows_wgrad(
-                        _lib.ptr(dy3x), _lib.ptr(zcol), _lib.ptr(slx), Epad * 4, 0, ctypes.byref(slabs_x), st()), "sgc_windows_wgrad"))
+                # im2col + plain ping-pong TN GEMM.  (Rows of z gathered by the window list inside the GEMM block - no column
+                # buffer, sgc_windows_wgrad_gather - measured 11.0 ms against 8.3 + 2.3 ms: the nine shifted re-reads of the z rows
+                # by different N tiles cost more than the im2col pass; kept in the C-ABI, not used by the step.)
+                zcol = ws.get("zcol", Epad * 4 * 9 * 512, torch.bfloat16)
+                self._timed("im2col_windows", lambda: _lib.check(lib.sgc_windows_im2col(_lib.ptr(z_bf), _lib.ptr(gather), _lib.ptr(gn), Epad,
+                                                                                       _lib.ptr(zcol), st()), "sgc_windows_im2col"))
+                self._timed("conv3_wgrad_windows", lambda: _lib.check(lib.sgc_windows_wgrad(
+                    _lib.ptr(dy3x), _lib.ptr(zcol), _lib.ptr(slx), Epad * 4, 0, ctypes.byref(slabs_x), st()), "sgc_windows_wgrad"))
             dW3r = self._slab_sum(sl, 1024 * 4608, slabs_n.value + slabs_x.value)
             grads["conv3_1.weight"] = dW3r.view(1024, 3, 3, 512).permute(0, 3, 1, 2).contiguous()
         # ---- data gradients
@@ -1081,10 +1106,10 @@ class RelHeadEngine:
     def _side_chain(self):
         """Callable context manager that runs its body on this device's side stream, ordered after everything enqueued on the
         caller's stream so far; ``join()`` orders the caller's stream after the side stream.  Both are no-ops with
-        ``SGC_BWD_STREAMS=0``."""
+        ``TUNING.bwd_streams`` off."""
         import contextlib
         eng = self
-        enabled = os.environ.get("SGC_BWD_STREAMS", "1") != "0"
+        enabled = TUNING.bwd_streams
 
         class Chain:
             def __init__(self):

@@ -153,8 +153,9 @@ def test_configs2_relation_head_half_16_images_predicted_objects():
 
 def test_two_stream_backward_is_bitwise_the_single_stream_backward(monkeypatch):
     """The weight-gradient chain runs on a side stream (engine.train_backward); every kernel is deterministic and the chains
-    only meet through events, so the gradients must be bit-identical to the one-stream order (SGC_BWD_STREAMS=0), also when the
+    only meet through events, so the gradients must be bit-identical to the one-stream order (TUNING.bwd_streams off), also when the
     step is repeated back to back (buffer reuse across steps)."""
+    from scene_graph_commonsense_amd import engine
     from scene_graph_commonsense_amd.pairs import flatten_scene
     from scene_graph_commonsense_amd.synthetic import HeadConfig, make_scene_batch
     cfg = HeadConfig()
@@ -164,7 +165,7 @@ def test_two_stream_backward_is_bitwise_the_single_stream_backward(monkeypatch):
     sc = flatten_scene(cfg, batch, "cuda:0")
     res = {}
     for mode in ("0", "1"):
-        monkeypatch.setenv("SGC_BWD_STREAMS", mode)
+        monkeypatch.setattr(engine.TUNING, "bwd_streams", mode == "1")
         model._step = 0
         out = []
         for rep in range(3):

@@ -15,7 +15,8 @@ pytestmark = pytest.mark.gpu
 def _always_shared(monkeypatch):
     """The edge-case boxes of these tests (full-image boxes next to tiny ones) make most windows pair-specific; the engine would
     switch such a scene to the per-pair kernels (``shared_conv3_enabled``).  Here the shared path is the subject."""
-    monkeypatch.setenv("SGC_SHARED_MAX_FRACTION", "2")
+    from scene_graph_commonsense_amd import engine
+    monkeypatch.setattr(engine.TUNING, "shared_max_fraction", 2.0)
 
 
 def _model(cfg, seed=1):
@@ -38,17 +39,15 @@ def _edge_boxes(batch):
     return batch
 
 
+_FIELD = {"SGC_SHARED_CONV3": "shared_conv3", "SGC_SHARED_FC1": "shared_fc1", "SGC_SHARED_OBJECTS": "shared_objects",
+          "SGC_SHARED_BWD": "shared_bwd"}
+
+
 def _with_env(env, fn):
-    old = {k: os.environ.get(k) for k in env}
-    os.environ.update(env)
-    try:
+    """Run ``fn`` with switches of ``engine.TUNING`` overridden (keys: the historical names of the switches, values "0" / "1")."""
+    from scene_graph_commonsense_amd import engine
+    with engine.tuning(**{_FIELD[k]: v != "0" for k, v in env.items()}):
         return fn()
-    finally:
-        for k, v in old.items():
-            if v is None:
-                del os.environ[k]
-            else:
-                os.environ[k] = v
 
 
 def _poison(eng):
@@ -239,7 +238,8 @@ def test_scenes_that_are_mostly_pair_specific_use_the_per_pair_kernels(monkeypat
     The host's window count sends the step to the per-pair kernels; the results are the per-pair results."""
     from scene_graph_commonsense_amd.pairs import flatten_scene
     from scene_graph_commonsense_amd.synthetic import HeadConfig, make_scene_batch
-    monkeypatch.delenv("SGC_SHARED_MAX_FRACTION")
+    from scene_graph_commonsense_amd import engine
+    monkeypatch.setattr(engine.TUNING, "shared_max_fraction", 0.5)
     cfg = HeadConfig()
     model = _model(cfg)
     batch = make_scene_batch(cfg, [6, 5], seed=4, connect_frac=0.3)

@@ -9,8 +9,8 @@ that leaves TRAINING: K optimisation steps through the product entry points (``p
 
 Bars: the loss curves agree within 1e-2 relative at EVERY step, and the weight update of every parameter tensor (w_k+1 - w_k,
 i.e. lr x momentum buffer) has cosine >= 0.99 with the oracle's at every step, its norm within 10 %.  At the reference's learning
-rate 1e-5 (``config.yaml:51``) the running-sum loss already falls by tens of percent over the K steps on these cases (asserted:
-the run must train, otherwise nothing is tested).
+rate (``config.yaml:51``; half of it for the VG case, see ``LR``) the running-sum loss falls by tens of percent over the K steps
+(asserted: the run must train, otherwise nothing is tested).
 """
 import numpy as np
 import pytest
@@ -22,7 +22,11 @@ pytestmark = pytest.mark.gpu
 
 K = 10
 MOMENTUM, WEIGHT_DECAY = 0.9, 1e-4
-LR = {"vg_full": 1e-5, "oiv6_full": 1e-5}      # the reference's learning rate (config.yaml:51): -35 % / -18 % loss in 6 oracle steps
+# oiv6_full: the reference's learning rate (config.yaml:51).  vg_full: half of it - at 1e-5 the ORACLE's own loss overshoots at step 9
+# (332 -> 412 -> 284) and from there the two runs separate beyond the bar (device 421 vs 412 at step 9, update cosines 0.95-0.98),
+# while steps 1-8 agree to <= 6e-3: an unstable step amplifies any difference, whatever its source.  At 5e-6 the oracle's loss
+# falls monotonically 643 -> 353 in 10 steps.
+LR = {"vg_full": 5e-6, "oiv6_full": 1e-5}
 
 
 def _seeds(dropout_seed, step):

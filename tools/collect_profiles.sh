@@ -12,19 +12,21 @@ cd /tmp && export TMPDIR=/tmp
 # line above is the shipped default (two streams)
 export SGC_BWD_STREAMS=0
 rm -rf /tmp/prof_ks /tmp/prof_f /tmp/prof_w /tmp/prof_s
-rocprofv3 --kernel-trace --stats -d /tmp/prof_ks -o ks -- python3 "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > /tmp/ks.log 2>&1
+rocprofv3 --kernel-trace --stats -d /tmp/prof_ks -o ks -- python3 "$R/bench.py" --steps 4 --warmup 2 --no-cpu-baseline --no-sensitivity > /tmp/ks.log 2>&1
 grep '^{"metric"' /tmp/ks.log | tail -1 > "$OUT/${TAG}_bench_under_rocprof.json"
-python3 "$R/tools/rocpd_summary.py" "$(find /tmp/prof_ks -name '*.db' | head -1)" "$OUT/${TAG}_kernel_stats.csv"
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/prof_f -o f --output-format csv -- python3 "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline > /tmp/f.log 2>&1
+# WARM-ONLY statistics: the two warm-up steps (code-object load, cold caches, one-time zeroing of the workspace) are dropped, so the
+# averages are comparable with the HIP-event means of the bench line (the cold first call spread them by 13 %)
+python3 "$R/tools/rocpd_summary.py" "$(find /tmp/prof_ks -name '*.db' | head -1)" "$OUT/${TAG}_kernel_stats.csv" --skip-steps 2
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/prof_f -o f --output-format csv -- python3 "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-sensitivity > /tmp/f.log 2>&1
 python3 "$R/tools/pmc_summary.py" "$(find /tmp/prof_f -name '*counter_collection.csv' | head -1)" "$OUT/${TAG}_pmc_f.csv"
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/prof_w -o w --output-format csv -- python3 "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline > /tmp/w.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/prof_w -o w --output-format csv -- python3 "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-sensitivity > /tmp/w.log 2>&1
 python3 "$R/tools/pmc_summary.py" "$(find /tmp/prof_w -name '*counter_collection.csv' | head -1)" "$OUT/${TAG}_pmc_w.csv"
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_VALU_MFMA_MOPS_BF16 \
-    -d /tmp/prof_s -o s --output-format csv -- python3 "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline > /tmp/s.log 2>&1
+    -d /tmp/prof_s -o s --output-format csv -- python3 "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-sensitivity > /tmp/s.log 2>&1
 python3 "$R/tools/pmc_summary.py" "$(find /tmp/prof_s -name '*counter_collection.csv' | head -1)" "$OUT/${TAG}_pmc_s.csv"
 # MFMA-busy cycles in their own pass (SQ_VALU_MFMA_BUSY_CYCLES counts cycles, = 32 x N_mfma for the 32x32x16 instructions)
 rm -rf /tmp/prof_m
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE -d /tmp/prof_m -o m --output-format csv -- python3 "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline > /tmp/m.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE -d /tmp/prof_m -o m --output-format csv -- python3 "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-sensitivity > /tmp/m.log 2>&1
 python3 "$R/tools/pmc_summary.py" "$(find /tmp/prof_m -name '*counter_collection.csv' | head -1)" "$OUT/${TAG}_pmc_m.csv"
 # the bench line comes LAST and reads the counter passes just taken (roofline.traffic is derived from them): shipped defaults again
 unset SGC_BWD_STREAMS
