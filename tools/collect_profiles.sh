@@ -16,7 +16,7 @@ rocprofv3 --kernel-trace --stats -d /tmp/prof_ks -o ks -- python3 "$R/bench.py" 
 grep '^{"metric"' /tmp/ks.log | tail -1 > "$OUT/${TAG}_bench_under_rocprof.json"
 # WARM-ONLY statistics: the two warm-up steps (code-object load, cold caches, one-time zeroing of the workspace) are dropped, so the
 # averages are comparable with the HIP-event means of the bench line (the cold first call spread them by 13 %)
-python3 "$R/tools/rocpd_summary.py" "$(find /tmp/prof_ks -name '*.db' | head -1)" "$OUT/${TAG}_kernel_stats.csv" --skip-steps 2
+python3 "$R/tools/rocpd_summary.py" "$(find /tmp/prof_ks -name '*.db' | head -1)" "$OUT/${TAG}_kernel_stats.csv" --skip-steps 3     # 1 flatten before the loop + 2 warm-up steps
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/prof_f -o f --output-format csv -- python3 "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-sensitivity > /tmp/f.log 2>&1
 python3 "$R/tools/pmc_summary.py" "$(find /tmp/prof_f -name '*counter_collection.csv' | head -1)" "$OUT/${TAG}_pmc_f.csv"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/prof_w -o w --output-format csv -- python3 "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-sensitivity > /tmp/w.log 2>&1

@@ -5,7 +5,7 @@
     rocpd_summary.py <db> [out.csv] [--skip-steps N] [--marker NAME]
 
 ``--skip-steps N``: WARM-ONLY statistics - dispatches before the (N+1)-th launch of the once-per-step marker kernel (default
-``scene_tables_kernel``, the first launch of every training / evaluation step) are dropped, so that the cold first call of
+``scene_pairs_kernel``: ``flatten_scene``, the first launch of every training / evaluation step - note that ``bench.py`` also flattens once before its loop) are dropped, so that the cold first call of
 every kernel (code-object load, cold caches, workspace zeroing) does not sit in the averages; an extra column gives ms per step.
 """
 import sqlite3
@@ -13,7 +13,7 @@ import sys
 
 
 def main(argv):
-    skip, marker = 0, "scene_tables_kernel"
+    skip, marker = 0, "scene_pairs_kernel"
     pos = []
     it = iter(argv)
     for a in it:
