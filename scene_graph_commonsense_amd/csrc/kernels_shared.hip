@@ -566,75 +566,77 @@ __global__ __launch_bounds__(256) void fc1_assemble_kernel(const float* __restri
 // ---- fc1 backward over the window-major rows
 // Gradient of the per-object rows (transpose of the assembly): G[(role, o)][w] = sum of dh1 over the pairs of o whose window w was
 // a copy of o's row - role 0: all windows outside the partner's rectangle; role 1: windows inside o's and outside the partner's.
-// With T = sum of dh1 over the object's pairs and D[w] = sum over the pairs whose PARTNER rectangle holds w, that is
-//   role 0: G[w] = T - D[w]        role 1: G[w] = [w in R_o] (T - D[w])
-// and D is a sum of rectangle indicators: every pair adds its gradient row at the four corners of the partner's rectangle in a 9x9
-// difference array (+ - - +), one 2-D prefix sum at the end turns the array into D.  4 additions per pair and channel instead of
-// 64 masked ones (the first version: one thread per channel holding 64 window sums, 1.7 ms at 8 x 64 - VALU-bound).
-// One workgroup per (role, object, 128 channels); thread = one channel; the difference array lives in LDS ([81][128] f32, the
-// corner index is uniform over the workgroup: conflict-free), pair ids and corners are staged in LDS in batches of 128 and the
-// gradient values of 8 pairs are loaded before they are added.  f32 sums in pair-list order per corner: deterministic.
-// Rows go to the window-major space: gwm[goff[w] + role*n_obj + o].
-__global__ __launch_bounds__(128) void fc1_gsum_kernel(const u16* __restrict__ dh, const int* __restrict__ bbox, const int* __restrict__ sub,
+// Per object that is a small matrix product  G[64 windows][4096] = M^T[64][pairs] x DH[pairs][4096]  with a 0/1 mask matrix M
+// (about 63 pairs at N = 64): 34 GFLOP over the minibatch - nothing for the matrix cores, but 1.7 ms as 64 masked VALU additions per
+// pair and channel (round 2), and 2.0 ms as a rectangle difference array in LDS (4 dependent read-modify-writes per pair: latency).
+// Here: v_mfma_f32_32x32x16_bf16 with A = mask (row = window, built in registers from the pairs' 64-bit window masks, exact 0 / 1),
+// B = the pairs' gradient rows (column = channel; a lane's 8 consecutive pairs are 8 two-byte loads - the rows are 8 KiB apart),
+// f32 accumulation over the pairs in list order of 16-pair steps, bf16 output.  One workgroup per (role, object, 1024 channels),
+// a wave per 32-channel tile.  Rows go to the window-major space: gwm[goff[w] + role*n_obj + o].
+constexpr int GSUM_MAXP = 512;
+__global__ __launch_bounds__(256) void fc1_gsum_kernel(const u16* __restrict__ dh, const int* __restrict__ bbox, const int* __restrict__ sub,
                                                        const int* __restrict__ obj, const int* __restrict__ sub_ptr,
                                                        const int* __restrict__ sub_list, const int* __restrict__ obj_ptr,
                                                        const int* __restrict__ obj_list, const int* __restrict__ goff, int n_obj,
                                                        u16* __restrict__ gwm) {
-    __shared__ float diff[81][128];
-    __shared__ int s_pair[128];
-    __shared__ int s_corner[128];                         // x0 | x1 << 4 | y0 << 8 | y1 << 12 of the partner's rectangle; 0 = empty
-    const int chunk = blockIdx.x & 31;
-    const int ps = blockIdx.x >> 5;
+    __shared__ int s_pair[GSUM_MAXP];
+    __shared__ unsigned long long s_mask[GSUM_MAXP];
+    const int chunk = blockIdx.x & 3;
+    const int ps = blockIdx.x >> 2;
     const int role = ps >= n_obj ? 1 : 0, o = ps - role * n_obj;
-    const int t = threadIdx.x, c = chunk * 128 + t;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int* ptr = role ? obj_ptr : sub_ptr;
     const int* list = role ? obj_list : sub_list;
     const int i0 = ptr[o], i1 = ptr[o + 1];
+    const WRect ro = object_windows(bbox + 4 * o);
+    unsigned long long own = 0ull;
+    for (int y = ro.y0; y < ro.y1; ++y) own |= (((1ull << ro.x1) - (1ull << ro.x0)) & 0xffull) << (8 * y);
+    const int l31 = lane & 31, kh = lane >> 5;
+    for (int tile = 0; tile < 8; ++tile) {
+        const int c = chunk * 1024 + (wid * 8 + tile) * 32 + l31;
+        f32x16 acc[2];
 #pragma unroll
-    for (int k = 0; k < 81; ++k) diff[k][t] = 0.f;
-    float total = 0.f;
-    for (int base = i0; base < i1; base += 128) {
-        __syncthreads();
-        const int n = min(128, i1 - base);
-        if (t < n) {
-            const int p = list[base + t];
-            const WRect r = object_windows(bbox + 4 * (role ? sub[p] : obj[p]));
-            s_pair[t] = p;
-            s_corner[t] = (r.x1 > r.x0) ? (r.x0 | (r.x1 << 4) | (r.y0 << 8) | (r.y1 << 12)) : 0;
-        }
-        __syncthreads();
-        for (int k = 0; k < n; k += 8) {
-            float v[8];
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = (k + u < n) ? bf16_bits_to_f32(dh[(long)s_pair[k + u] * 4096 + c]) : 0.f;
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                if (k + u >= n) break;
-                total += v[u];
-                const int cr = s_corner[k + u];
-                if (cr) {
-                    const int x0 = cr & 15, x1 = (cr >> 4) & 15, y0 = (cr >> 8) & 15, y1 = (cr >> 12) & 15;
-                    diff[y0 * 9 + x0][t] += v[u];
-                    diff[y0 * 9 + x1][t] -= v[u];
-                    diff[y1 * 9 + x0][t] -= v[u];
-                    diff[y1 * 9 + x1][t] += v[u];
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        for (int base = i0; base < i1; base += GSUM_MAXP) {
+            const int n = min(GSUM_MAXP, i1 - base);
+            if (tile == 0 || i1 - i0 > GSUM_MAXP) {          // the usual case (<= 512 partners): staged once, before the first tile
+                __syncthreads();
+                for (int k = threadIdx.x; k < n; k += 256) {
+                    const int p = list[base + k];
+                    const WRect r = object_windows(bbox + 4 * (role ? sub[p] : obj[p]));
+                    unsigned long long pm = 0ull;
+                    for (int y = r.y0; y < r.y1; ++y) pm |= (((1ull << r.x1) - (1ull << r.x0)) & 0xffull) << (8 * y);
+                    s_pair[k] = p;
+                    s_mask[k] = role ? (own & ~pm) : ~pm;
                 }
+                __syncthreads();
+            }
+            for (int k0 = 0; k0 < n; k0 += 16) {
+                // this lane's 8 pairs of the 16-pair step: k0 + 8*kh + j
+                s16x8 bfr, af0, af1;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int k = k0 + 8 * kh + j;
+                    const bool ok = k < n;
+                    const unsigned long long m = ok ? s_mask[k] : 0ull;
+                    bfr[j] = ok ? (short)dh[(long)s_pair[k] * 4096 + c] : (short)0;
+                    af0[j] = ((m >> l31) & 1ull) ? (short)0x3F80 : (short)0;             // bf16 1.0: windows 0..31
+                    af1[j] = ((m >> (32 + l31)) & 1ull) ? (short)0x3F80 : (short)0;      // windows 32..63
+                }
+                acc[0] = mfma32<ELEM_BF16>(af0, bfr, acc[0]);
+                acc[1] = mfma32<ELEM_BF16>(af1, bfr, acc[1]);
             }
         }
-    }
-    const WRect own = object_windows(bbox + 4 * o);
-    float col[8];
+        // C layout: column = lane & 31 (channel), row (window inside the 32) = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
 #pragma unroll
-    for (int x = 0; x < 8; ++x) col[x] = 0.f;
-    for (int y = 0; y < 8; ++y) {
-        float run = 0.f;
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int x = 0; x < 8; ++x) {
-            run += diff[y * 9 + x][t];
-            col[x] += run;                                           // D[y][x]
-            const bool live = role == 0 || in_rect(own, x, y);
-            gwm[((long)goff[y * 8 + x] + ps) * 4096 + c] = f32_to_bf16_bits(live ? total - col[x] : 0.f);
-        }
+            for (int r = 0; r < 16; ++r) {
+                const int w = j * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                gwm[((long)goff[w] + ps) * 4096 + c] = f32_to_bf16_bits(acc[j][r]);
+            }
     }
 }
 
@@ -837,7 +839,7 @@ int sgc_fc1_assemble(const float* S, const float* owm, const int* bbox, const in
 int sgc_fc1_gsum(const void* dh1, const int* bbox, const int* sub_idx, const int* obj_idx, const int* sub_ptr, const int* sub_list,
                  const int* obj_ptr, const int* obj_list, const int* goff, int n_obj, void* gwm, void* stream) {
     if (n_obj <= 0) return SGC_OK;
-    SGC_LAUNCH(fc1_gsum_kernel, dim3((unsigned)(2 * n_obj * 32)), dim3(128), 0, (hipStream_t)stream, (const u16*)dh1, bbox, sub_idx, obj_idx,
+    SGC_LAUNCH(fc1_gsum_kernel, dim3((unsigned)(2 * n_obj * 4)), dim3(256), 0, (hipStream_t)stream, (const u16*)dh1, bbox, sub_idx, obj_idx,
                sub_ptr, sub_list, obj_ptr, obj_list, goff, n_obj, (u16*)gwm);
     SGC_CHECK_LAUNCH();
     return SGC_OK;
