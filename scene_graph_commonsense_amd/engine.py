@@ -130,7 +130,7 @@ class TrainContext:
 @dataclass
 class Tuning:
     """The switches of the product path, in ONE place, read once at import.  Defaults are the measured best.
-    Environment (four documented variables; tests and tools flip the fields directly, e.g. ``with engine.tuning(shared_fc1=False)``):
+    Environment (five documented variables; tests and tools flip the fields directly, e.g. ``with engine.tuning(shared_fc1=False)``):
 
       SGC_SHARED_LEVEL         0 per-pair kernels | 1 conv3 over shared windows | 2 + fc1 over the same windows | 3 (default) + the
                                per-object maps shared with the image's background map (second level)
@@ -138,6 +138,7 @@ class Tuning:
       SGC_SHARED_MAX_FRACTION  share of pair-specific windows above which a scene goes to the per-pair kernels (default 0.5:
                                profiles/r03_box_sweep.txt - the step time crosses near 0.65 but the workspace reaches 170 GB at 0.5)
       SGC_BWD_STREAMS          0: weight-gradient chain on the caller's stream (single-stream profiles, tools/collect_profiles.sh)
+      SGC_GEMMS_APART          0: round 2's order of the two-stream backward (data- and weight-gradient GEMM of a layer side by side)
     Decided and no longer switchable: sparse-MFMA conv3 weight gradient, un-pool fused into the conv3 data gradient, im2col + plain
     GEMM (not the gathered TN block) for the weight gradient over the listed windows."""
     shared_conv3: bool = True
@@ -146,6 +147,7 @@ class Tuning:
     shared_bwd: bool = True
     shared_max_fraction: float = 0.5
     bwd_streams: bool = True
+    gemms_apart: bool = True          # two-stream backward: keep the big GEMMs of the two chains from running side by side
 
     @classmethod
     def from_env(cls):
@@ -153,7 +155,8 @@ class Tuning:
         return cls(shared_conv3=lvl >= 1, shared_fc1=lvl >= 2, shared_objects=lvl >= 3,
                    shared_bwd=os.environ.get("SGC_SHARED_BWD", "1") != "0",
                    shared_max_fraction=float(os.environ.get("SGC_SHARED_MAX_FRACTION", "0.5")),
-                   bwd_streams=os.environ.get("SGC_BWD_STREAMS", "1") != "0")
+                   bwd_streams=os.environ.get("SGC_BWD_STREAMS", "1") != "0",
+                   gemms_apart=os.environ.get("SGC_GEMMS_APART", "1") != "0")
 
 
 TUNING = Tuning.from_env()
@@ -978,14 +981,29 @@ class RelHeadEngine:
                                         _lib.ptr(gwm), st()), "sgc_fc1_gsum"),
             _lib.check(lib.sgc_fc1_xrows(_lib.ptr(dh1), _lib.ptr(sh["gather"]), _lib.ptr(wm["dest"]), wm["E"], _lib.ptr(wm["goff"]),
                                          _lib.ptr(wm["gend"]), _lib.ptr(gwm), _lib.ptr(sh["ywm_bf"]), st()), "sgc_fc1_xrows")))
-        with side():
-            dW1p = ws.get("dW1p", 4096 * 65536, torch.float32)
-            self._timed("fc1_wgrad", lambda: _lib.check(lib.sgc_fc1_windows_wgrad(_lib.ptr(gwm), _lib.ptr(sh["ywm_bf"]), _lib.ptr(wm["goff"]),
-                                                                                  _lib.ptr(dW1p), wm["rows"], st()), "sgc_fc1_windows_wgrad"))
-            self._fc1_finish_wgrad(dW1p, dh1, ctx.Ppad, grads, grad_hook)
         dy = ws.get("dywm", wm["rows"] * 1024, torch.bfloat16)
-        self._timed("fc1_dgrad", lambda: _lib.check(lib.sgc_fc1_windows_dgrad(_lib.ptr(gwm), _lib.ptr(w["w1pT"]), _lib.ptr(wm["tile_group"]),
-                                                                              _lib.ptr(dy), wm["rows"], st()), "sgc_fc1_windows_dgrad"))
+
+        def wgrad():
+            with side():
+                dW1p = ws.get("dW1p", 4096 * 65536, torch.float32)
+                self._timed("fc1_wgrad", lambda: _lib.check(lib.sgc_fc1_windows_wgrad(_lib.ptr(gwm), _lib.ptr(sh["ywm_bf"]), _lib.ptr(wm["goff"]),
+                                                                                      _lib.ptr(dW1p), wm["rows"], st()), "sgc_fc1_windows_wgrad"))
+                self._fc1_finish_wgrad(dW1p, dh1, ctx.Ppad, grads, grad_hook)
+
+        def dgrad():
+            self._timed("fc1_dgrad", lambda: _lib.check(lib.sgc_fc1_windows_dgrad(_lib.ptr(gwm), _lib.ptr(w["w1pT"]), _lib.ptr(wm["tile_group"]),
+                                                                                  _lib.ptr(dy), wm["rows"], st()), "sgc_fc1_windows_dgrad"))
+        # GEMM beside GEMM buys nothing on this chip (two ping-pong GEMMs on two streams: 13.5 ms against 13.4 back to back) while an
+        # HBM-bound kernel beside a GEMM hides ~40 % of its time (profiles/r03_overlap_microbench.txt).  ``TUNING.gemms_apart``: the
+        # weight-gradient GEMM is enqueued AFTER the data-gradient GEMM - ``side()`` orders the side stream behind everything enqueued on
+        # the caller's stream so far - and so runs beside the row sums / un-pool kernels that follow the data gradient instead of
+        # beside the data gradient itself.  Off: round 2's order (both GEMMs at once).
+        if TUNING.gemms_apart:
+            dgrad()
+            wgrad()
+        else:
+            wgrad()
+            dgrad()
         return dy
 
     def _conv3_backward_pairs(self, ctx, dy, side, sl, grads):
@@ -1076,18 +1094,29 @@ class RelHeadEngine:
             self._timed("conv3_wgrad_objects", lambda: _lib.check(lib.sgc_conv3_wgrad_sparse(
                 None, None, _lib.ptr(z_bf_maps), _lib.ptr(pack_a), _lib.ptr(pack_i), _lib.ptr(sl), n_maps, 0, ctypes.byref(slabs_n), st()),
                 "sgc_conv3_wgrad_sparse"))
+            zcol = None
             if Epad:
-                slx = sl[slabs_n.value * 1024 * 4608:]
                 # im2col + plain ping-pong TN GEMM.  (Rows of z gathered by the window list inside the GEMM block - no column
                 # buffer, sgc_windows_wgrad_gather - measured 11.0 ms against 8.3 + 2.3 ms: the nine shifted re-reads of the z rows
                 # by different N tiles cost more than the im2col pass; kept in the C-ABI, not used by the step.)
                 zcol = ws.get("zcol", Epad * 4 * 9 * 512, torch.bfloat16)
                 self._timed("im2col_windows", lambda: _lib.check(lib.sgc_windows_im2col(_lib.ptr(z_bf), _lib.ptr(gather), _lib.ptr(gn), Epad,
                                                                                        _lib.ptr(zcol), st()), "sgc_windows_im2col"))
-                self._timed("conv3_wgrad_windows", lambda: _lib.check(lib.sgc_windows_wgrad(
-                    _lib.ptr(dy3x), _lib.ptr(zcol), _lib.ptr(slx), Epad * 4, 0, ctypes.byref(slabs_x), st()), "sgc_windows_wgrad"))
-            dW3r = self._slab_sum(sl, 1024 * 4608, slabs_n.value + slabs_x.value)
-            grads["conv3_1.weight"] = dW3r.view(1024, 3, 3, 512).permute(0, 3, 1, 2).contiguous()
+
+        def wgrad_windows():
+            # the second big GEMM of the window backward.  With ``TUNING.gemms_apart`` it is enqueued after the data-gradient GEMM
+            # (the side stream then waits for it) and runs beside col2im / the pair contraction; the im2col above runs beside the
+            # data-gradient GEMM.  Round 2 let the two GEMMs run side by side: 18.8 ms for the pair against 7.7 + 7.6 alone.
+            with side():
+                if Epad:
+                    slx = sl[slabs_n.value * 1024 * 4608:]
+                    self._timed("conv3_wgrad_windows", lambda: _lib.check(lib.sgc_windows_wgrad(
+                        _lib.ptr(dy3x), _lib.ptr(zcol), _lib.ptr(slx), Epad * 4, 0, ctypes.byref(slabs_x), st()), "sgc_windows_wgrad"))
+                dW3r = self._slab_sum(sl, 1024 * 4608, slabs_n.value + slabs_x.value)
+                grads["conv3_1.weight"] = dW3r.view(1024, 3, 3, 512).permute(0, 3, 1, 2).contiguous()
+
+        if not TUNING.gemms_apart:
+            wgrad_windows()
         # ---- data gradients
         self._timed("conv3_dgrad_objects", lambda: _lib.check(lib.sgc_conv3_dgrad_pooled(
             _lib.ptr(dy_maps), _lib.ptr(am_maps), _lib.ptr(w["wd3"]), _lib.ptr(dz_maps), n_maps, st()), "sgc_conv3_dgrad_pooled"))
@@ -1095,11 +1124,15 @@ class RelHeadEngine:
             col = ws.get("xcol", Epad * 4 * 9 * 512, torch.bfloat16)
             self._timed("conv3_dgrad_windows", lambda: _lib.check(lib.sgc_windows_dgrad_cols(_lib.ptr(dy3x), _lib.ptr(w["w3col"]), _lib.ptr(col), Epad * 4, st()),
                                                                   "sgc_windows_dgrad_cols"))
+            if TUNING.gemms_apart:
+                wgrad_windows()                      # side stream: after the data-gradient GEMM, beside col2im / the contraction
             self._timed("col2im_windows", lambda: (
                 _lib.check(lib.sgc_windows_col2im(_lib.ptr(col), _lib.ptr(ctx.bbox), _lib.ptr(ctx.sub_idx), _lib.ptr(ctx.obj_idx), _lib.ptr(sh["incl"]),
                                                   P, _lib.ptr(dz), st()), "sgc_windows_col2im"),
                 _lib.check(lib.sgc_windows_col2im_objects(_lib.ptr(col), _lib.ptr(ctx.bbox), n_obj, P, _lib.ptr(sh["incl"]), _lib.ptr(dz), st()),
                            "sgc_windows_col2im_objects") if objects else None))
+        elif TUNING.gemms_apart:
+            wgrad_windows()
         return dz
 
     # ------------------------------------------------------------------ two-stream backward
