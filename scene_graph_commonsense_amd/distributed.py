@@ -318,7 +318,6 @@ class ShardedSGD:
         g0 = self.param_groups[0]
         lr, mom, wd = float(g0["lr"]), float(g0["momentum"]), float(g0["weight_decay"])
         named = dict(self.named)
-        nccl = self.world > 1 and dist.get_backend(self.group) == "nccl"
         # ---- big parameters: update this rank's piece of every row block in place, gather the block
         for n in self.big:
             flat = named[n].view(-1)
@@ -331,7 +330,7 @@ class ShardedSGD:
                 self.update(mine, pc.acc, pc.mom, lr, mom, wd, pc.first)
                 pc.first = False
                 if self.world > 1:
-                    src = mine if nccl else mine.clone()          # NCCL's in-place all-gather: input = output + rank * count
+                    src = mine.clone()        # a copy of the shard (1/W of the block): no aliasing of a collective's input and output
                     self.gathers.append((self._all_gather(flat[pc.bucket_off:pc.bucket_off + pc.bucket_len], src), src))
         # ---- small parameters: one flat bucket
         if self.small and self.pieces["__small__"][0].acc is not None:
