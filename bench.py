@@ -164,7 +164,7 @@ def executed_flops(P, n_img, n_obj, n_x, n_list, shared, forward_only=False):
     return f
 
 
-def cpu_baseline(cfg, sd, budget_s=20.0):
+def cpu_baseline(cfg, sd, budget_s=25.0):
     """The CPU oracle (literal reference restatement) timed on this host: fwd + loss + bwd of the reference's
     per-step calls (b = 8 images per call), bounded sample, all host cores."""
     import torch
@@ -177,7 +177,7 @@ def cpu_baseline(cfg, sd, budget_s=20.0):
     out = O.run_pair_loop(sdr, batch, cfg, mode="train", weights=w, max_steps=1)
     out["losses"].backward()
     one = time.time() - t0                         # warm-up + cost estimate of one (g,e) step = 2 calls of b=8
-    steps = int(max(1, min(12, budget_s / max(one, 1e-3))))
+    steps = int(max(1, min(16, budget_s / max(one, 1e-3))))
     for p in sdr.values():
         p.grad = None
     t0 = time.time()
