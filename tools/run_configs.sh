@@ -17,7 +17,7 @@ ARGS="" run "8x64 SGC_SHARED_LEVEL=1 (fc1 per pair)" SGC_SHARED_LEVEL=1
 ARGS="" run "8x64 SGC_SHARED_LEVEL=0 (everything per pair)" SGC_SHARED_LEVEL=0
 ARGS="--forward-only" run "8x64 forward only" SGC_NOOP=1
 ARGS="--objects 36" run "8x36 (configs[1])" SGC_NOOP=1
-ARGS="--objects 20 --images 12" run "12x20 (the reference's own largest case)" SGC_NOOP=1
+ARGS="--objects 20 --images 12" run "12x20 (the largest case of the reference: N <= 20, batch 12)" SGC_NOOP=1
 ARGS="--objects 20 --images 10" run "10x20 (configs[0] size)" SGC_NOOP=1
 ARGS="--objects 100 --images 4 --dataset oiv6" run "OpenImages 4x100 (configs[4])" SGC_NOOP=1
 ARGS="--images 16" run "16x64" SGC_NOOP=1
