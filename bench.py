@@ -145,7 +145,7 @@ def scale_boxes(batch, factor):
     return batch
 
 
-def executed_flops(P, n_img, n_obj, n_x, n_list, shared, forward_only=False):
+def executed_flops(P, n_img, n_obj, n_x, n_list, shared, forward_only=False, linear=None):
     """Matrix flops one step really executes (2 x multiply-adds of every GEMM launch, padding rows not counted): what
     ``roofline.step_frac`` divides by the step time.  ``shared``: conv3 / fc1 over shared windows (csrc/kernels_shared.hip) - the
     per-pair GEMMs run over the ``n_list`` listed windows (``n_x`` of them pair-specific) and whole conv3 maps remain only for the
@@ -157,6 +157,8 @@ def executed_flops(P, n_img, n_obj, n_x, n_list, shared, forward_only=False):
          "fc2": 2.0 * P * 4096 * 512 * passes}
     if shared:
         f["conv3"] = (2.0 * n_list * 4 * 1024 * 4608 + 2.0 * n_img * 256 * 1024 * 4608) * passes
+        if linear:          # linear pairs: one forward launch for the raw pre-activations of the per-object entries + the background windows
+            f["conv3"] += 2.0 * (linear[1] + 64 * n_img) * 4 * 1024 * 4608
         f["fc1"] = 2.0 * (n_x + 64 * 2 * n_obj) * 1024 * 4096 * passes
     else:
         f["conv3"] = 2.0 * P * 256 * 1024 * 4608 * passes
@@ -309,6 +311,7 @@ def run_rank(args):
         n_list = (int(state_plan_total(eng)) if state_plan_total(eng) else n_x) if xw is not None else 0
         return dict(dt=dt, loss=None if loss is None else float(loss), first_loss=first_loss, kern=kern, P=scene0.n_pairs,
                     shared=xw is not None, n_x=n_x, n_list=n_list, n_obj=int(scene0.obj_img.shape[0]),
+                    linear=getattr(eng, "_xw_linear", None) if xw is not None else None,
                     exposed_ms=reducer.pop_exposed_ms() / max(steps, 1),
                     peak_gb=torch.cuda.max_memory_allocated(dev) / 1e9)
 
@@ -337,7 +340,7 @@ def run_rank(args):
             b2 = scale_boxes(make_scene_batch(cfg, [args.objects] * args.images, seed=1000 + rank, connect_frac=0.02), factor)
             b2.image_feature, b2.image_depth = batch.image_feature, batch.image_depth
             r = measure(b2, 2, 1)
-            fl = executed_flops(r["P"], args.images, r["n_obj"], r["n_x"], r["n_list"], r["shared"])
+            fl = executed_flops(r["P"], args.images, r["n_obj"], r["n_x"], r["n_list"], r["shared"], linear=r["linear"])
             sensitivity.append({"boxes": label, "pair_specific_fraction": round(r["n_x"] / max(64 * r["P"], 1), 4) if r["shared"] else 1.0,
                                 "path": "shared windows" if r["shared"] else "per-pair kernels (more than SGC_SHARED_MAX_FRACTION of the windows pair-specific)",
                                 "ms_per_step": round(r["dt"] / 2 * 1e3, 2), "pairs_per_s": round(r["P"] * 2 / r["dt"], 1),
@@ -376,7 +379,7 @@ def run_rank(args):
                     "traffic_note": "bytes/launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from profiles/%s_pmc_{f,w}.csv "
                                     "(separate rocprofv3 --pmc passes at this workload); algorithmic ~2.9e9 (z next to the windows 1.7 + outputs 1.2 + weights 0.01)" % tag,
                     "ms_per_launch": round(kern[dom], 3)}
-        ex = executed_flops(P, args.images, m["n_obj"], n_x, n_list, m["shared"], args.forward_only)
+        ex = executed_flops(P, args.images, m["n_obj"], n_x, n_list, m["shared"], args.forward_only, linear=m["linear"])
         if roof is not None:
             # whole-step efficiency on EXECUTED matrix flops (the per-pair form SURVEY 8d prices is mostly not executed any more)
             roof["step_frac"] = round(sum(ex.values()) / (dt / args.steps) / 1e12 / MFMA_PEAK_TFLOPS, 4)
@@ -397,6 +400,7 @@ def run_rank(args):
             # irreducible; with the shared windows most of that is no longer executed, so this is an equivalence, not a rate
             "survey_equivalent_tflops": round(value / max(world, 1) * (2.996e9 if args.forward_only else 8.99e9) / 1e12, 1),
             "shared_windows": None if xw is None else {"pair_specific": n_x, "of": P * 64, "fraction": round(n_x / max(P * 64, 1), 4),
+                                                       "combined_not_convolved": m["linear"][0] if m["linear"] else 0,
                                                        "note": "conv3 and fc1 run per pair only on these pooling windows; the rest is computed "
                                                                "once per object (csrc/kernels_shared.hip)"},
             "kernels_ms": {k: round(v, 3) for k, v in sorted(kern.items()) if k in fwd_only or not two_streams},

@@ -78,6 +78,40 @@ int sgc_shared_windows_assemble(const int* bbox, const int* sub_idx, const int* 
                                 const unsigned char* argmax_obj, const void* y_obj_bf16, void* y, unsigned char* argmax, void* y_bf16,
                                 void* stream);
 
+/* Linear pairs (csrc/kernels_shared.hip, "sixth identity"): when the 16-grid regions where two objects' conv2 halves differ from the
+ * background's are disjoint, z_ij = z_(i,bg) + z_(bg,j) - z_(bg,bg) pixel by pixel, and conv3_1 (model.py:145, linear up to its ReLU)
+ * gives pre_ij = pre_(i,bg) + pre_(bg,j) - pre_(bg,bg) on the pair's X windows: no convolution of its own, combined from the
+ * pre-activations of the per-object window entries; backward = the un-pooled gradient added to those entries, subtracted from the
+ * image's background map.
+ *   sgc_shared_windows_count3          count_all[p] = |X_p|, count_conv[p] / count_linear[p] = |X_p| for the pairs of that class (else
+ *                                      0), pixel_rect_conv[p] = sgc_shared_windows_count's rectangle, empty for a linear pair
+ *   sgc_shared_windows_fill_class      sgc_shared_windows_fill for one class (cls 1 = not linear, 2 = linear) and its prefix counts
+ *   sgc_conv3_windows_raw              raw [4*max_entries][1024] f32 = conv3x3(z_pad, w3r) of the listed windows, no bias / ReLU / pool
+ *   sgc_windows_linear_forward         y / y_bf16 (row dest_all[entry in the list of ALL X windows]) and argmax (row pair*64 + window) of
+ *                                      the linear pairs' windows from raw = [per-object entries in list order | 64 windows of every
+ *                                      image's background map]; count_incl_all over [pairs | 2 n_obj pseudo-pairs]
+ *   sgc_windows_linear_backward_objects  dy3x rows of the n_object_entries per-object entries (list positions first_object_entry ..) +=
+ *                                      un-pooled gradient of the linear pairs' windows that used them
+ *   sgc_windows_linear_backward_bg     dy3_bg_pad [n_img][18][18][1024] -= the same per (image, window); order / segments = the linear
+ *                                      list sorted by image*64 + window and its 64 n_img + 1 range starts; bias_part [64 n_img][1024] */
+int sgc_shared_windows_count3(const int* bbox, const int* sub_idx, const int* obj_idx, int n_pairs, int* count_all, int* count_conv,
+                              int* count_linear, int* pixel_rect_conv, void* stream);
+int sgc_shared_windows_fill_class(const int* bbox, const int* sub_idx, const int* obj_idx, int n_pairs, const int* count_incl, int* gather,
+                                  int cls, void* stream);
+int sgc_conv3_windows_raw(const void* z_pad, const void* w3r, const int* gather, const int* gather_n, int max_entries, float* raw,
+                          void* stream);
+int sgc_windows_linear_forward(const int* bbox, const int* sub_idx, const int* obj_idx, const int* obj_img, int n_obj, int n_real_pairs,
+                               const int* gather_linear, const int* n_linear, int max_linear, const int* count_incl_all,
+                               const int* dest_all, const float* raw, long n_object_entries, const float* b3, void* ywm, void* ywm_bf16,
+                               unsigned char* argmax, void* stream);
+int sgc_windows_linear_backward_objects(const int* bbox, const int* sub_idx, const int* obj_idx, const int* sub_ptr, const int* sub_list,
+                                        const int* obj_ptr, const int* obj_list, int n_obj, int n_real_pairs, const int* gather_conv,
+                                        int first_object_entry, int n_object_entries, const int* count_incl_all, const int* dest_all,
+                                        const void* dywm, const unsigned char* argmax, void* dy3x, void* stream);
+int sgc_windows_linear_backward_bg(const int* bbox, const int* sub_idx, const int* obj_idx, const int* gather_linear, const int* order,
+                                   const int* segments, int n_img, const int* count_incl_all, const int* dest_all, const void* dywm,
+                                   const unsigned char* argmax, void* dy3_bg_pad, float* bias_part, void* stream);
+
 /* Backward of the shared-window conv3 (autodiff of the graph above; same citations).  All gradients bf16, sums f32.
  *   sgc_shared_windows_assemble_bwd  dy_obj [2*n_obj*64][1024] = per-object sums of the rows of dy [n_pairs*64][1024] that were copies
  *                                    (I windows -> subject's row, J windows -> object's row); sub_ptr/sub_list, obj_ptr/obj_list =

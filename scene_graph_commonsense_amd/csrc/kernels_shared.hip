@@ -363,8 +363,10 @@ __global__ __launch_bounds__(256) void windows_col2im_kernel(const u16* __restri
                                                              const int* __restrict__ sub, const int* __restrict__ obj,
                                                              const int* __restrict__ incl, u16* __restrict__ dz) {
     const int p = blockIdx.x;
+    const int e0 = p ? incl[p - 1] : 0;
+    if (incl[p] == e0) return;                 // no entries of its own in this list (no X window, or a linear pair: no dz either)
     const WRect x = pair_windows(object_windows(bbox + 4 * sub[p]), object_windows(bbox + 4 * obj[p]));
-    col2im_rect(col, x, p ? incl[p - 1] : 0, p, dz);
+    col2im_rect(col, x, e0, p, dz);
 }
 
 // the same for the window-list entries of the pseudo-pairs (pair index n_real + ps, windows R_o)
@@ -667,6 +669,248 @@ __global__ __launch_bounds__(256) void fc1_xrows_kernel(const u16* __restrict__ 
     }
 }
 
+
+// ================================================================================================ linear pairs (sixth identity)
+// z_ij = maxpool2(relu(U_i + V_j)) equals z_(i,bg) wherever V_j is the background's and z_(bg,j) wherever U_i is.  When the two
+// objects' regions of influence on the 16-grid (D16: the box, +-1 pixel for conv2_1, pooled) are DISJOINT, every pixel is one or the
+// other (or both = the all-background value), i.e.  z_ij = z_(i,bg) + z_(bg,j) - z_(bg,bg)  exactly, pixel by pixel - and conv3 is
+// linear up to its ReLU, so on the pair's X windows
+//     pre_ij = pre_(i,bg) + pre_(bg,j) - pre_(bg,bg)          (pre = conv3 output before bias / ReLU / max-pool)
+// in real arithmetic (in f32: three accumulations added instead of one - round-off).  Such a pair needs NO convolution of its own: its
+// X windows (rectangles still overlap - conv3's 3x3 and the second pooling widen them - although the inputs do not) are combined from
+// pre-activations the per-object window entries produce anyway.  On the benchmark's boxes 12.4 % of the X windows belong to such
+// pairs.  Backward = autodiff: the un-pooled gradient of a combined window is ADDED to the un-pooled gradient rows of the two
+// per-object entries and SUBTRACTED from the image's background map; the pair contributes no rows to the column GEMMs, no z / dz.
+struct PRect { int x0, x1, y0, y1; };
+__device__ __forceinline__ void axis_d16(int b0, int b1, int& p0, int& p1) {
+    int lo = b0 < 0 ? 0 : b0, hi = b1 > 32 ? 32 : b1;
+    if (hi <= lo) { p0 = 0; p1 = 0; return; }
+    lo = lo > 0 ? lo - 1 : 0;  hi = hi < 32 ? hi + 1 : 32;
+    p0 = lo >> 1;              p1 = (hi + 1) >> 1;
+}
+// true when the pair's D16 rectangles do not intersect (caller: the X rectangle is not empty)
+__device__ __forceinline__ bool d16_disjoint(const int* __restrict__ bi, const int* __restrict__ bj) {
+    int ax0, ax1, ay0, ay1, bx0, bx1, by0, by1;
+    axis_d16(bi[0], bi[1], ax0, ax1); axis_d16(bi[2], bi[3], ay0, ay1);
+    axis_d16(bj[0], bj[1], bx0, bx1); axis_d16(bj[2], bj[3], by0, by1);
+    return !(max(ax0, bx0) < min(ax1, bx1) && max(ay0, by0) < min(ay1, by1));
+}
+
+// count_all[p] = |X_p|; count_conv[p] = |X_p| unless the pair is linear (then 0); count_lin[p] = |X_p| for linear pairs, else 0;
+// pixrect_conv[p] = the pixels the pair's own z / dz are needed at (none for a linear pair)
+__global__ __launch_bounds__(256) void shared_count3_kernel(const int* __restrict__ bbox, const int* __restrict__ sub, const int* __restrict__ obj,
+                                                            int n_pairs, int* __restrict__ count_all, int* __restrict__ count_conv,
+                                                            int* __restrict__ count_lin, int* __restrict__ pixrect_conv) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= n_pairs) return;
+    const int* bi = bbox + 4 * sub[p];
+    const int* bj = bbox + 4 * obj[p];
+    const WRect x = pair_windows(object_windows(bi), object_windows(bj));
+    const int n = (x.x1 - x.x0) * (x.y1 - x.y0);
+    const bool lin = n > 0 && d16_disjoint(bi, bj);
+    count_all[p] = n;
+    count_conv[p] = lin ? 0 : n;
+    count_lin[p] = lin ? n : 0;
+    pixrect_conv[p] = lin ? 0 : pack_pixel_rect(x);
+}
+
+// gather[e] = pair*64 + window for the X windows of the pairs of one class (1: not linear, 2: linear), given that class's prefix counts
+__global__ __launch_bounds__(256) void shared_fill_class_kernel(const int* __restrict__ bbox, const int* __restrict__ sub, const int* __restrict__ obj,
+                                                                int n_pairs, const int* __restrict__ incl, int* __restrict__ gather, int cls) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= n_pairs) return;
+    const int* bi = bbox + 4 * sub[p];
+    const int* bj = bbox + 4 * obj[p];
+    const WRect x = pair_windows(object_windows(bi), object_windows(bj));
+    if (x.x1 <= x.x0) return;
+    const bool lin = d16_disjoint(bi, bj);
+    if ((cls == 1 && lin) || (cls == 2 && !lin)) return;
+    int e = p ? incl[p - 1] : 0;
+    for (int wy = x.y0; wy < x.y1; ++wy)
+        for (int wx = x.x0; wx < x.x1; ++wx) gather[e++] = p * 64 + wy * 8 + wx;
+}
+
+// index of window (wx, wy) inside the row-major list of a rectangle
+__device__ __forceinline__ int rect_local(const WRect& r, int wx, int wy) { return (wy - r.y0) * (r.x1 - r.x0) + (wx - r.x0); }
+
+// Forward of the linear pairs' windows.  raw [(n_pe + 64 n_img) * 4][1024] f32: conv3 pre-activations (no bias) of the per-object
+// window entries in list order (pseudo-pair ps: entries incl_all[n_real + ps - 1] - incl_all[n_real - 1] ..) followed by every window
+// of every image's background map.  One wavefront per listed window: 4 pixels x 1024 channels, lane = 16 channels.
+__global__ __launch_bounds__(256) void windows_linear_fwd_kernel(const int* __restrict__ bbox, const int* __restrict__ sub, const int* __restrict__ obj,
+                                                                 const int* __restrict__ obj_img, int n_obj, int n_real,
+                                                                 const int* __restrict__ gather_l, const int* __restrict__ n_l,
+                                                                 const int* __restrict__ incl_all, const int* __restrict__ dest_all,
+                                                                 const float* __restrict__ raw, long n_pe, const float* __restrict__ bias,
+                                                                 u16* __restrict__ y, u16* __restrict__ y_bf, unsigned char* __restrict__ am) {
+    const int lane = threadIdx.x & 63;
+    const int total = *n_l;
+    const int base_ps = n_real ? incl_all[n_real - 1] : 0;
+    for (int t = blockIdx.x * 4 + (threadIdx.x >> 6); t < total; t += gridDim.x * 4) {
+        const int code = gather_l[t];
+        const int p = code >> 6, w = code & 63, wy = w >> 3, wx = w & 7;
+        const int i = sub[p], j = obj[p];
+        const WRect ri = object_windows(bbox + 4 * i), rj = object_windows(bbox + 4 * j);
+        const WRect x = pair_windows(ri, rj);
+        const long drow = dest_all[(p ? incl_all[p - 1] : 0) + rect_local(x, wx, wy)];
+        // exclusive prefix count at pair-index k = first list entry of that pair; per-object entries are counted from the first pseudo-pair
+        const long ei = (long)(n_real + i > 0 ? incl_all[n_real + i - 1] : 0) - base_ps + rect_local(ri, wx, wy);
+        const long ej = (long)incl_all[n_real + n_obj + j - 1] - base_ps + rect_local(rj, wx, wy);
+        const long eb = n_pe + (long)obj_img[i] * 64 + w;
+        const int c0 = lane * 16;
+        float best[16];
+        unsigned char arg[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float* a = raw + ((ei * 4 + q) << 10) + c0;
+            const float* b = raw + ((ej * 4 + q) << 10) + c0;
+            const float* g = raw + ((eb * 4 + q) << 10) + c0;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const float4 fa = reinterpret_cast<const float4*>(a)[v], fb = reinterpret_cast<const float4*>(b)[v];
+                const float4 fg = reinterpret_cast<const float4*>(g)[v];
+                const float s[4] = {(fa.x + fb.x) - fg.x, (fa.y + fb.y) - fg.y, (fa.z + fb.z) - fg.z, (fa.w + fb.w) - fg.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (q == 0) { best[4 * v + k] = s[k]; arg[4 * v + k] = 0; }
+                    else if (s[k] > best[4 * v + k]) { best[4 * v + k] = s[k]; arg[4 * v + k] = (unsigned char)q; }
+                }
+            }
+        }
+        uint4 o16[2], ob[2], oa;
+        u16* oh = reinterpret_cast<u16*>(o16);
+        u16* bh = reinterpret_cast<u16*>(ob);
+        unsigned char* ah = reinterpret_cast<unsigned char*>(&oa);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            float v = best[k] + bias[c0 + k];
+            unsigned char a = arg[k];
+            if (!(v > 0.f)) { v = 0.f; a = 4; }                 // ReLU killed: no gradient path (same rule as the GEMM's pooled epilogue)
+            oh[k] = f32_to_f16_bits(v);
+            bh[k] = f32_to_bf16_bits(v);
+            ah[k] = a;
+        }
+        uint4* yo = reinterpret_cast<uint4*>(y + drow * 1024 + c0);
+        yo[0] = o16[0]; yo[1] = o16[1];
+        if (y_bf) { uint4* yb = reinterpret_cast<uint4*>(y_bf + drow * 1024 + c0); yb[0] = ob[0]; yb[1] = ob[1]; }
+        if (am) *reinterpret_cast<uint4*>(am + (long)code * 1024 + c0) = oa;
+    }
+}
+
+// un-pooled gradient of one combined window: acc[q][k] += (code == q) ? dy : 0 for the lane's 16 channels
+__device__ __forceinline__ void linear_unpool_acc(float (&acc)[4][16], const u16* __restrict__ dyrow, const unsigned char* __restrict__ amrow,
+                                                  int c0) {
+    const uint4 g0 = *reinterpret_cast<const uint4*>(dyrow + c0), g1 = *reinterpret_cast<const uint4*>(dyrow + c0 + 8);
+    const uint4 cd = *reinterpret_cast<const uint4*>(amrow + c0);
+    u16 gh[16];
+    *reinterpret_cast<uint4*>(gh) = g0;
+    *reinterpret_cast<uint4*>(gh + 8) = g1;
+    const unsigned char* ch = reinterpret_cast<const unsigned char*>(&cd);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const float v = bf16_bits_to_f32(gh[k]);
+        const unsigned code = ch[k];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q][k] += (code == (unsigned)q) ? v : 0.f;
+    }
+}
+
+// Backward, per-object side: dy3x rows of the per-object entry k (list position e0 + k: pseudo-pair ps, window w) += sum over the LINEAR
+// pairs of the object whose X rectangle holds w of the un-pooled gradient of their combined window.  One wavefront per entry; f32
+// sums in pair-list order, one bf16 rounding.
+__global__ __launch_bounds__(256) void windows_linear_bwd_objects_kernel(const int* __restrict__ bbox, const int* __restrict__ sub,
+                                                                         const int* __restrict__ obj, const int* __restrict__ sub_ptr,
+                                                                         const int* __restrict__ sub_list, const int* __restrict__ obj_ptr,
+                                                                         const int* __restrict__ obj_list, int n_obj, int n_real,
+                                                                         const int* __restrict__ gather_c, int e0, int n_pe,
+                                                                         const int* __restrict__ incl_all, const int* __restrict__ dest_all,
+                                                                         const u16* __restrict__ dy, const unsigned char* __restrict__ am,
+                                                                         u16* __restrict__ dy3x) {
+    const int lane = threadIdx.x & 63, c0 = lane * 16;
+    for (int k = blockIdx.x * 4 + (threadIdx.x >> 6); k < n_pe; k += gridDim.x * 4) {
+        const int code = gather_c[e0 + k];
+        const int ps = (code >> 6) - n_real, w = code & 63, wy = w >> 3, wx = w & 7;
+        const int role = ps >= n_obj ? 1 : 0, o = ps - role * n_obj;
+        const int* ptr = role ? obj_ptr : sub_ptr;
+        const int* list = role ? obj_list : sub_list;
+        const int* bo = bbox + 4 * o;
+        const WRect ro = object_windows(bo);
+        float acc[4][16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int c = 0; c < 16; ++c) acc[q][c] = 0.f;
+        bool any = false;
+        for (int it = ptr[o]; it < ptr[o + 1]; ++it) {
+            const int p = list[it];
+            const int* bp = bbox + 4 * (role ? sub[p] : obj[p]);
+            const WRect rp = object_windows(bp);
+            if (!in_rect(rp, wx, wy) || !d16_disjoint(bo, bp)) continue;
+            const WRect x = pair_windows(ro, rp);
+            const long drow = dest_all[(p ? incl_all[p - 1] : 0) + rect_local(x, wx, wy)];
+            linear_unpool_acc(acc, dy + drow * 1024, am + ((long)p * 64 + w) * 1024, c0);
+            any = true;
+        }
+        if (!any) continue;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            u16* row = dy3x + ((long)(e0 + k) * 4 + q) * 1024 + c0;
+            u16 h[16];
+            *reinterpret_cast<uint4*>(h) = *reinterpret_cast<const uint4*>(row);
+            *reinterpret_cast<uint4*>(h + 8) = *reinterpret_cast<const uint4*>(row + 8);
+#pragma unroll
+            for (int c = 0; c < 16; ++c) h[c] = f32_to_bf16_bits(bf16_bits_to_f32(h[c]) + acc[q][c]);
+            *reinterpret_cast<uint4*>(row) = *reinterpret_cast<const uint4*>(h);
+            *reinterpret_cast<uint4*>(row + 8) = *reinterpret_cast<const uint4*>(h + 8);
+        }
+    }
+}
+
+// Backward, background side: the un-pooled gradient of every combined window is SUBTRACTED from its image's background map
+// (dy3_bg [n_img][18][18][1024] bf16, interior already holding the map's own un-pooled gradient) and counts once for conv3's bias.
+// order [n_l]: the listed windows sorted by (image, window) (stable: sums in list order); seg [64 n_img + 1] their ranges.
+// One wavefront per (image, window); bias_part [64 n_img][1024].
+__global__ __launch_bounds__(256) void windows_linear_bwd_bg_kernel(const int* __restrict__ bbox, const int* __restrict__ sub, const int* __restrict__ obj,
+                                                                    const int* __restrict__ gather_l, const int* __restrict__ order,
+                                                                    const int* __restrict__ seg, int n_items,
+                                                                    const int* __restrict__ incl_all, const int* __restrict__ dest_all,
+                                                                    const u16* __restrict__ dy, const unsigned char* __restrict__ am,
+                                                                    u16* __restrict__ dy3_bg, float* __restrict__ bias_part) {
+    const int lane = threadIdx.x & 63, c0 = lane * 16;
+    for (int it = blockIdx.x * 4 + (threadIdx.x >> 6); it < n_items; it += gridDim.x * 4) {
+        const int b = it >> 6, w = it & 63, wy = w >> 3, wx = w & 7;
+        float acc[4][16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int c = 0; c < 16; ++c) acc[q][c] = 0.f;
+        for (int s = seg[it]; s < seg[it + 1]; ++s) {
+            const int code = gather_l[order[s]];
+            const int p = code >> 6;
+            const WRect x = pair_windows(object_windows(bbox + 4 * sub[p]), object_windows(bbox + 4 * obj[p]));
+            const long drow = dest_all[(p ? incl_all[p - 1] : 0) + rect_local(x, wx, wy)];
+            linear_unpool_acc(acc, dy + drow * 1024, am + (long)code * 1024, c0);
+        }
+        float bs[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) bs[c] = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int Y = 2 * wy + (q >> 1) + 1, X = 2 * wx + (q & 1) + 1;
+            u16* row = dy3_bg + (((long)b * 18 + Y) * 18 + X) * 1024 + c0;
+            u16 h[16];
+            *reinterpret_cast<uint4*>(h) = *reinterpret_cast<const uint4*>(row);
+            *reinterpret_cast<uint4*>(h + 8) = *reinterpret_cast<const uint4*>(row + 8);
+#pragma unroll
+            for (int c = 0; c < 16; ++c) { h[c] = f32_to_bf16_bits(bf16_bits_to_f32(h[c]) - acc[q][c]); bs[c] += acc[q][c]; }
+            *reinterpret_cast<uint4*>(row) = *reinterpret_cast<const uint4*>(h);
+            *reinterpret_cast<uint4*>(row + 8) = *reinterpret_cast<const uint4*>(h + 8);
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+            reinterpret_cast<float4*>(bias_part + (long)it * 1024 + c0)[v] = make_float4(bs[4 * v], bs[4 * v + 1], bs[4 * v + 2], bs[4 * v + 3]);
+    }
+}
+
 static inline int grid_cap(long items, long per_block, int cap) {
     long b = (items + per_block - 1) / per_block;
     if (b > cap) b = cap;
@@ -836,6 +1080,65 @@ int sgc_fc1_assemble(const float* S, const float* owm, const int* bbox, const in
 }
 
 // ---- fc1 backward over the window-major rows
+// ---- linear pairs (see "linear pairs (sixth identity)" above)
+int sgc_shared_windows_count3(const int* bbox, const int* sub_idx, const int* obj_idx, int n_pairs, int* count_all, int* count_conv,
+                              int* count_linear, int* pixel_rect_conv, void* stream) {
+    if (n_pairs <= 0) return SGC_OK;
+    SGC_LAUNCH(shared_count3_kernel, dim3((n_pairs + 255) / 256), dim3(256), 0, (hipStream_t)stream, bbox, sub_idx, obj_idx, n_pairs,
+               count_all, count_conv, count_linear, pixel_rect_conv);
+    SGC_CHECK_LAUNCH();
+    return SGC_OK;
+}
+int sgc_shared_windows_fill_class(const int* bbox, const int* sub_idx, const int* obj_idx, int n_pairs, const int* count_incl, int* gather,
+                                  int cls, void* stream) {
+    if (n_pairs <= 0) return SGC_OK;
+    if (cls != 1 && cls != 2) return SGC_ERR_ARG;
+    SGC_LAUNCH(shared_fill_class_kernel, dim3((n_pairs + 255) / 256), dim3(256), 0, (hipStream_t)stream, bbox, sub_idx, obj_idx, n_pairs,
+               count_incl, gather, cls);
+    SGC_CHECK_LAUNCH();
+    return SGC_OK;
+}
+// raw [4 * max_entries][1024] f32 = conv3x3(z_pad, w3r) of the listed windows, NO bias / ReLU / pooling (row 4e + q = pixel q of entry e)
+int sgc_conv3_windows_raw(const void* z_pad, const void* w3r, const int* gather, const int* gather_n, int max_entries, float* raw,
+                          void* stream) {
+    if (max_entries <= 0) return SGC_OK;
+    NtParams p{};
+    p.A = (const u16*)z_pad; p.B = (const u16*)w3r; p.C = raw; p.M = max_entries * 4; p.N = 1024; p.K = 9 * 512;
+    p.ldb = 9 * 512; p.ldc = 1024; p.lgS = 4; p.Cin = 512; p.gather = gather; p.gather_n = gather_n;
+    return launch_gemm_nt_pp_conv_gather<ELEM_F16, EPI_STORE_F32>(p, (hipStream_t)stream);
+}
+int sgc_windows_linear_forward(const int* bbox, const int* sub_idx, const int* obj_idx, const int* obj_img, int n_obj, int n_real_pairs,
+                               const int* gather_linear, const int* n_linear, int max_linear, const int* count_incl_all,
+                               const int* dest_all, const float* raw, long n_object_entries, const float* b3, void* ywm, void* ywm_bf16,
+                               unsigned char* argmax, void* stream) {
+    if (max_linear <= 0) return SGC_OK;
+    SGC_LAUNCH(windows_linear_fwd_kernel, dim3(grid_cap(max_linear, 4, 65536)), dim3(256), 0, (hipStream_t)stream, bbox, sub_idx, obj_idx,
+               obj_img, n_obj, n_real_pairs, gather_linear, n_linear, count_incl_all, dest_all, raw, n_object_entries, b3, (u16*)ywm,
+               (u16*)ywm_bf16, argmax);
+    SGC_CHECK_LAUNCH();
+    return SGC_OK;
+}
+int sgc_windows_linear_backward_objects(const int* bbox, const int* sub_idx, const int* obj_idx, const int* sub_ptr, const int* sub_list,
+                                        const int* obj_ptr, const int* obj_list, int n_obj, int n_real_pairs, const int* gather_conv,
+                                        int first_object_entry, int n_object_entries, const int* count_incl_all, const int* dest_all,
+                                        const void* dywm, const unsigned char* argmax, void* dy3x, void* stream) {
+    if (n_object_entries <= 0) return SGC_OK;
+    SGC_LAUNCH(windows_linear_bwd_objects_kernel, dim3(grid_cap(n_object_entries, 4, 65536)), dim3(256), 0, (hipStream_t)stream, bbox,
+               sub_idx, obj_idx, sub_ptr, sub_list, obj_ptr, obj_list, n_obj, n_real_pairs, gather_conv, first_object_entry,
+               n_object_entries, count_incl_all, dest_all, (const u16*)dywm, argmax, (u16*)dy3x);
+    SGC_CHECK_LAUNCH();
+    return SGC_OK;
+}
+int sgc_windows_linear_backward_bg(const int* bbox, const int* sub_idx, const int* obj_idx, const int* gather_linear, const int* order,
+                                   const int* segments, int n_img, const int* count_incl_all, const int* dest_all, const void* dywm,
+                                   const unsigned char* argmax, void* dy3_bg_pad, float* bias_part, void* stream) {
+    if (n_img <= 0) return SGC_OK;
+    SGC_LAUNCH(windows_linear_bwd_bg_kernel, dim3(grid_cap(64L * n_img, 4, 65536)), dim3(256), 0, (hipStream_t)stream, bbox, sub_idx,
+               obj_idx, gather_linear, order, segments, 64 * n_img, count_incl_all, dest_all, (const u16*)dywm, argmax, (u16*)dy3_bg_pad,
+               bias_part);
+    SGC_CHECK_LAUNCH();
+    return SGC_OK;
+}
 int sgc_fc1_gsum(const void* dh1, const int* bbox, const int* sub_idx, const int* obj_idx, const int* sub_ptr, const int* sub_list,
                  const int* obj_ptr, const int* obj_list, const int* goff, int n_obj, void* gwm, void* stream) {
     if (n_obj <= 0) return SGC_OK;

@@ -130,7 +130,7 @@ class TrainContext:
 @dataclass
 class Tuning:
     """The switches of the product path, in ONE place, read once at import.  Defaults are the measured best.
-    Environment (five documented variables; tests and tools flip the fields directly, e.g. ``with engine.tuning(shared_fc1=False)``):
+    Environment (six documented variables; tests and tools flip the fields directly, e.g. ``with engine.tuning(shared_fc1=False)``):
 
       SGC_SHARED_LEVEL         0 per-pair kernels | 1 conv3 over shared windows | 2 + fc1 over the same windows | 3 (default) + the
                                per-object maps shared with the image's background map (second level)
@@ -139,6 +139,7 @@ class Tuning:
                                profiles/r03_box_sweep.txt - the step time crosses near 0.65 but the workspace reaches 170 GB at 0.5)
       SGC_BWD_STREAMS          0: weight-gradient chain on the caller's stream (single-stream profiles, tools/collect_profiles.sh)
       SGC_GEMMS_APART          0: round 2's order of the two-stream backward (data- and weight-gradient GEMM of a layer side by side)
+      SGC_SHARED_LINEAR        0: every pair convolves its own X windows (off: the sixth identity of csrc/kernels_shared.hip)
     Decided and no longer switchable: sparse-MFMA conv3 weight gradient, un-pool fused into the conv3 data gradient, im2col + plain
     GEMM (not the gathered TN block) for the weight gradient over the listed windows."""
     shared_conv3: bool = True
@@ -148,6 +149,7 @@ class Tuning:
     shared_max_fraction: float = 0.5
     bwd_streams: bool = True
     gemms_apart: bool = True          # two-stream backward: keep the big GEMMs of the two chains from running side by side
+    shared_linear: bool = True        # pairs whose regions of influence on the 16-grid are disjoint: X windows combined, not convolved
 
     @classmethod
     def from_env(cls):
@@ -156,7 +158,8 @@ class Tuning:
                    shared_bwd=os.environ.get("SGC_SHARED_BWD", "1") != "0",
                    shared_max_fraction=float(os.environ.get("SGC_SHARED_MAX_FRACTION", "0.5")),
                    bwd_streams=os.environ.get("SGC_BWD_STREAMS", "1") != "0",
-                   gemms_apart=os.environ.get("SGC_GEMMS_APART", "1") != "0")
+                   gemms_apart=os.environ.get("SGC_GEMMS_APART", "1") != "0",
+                   shared_linear=lvl >= 3 and os.environ.get("SGC_SHARED_LINEAR", "1") != "0")
 
 
 TUNING = Tuning.from_env()
@@ -389,7 +392,7 @@ class RelHeadEngine:
 
     FULL_PIXRECT = (16 << 5) | (16 << 15)          # packed pixel rectangle covering the whole 16x16 map
 
-    def shared_plan(self, bbox, sub_idx, obj_idx, P, bound=None, keep=False, n_obj=0, n_img=0, objects=False):
+    def shared_plan(self, bbox, sub_idx, obj_idx, P, bound=None, keep=False, n_obj=0, n_img=0, objects=False, obj_img=None):
         """The window list of a pair list (``csrc/kernels_shared.hip``).  Pair index space: [P real pairs][2*n_obj pseudo-pairs
         (o, bg), (bg, o)][n_img all-background maps].  ``gather`` = pair*64 + window of every listed window (the X windows of the
         real pairs and - second level, ``objects`` - the windows R_o of the pseudo-pairs), ``incl`` inclusive prefix counts over
@@ -402,6 +405,9 @@ class RelHeadEngine:
         own = self.ws if keep else self.scratch
         n2 = 2 * n_obj
         Pt = P + n2 + n_img
+        if (objects and TUNING.shared_linear and obj_img is not None and hint.get("linear_windows") and hint.get("windows") is not None
+                and hint.get("object_windows") is not None and P > 0):
+            return self._shared_plan_linear(bbox, sub_idx, obj_idx, P, hint, own, n_obj, n_img, obj_img)
         cnt = self.scratch.get("xw_count", Pt, torch.int32)
         pixrect = own.get("xw_pixrect", Pt, torch.int32)
         _lib.check(lib.sgc_shared_windows_count(_lib.ptr(bbox), _lib.ptr(sub_idx), _lib.ptr(obj_idx), P, _lib.ptr(cnt), _lib.ptr(pixrect),
@@ -428,9 +434,56 @@ class RelHeadEngine:
             total = min(total, int(e_real) + n2 * 64)
         self._xw = (gather, incl[:P] if P else incl)
         self._xw_total = incl[Pt - 1:]
+        self._xw_linear = None
         return dict(gather=gather, incl=incl, n_total=incl[Pt - 1:], pixrect=pixrect, bound=total, entries=total if exact else None,
                     entries_real=e_real if exact else None, window_entries=hint.get("per_window"), objects=objects, P=P, n_obj=n_obj,
                     n_img=n_img)
+
+    def _shared_plan_linear(self, bbox, sub_idx, obj_idx, P, hint, own, n_obj, n_img, obj_img):
+        """``shared_plan`` with the LINEAR pairs split off (csrc/kernels_shared.hip, sixth identity; full scenes only: the host knows
+        every count).  Three lists over the same pair index space: ALL X windows (what fc1 multiplies: ``gather_all`` / ``incl_all``,
+        the window-major destinations are per entry of this list), the CONV list (pairs that convolve their own windows + the
+        per-object entries: under the plan's usual names ``gather`` / ``incl`` / ``n_total`` / ``pixrect``, so the conv3 kernels of
+        both directions run on it unchanged) and the LINEAR list (``lin``: windows combined from per-object pre-activations)."""
+        lib, dev = self.lib, self.device
+        n2 = 2 * n_obj
+        Pt = P + n2 + n_img
+        e_all, e_obj, e_lin = int(hint["windows"]), int(hint["object_windows"]), int(hint["linear_windows"])
+        cnt = self.scratch.get("xw_count3", 3 * Pt, torch.int32).view(3, Pt)
+        pixrect = own.get("xw_pixrect", Pt, torch.int32)
+        _lib.check(lib.sgc_shared_windows_count3(_lib.ptr(bbox), _lib.ptr(sub_idx), _lib.ptr(obj_idx), P, _lib.ptr(cnt[0]), _lib.ptr(cnt[1]),
+                                                 _lib.ptr(cnt[2]), _lib.ptr(pixrect), self._st()), "sgc_shared_windows_count3")
+        cnt[:, P:].zero_()
+        pixrect[P:].fill_(self.FULL_PIXRECT)
+        _lib.check(lib.sgc_shared_objects_count(_lib.ptr(bbox), n_obj, _lib.ptr(cnt[0, P:]), _lib.ptr(pixrect[P:]), self._st()),
+                   "sgc_shared_objects_count")
+        cnt[1, P:P + n2] = cnt[0, P:P + n2]
+        incl = torch.cumsum(cnt, 1, dtype=torch.int32)                          # [3][Pt]: all / conv / linear
+        incl_all, incl_c, incl_l = incl[0].contiguous(), incl[1].contiguous(), incl[2].contiguous()
+        e_c = e_all - e_lin
+        gather_all = own.get("xw_gather_all", e_all + e_obj + 64, torch.int32)
+        gather_c = own.get("xw_gather", e_c + e_obj + 64, torch.int32)
+        gather_l = own.get("xw_gather_lin", e_lin + 64, torch.int32)
+        _lib.check(lib.sgc_shared_windows_fill(_lib.ptr(bbox), _lib.ptr(sub_idx), _lib.ptr(obj_idx), P, _lib.ptr(incl_all), _lib.ptr(gather_all),
+                                               self._st()), "sgc_shared_windows_fill")
+        _lib.check(lib.sgc_shared_windows_fill_class(_lib.ptr(bbox), _lib.ptr(sub_idx), _lib.ptr(obj_idx), P, _lib.ptr(incl_c), _lib.ptr(gather_c),
+                                                     1, self._st()), "sgc_shared_windows_fill_class")
+        _lib.check(lib.sgc_shared_windows_fill_class(_lib.ptr(bbox), _lib.ptr(sub_idx), _lib.ptr(obj_idx), P, _lib.ptr(incl_l), _lib.ptr(gather_l),
+                                                     2, self._st()), "sgc_shared_windows_fill_class")
+        for inc, ga in ((incl_all, gather_all), (incl_c, gather_c)):
+            _lib.check(lib.sgc_shared_objects_fill(_lib.ptr(bbox), n_obj, P, _lib.ptr(inc), _lib.ptr(ga), self._st()), "sgc_shared_objects_fill")
+        # the linear windows sorted by (image, window) for the background side of the backward (stable: sums in list order)
+        code_l = gather_l[:e_lin].long()
+        keys = obj_img.long()[sub_idx.long()[code_l >> 6]] * 64 + (code_l & 63)
+        skeys, order = torch.sort(keys, stable=True)
+        seg = torch.searchsorted(skeys, torch.arange(64 * n_img + 1, device=dev)).to(torch.int32)
+        lin = dict(gather=gather_l, n=incl_l[P - 1:P].contiguous(), max=e_lin, order=order.to(torch.int32).contiguous(), seg=seg.contiguous())
+        self._xw = (gather_all, incl_all[:P])
+        self._xw_total = incl_c[Pt - 1:]
+        self._xw_linear = (e_lin, e_obj)          # bench accounting: windows combined instead of convolved, per-object entries
+        return dict(gather=gather_c, incl=incl_c, n_total=incl_c[Pt - 1:], pixrect=pixrect, bound=e_c + e_obj, entries=e_c + e_obj,
+                    entries_real=e_c, window_entries=hint.get("per_window"), objects=True, P=P, n_obj=n_obj, n_img=n_img,
+                    gather_all=gather_all, incl_all=incl_all, entries_all=e_all + e_obj, entries_real_all=e_all, lin=lin)
 
     def window_major_rows(self, plan, P, n2):
         """Window-major row space of the shared fc1 (``csrc/kernels_shared.hip``): device group offsets, tile -> group table and the
@@ -439,10 +492,11 @@ class RelHeadEngine:
         ``DeviceScene.window_entries``); a pair subset costs one read-back."""
         from .pairs import window_major_layout
         dev = self.device
-        gather = plan["gather"]
+        split = "gather_all" in plan                  # linear pairs split off: the rows are those of the list of ALL X windows
+        gather = plan["gather_all"] if split else plan["gather"]
         counts = plan.get("window_entries")
         if counts is None:
-            E = int(plan["incl"][P - 1]) if P else 0
+            E = int((plan["incl_all"] if split else plan["incl"])[P - 1]) if P else 0
             counts = torch.bincount((gather[:E] & 63).long(), minlength=64).cpu().numpy()
         E = int(np.asarray(counts).sum())
         goff, tile_group = window_major_layout(counts, n2)
@@ -452,7 +506,9 @@ class RelHeadEngine:
         skeys, order = torch.sort(keys, stable=True)
         base = torch.from_numpy(goff[:64].astype(np.int64) + n2 - cex).to(dev)
         Et = E
-        if plan.get("objects"):
+        if split:
+            Et = plan["entries_all"]
+        elif plan.get("objects"):
             Et = plan["entries"] if plan["entries"] is not None else int(plan["n_total"][0])
         dest = torch.empty(max(Et, 1), dtype=torch.int32, device=dev)
         dest[order] = (base[skeys] + torch.arange(E, device=dev)).int()
@@ -460,8 +516,16 @@ class RelHeadEngine:
             code = gather[E:Et].long()
             dest[E:Et] = (goff_d[:64].long()[code & 63] + (code >> 6) - P).int()
         gend = torch.from_numpy((goff[:64].astype(np.int64) + n2 + np.asarray(counts, dtype=np.int64)).astype(np.int32)).to(dev)
-        return dict(goff=goff_d, goff_host=goff, gend=gend, tile_group=torch.from_numpy(tile_group).to(dev), dest=dest, rows=int(goff[64]),
-                    E=E, E_total=Et, n2=n2)
+        dest_conv = dest
+        if split:
+            # destination of every entry of the CONV list: the same (pair, window) sits at  first(pair, all) + its rank in the pair's
+            # rectangle  in the list of all X windows (a pair is in the conv list with all of its windows or with none)
+            Ec = plan["entries"]
+            pair_k = (plan["gather"][:Ec] >> 6).long()
+            first = lambda inc: torch.cat([inc.new_zeros(1), inc[:-1]]).long()
+            dest_conv = dest[torch.arange(Ec, device=dev) - first(plan["incl"])[pair_k] + first(plan["incl_all"])[pair_k]].contiguous()
+        return dict(goff=goff_d, goff_host=goff, gend=gend, tile_group=torch.from_numpy(tile_group).to(dev), dest=dest, dest_conv=dest_conv,
+                    rows=int(goff[64]), E=E, E_total=Et, n2=n2)
 
     def fc1_shared(self, wm, ywm, bbox, sub_idx, obj_idx, incl, P, n_obj, h1, dropout, seed):
         """fc1 + ReLU (+ dropout) from the window-major rows: grouped GEMM, per-object 2-D prefix sums, per-pair assembly."""
@@ -526,8 +590,26 @@ class RelHeadEngine:
                     _lib.ptr(zt), _lib.ptr(self.w["w3r"]), _lib.ptr(self.w["b3"]), _lib.ptr(wm["goff"]), _lib.ptr(y), _lib.ptr(am_ps), _lib.ptr(y_bf),
                     n2, self._st()), "sgc_conv3_relu_pool_wm"))
             self._timed("conv3_fwd_windows", lambda: _lib.check(lib.sgc_conv3_relu_pool_windows_wm(
-                _lib.ptr(z), _lib.ptr(self.w["w3r"]), _lib.ptr(self.w["b3"]), _lib.ptr(gather), _lib.ptr(plan["n_total"]), _lib.ptr(wm["dest"]),
+                _lib.ptr(z), _lib.ptr(self.w["w3r"]), _lib.ptr(self.w["b3"]), _lib.ptr(gather), _lib.ptr(plan["n_total"]), _lib.ptr(wm["dest_conv"]),
                 plan["bound"], _lib.ptr(y), _lib.ptr(am), _lib.ptr(y_bf), self._st()), "sgc_conv3_relu_pool_windows_wm"))
+            lin = plan.get("lin")
+            if lin is not None and objects:
+                # linear pairs: their X windows are combined from the pre-activations of the per-object entries and of the images'
+                # background maps (one small raw launch of the gathered convolution: the list's per-object tail + 64 windows per image)
+                n_pe = plan["entries"] - plan["entries_real"]
+                bg_codes = ((P + n2 + torch.arange(n_img, device=self.device, dtype=torch.int32))[:, None] * 64
+                            + torch.arange(64, device=self.device, dtype=torch.int32)[None, :]).reshape(-1)
+                raw_list = torch.cat([gather[plan["entries_real"]:plan["entries"]], bg_codes]).contiguous()
+                n_raw = n_pe + 64 * n_img
+                raw_n = torch.full((1,), n_raw, dtype=torch.int32, device=self.device)
+                raw = sc.get("raw_pre", n_raw * 4 * 1024, torch.float32)
+                self._timed("conv3_fwd_raw", lambda: _lib.check(lib.sgc_conv3_windows_raw(
+                    _lib.ptr(z), _lib.ptr(self.w["w3r"]), _lib.ptr(raw_list), _lib.ptr(raw_n), n_raw, _lib.ptr(raw), self._st()),
+                    "sgc_conv3_windows_raw"))
+                self._timed("conv3_fwd_linear", lambda: _lib.check(lib.sgc_windows_linear_forward(
+                    _lib.ptr(bbox), _lib.ptr(sub_idx), _lib.ptr(obj_idx), _lib.ptr(obj_img), n_obj, P, _lib.ptr(lin["gather"]), _lib.ptr(lin["n"]),
+                    lin["max"], _lib.ptr(plan["incl_all"]), _lib.ptr(wm["dest"]), _lib.ptr(raw), _c_long(n_pe), _lib.ptr(self.w["b3"]),
+                    _lib.ptr(y), _lib.ptr(y_bf), _lib.ptr(am), self._st()), "sgc_windows_linear_forward"))
             out["am_ps"] = am_ps
             return out
         am_ps = own.get("am_ps", n2 * 65536, torch.uint8) if am is not None else None
@@ -556,7 +638,7 @@ class RelHeadEngine:
             n_img = int(U.numel()) // (1024 * 512) - n_obj                 # the background objects behind the real ones
             wm_mode = shared_fc1_enabled()
             plan = self.shared_plan(shared[0], sub_idx, obj_idx, P, shared[2], n_obj=n_obj, n_img=n_img,
-                                    objects=wm_mode and shared_objects_enabled())
+                                    objects=wm_mode and shared_objects_enabled(), obj_img=shared[1])
             Pt = P + 2 * n_obj + n_img
         z = ws.get("z_pad", Pt * 18 * 18 * 512, torch.float16)     # border stays zero: only interiors are written
         self.expand(U, V, sub_idx, obj_idx, P, z, dense=dense, pixrect=None if plan is None else plan["pixrect"])
@@ -567,7 +649,7 @@ class RelHeadEngine:
             wm = self.window_major_rows(plan, P, 2 * n_obj)
             ywm = ws.get("ywm", wm["rows"] * 1024, torch.float16)
             self.conv3_shared(plan, z, U, V, shared[0], shared[1], sub_idx, obj_idx, P, ywm, am, None, wm=wm)
-            self.fc1_shared(wm, ywm, shared[0], sub_idx, obj_idx, plan["incl"], P, n_obj, h1, train, seeds[0])
+            self.fc1_shared(wm, ywm, shared[0], sub_idx, obj_idx, plan.get("incl_all", plan["incl"]), P, n_obj, h1, train, seeds[0])
         else:
             y = ws.get("y", Ppad * 65536, torch.float16)
             if shared is not None:
@@ -736,7 +818,7 @@ class RelHeadEngine:
         narrow = share and TUNING.shared_bwd
         wm_mode = narrow and shared_fc1_enabled()
         plan = self.shared_plan(bbox, sub_idx, obj_idx, P, shared_windows, keep=True, n_obj=ctx.n_obj, n_img=ctx.n_img,
-                                objects=wm_mode and shared_objects_enabled()) if share else None
+                                objects=wm_mode and shared_objects_enabled(), obj_img=obj_img) if share else None
         Pt = P + (2 * ctx.n_obj + ctx.n_img if share else 0)         # pseudo-pairs and background maps live behind the real pairs
         z = sc.get("z_pad", Pt * 18 * 18 * 512, torch.float16)
         z_bf = ws.get("z_pad_bf", Pt * 18 * 18 * 512, torch.bfloat16)
@@ -753,7 +835,7 @@ class RelHeadEngine:
             ywm_bf = ws.get("ywm_bf", wm["rows"] * 1024, torch.bfloat16)
             ctx.shared = self.conv3_shared(plan, z, ctx.uv[0], ctx.uv[1], bbox, obj_img, sub_idx, obj_idx, P, ywm, am, ywm_bf, keep=(z_bf, amz), wm=wm)
             ctx.shared["ywm_bf"] = ywm_bf
-            self.fc1_shared(wm, ywm, bbox, sub_idx, obj_idx, plan["incl"], P, ctx.n_obj, h1, dropout, seeds[0])
+            self.fc1_shared(wm, ywm, bbox, sub_idx, obj_idx, plan.get("incl_all", plan["incl"]), P, ctx.n_obj, h1, dropout, seeds[0])
         else:
             y = sc.get("y", Ppad * 65536, torch.float16)
             y_bf = ws.get("y_bf", Ppad * 65536, torch.bfloat16)     # bf16 copy for the fc1 weight gradient, written by the same epilogue
@@ -979,7 +1061,7 @@ class RelHeadEngine:
             _lib.check(lib.sgc_fc1_gsum(_lib.ptr(dh1), _lib.ptr(ctx.bbox), _lib.ptr(ctx.sub_idx), _lib.ptr(ctx.obj_idx), _lib.ptr(sub_csr[0]),
                                         _lib.ptr(sub_csr[1]), _lib.ptr(obj_csr[0]), _lib.ptr(obj_csr[1]), _lib.ptr(wm["goff"]), ctx.n_obj,
                                         _lib.ptr(gwm), st()), "sgc_fc1_gsum"),
-            _lib.check(lib.sgc_fc1_xrows(_lib.ptr(dh1), _lib.ptr(sh["gather"]), _lib.ptr(wm["dest"]), wm["E"], _lib.ptr(wm["goff"]),
+            _lib.check(lib.sgc_fc1_xrows(_lib.ptr(dh1), _lib.ptr(sh.get("gather_all", sh["gather"])), _lib.ptr(wm["dest"]), wm["E"], _lib.ptr(wm["goff"]),
                                          _lib.ptr(wm["gend"]), _lib.ptr(gwm), _lib.ptr(sh["ywm_bf"]), st()), "sgc_fc1_xrows")))
         dy = ws.get("dywm", wm["rows"] * 1024, torch.bfloat16)
 
@@ -1071,29 +1153,57 @@ class RelHeadEngine:
                     _lib.ptr(ctx.bbox), _lib.ptr(ctx.sub_idx), _lib.ptr(ctx.obj_idx), _lib.ptr(sub_csr[0]), _lib.ptr(sub_csr[1]), _lib.ptr(obj_csr[0]),
                     _lib.ptr(obj_csr[1]), n_obj, _lib.ptr(dy), _lib.ptr(dy_maps), st()), "sgc_shared_windows_assemble_bwd"))
             am_maps = sh["am_ps"]
-        dest = wm["dest"] if wm is not None else None
+        dest = wm["dest_conv"] if wm is not None else None
+        lin = sh.get("lin") if objects else None
         z_bf_maps = z_bf[map0 * 18 * 18 * 512:]
         dz_maps = dz[map0 * 256 * 512:]
         bpart = ws.get("b3_part", 2048 * 1024, torch.float32)
         bpart_x = ws.get("b3_part_x", 1024 * 1024, torch.float32)
         pack_a = ws.get("w3_pack_a", n_maps * 4 * 1024 * 64, torch.uint8)
         pack_i = ws.get("w3_pack_i", n_maps * 4 * 1024 * 8, torch.uint8)
-        self._timed("unpool_objects", lambda: _lib.check(lib.sgc_unpool_relu_bwd_pack(
-            _lib.ptr(dy_maps), _lib.ptr(am_maps), None, _lib.ptr(bpart), ctypes.byref(nparts), _lib.ptr(pack_a), _lib.ptr(pack_i), n_maps, st()),
-            "sgc_unpool_relu_bwd_pack"))
+        dy3_bg = bpart_l = None
+        if lin is None:
+            self._timed("unpool_objects", lambda: _lib.check(lib.sgc_unpool_relu_bwd_pack(
+                _lib.ptr(dy_maps), _lib.ptr(am_maps), None, _lib.ptr(bpart), ctypes.byref(nparts), _lib.ptr(pack_a), _lib.ptr(pack_i), n_maps, st()),
+                "sgc_unpool_relu_bwd_pack"))
+        else:
+            # the background maps also collect (minus) the gradient of the linear pairs' windows: their un-pooled gradient is dense,
+            # so they take the two-pass un-pool and the dense conv3 backward (n_img maps)
+            dy3_bg = ws.get("dy3_bg_pad", n_maps * 18 * 18 * 1024, torch.bfloat16)        # created zeroed: the halo stays zero
+            self._timed("unpool_objects", lambda: _lib.check(lib.sgc_unpool_relu_bwd(
+                _lib.ptr(dy_maps), _lib.ptr(am_maps), _lib.ptr(dy3_bg), _lib.ptr(bpart), ctypes.byref(nparts), n_maps, st()), "sgc_unpool_relu_bwd"))
         # ---- listed windows: compact un-pool
         dy3x = ws.get("dy3x", max(Epad, 16) * 4 * 1024, torch.bfloat16)
         self._timed("unpool_windows", lambda: _lib.check(lib.sgc_windows_unpool(
             _lib.ptr(dy), _lib.ptr(ctx.am), _lib.ptr(gather), _lib.ptr(gn), _lib.ptr(dest), Epad, _lib.ptr(dy3x), _lib.ptr(bpart_x),
             ctypes.byref(nparts_x), st()), "sgc_windows_unpool"))
+        if lin is not None:
+            # transpose of sgc_windows_linear_forward: + into the un-pooled rows of the two per-object entries, - into the background map
+            e_real = sh["entries_real"]
+            bpart_l = ws.get("b3_part_l", 64 * n_img * 1024, torch.float32)
+            self._timed("linear_bwd", lambda: (
+                _lib.check(lib.sgc_windows_linear_backward_objects(
+                    _lib.ptr(ctx.bbox), _lib.ptr(ctx.sub_idx), _lib.ptr(ctx.obj_idx), _lib.ptr(sub_csr[0]), _lib.ptr(sub_csr[1]), _lib.ptr(obj_csr[0]),
+                    _lib.ptr(obj_csr[1]), n_obj, P, _lib.ptr(gather), e_real, E - e_real, _lib.ptr(sh["incl_all"]), _lib.ptr(wm["dest"]),
+                    _lib.ptr(dy), _lib.ptr(ctx.am), _lib.ptr(dy3x), st()), "sgc_windows_linear_backward_objects"),
+                _lib.check(lib.sgc_windows_linear_backward_bg(
+                    _lib.ptr(ctx.bbox), _lib.ptr(ctx.sub_idx), _lib.ptr(ctx.obj_idx), _lib.ptr(lin["gather"]), _lib.ptr(lin["order"]),
+                    _lib.ptr(lin["seg"]), n_img, _lib.ptr(sh["incl_all"]), _lib.ptr(wm["dest"]), _lib.ptr(dy), _lib.ptr(ctx.am),
+                    _lib.ptr(dy3_bg), _lib.ptr(bpart_l), st()), "sgc_windows_linear_backward_bg")))
         with side():
             gb = self._slab_sum(bpart, 1024, nparts.value)
             if nparts_x.value:
                 gb = gb + self._slab_sum(bpart_x, 1024, nparts_x.value)
+            if bpart_l is not None:
+                gb = gb + self._slab_sum(bpart_l, 1024, 64 * n_img)
             grads["conv3_1.bias"] = gb
-            self._timed("conv3_wgrad_objects", lambda: _lib.check(lib.sgc_conv3_wgrad_sparse(
-                None, None, _lib.ptr(z_bf_maps), _lib.ptr(pack_a), _lib.ptr(pack_i), _lib.ptr(sl), n_maps, 0, ctypes.byref(slabs_n), st()),
-                "sgc_conv3_wgrad_sparse"))
+            if lin is None:
+                self._timed("conv3_wgrad_objects", lambda: _lib.check(lib.sgc_conv3_wgrad_sparse(
+                    None, None, _lib.ptr(z_bf_maps), _lib.ptr(pack_a), _lib.ptr(pack_i), _lib.ptr(sl), n_maps, 0, ctypes.byref(slabs_n), st()),
+                    "sgc_conv3_wgrad_sparse"))
+            else:
+                self._timed("conv3_wgrad_objects", lambda: _lib.check(lib.sgc_conv3_wgrad(
+                    _lib.ptr(dy3_bg), _lib.ptr(z_bf_maps), _lib.ptr(sl), n_maps, 0, ctypes.byref(slabs_n), st()), "sgc_conv3_wgrad"))
             zcol = None
             if Epad:
                 # im2col + plain ping-pong TN GEMM.  (Rows of z gathered by the window list inside the GEMM block - no column
@@ -1118,8 +1228,12 @@ class RelHeadEngine:
         if not TUNING.gemms_apart:
             wgrad_windows()
         # ---- data gradients
-        self._timed("conv3_dgrad_objects", lambda: _lib.check(lib.sgc_conv3_dgrad_pooled(
-            _lib.ptr(dy_maps), _lib.ptr(am_maps), _lib.ptr(w["wd3"]), _lib.ptr(dz_maps), n_maps, st()), "sgc_conv3_dgrad_pooled"))
+        if lin is None:
+            self._timed("conv3_dgrad_objects", lambda: _lib.check(lib.sgc_conv3_dgrad_pooled(
+                _lib.ptr(dy_maps), _lib.ptr(am_maps), _lib.ptr(w["wd3"]), _lib.ptr(dz_maps), n_maps, st()), "sgc_conv3_dgrad_pooled"))
+        else:
+            self._timed("conv3_dgrad_objects", lambda: _lib.check(lib.sgc_conv3_dgrad(
+                _lib.ptr(dy3_bg), _lib.ptr(w["wd3"]), _lib.ptr(dz_maps), n_maps, st()), "sgc_conv3_dgrad"))
         if Epad:
             col = ws.get("xcol", Epad * 4 * 9 * 512, torch.bfloat16)
             self._timed("conv3_dgrad_windows", lambda: _lib.check(lib.sgc_windows_dgrad_cols(_lib.ptr(dy3x), _lib.ptr(w["w3col"]), _lib.ptr(col), Epad * 4, st()),

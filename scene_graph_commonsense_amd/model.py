@@ -28,7 +28,8 @@ def _shared_hint(scene):
     """What the host already knows about the scene's pair-specific windows (count, per-window counts) - saves a device read-back."""
     n = getattr(scene, "shared_windows", None)
     return None if n is None else dict(windows=n, per_window=getattr(scene, "window_entries", None),
-                                       object_windows=getattr(scene, "object_windows", None))
+                                       object_windows=getattr(scene, "object_windows", None),
+                                       linear_windows=getattr(scene, "linear_windows", None))
 
 
 def _dense(scene):

@@ -217,6 +217,39 @@ def count_shared_windows(bb: np.ndarray, img_ptr) -> int:
     return total
 
 
+def object_d16_rects(bb: np.ndarray) -> np.ndarray:
+    """[n,4] normalised boxes -> [n,4] half-open rectangles (x0,x1,y0,y1) on the 16-grid of conv3's INPUT where the object's conv2
+    half differs from the background's: the box, +-1 pixel (conv2_1 is 3x3), pooled 2x2 (host replica of
+    ``csrc/kernels_shared.hip:axis_d16``; zero rectangle for an empty box)."""
+    bb = np.asarray(bb, dtype=np.int64).reshape(-1, 4)
+    out = np.zeros_like(bb)
+    for a in (0, 2):
+        lo, hi = np.clip(bb[:, a], 0, None), np.clip(bb[:, a + 1], None, 32)
+        ok = hi > lo
+        lo, hi = np.maximum(lo - 1, 0), np.minimum(hi + 1, 32)
+        out[:, a], out[:, a + 1] = np.where(ok, lo >> 1, 0), np.where(ok, (hi + 1) >> 1, 0)
+    return out
+
+
+def count_linear_windows(bb: np.ndarray, img_ptr) -> int:
+    """X windows of the LINEAR pairs (``csrc/kernels_shared.hip``, sixth identity): ordered pairs whose window rectangles intersect
+    while their 16-grid regions of influence do not - their conv3 pre-activation on those windows is the sum of per-object ones."""
+    r, d = object_window_rects(bb), object_d16_rects(bb)
+    total = 0
+    for b in range(len(img_ptr) - 1):
+        q, e = r[int(img_ptr[b]):int(img_ptr[b + 1])], d[int(img_ptr[b]):int(img_ptr[b + 1])]
+        if len(q) < 2:
+            continue
+        ox = np.clip(np.minimum(q[:, None, 1], q[None, :, 1]) - np.maximum(q[:, None, 0], q[None, :, 0]), 0, None)
+        oy = np.clip(np.minimum(q[:, None, 3], q[None, :, 3]) - np.maximum(q[:, None, 2], q[None, :, 2]), 0, None)
+        a = ox * oy
+        meet = (np.minimum(e[:, None, 1], e[None, :, 1]) > np.maximum(e[:, None, 0], e[None, :, 0])) & \
+               (np.minimum(e[:, None, 3], e[None, :, 3]) > np.maximum(e[:, None, 2], e[None, :, 2]))
+        np.fill_diagonal(a, 0)
+        total += int(a[~meet].sum())
+    return total
+
+
 def count_object_windows(bb: np.ndarray) -> int:
     """Windows of the pseudo-pairs (o, background) and (background, o) that are computed per object (second level of sharing):
     2 * sum |R_o|."""
@@ -332,6 +365,7 @@ def flatten_scene(cfg, batch, device) -> DeviceScene:
                        shared_windows=count_shared_windows(bb, img_ptr) if (n_obj and F == 32) else None,
                        window_entries=window_entry_counts(bb, img_ptr) if (n_obj and F == 32) else None,
                        object_windows=count_object_windows(bb) if (n_obj and F == 32) else None,
+                       linear_windows=count_linear_windows(bb, img_ptr) if (n_obj and F == 32) else None,
                        _rel_src=getattr(batch, "relationships", None) if rel is not None else None)
 
 

@@ -17,6 +17,9 @@ def _always_shared(monkeypatch):
     switch such a scene to the per-pair kernels (``shared_conv3_enabled``).  Here the shared path is the subject."""
     from scene_graph_commonsense_amd import engine
     monkeypatch.setattr(engine.TUNING, "shared_max_fraction", 2.0)
+    # the bit-for-bit statements of this file are about windows that are CONVOLVED; the linear pairs' windows (combined from three
+    # per-object pre-activations: f32 round-off apart) have their own test, test_linear_pairs_*
+    monkeypatch.setattr(engine.TUNING, "shared_linear", False)
 
 
 def _model(cfg, seed=1):
@@ -265,3 +268,46 @@ def test_scenes_that_are_mostly_pair_specific_use_the_per_pair_kernels(monkeypat
     assert l0 == l1
     for n in g0:
         assert torch.equal(g0[n], g1[n]), n
+
+
+def test_linear_pairs_combined_windows_match_convolved_windows(monkeypatch):
+    """Sixth identity (csrc/kernels_shared.hip, "linear pairs"): a pair whose two objects' regions of influence on the 16-grid are
+    disjoint gets its X windows from  pre_(i,bg) + pre_(bg,j) - pre_(bg,bg)  instead of a convolution of its own.  Exact in real
+    arithmetic; on the device three f32 accumulations are added instead of one, so the training step with the identity ON must
+    reproduce the step with it OFF to f32 round-off in the forward (an f16 ulp on h1 here and there, a max-pool route flipped at
+    an exact near-tie) and to the bf16 noise of one more summation level in the gradients."""
+    from scene_graph_commonsense_amd import engine
+    from scene_graph_commonsense_amd.pairs import flatten_scene
+    from scene_graph_commonsense_amd.synthetic import HeadConfig, make_scene_batch
+    monkeypatch.setattr(engine.TUNING, "shared_max_fraction", 0.5)
+    cfg = HeadConfig()
+    model = _model(cfg, seed=3)
+    batch = make_scene_batch(cfg, [24, 17, 9, 30], seed=31, connect_frac=0.2)
+    sc = flatten_scene(cfg, batch, "cuda:0")
+    assert sc.linear_windows > 0.05 * sc.shared_windows, (sc.linear_windows, sc.shared_windows)
+
+    def run():
+        eng = model.refresh_weights(backward=True)
+        _poison(eng)
+        model.zero_grad(set_to_none=True)
+        loss = model.training_step(sc)
+        torch.cuda.synchronize()
+        out = model.last_outputs
+        return (float(loss), out.relation.clone(), out.hidden.clone(), out.connectivity.clone(),
+                {n: p.grad.clone() for n, p in model.named_parameters()}, getattr(eng, "_xw_linear", None))
+
+    with engine.tuning(shared_linear=False):
+        l0, r0, h0, c0, g0, x0 = run()
+    with engine.tuning(shared_linear=True):
+        l1, r1, h1, c1, g1, x1 = run()
+    assert x0 is None and x1 is not None and x1[0] == sc.linear_windows
+    print("linear windows %d of %d X windows; loss %.6f vs %.6f" % (sc.linear_windows, sc.shared_windows, l0, l1))
+    assert torch.isfinite(r1).all() and torch.isfinite(h1).all()
+    assert abs(l0 - l1) <= 1e-5 * abs(l0)
+    scale = float(h0.abs().max())
+    assert float((h0 - h1).abs().max()) <= 2e-3 * scale                         # a handful of f16 ulps of h1 through fc2
+    assert float((r0 - r1).abs().max()) <= 1e-4 and float((c0 - c1).abs().max()) <= 1e-4 * max(1.0, float(c0.abs().max()))
+    worst = {n: float((g0[n].double() - g1[n].double()).norm() / g0[n].double().norm().clamp(min=1e-30)) for n in g0}
+    print({k: "%.1e" % v for k, v in worst.items()})
+    for n, e in worst.items():
+        assert e <= 5e-3, (n, e)
