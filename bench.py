@@ -356,7 +356,7 @@ def run_rank(args):
         dom = "conv3_fwd_windows"
         from scene_graph_commonsense_amd.engine import TUNING
         two_streams = TUNING.bwd_streams and not args.forward_only
-        fwd_only = ("conv2_fwd", "expand_dense", "expand", "expand_train", "conv3_fwd", "conv3_fwd_objects", "conv3_fwd_windows",
+        fwd_only = ("conv2_fwd", "expand_dense", "expand", "expand_train", "conv3_fwd", "conv3_fwd_objects", "conv3_fwd_windows", "conv3_fwd_raw", "conv3_fwd_linear",
                     "conv3_fwd_assemble", "fc1_fwd", "fc1_fwd_windows", "fc1_fwd_integral", "fc1_fwd_assemble", "fc2_fwd")
         xw = True if m["shared"] else None
         n_x, n_list = m["n_x"], m["n_list"]          # X windows; X windows + the pseudo-pairs' own windows

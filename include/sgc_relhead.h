@@ -100,6 +100,11 @@ int sgc_shared_windows_fill_class(const int* bbox, const int* sub_idx, const int
                                   int cls, void* stream);
 int sgc_conv3_windows_raw(const void* z_pad, const void* w3r, const int* gather, const int* gather_n, int max_entries, float* raw,
                           void* stream);
+/* sgc_conv3_relu_pool_windows_wm that also stores the accumulators (no bias / ReLU / pooling) of the entries e >= raw_first - the
+ * per-object entries at the tail of the list - to raw[(e - raw_first)*4 + pixel][1024] f32: no second launch for them */
+int sgc_conv3_relu_pool_windows_wm_raw(const void* z_pad, const void* w3r, const float* b3, const int* gather, const int* gather_n,
+                                       const int* dest, int max_entries, void* ywm, unsigned char* argmax, void* ywm_bf16, float* raw,
+                                       int raw_first, void* stream);
 int sgc_windows_linear_forward(const int* bbox, const int* sub_idx, const int* obj_idx, const int* obj_img, int n_obj, int n_real_pairs,
                                const int* gather_linear, const int* n_linear, int max_linear, const int* count_incl_all,
                                const int* dest_all, const float* raw, long n_object_entries, const float* b3, void* ywm, void* ywm_bf16,

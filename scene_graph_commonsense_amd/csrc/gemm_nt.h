@@ -44,6 +44,8 @@ struct NtParams {
     // window-major row space of the shared fc1 (csrc/kernels_shared.hip): rows grouped by pooling window, groups padded to 256 rows
     const int* dest;                                // AMODE_CONV_GATHER + EPI_POOL: y / bf16 copy of entry e go to row dest[e] (argmax stays at gather[e])
     const int* wm_goff;                             // EPI_POOL: y / bf16 copy of pooled row r go to row wm_goff[r & 63] + (r >> 6) (argmax stays at r)
+    float* raw; int raw_first;                      // AMODE_CONV_GATHER + EPI_POOL: the accumulators (no bias / ReLU / pooling) of the entries
+                                                    // e >= raw_first also go to raw[(e - raw_first) * 4 + pixel][ldc] (linear pairs, kernels_shared.hip)
     const int* tile_group; long group_stride;       // gemm_nt_pp_kernel: M tile t multiplies with B + tile_group[t] * group_stride
 };
 
@@ -93,7 +95,13 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x16 (&acc)[TM]
                     const int prow = (rbase >> 2) + 2 * w + h;
                     if (prow * 4 < M) {
                         long arow = prow, yrow = prow;
-                        if constexpr (GATHER) { arow = p.gather[prow]; yrow = p.dest ? p.dest[prow] : arow; }
+                        if constexpr (GATHER) {
+                            arow = p.gather[prow]; yrow = p.dest ? p.dest[prow] : arow;
+                            if (p.raw && prow >= p.raw_first) {
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) p.raw[((long)(prow - p.raw_first) * 4 + q) * p.ldc + col] = acc[i][j][4 * w + q];
+                            }
+                        }
                         else if (p.wm_goff) yrow = p.wm_goff[prow & 63] + (prow >> 6);
                         if (!(v > 0.f)) { v = 0.f; am = 4; }        // ReLU killed: no gradient path
                         out[yrow * p.ldc + col] = to_elem<ELEM>(v);

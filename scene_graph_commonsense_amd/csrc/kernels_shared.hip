@@ -1053,6 +1053,17 @@ int sgc_conv3_relu_pool_windows_wm(const void* z_pad, const void* w3r, const flo
     if (sgc_tuning().gather_pp) return launch_gemm_nt_pp_conv_gather<ELEM_F16, EPI_POOL>(p, (hipStream_t)stream);
     return launch_gemm_nt_cfg<ELEM_F16, AMODE_CONV_GATHER, EPI_POOL, 2, 4, 4, 2>(p, (hipStream_t)stream);
 }
+// the same, also writing the accumulators (before bias / ReLU / pooling) of the entries e >= raw_first to raw[(e - raw_first)*4 + pixel]
+int sgc_conv3_relu_pool_windows_wm_raw(const void* z_pad, const void* w3r, const float* b3, const int* gather, const int* gather_n,
+                                       const int* dest, int max_entries, void* ywm, unsigned char* argmax, void* ywm_bf16, float* raw,
+                                       int raw_first, void* stream) {
+    if (max_entries <= 0) return SGC_OK;
+    NtParams p{};
+    p.A = (const u16*)z_pad; p.B = (const u16*)w3r; p.C = ywm; p.M = max_entries * 4; p.N = 1024; p.K = 9 * 512;
+    p.ldb = 9 * 512; p.ldc = 1024; p.lgS = 4; p.Cin = 512; p.bias = b3; p.argmax = argmax; p.C2 = (u16*)ywm_bf16;
+    p.gather = gather; p.gather_n = gather_n; p.dest = dest; p.raw = raw; p.raw_first = raw_first;
+    return launch_gemm_nt_pp_conv_gather<ELEM_F16, EPI_POOL>(p, (hipStream_t)stream);
+}
 // owm [rows][4096] f32 = ywm [rows][1024] f16 * w1p[:, g*1024 .. +1024]^T, g = tile_group[row / 256]  (rows a multiple of 256)
 int sgc_fc1_windows_gemm(const void* ywm, const void* w1p, const int* tile_group, float* owm, int rows, void* stream) {
     if (rows <= 0) return SGC_OK;

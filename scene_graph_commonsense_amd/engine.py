@@ -589,22 +589,26 @@ class RelHeadEngine:
                 self._timed("conv3_fwd_objects", lambda: _lib.check(lib.sgc_conv3_relu_pool_wm(
                     _lib.ptr(zt), _lib.ptr(self.w["w3r"]), _lib.ptr(self.w["b3"]), _lib.ptr(wm["goff"]), _lib.ptr(y), _lib.ptr(am_ps), _lib.ptr(y_bf),
                     n2, self._st()), "sgc_conv3_relu_pool_wm"))
-            self._timed("conv3_fwd_windows", lambda: _lib.check(lib.sgc_conv3_relu_pool_windows_wm(
-                _lib.ptr(z), _lib.ptr(self.w["w3r"]), _lib.ptr(self.w["b3"]), _lib.ptr(gather), _lib.ptr(plan["n_total"]), _lib.ptr(wm["dest_conv"]),
-                plan["bound"], _lib.ptr(y), _lib.ptr(am), _lib.ptr(y_bf), self._st()), "sgc_conv3_relu_pool_windows_wm"))
-            lin = plan.get("lin")
-            if lin is not None and objects:
-                # linear pairs: their X windows are combined from the pre-activations of the per-object entries and of the images'
-                # background maps (one small raw launch of the gathered convolution: the list's per-object tail + 64 windows per image)
+            lin = plan.get("lin") if objects else None
+            if lin is None:
+                self._timed("conv3_fwd_windows", lambda: _lib.check(lib.sgc_conv3_relu_pool_windows_wm(
+                    _lib.ptr(z), _lib.ptr(self.w["w3r"]), _lib.ptr(self.w["b3"]), _lib.ptr(gather), _lib.ptr(plan["n_total"]), _lib.ptr(wm["dest_conv"]),
+                    plan["bound"], _lib.ptr(y), _lib.ptr(am), _lib.ptr(y_bf), self._st()), "sgc_conv3_relu_pool_windows_wm"))
+            else:
+                # linear pairs: their X windows are combined from the pre-activations of the per-object entries (the tail of the list:
+                # the same launch stores their accumulators) and of the images' background maps (a 64 n_img-window launch of their own)
                 n_pe = plan["entries"] - plan["entries_real"]
-                bg_codes = ((P + n2 + torch.arange(n_img, device=self.device, dtype=torch.int32))[:, None] * 64
-                            + torch.arange(64, device=self.device, dtype=torch.int32)[None, :]).reshape(-1)
-                raw_list = torch.cat([gather[plan["entries_real"]:plan["entries"]], bg_codes]).contiguous()
                 n_raw = n_pe + 64 * n_img
-                raw_n = torch.full((1,), n_raw, dtype=torch.int32, device=self.device)
                 raw = sc.get("raw_pre", n_raw * 4 * 1024, torch.float32)
+                self._timed("conv3_fwd_windows", lambda: _lib.check(lib.sgc_conv3_relu_pool_windows_wm_raw(
+                    _lib.ptr(z), _lib.ptr(self.w["w3r"]), _lib.ptr(self.w["b3"]), _lib.ptr(gather), _lib.ptr(plan["n_total"]), _lib.ptr(wm["dest_conv"]),
+                    plan["bound"], _lib.ptr(y), _lib.ptr(am), _lib.ptr(y_bf), _lib.ptr(raw), plan["entries_real"], self._st()),
+                    "sgc_conv3_relu_pool_windows_wm_raw"))
+                bg_codes = ((P + n2 + torch.arange(n_img, device=self.device, dtype=torch.int32))[:, None] * 64
+                            + torch.arange(64, device=self.device, dtype=torch.int32)[None, :]).reshape(-1).contiguous()
+                raw_n = torch.full((1,), 64 * n_img, dtype=torch.int32, device=self.device)
                 self._timed("conv3_fwd_raw", lambda: _lib.check(lib.sgc_conv3_windows_raw(
-                    _lib.ptr(z), _lib.ptr(self.w["w3r"]), _lib.ptr(raw_list), _lib.ptr(raw_n), n_raw, _lib.ptr(raw), self._st()),
+                    _lib.ptr(z), _lib.ptr(self.w["w3r"]), _lib.ptr(bg_codes), _lib.ptr(raw_n), 64 * n_img, _lib.ptr(raw[n_pe * 4096:]), self._st()),
                     "sgc_conv3_windows_raw"))
                 self._timed("conv3_fwd_linear", lambda: _lib.check(lib.sgc_windows_linear_forward(
                     _lib.ptr(bbox), _lib.ptr(sub_idx), _lib.ptr(obj_idx), _lib.ptr(obj_img), n_obj, P, _lib.ptr(lin["gather"]), _lib.ptr(lin["n"]),

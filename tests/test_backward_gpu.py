@@ -52,8 +52,9 @@ def run_train(cfg, sd, batch, dropout=False):
     sub_csr = tuple(torch.from_numpy(a).to(dev) for a in csr_by(pidx.sub, n_obj))
     obj_csr = tuple(torch.from_numpy(a).to(dev) for a in csr_by(pidx.obj, n_obj))
     img_ptr = torch.from_numpy(pidx.obj_offset.astype(np.int32)).to(dev)
+    from scene_graph_commonsense_amd.model import _shared_hint
     ctx = eng.train_forward(sc.image_feature, sc.image_depth, sc.obj_img, sc.bbox, sc.cats, sc.super_mh, sc.sub_idx, sc.obj_idx,
-                            dropout=dropout)
+                            dropout=dropout, shared_windows=_shared_hint(sc))
     loss, grads = eng.train_backward(ctx, coefs_d, sub_csr, obj_csr, img_ptr)
     torch.cuda.synchronize()
     return float(loss), {k: v.float().cpu() for k, v in grads.items()}
