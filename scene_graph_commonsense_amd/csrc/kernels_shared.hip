@@ -868,46 +868,52 @@ __global__ __launch_bounds__(256) void windows_linear_bwd_objects_kernel(const i
 // Backward, background side: the un-pooled gradient of every combined window is SUBTRACTED from its image's background map
 // (dy3_bg [n_img][18][18][1024] bf16, interior already holding the map's own un-pooled gradient) and counts once for conv3's bias.
 // order [n_l]: the listed windows sorted by (image, window) (stable: sums in list order); seg [64 n_img + 1] their ranges.
-// One wavefront per (image, window); bias_part [64 n_img][1024].
+// One wavefront per (image, window, quarter of the channels) - a (image, window) sums ~60 windows on the benchmark, and there are
+// only 64 n_img of them: the channel split is what fills the chip (0.88 ms with one wavefront per (image, window));
+// bias_part [64 n_img][1024].
 __global__ __launch_bounds__(256) void windows_linear_bwd_bg_kernel(const int* __restrict__ bbox, const int* __restrict__ sub, const int* __restrict__ obj,
                                                                     const int* __restrict__ gather_l, const int* __restrict__ order,
                                                                     const int* __restrict__ seg, int n_items,
                                                                     const int* __restrict__ incl_all, const int* __restrict__ dest_all,
                                                                     const u16* __restrict__ dy, const unsigned char* __restrict__ am,
                                                                     u16* __restrict__ dy3_bg, float* __restrict__ bias_part) {
-    const int lane = threadIdx.x & 63, c0 = lane * 16;
-    for (int it = blockIdx.x * 4 + (threadIdx.x >> 6); it < n_items; it += gridDim.x * 4) {
+    const int lane = threadIdx.x & 63;
+    for (int job = blockIdx.x * 4 + (threadIdx.x >> 6); job < 4 * n_items; job += gridDim.x * 4) {
+        const int it = job >> 2, c0 = (job & 3) * 256 + lane * 4;
         const int b = it >> 6, w = it & 63, wy = w >> 3, wx = w & 7;
-        float acc[4][16];
+        float acc[4][4];
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int c = 0; c < 16; ++c) acc[q][c] = 0.f;
+            for (int c = 0; c < 4; ++c) acc[q][c] = 0.f;
         for (int s = seg[it]; s < seg[it + 1]; ++s) {
             const int code = gather_l[order[s]];
             const int p = code >> 6;
             const WRect x = pair_windows(object_windows(bbox + 4 * sub[p]), object_windows(bbox + 4 * obj[p]));
             const long drow = dest_all[(p ? incl_all[p - 1] : 0) + rect_local(x, wx, wy)];
-            linear_unpool_acc(acc, dy + drow * 1024, am + (long)code * 1024, c0);
-        }
-        float bs[16];
+            const uint2 g = *reinterpret_cast<const uint2*>(dy + drow * 1024 + c0);
+            const unsigned cd = *reinterpret_cast<const unsigned*>(am + (long)code * 1024 + c0);
+            const u16* gh = reinterpret_cast<const u16*>(&g);
 #pragma unroll
-        for (int c = 0; c < 16; ++c) bs[c] = 0.f;
+            for (int c = 0; c < 4; ++c) {
+                const float v = bf16_bits_to_f32(gh[c]);
+                const unsigned k = (cd >> (8 * c)) & 255u;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q][c] += (k == (unsigned)q) ? v : 0.f;
+            }
+        }
+        float bs[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int Y = 2 * wy + (q >> 1) + 1, X = 2 * wx + (q & 1) + 1;
             u16* row = dy3_bg + (((long)b * 18 + Y) * 18 + X) * 1024 + c0;
-            u16 h[16];
-            *reinterpret_cast<uint4*>(h) = *reinterpret_cast<const uint4*>(row);
-            *reinterpret_cast<uint4*>(h + 8) = *reinterpret_cast<const uint4*>(row + 8);
+            uint2 hv = *reinterpret_cast<const uint2*>(row);
+            u16* h = reinterpret_cast<u16*>(&hv);
 #pragma unroll
-            for (int c = 0; c < 16; ++c) { h[c] = f32_to_bf16_bits(bf16_bits_to_f32(h[c]) - acc[q][c]); bs[c] += acc[q][c]; }
-            *reinterpret_cast<uint4*>(row) = *reinterpret_cast<const uint4*>(h);
-            *reinterpret_cast<uint4*>(row + 8) = *reinterpret_cast<const uint4*>(h + 8);
+            for (int c = 0; c < 4; ++c) { h[c] = f32_to_bf16_bits(bf16_bits_to_f32(h[c]) - acc[q][c]); bs[c] += acc[q][c]; }
+            *reinterpret_cast<uint2*>(row) = hv;
         }
-#pragma unroll
-        for (int v = 0; v < 4; ++v)
-            reinterpret_cast<float4*>(bias_part + (long)it * 1024 + c0)[v] = make_float4(bs[4 * v], bs[4 * v + 1], bs[4 * v + 2], bs[4 * v + 3]);
+        *reinterpret_cast<float4*>(bias_part + (long)it * 1024 + c0) = make_float4(bs[0], bs[1], bs[2], bs[3]);
     }
 }
 
@@ -1144,7 +1150,7 @@ int sgc_windows_linear_backward_bg(const int* bbox, const int* sub_idx, const in
                                    const int* segments, int n_img, const int* count_incl_all, const int* dest_all, const void* dywm,
                                    const unsigned char* argmax, void* dy3_bg_pad, float* bias_part, void* stream) {
     if (n_img <= 0) return SGC_OK;
-    SGC_LAUNCH(windows_linear_bwd_bg_kernel, dim3(grid_cap(64L * n_img, 4, 65536)), dim3(256), 0, (hipStream_t)stream, bbox, sub_idx,
+    SGC_LAUNCH(windows_linear_bwd_bg_kernel, dim3(grid_cap(256L * n_img, 4, 65536)), dim3(256), 0, (hipStream_t)stream, bbox, sub_idx,
                obj_idx, gather_linear, order, segments, 64 * n_img, count_incl_all, dest_all, (const u16*)dywm, argmax, (u16*)dy3_bg_pad,
                bias_part);
     SGC_CHECK_LAUNCH();
