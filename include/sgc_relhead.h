@@ -78,6 +78,18 @@ int sgc_shared_windows_assemble(const int* bbox, const int* sub_idx, const int* 
                                 const unsigned char* argmax_obj, const void* y_obj_bf16, void* y, unsigned char* argmax, void* y_bf16,
                                 void* stream);
 
+/* conv2_1 halves on the objects' own regions (model.py:143 on the masked maps of train_test.py:194-195): outside its box an object's
+ * masked map is the constant tanh(b1), so U_o / V_o equal the background's at every pixel whose 3x3 neighbourhood misses the box.
+ *   sgc_conv2_regions_count / _fill   the 2x2-pixel windows of the 32-grid that can differ: count[o], gather[e] = o*256 + wy*16 + wx
+ *   sgc_conv2_object_regions          sgc_conv2_object for the listed windows, rows written to their window-major place in uv
+ *   sgc_conv2_fill_background         every other row of objects 0 .. n_obj-1 = the row of the background object n_obj + obj_img[o]
+ *                                     (uv [n_obj + n_img][1024][512] f16; the background objects' maps are computed whole beforehand) */
+int sgc_conv2_regions_count(const int* bbox, int n_obj, int* count, void* stream);
+int sgc_conv2_regions_fill(const int* bbox, int n_obj, const int* count_incl, int* gather, void* stream);
+int sgc_conv2_object_regions(const void* a_pad, const void* w2r, const float* bias, const int* gather, const int* gather_n,
+                             int max_entries, void* uv, void* stream);
+int sgc_conv2_fill_background(const int* bbox, const int* obj_img, int n_obj, void* uv, void* stream);
+
 /* Linear pairs (csrc/kernels_shared.hip, "sixth identity"): when the 16-grid regions where two objects' conv2 halves differ from the
  * background's are disjoint, z_ij = z_(i,bg) + z_(bg,j) - z_(bg,bg) pixel by pixel, and conv3_1 (model.py:145, linear up to its ReLU)
  * gives pre_ij = pre_(i,bg) + pre_(bg,j) - pre_(bg,bg) on the pair's X windows: no convolution of its own, combined from the

@@ -115,7 +115,9 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x16 (&acc)[TM]
                     const int row = rbase + (r & 3) + 8 * (r >> 2) + 4 * h;
                     if (row >= M) continue;
                     float v = acc[i][j][r];
-                    const long o = (long)row * p.ldc + col;
+                    long o = (long)row * p.ldc + col;
+                    if constexpr (GATHER && EPI == EPI_STORE)      // gathered 16-bit store: back to the window-major row of the listed window
+                        o = ((long)p.gather[row >> 2] * 4 + (row & 3)) * p.ldc + col;
                     if constexpr (EPI == EPI_STORE) {
                         reinterpret_cast<u16*>(p.C)[o] = to_elem<ELEM>(v + bias);
                     } else if constexpr (EPI == EPI_STORE_F32) {

@@ -79,8 +79,8 @@ __device__ __forceinline__ bool xcd_patch_map_aligned(int id, int tiles_m, int t
 }
 
 // ABL (tools/gemm_microbench.py only): 0 normal, 1 no global loads inside the K loop.
-// ACG = 1: the A operand is the implicit 3x3 convolution over a LIST of 2x2 windows of 16x16 maps (AMODE_CONV_GATHER of gemm_nt.h:
-// row m = pixel m&3 of window gather[m>>2] = image*64 + window, *gather_n entries, p.M only bounds the launch).  The rows of one
+// ACG = 1: the A operand is the implicit 3x3 convolution over a LIST of 2x2 windows of S x S maps, S = 16 or 32 (AMODE_CONV_GATHER of
+// gemm_nt.h: row m = pixel m&3 of window gather[m>>2] = image*(S/2)^2 + window, *gather_n entries, p.M only bounds the launch).  The rows of one
 // tile come from a few consecutive images (the list is sorted), so their byte offsets from the tile's first image fit the 32-bit
 // per-lane offset of the buffer load; the K step (64-channel chunk, tap) is a wave-uniform byte offset.
 template <int ELEM, int EPI, int ABL = 0, int ACG = 0>
@@ -102,12 +102,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(const NtParams p) {
     if constexpr (ACG) {
         Mlim = min(p.M, 4 * *p.gather_n);
         if (m0 >= Mlim) return;                      // the grid is sized for the bound (uniform exit, before any barrier)
-        img0 = p.gather[m0 >> 2] >> 6;
+        img0 = p.gather[m0 >> 2] >> (2 * p.lgS - 2);       // windows per map: (S/2)^2
     }
+    const int SP = (1 << p.lgS) + 2;                  // padded map side (ACG only)
+    const long img_elems = (long)SP * SP * p.Cin;
 
     // ---- staging sources: wave w writes LDS rows (2w+q)*8 .. +7 of every half tile (q = 0,1), 8 lanes per 128-B row
     const int lrow = lane >> 3, cpos = lane & 7;
-    const u16* const a_blk = ACG ? p.A + img0 * (324L * p.Cin) : p.A + (long)m0 * p.lda;
+    const u16* const a_blk = ACG ? p.A + img0 * img_elems : p.A + (long)m0 * p.lda;
     const u16* const b_blk = p.B + (long)n0 * p.ldb + (p.tile_group ? (long)p.tile_group[tm] * p.group_stride : 0L);
     int voff[4][2];                                  // byte offsets from a_blk / b_blk
 #pragma unroll
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(const NtParams p) {
             if constexpr (ACG) {
                 const int mg = m0 + m;
                 const int mv = p.gather[mg >> 2] * 4 + (mg & 3);
-                voff[h ? 3 : 0][q] = (int)((conv_row_base(mv, 4, p.Cin) - img0 * (324L * p.Cin) + chunk) * 2);
+                voff[h ? 3 : 0][q] = (int)((conv_row_base(mv, p.lgS, p.Cin) - img0 * img_elems + chunk) * 2);
             } else {
                 voff[h ? 3 : 0][q] = (int)((m * p.lda + chunk) * 2);
             }
@@ -138,7 +140,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(const NtParams p) {
             if (kind == 0 || kind == 3) {            // K tile t = (64-channel chunk t/9, tap t%9) of the padded 18x18 map
                 const int cc = t / 9, tap = t - cc * 9;
                 const int ky = tap / 3, kx = tap - 3 * ky;
-                soff = ((ky * 18 + kx) * p.Cin + (cc << 6)) * 2;
+                soff = ((ky * SP + kx) * p.Cin + (cc << 6)) * 2;
             }
         }
         buf_load_lds16(g, voff[kind][0], soff, base);
@@ -218,7 +220,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(const NtParams p) {
     for (; t < nk; ++t) tile(t, t & 1, std::false_type{});
     if (wr == 0) __builtin_amdgcn_s_barrier();        // re-align the two wave rows
 
-    if constexpr (EPI == EPI_STORE) {
+    if constexpr (EPI == EPI_STORE && !ACG) {         // (gathered rows are scattered: the generic epilogue)
         if (p.epi_lds) { nt_epilogue_store16<ELEM>(p, acc, m0, n0, wr, wc, lane, wid, smem); return; }
     }
     if constexpr (ACG) nt_epilogue<ELEM, EPI, 4, 2, true>(p, acc, m0, n0, wr, wc, lane, Mlim);
@@ -229,7 +231,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(const NtParams p) {
 template <int ELEM, int EPI>
 static int launch_gemm_nt_pp_conv_gather(NtParams p, hipStream_t stream) {
     constexpr int LDS = 8 * 16384;
-    if (p.lgS != 4 || (p.Cin & 63) || p.K != 9 * p.Cin || (p.N & 255)) return SGC_ERR_ARG;
+    if ((p.lgS != 4 && p.lgS != 5) || (p.Cin & 63) || p.K != 9 * p.Cin || (p.N & 255)) return SGC_ERR_ARG;
     p.tiles_m = (p.M + 255) / 256;
     p.tiles_n = p.N / 256;
     const int al = sgc_tuning().acg_aligned;      // 1: grid padded to whole per-XCD patches

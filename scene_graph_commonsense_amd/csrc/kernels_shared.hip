@@ -917,6 +917,50 @@ __global__ __launch_bounds__(256) void windows_linear_bwd_bg_kernel(const int* _
     }
 }
 
+
+// ================================================================================================ conv2 halves on the objects' own regions
+// The same argument one layer down: object o's masked map equals the constant tanh(b1) outside its box, so its conv2 half U_o (V_o)
+// equals the background's half at every 32-grid pixel whose 3x3 neighbourhood misses the box.  The pixels that can differ are the
+// 2x2-pixel windows of the D16 rectangle (axis_d16: box, +-1 pixel, in units of 2 pixels): conv2_1 is computed on those windows only
+// (gemm_nt_pp_kernel<.., ACG> on 32x32 maps, rows scattered back to their window-major place) and the other rows of U_o are copies
+// of the background map of the object's image - identical inputs, identical arithmetic, identical bits.
+__global__ __launch_bounds__(256) void conv2_regions_count_kernel(const int* __restrict__ bbox, int n_obj, int* __restrict__ count) {
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    if (o >= n_obj) return;
+    int x0, x1, y0, y1;
+    axis_d16(bbox[4 * o], bbox[4 * o + 1], x0, x1);
+    axis_d16(bbox[4 * o + 2], bbox[4 * o + 3], y0, y1);
+    count[o] = (x1 > x0 && y1 > y0) ? (x1 - x0) * (y1 - y0) : 0;
+}
+__global__ __launch_bounds__(256) void conv2_regions_fill_kernel(const int* __restrict__ bbox, int n_obj, const int* __restrict__ incl,
+                                                                 int* __restrict__ gather) {
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    if (o >= n_obj) return;
+    int x0, x1, y0, y1;
+    axis_d16(bbox[4 * o], bbox[4 * o + 1], x0, x1);
+    axis_d16(bbox[4 * o + 2], bbox[4 * o + 3], y0, y1);
+    if (x1 <= x0 || y1 <= y0) return;
+    int e = o ? incl[o - 1] : 0;
+    for (int wy = y0; wy < y1; ++wy)
+        for (int wx = x0; wx < x1; ++wx) gather[e++] = o * 256 + wy * 16 + wx;
+}
+// rows of object o outside its region <- the rows of the background object n_obj + obj_img[o]; one wavefront per (object, window): 4 KiB
+__global__ __launch_bounds__(256) void conv2_fill_background_kernel(const int* __restrict__ bbox, const int* __restrict__ obj_img, int n_obj,
+                                                                    uint4* __restrict__ uv, long n_items) {
+    const int lane = threadIdx.x & 63;
+    for (long it = (long)blockIdx.x * 4 + (threadIdx.x >> 6); it < n_items; it += (long)gridDim.x * 4) {
+        const int o = (int)(it >> 8), w = (int)(it & 255), wy = w >> 4, wx = w & 15;
+        int x0, x1, y0, y1;
+        axis_d16(bbox[4 * o], bbox[4 * o + 1], x0, x1);
+        axis_d16(bbox[4 * o + 2], bbox[4 * o + 3], y0, y1);
+        if (wx >= x0 && wx < x1 && wy >= y0 && wy < y1) continue;               // computed for the object
+        const uint4* src = uv + (((long)(n_obj + obj_img[o]) * 256 + w) * 4) * 64;   // a 512-channel f16 row = 64 uint4
+        uint4* dst = uv + (((long)o * 256 + w) * 4) * 64;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dst[q * 64 + lane] = src[q * 64 + lane];
+    }
+}
+
 static inline int grid_cap(long items, long per_block, int cap) {
     long b = (items + per_block - 1) / per_block;
     if (b > cap) b = cap;
@@ -1097,6 +1141,36 @@ int sgc_fc1_assemble(const float* S, const float* owm, const int* bbox, const in
 }
 
 // ---- fc1 backward over the window-major rows
+// ---- conv2 halves on the objects' own regions (see above)
+int sgc_conv2_regions_count(const int* bbox, int n_obj, int* count, void* stream) {
+    if (n_obj <= 0) return SGC_OK;
+    SGC_LAUNCH(conv2_regions_count_kernel, dim3((n_obj + 255) / 256), dim3(256), 0, (hipStream_t)stream, bbox, n_obj, count);
+    SGC_CHECK_LAUNCH();
+    return SGC_OK;
+}
+int sgc_conv2_regions_fill(const int* bbox, int n_obj, const int* count_incl, int* gather, void* stream) {
+    if (n_obj <= 0) return SGC_OK;
+    SGC_LAUNCH(conv2_regions_fill_kernel, dim3((n_obj + 255) / 256), dim3(256), 0, (hipStream_t)stream, bbox, n_obj, count_incl, gather);
+    SGC_CHECK_LAUNCH();
+    return SGC_OK;
+}
+// uv rows 4*gather[e] + q (window-major rows of [n][1024][512]) = conv3x3(a_pad, w2r) (+ bias) for the listed 2x2-pixel windows
+int sgc_conv2_object_regions(const void* a_pad, const void* w2r, const float* bias, const int* gather, const int* gather_n,
+                             int max_entries, void* uv, void* stream) {
+    if (max_entries <= 0) return SGC_OK;
+    NtParams p{};
+    p.A = (const u16*)a_pad; p.B = (const u16*)w2r; p.C = uv; p.M = max_entries * 4; p.N = 512; p.K = 9 * 128;
+    p.ldb = 9 * 128; p.ldc = 512; p.lgS = 5; p.Cin = 128; p.bias = bias; p.gather = gather; p.gather_n = gather_n;
+    return launch_gemm_nt_pp_conv_gather<ELEM_F16, EPI_STORE>(p, (hipStream_t)stream);
+}
+int sgc_conv2_fill_background(const int* bbox, const int* obj_img, int n_obj, void* uv, void* stream) {
+    if (n_obj <= 0) return SGC_OK;
+    const long items = (long)n_obj * 256;
+    SGC_LAUNCH(conv2_fill_background_kernel, dim3(grid_cap(items, 4, 131072)), dim3(256), 0, (hipStream_t)stream, bbox, obj_img, n_obj,
+               (uint4*)uv, items);
+    SGC_CHECK_LAUNCH();
+    return SGC_OK;
+}
 // ---- linear pairs (see "linear pairs (sixth identity)" above)
 int sgc_shared_windows_count3(const int* bbox, const int* sub_idx, const int* obj_idx, int n_pairs, int* count_all, int* count_conv,
                               int* count_linear, int* pixel_rect_conv, void* stream) {

@@ -130,7 +130,7 @@ class TrainContext:
 @dataclass
 class Tuning:
     """The switches of the product path, in ONE place, read once at import.  Defaults are the measured best.
-    Environment (six documented variables; tests and tools flip the fields directly, e.g. ``with engine.tuning(shared_fc1=False)``):
+    Environment (seven documented variables; tests and tools flip the fields directly, e.g. ``with engine.tuning(shared_fc1=False)``):
 
       SGC_SHARED_LEVEL         0 per-pair kernels | 1 conv3 over shared windows | 2 + fc1 over the same windows | 3 (default) + the
                                per-object maps shared with the image's background map (second level)
@@ -140,6 +140,7 @@ class Tuning:
       SGC_BWD_STREAMS          0: weight-gradient chain on the caller's stream (single-stream profiles, tools/collect_profiles.sh)
       SGC_GEMMS_APART          0: round 2's order of the two-stream backward (data- and weight-gradient GEMM of a layer side by side)
       SGC_SHARED_LINEAR        0: every pair convolves its own X windows (off: the sixth identity of csrc/kernels_shared.hip)
+      SGC_SHARED_CONV2         0: conv2 halves computed on whole object maps
     Decided and no longer switchable: sparse-MFMA conv3 weight gradient, un-pool fused into the conv3 data gradient, im2col + plain
     GEMM (not the gathered TN block) for the weight gradient over the listed windows."""
     shared_conv3: bool = True
@@ -150,6 +151,7 @@ class Tuning:
     bwd_streams: bool = True
     gemms_apart: bool = True          # two-stream backward: keep the big GEMMs of the two chains from running side by side
     shared_linear: bool = True        # pairs whose regions of influence on the 16-grid are disjoint: X windows combined, not convolved
+    shared_conv2: bool = True         # conv2 halves computed on the objects' own regions, the rest copied from the image's background half
 
     @classmethod
     def from_env(cls):
@@ -159,7 +161,8 @@ class Tuning:
                    shared_max_fraction=float(os.environ.get("SGC_SHARED_MAX_FRACTION", "0.5")),
                    bwd_streams=os.environ.get("SGC_BWD_STREAMS", "1") != "0",
                    gemms_apart=os.environ.get("SGC_GEMMS_APART", "1") != "0",
-                   shared_linear=lvl >= 3 and os.environ.get("SGC_SHARED_LINEAR", "1") != "0")
+                   shared_linear=lvl >= 3 and os.environ.get("SGC_SHARED_LINEAR", "1") != "0",
+                   shared_conv2=lvl >= 1 and os.environ.get("SGC_SHARED_CONV2", "1") != "0")
 
 
 TUNING = Tuning.from_env()
@@ -348,17 +351,30 @@ class RelHeadEngine:
         self._x = x
         return out
 
-    def object_halves(self, a_img, obj_img: torch.Tensor, bbox: torch.Tensor, roles=(0, 1), with_bg=False):
+    def object_halves(self, a_img, obj_img: torch.Tensor, bbox: torch.Tensor, roles=(0, 1), with_bg=False, regions=None):
         """Per-object masked maps and conv2 halves U (role 0) / V (role 1, carries the bias).
         ``with_bg``: one object with an EMPTY box per image is appended (index n_obj + image) - the constant map tanh(b1) every
         masked map equals outside its box; its halves are the background of ``conv3_shared``.  (One per image rather than one in
-        all: the backward sums the background's gradient per image, so a step over B images stays the sum of B one-image steps.)"""
+        all: the backward sums the background's gradient per image, so a step over B images stays the sum of B one-image steps.)
+        ``regions`` (host count of the 2x2-pixel windows of all objects' D16 rectangles, ``DeviceScene.conv2_windows``; needs
+        ``with_bg``): conv2 runs on those windows only - outside them an object's half IS its image's background half (the map is
+        the constant tanh(b1) outside the box), copied row by row: same bits, 17 % of the rows on the benchmark's boxes."""
         lib, ws = self.lib, self.ws
+        n_real = int(obj_img.shape[0])
+        n_img = 0
         if with_bg:
             n_img = int(a_img[roles[0]].numel()) // (1024 * 128)
             obj_img = torch.cat([obj_img, torch.arange(n_img, dtype=obj_img.dtype, device=obj_img.device)])
             bbox = torch.cat([bbox, bbox.new_zeros(n_img, 4)])
         n_obj = obj_img.shape[0]
+        by_region = bool(with_bg and regions and TUNING.shared_conv2 and n_real > 0)
+        if by_region:
+            cnt = torch.empty(n_real, dtype=torch.int32, device=self.device)
+            _lib.check(lib.sgc_conv2_regions_count(_lib.ptr(bbox), n_real, _lib.ptr(cnt), self._st()), "sgc_conv2_regions_count")
+            incl = torch.cumsum(cnt, 0, dtype=torch.int32)
+            rlist = self.scratch.get("conv2_regions", int(regions) + 64, torch.int32)
+            _lib.check(lib.sgc_conv2_regions_fill(_lib.ptr(bbox), n_real, _lib.ptr(incl), _lib.ptr(rlist), self._st()), "sgc_conv2_regions_fill")
+            rn = incl[n_real - 1:]
         res = {}
         for r in roles:
             a_pad = ws.get("a_pad_%d" % r, n_obj * 34 * 34 * 128, torch.float16)
@@ -366,9 +382,19 @@ class RelHeadEngine:
                                                   _lib.ptr(self.w["cst"][r]), _lib.ptr(a_pad), n_obj, 32, 128,
                                                   self._st()), "sgc_object_masked_maps")
             uv = self.scratch.get("uv_%d" % r, n_obj * 1024 * 512, torch.float16)
-            self._timed("conv2_fwd", lambda: _lib.check(lib.sgc_conv2_object(_lib.ptr(a_pad), _lib.ptr(self.w["w2r"][r]),
-                                            _lib.ptr(self.w["b2"]) if r == 1 else None, _lib.ptr(uv), n_obj, self._st()),
-                       "sgc_conv2_object"))
+            bias = _lib.ptr(self.w["b2"]) if r == 1 else None
+            if by_region:
+                def run(a_pad=a_pad, uv=uv, bias=bias, r=r):
+                    _lib.check(lib.sgc_conv2_object(_lib.ptr(a_pad[n_real * 34 * 34 * 128:]), _lib.ptr(self.w["w2r"][r]), bias,
+                                                    _lib.ptr(uv[n_real * 1024 * 512:]), n_img, self._st()), "sgc_conv2_object")
+                    _lib.check(lib.sgc_conv2_object_regions(_lib.ptr(a_pad), _lib.ptr(self.w["w2r"][r]), bias, _lib.ptr(rlist), _lib.ptr(rn),
+                                                            int(regions), _lib.ptr(uv), self._st()), "sgc_conv2_object_regions")
+                    _lib.check(lib.sgc_conv2_fill_background(_lib.ptr(bbox), _lib.ptr(obj_img), n_real, _lib.ptr(uv), self._st()),
+                               "sgc_conv2_fill_background")
+                self._timed("conv2_fwd", run)
+            else:
+                self._timed("conv2_fwd", lambda: _lib.check(lib.sgc_conv2_object(_lib.ptr(a_pad), _lib.ptr(self.w["w2r"][r]), bias, _lib.ptr(uv),
+                                                                                n_obj, self._st()), "sgc_conv2_object"))
             res[r] = uv
         return res
 
@@ -698,7 +724,8 @@ class RelHeadEngine:
         gives them in the evaluator, ``evaluator.py:131-134``), prediction 0, zero log-probs and hidden vectors."""
         a_img = self.image_maps(image_feature, image_depth)
         share = shared_conv3_enabled(shared_windows, int(sub_idx.shape[0]))
-        uv = self.object_halves(a_img, obj_img, bbox, with_bg=share)
+        uv = self.object_halves(a_img, obj_img, bbox, with_bg=share,
+                                regions=shared_windows.get("conv2_windows") if (share and isinstance(shared_windows, dict)) else None)
         shared = (bbox, obj_img, shared_windows) if share else None
         lsub, lobj = self.label_vectors(cats, super_mh)
         self._lsub, self._lobj = lsub, lobj
@@ -815,7 +842,8 @@ class RelHeadEngine:
             a_o = self.image_maps(role_inputs[1], None, roles=(1,), tag="o")
             ctx.a_img, ctx.x = {0: a_s[0], 1: a_o[1]}, (x_s, self._x)
         share = role_inputs is None and shared_conv3_enabled(shared_windows, P)   # per-step calls: every crop is one full-size box, nothing is shared
-        ctx.uv = self.object_halves(ctx.a_img, obj_img, bbox, with_bg=share)
+        ctx.uv = self.object_halves(ctx.a_img, obj_img, bbox, with_bg=share,
+                                    regions=shared_windows.get("conv2_windows") if (share and isinstance(shared_windows, dict)) else None)
         ctx.lsub, lobj_same = self.label_vectors(ctx.cats[0], ctx.super_mh[0])
         ctx.lobj = lobj_same if role_inputs is None else self.label_vectors(ctx.cats[1], ctx.super_mh[1])[1]
         # the per-pair backward (TUNING.shared_bwd off, A/B) reads every pixel of z / amz; the shared one only those next to X windows

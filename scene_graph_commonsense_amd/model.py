@@ -29,7 +29,8 @@ def _shared_hint(scene):
     n = getattr(scene, "shared_windows", None)
     return None if n is None else dict(windows=n, per_window=getattr(scene, "window_entries", None),
                                        object_windows=getattr(scene, "object_windows", None),
-                                       linear_windows=getattr(scene, "linear_windows", None))
+                                       linear_windows=getattr(scene, "linear_windows", None),
+                                       conv2_windows=getattr(scene, "conv2_windows", None))
 
 
 def _dense(scene):

@@ -231,6 +231,12 @@ def object_d16_rects(bb: np.ndarray) -> np.ndarray:
     return out
 
 
+def count_conv2_windows(bb: np.ndarray) -> int:
+    """2x2-pixel windows of the 32-grid on which an object's conv2 half can differ from the background's: sum of the D16 areas."""
+    d = object_d16_rects(bb)
+    return int(((d[:, 1] - d[:, 0]) * (d[:, 3] - d[:, 2])).sum())
+
+
 def count_linear_windows(bb: np.ndarray, img_ptr) -> int:
     """X windows of the LINEAR pairs (``csrc/kernels_shared.hip``, sixth identity): ordered pairs whose window rectangles intersect
     while their 16-grid regions of influence do not - their conv3 pre-activation on those windows is the sum of per-object ones."""
@@ -366,6 +372,7 @@ def flatten_scene(cfg, batch, device) -> DeviceScene:
                        window_entries=window_entry_counts(bb, img_ptr) if (n_obj and F == 32) else None,
                        object_windows=count_object_windows(bb) if (n_obj and F == 32) else None,
                        linear_windows=count_linear_windows(bb, img_ptr) if (n_obj and F == 32) else None,
+                       conv2_windows=count_conv2_windows(bb) if (n_obj and F == 32) else None,
                        _rel_src=getattr(batch, "relationships", None) if rel is not None else None)
 
 
