@@ -105,7 +105,8 @@ int sgc_conv2_fill_background(const int* bbox, const int* obj_img, int n_obj, vo
  *   sgc_windows_linear_backward_objects  dy3x rows of the n_object_entries per-object entries (list positions first_object_entry ..) +=
  *                                      un-pooled gradient of the linear pairs' windows that used them
  *   sgc_windows_linear_backward_bg     dy3_bg_pad [n_img][18][18][1024] -= the same per (image, window); order / segments = the linear
- *                                      list sorted by image*64 + window and its 64 n_img + 1 range starts; bias_part [64 n_img][1024] */
+ *                                      list sorted by image*64 + window and its 64 n_img + 1 range starts; dest_linear from the
+ *                                      forward; bias_part [64 n_img][1024] */
 int sgc_shared_windows_count3(const int* bbox, const int* sub_idx, const int* obj_idx, int n_pairs, int* count_all, int* count_conv,
                               int* count_linear, int* pixel_rect_conv, void* stream);
 int sgc_shared_windows_fill_class(const int* bbox, const int* sub_idx, const int* obj_idx, int n_pairs, const int* count_incl, int* gather,
@@ -120,14 +121,13 @@ int sgc_conv3_relu_pool_windows_wm_raw(const void* z_pad, const void* w3r, const
 int sgc_windows_linear_forward(const int* bbox, const int* sub_idx, const int* obj_idx, const int* obj_img, int n_obj, int n_real_pairs,
                                const int* gather_linear, const int* n_linear, int max_linear, const int* count_incl_all,
                                const int* dest_all, const float* raw, long n_object_entries, const float* b3, void* ywm, void* ywm_bf16,
-                               unsigned char* argmax, void* stream);
+                               unsigned char* argmax, int* dest_linear, void* stream);
 int sgc_windows_linear_backward_objects(const int* bbox, const int* sub_idx, const int* obj_idx, const int* sub_ptr, const int* sub_list,
                                         const int* obj_ptr, const int* obj_list, int n_obj, int n_real_pairs, const int* gather_conv,
                                         int first_object_entry, int n_object_entries, const int* count_incl_all, const int* dest_all,
                                         const void* dywm, const unsigned char* argmax, void* dy3x, void* stream);
-int sgc_windows_linear_backward_bg(const int* bbox, const int* sub_idx, const int* obj_idx, const int* gather_linear, const int* order,
-                                   const int* segments, int n_img, const int* count_incl_all, const int* dest_all, const void* dywm,
-                                   const unsigned char* argmax, void* dy3_bg_pad, float* bias_part, void* stream);
+int sgc_windows_linear_backward_bg(const int* gather_linear, const int* dest_linear, const int* order, const int* segments, int n_img,
+                                   const void* dywm, const unsigned char* argmax, void* dy3_bg_pad, float* bias_part, void* stream);
 
 /* Backward of the shared-window conv3 (autodiff of the graph above; same citations).  All gradients bf16, sums f32.
  *   sgc_shared_windows_assemble_bwd  dy_obj [2*n_obj*64][1024] = per-object sums of the rows of dy [n_pairs*64][1024] that were copies

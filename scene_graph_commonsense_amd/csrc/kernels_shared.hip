@@ -741,7 +741,8 @@ __global__ __launch_bounds__(256) void windows_linear_fwd_kernel(const int* __re
                                                                  const int* __restrict__ gather_l, const int* __restrict__ n_l,
                                                                  const int* __restrict__ incl_all, const int* __restrict__ dest_all,
                                                                  const float* __restrict__ raw, long n_pe, const float* __restrict__ bias,
-                                                                 u16* __restrict__ y, u16* __restrict__ y_bf, unsigned char* __restrict__ am) {
+                                                                 u16* __restrict__ y, u16* __restrict__ y_bf, unsigned char* __restrict__ am,
+                                                                 int* __restrict__ drow_out) {
     const int lane = threadIdx.x & 63;
     const int total = *n_l;
     const int base_ps = n_real ? incl_all[n_real - 1] : 0;
@@ -752,6 +753,7 @@ __global__ __launch_bounds__(256) void windows_linear_fwd_kernel(const int* __re
         const WRect ri = object_windows(bbox + 4 * i), rj = object_windows(bbox + 4 * j);
         const WRect x = pair_windows(ri, rj);
         const long drow = dest_all[(p ? incl_all[p - 1] : 0) + rect_local(x, wx, wy)];
+        if (drow_out && lane == 0) drow_out[t] = (int)drow;          // the backward's background side reads it instead of re-deriving it
         // exclusive prefix count at pair-index k = first list entry of that pair; per-object entries are counted from the first pseudo-pair
         const long ei = (long)(n_real + i > 0 ? incl_all[n_real + i - 1] : 0) - base_ps + rect_local(ri, wx, wy);
         const long ej = (long)incl_all[n_real + n_obj + j - 1] - base_ps + rect_local(rj, wx, wy);
@@ -840,15 +842,30 @@ __global__ __launch_bounds__(256) void windows_linear_bwd_objects_kernel(const i
 #pragma unroll
             for (int c = 0; c < 16; ++c) acc[q][c] = 0.f;
         bool any = false;
-        for (int it = ptr[o]; it < ptr[o + 1]; ++it) {
-            const int p = list[it];
-            const int* bp = bbox + 4 * (role ? sub[p] : obj[p]);
-            const WRect rp = object_windows(bp);
-            if (!in_rect(rp, wx, wy) || !d16_disjoint(bo, bp)) continue;
-            const WRect x = pair_windows(ro, rp);
-            const long drow = dest_all[(p ? incl_all[p - 1] : 0) + rect_local(x, wx, wy)];
-            linear_unpool_acc(acc, dy + drow * 1024, am + ((long)p * 64 + w) * 1024, c0);
-            any = true;
+        // the object's pairs, 64 at a time: lane k tests pair k (linear, and its X rectangle holds w) and looks its gradient row up; a
+        // ballot then walks the few that qualify (the serial walk over all ~63 partners was a chain of dependent look-ups: 0.44 ms)
+        for (int base = ptr[o]; base < ptr[o + 1]; base += 64) {
+            const int it = base + lane;
+            int p = 0, drow = 0;
+            bool ok = false;
+            if (it < ptr[o + 1]) {
+                p = list[it];
+                const int* bp = bbox + 4 * (role ? sub[p] : obj[p]);
+                const WRect rp = object_windows(bp);
+                if (in_rect(rp, wx, wy) && d16_disjoint(bo, bp)) {
+                    const WRect x = pair_windows(ro, rp);
+                    drow = dest_all[(p ? incl_all[p - 1] : 0) + rect_local(x, wx, wy)];
+                    ok = true;
+                }
+            }
+            unsigned long long m = __ballot(ok);
+            while (m) {
+                const int bsel = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                const long pp = __shfl(p, bsel), dr = __shfl(drow, bsel);
+                linear_unpool_acc(acc, dy + dr * 1024, am + (pp * 64 + w) * 1024, c0);
+                any = true;
+            }
         }
         if (!any) continue;
 #pragma unroll
@@ -867,14 +884,13 @@ __global__ __launch_bounds__(256) void windows_linear_bwd_objects_kernel(const i
 
 // Backward, background side: the un-pooled gradient of every combined window is SUBTRACTED from its image's background map
 // (dy3_bg [n_img][18][18][1024] bf16, interior already holding the map's own un-pooled gradient) and counts once for conv3's bias.
-// order [n_l]: the listed windows sorted by (image, window) (stable: sums in list order); seg [64 n_img + 1] their ranges.
+// order [n_l]: the listed windows sorted by (image, window) (stable: sums in list order); seg [64 n_img + 1] their ranges;
+// lin_drow [n_l]: the window-major gradient row of every listed window (written by the forward).
 // One wavefront per (image, window, quarter of the channels) - a (image, window) sums ~60 windows on the benchmark, and there are
-// only 64 n_img of them: the channel split is what fills the chip (0.88 ms with one wavefront per (image, window));
+// only 64 n_img of them; the first version re-derived every window's gradient row through five dependent look-ups (0.88 ms);
 // bias_part [64 n_img][1024].
-__global__ __launch_bounds__(256) void windows_linear_bwd_bg_kernel(const int* __restrict__ bbox, const int* __restrict__ sub, const int* __restrict__ obj,
-                                                                    const int* __restrict__ gather_l, const int* __restrict__ order,
-                                                                    const int* __restrict__ seg, int n_items,
-                                                                    const int* __restrict__ incl_all, const int* __restrict__ dest_all,
+__global__ __launch_bounds__(256) void windows_linear_bwd_bg_kernel(const int* __restrict__ gather_l, const int* __restrict__ lin_drow,
+                                                                    const int* __restrict__ order, const int* __restrict__ seg, int n_items,
                                                                     const u16* __restrict__ dy, const unsigned char* __restrict__ am,
                                                                     u16* __restrict__ dy3_bg, float* __restrict__ bias_part) {
     const int lane = threadIdx.x & 63;
@@ -886,20 +902,28 @@ __global__ __launch_bounds__(256) void windows_linear_bwd_bg_kernel(const int* _
         for (int q = 0; q < 4; ++q)
 #pragma unroll
             for (int c = 0; c < 4; ++c) acc[q][c] = 0.f;
-        for (int s = seg[it]; s < seg[it + 1]; ++s) {
-            const int code = gather_l[order[s]];
-            const int p = code >> 6;
-            const WRect x = pair_windows(object_windows(bbox + 4 * sub[p]), object_windows(bbox + 4 * obj[p]));
-            const long drow = dest_all[(p ? incl_all[p - 1] : 0) + rect_local(x, wx, wy)];
-            const uint2 g = *reinterpret_cast<const uint2*>(dy + drow * 1024 + c0);
-            const unsigned cd = *reinterpret_cast<const unsigned*>(am + (long)code * 1024 + c0);
-            const u16* gh = reinterpret_cast<const u16*>(&g);
+        const int s1 = seg[it + 1];
+        for (int s0 = seg[it]; s0 < s1; s0 += 4) {                   // four windows in flight: the look-up chain is what costs
+            uint2 g[4];
+            unsigned cd[4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const float v = bf16_bits_to_f32(gh[c]);
-                const unsigned k = (cd >> (8 * c)) & 255u;
+            for (int u = 0; u < 4; ++u) {
+                const bool ok = s0 + u < s1;
+                const int t = order[ok ? s0 + u : s0];
+                const long drow = lin_drow[t], code = gather_l[t];
+                g[u] = ok ? *reinterpret_cast<const uint2*>(dy + drow * 1024 + c0) : make_uint2(0, 0);
+                cd[u] = ok ? *reinterpret_cast<const unsigned*>(am + code * 1024 + c0) : 0x04040404u;
+            }
 #pragma unroll
-                for (int q = 0; q < 4; ++q) acc[q][c] += (k == (unsigned)q) ? v : 0.f;
+            for (int u = 0; u < 4; ++u) {
+                const u16* gh = reinterpret_cast<const u16*>(&g[u]);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float v = bf16_bits_to_f32(gh[c]);
+                    const unsigned k = (cd[u] >> (8 * c)) & 255u;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[q][c] += (k == (unsigned)q) ? v : 0.f;
+                }
             }
         }
         float bs[4] = {0.f, 0.f, 0.f, 0.f};
@@ -1201,11 +1225,11 @@ int sgc_conv3_windows_raw(const void* z_pad, const void* w3r, const int* gather,
 int sgc_windows_linear_forward(const int* bbox, const int* sub_idx, const int* obj_idx, const int* obj_img, int n_obj, int n_real_pairs,
                                const int* gather_linear, const int* n_linear, int max_linear, const int* count_incl_all,
                                const int* dest_all, const float* raw, long n_object_entries, const float* b3, void* ywm, void* ywm_bf16,
-                               unsigned char* argmax, void* stream) {
+                               unsigned char* argmax, int* dest_linear, void* stream) {
     if (max_linear <= 0) return SGC_OK;
     SGC_LAUNCH(windows_linear_fwd_kernel, dim3(grid_cap(max_linear, 4, 65536)), dim3(256), 0, (hipStream_t)stream, bbox, sub_idx, obj_idx,
                obj_img, n_obj, n_real_pairs, gather_linear, n_linear, count_incl_all, dest_all, raw, n_object_entries, b3, (u16*)ywm,
-               (u16*)ywm_bf16, argmax);
+               (u16*)ywm_bf16, argmax, dest_linear);
     SGC_CHECK_LAUNCH();
     return SGC_OK;
 }
@@ -1220,13 +1244,11 @@ int sgc_windows_linear_backward_objects(const int* bbox, const int* sub_idx, con
     SGC_CHECK_LAUNCH();
     return SGC_OK;
 }
-int sgc_windows_linear_backward_bg(const int* bbox, const int* sub_idx, const int* obj_idx, const int* gather_linear, const int* order,
-                                   const int* segments, int n_img, const int* count_incl_all, const int* dest_all, const void* dywm,
-                                   const unsigned char* argmax, void* dy3_bg_pad, float* bias_part, void* stream) {
+int sgc_windows_linear_backward_bg(const int* gather_linear, const int* dest_linear, const int* order, const int* segments, int n_img,
+                                   const void* dywm, const unsigned char* argmax, void* dy3_bg_pad, float* bias_part, void* stream) {
     if (n_img <= 0) return SGC_OK;
-    SGC_LAUNCH(windows_linear_bwd_bg_kernel, dim3(grid_cap(256L * n_img, 4, 65536)), dim3(256), 0, (hipStream_t)stream, bbox, sub_idx,
-               obj_idx, gather_linear, order, segments, 64 * n_img, count_incl_all, dest_all, (const u16*)dywm, argmax, (u16*)dy3_bg_pad,
-               bias_part);
+    SGC_LAUNCH(windows_linear_bwd_bg_kernel, dim3(grid_cap(256L * n_img, 4, 65536)), dim3(256), 0, (hipStream_t)stream, gather_linear,
+               dest_linear, order, segments, 64 * n_img, (const u16*)dywm, argmax, (u16*)dy3_bg_pad, bias_part);
     SGC_CHECK_LAUNCH();
     return SGC_OK;
 }

@@ -503,7 +503,8 @@ class RelHeadEngine:
         keys = obj_img.long()[sub_idx.long()[code_l >> 6]] * 64 + (code_l & 63)
         skeys, order = torch.sort(keys, stable=True)
         seg = torch.searchsorted(skeys, torch.arange(64 * n_img + 1, device=dev)).to(torch.int32)
-        lin = dict(gather=gather_l, n=incl_l[P - 1:P].contiguous(), max=e_lin, order=order.to(torch.int32).contiguous(), seg=seg.contiguous())
+        lin = dict(gather=gather_l, n=incl_l[P - 1:P].contiguous(), max=e_lin, order=order.to(torch.int32).contiguous(), seg=seg.contiguous(),
+                   drow=own.get("xw_lin_drow", e_lin + 64, torch.int32))
         self._xw = (gather_all, incl_all[:P])
         self._xw_total = incl_c[Pt - 1:]
         self._xw_linear = (e_lin, e_obj)          # bench accounting: windows combined instead of convolved, per-object entries
@@ -639,7 +640,7 @@ class RelHeadEngine:
                 self._timed("conv3_fwd_linear", lambda: _lib.check(lib.sgc_windows_linear_forward(
                     _lib.ptr(bbox), _lib.ptr(sub_idx), _lib.ptr(obj_idx), _lib.ptr(obj_img), n_obj, P, _lib.ptr(lin["gather"]), _lib.ptr(lin["n"]),
                     lin["max"], _lib.ptr(plan["incl_all"]), _lib.ptr(wm["dest"]), _lib.ptr(raw), _c_long(n_pe), _lib.ptr(self.w["b3"]),
-                    _lib.ptr(y), _lib.ptr(y_bf), _lib.ptr(am), self._st()), "sgc_windows_linear_forward"))
+                    _lib.ptr(y), _lib.ptr(y_bf), _lib.ptr(am), _lib.ptr(lin["drow"]), self._st()), "sgc_windows_linear_forward"))
             out["am_ps"] = am_ps
             return out
         am_ps = own.get("am_ps", n2 * 65536, torch.uint8) if am is not None else None
@@ -1219,9 +1220,8 @@ class RelHeadEngine:
                     _lib.ptr(obj_csr[1]), n_obj, P, _lib.ptr(gather), e_real, E - e_real, _lib.ptr(sh["incl_all"]), _lib.ptr(wm["dest"]),
                     _lib.ptr(dy), _lib.ptr(ctx.am), _lib.ptr(dy3x), st()), "sgc_windows_linear_backward_objects"),
                 _lib.check(lib.sgc_windows_linear_backward_bg(
-                    _lib.ptr(ctx.bbox), _lib.ptr(ctx.sub_idx), _lib.ptr(ctx.obj_idx), _lib.ptr(lin["gather"]), _lib.ptr(lin["order"]),
-                    _lib.ptr(lin["seg"]), n_img, _lib.ptr(sh["incl_all"]), _lib.ptr(wm["dest"]), _lib.ptr(dy), _lib.ptr(ctx.am),
-                    _lib.ptr(dy3_bg), _lib.ptr(bpart_l), st()), "sgc_windows_linear_backward_bg")))
+                    _lib.ptr(lin["gather"]), _lib.ptr(lin["drow"]), _lib.ptr(lin["order"]), _lib.ptr(lin["seg"]), n_img, _lib.ptr(dy),
+                    _lib.ptr(ctx.am), _lib.ptr(dy3_bg), _lib.ptr(bpart_l), st()), "sgc_windows_linear_backward_bg")))
         with side():
             gb = self._slab_sum(bpart, 1024, nparts.value)
             if nparts_x.value:
