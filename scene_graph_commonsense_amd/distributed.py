@@ -41,15 +41,16 @@ class GradReducer:
     accumulation over several steps sums mean gradients exactly as DDP + autograd would and never reads a tensor RCCL is
     still writing."""
 
-    def __init__(self, world: int, early=("fc1.weight",)):
+    def __init__(self, world: int, early=("fc1.weight",), force_collectives: bool = False):
         self.world = world
+        self.active = world > 1 or force_collectives   # forced: a one-rank RCCL group still runs every collective (tests)
         self.early = set(early)
         self.pending: List = []          # (work handle, tensor) of the early reductions in flight
         self.done = set()
         self.exposed_events: List = []   # (start, end) event pairs around the waits on the compute stream
 
     def hook(self, name: str, grad: torch.Tensor):
-        if self.world <= 1 or name not in self.early or name in self.done:
+        if not self.active or name not in self.early or name in self.done:
             return
         self.pending.append((dist.all_reduce(grad, op=dist.ReduceOp.SUM, async_op=True), grad))
         self.done.add(name)
@@ -88,7 +89,7 @@ class GradReducer:
 
     def finish_grads(self, grads: Dict[str, torch.Tensor]):
         """Reduce the step's gradient dict in place: everything not handed to ``hook`` goes in one flat bucket."""
-        if self.world > 1:
+        if self.active:
             for k in grads:
                 if not grads[k].is_contiguous():
                     grads[k] = grads[k].contiguous()
@@ -97,7 +98,7 @@ class GradReducer:
 
     def finish(self, named_params):
         """Same on ``param.grad`` (for callers that wrote the step's gradients there themselves)."""
-        if self.world > 1:
+        if self.active:
             self._flat([p.grad for n, p in named_params if p.grad is not None and n not in self.done])
         self._drain()
 
@@ -155,9 +156,10 @@ class ShardedSGD:
     owns_grads = True
 
     def __init__(self, named_params, world: int = 1, rank: int = 0, lr: float = 1e-3, momentum: float = 0.0, weight_decay: float = 0.0,
-                 big=("fc1.weight",), buckets: int = 8, update_fn=None, group=None):
+                 big=("fc1.weight",), buckets: int = 8, update_fn=None, group=None, force_collectives: bool = False):
         self.named = [(n, p) for n, p in named_params]
         self.world, self.rank, self.group = int(world), int(rank), group
+        self.collective = self.world > 1 or bool(force_collectives)   # forced: a one-rank RCCL group still runs every collective (tests)
         self.param_groups = [dict(lr=lr, momentum=momentum, weight_decay=weight_decay, params=[p for _, p in self.named])]
         self.update = update_fn or _hip_sgd_update
         self.big = [n for n, p in self.named if n in set(big) and p.numel() % (self.world * 4) == 0]
@@ -190,7 +192,7 @@ class ShardedSGD:
     def _reduce_scatter(self, out, inp, async_op):
         """out = this rank's 1/W of sum over ranks of inp.  Backends without a native reduce-scatter for this tensor type (gloo
         with GPU tensors in the one-GPU tests) fall back to all-reduce + slice: same values."""
-        if self.world == 1:
+        if not self.collective:
             out.copy_(inp)
             return None
         if self._native_rs is not False:
@@ -252,7 +254,7 @@ class ShardedSGD:
             return
         g = grad.reshape(-1)
         for pc in self.pieces[name]:
-            if self.world == 1:
+            if not self.collective:
                 self.pending.append((None, g[pc.offset:pc.offset + pc.length], pc))
                 continue
             out = torch.empty(pc.length, dtype=g.dtype, device=g.device)
@@ -281,7 +283,7 @@ class ShardedSGD:
         for work, shard, pc in self.pending:
             self._wait(work)
             if pc.acc is None:        # world 1: the shard is a view of the engine's gradient buffer (reused next step) - own it
-                pc.acc = shard.clone() if self.world == 1 else shard.mul_(inv)
+                pc.acc = shard.clone() if not self.collective else shard.mul_(inv)
             else:
                 pc.acc.add_(shard, alpha=inv)
         self.pending.clear()
@@ -329,7 +331,7 @@ class ShardedSGD:
                     pc.mom = torch.empty_like(mine)
                 self.update(mine, pc.acc, pc.mom, lr, mom, wd, pc.first)
                 pc.first = False
-                if self.world > 1:
+                if self.collective:
                     src = mine.clone()        # a copy of the shard (1/W of the block): no aliasing of a collective's input and output
                     self.gathers.append((self._all_gather(flat[pc.bucket_off:pc.bucket_off + pc.bucket_len], src), src))
         # ---- small parameters: one flat bucket
@@ -346,7 +348,7 @@ class ShardedSGD:
                 pc.mom = torch.empty_like(mine)
             self.update(mine, pc.acc, pc.mom, lr, mom, wd, pc.first)
             pc.first = False
-            if self.world > 1:
+            if self.collective:
                 src = mine.clone()
                 self.gathers.append((self._all_gather(flat, src), src))
             self._small_flat = flat
