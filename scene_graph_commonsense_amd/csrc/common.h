@@ -34,6 +34,7 @@ struct SgcTuning {
     int tn_xcd = 1;          // SGC_TN_XCD: XCD-aware assignment of the 4 x 18 conv weight-gradient tile grid
     int tn_patch = 1;        // SGC_TN_PATCH: per-XCD 4x8 patches for TN grids with >= 8 M tiles
     int gather_pp = 1;       // SGC_GATHER_PP: ping-pong block for the gathered conv3 forward
+    int f32_swap = 1;        // SGC_F32_SWAP: f32 products of fc1 over the window-major rows leave as 16-byte stores (operands swapped in the MFMA)
 };
 inline const SgcTuning& sgc_tuning() {
     static const SgcTuning t = [] {
@@ -45,7 +46,7 @@ inline const SgcTuning& sgc_tuning() {
         v.epi_lds = rd("SGC_EPI_LDS", v.epi_lds);          v.acg_aligned = rd("SGC_ACG_ALIGNED", v.acg_aligned);
         v.nt_aligned = rd("SGC_NT_ALIGNED", v.nt_aligned); v.halo_walk = rd("SGC_HALO_WALK", v.halo_walk);
         v.tn_xcd = rd("SGC_TN_XCD", v.tn_xcd);             v.tn_patch = rd("SGC_TN_PATCH", v.tn_patch);
-        v.gather_pp = rd("SGC_GATHER_PP", v.gather_pp);
+        v.gather_pp = rd("SGC_GATHER_PP", v.gather_pp);    v.f32_swap = rd("SGC_F32_SWAP", v.f32_swap);
 #endif
         return v;
     }();

@@ -18,7 +18,8 @@
 #include <type_traits>
 
 enum { AMODE_PLAIN = 0, AMODE_CONV = 1, AMODE_CONV_GATHER = 2 };   // GATHER: conv rows come from a list of 2x2 windows (see NtParams::gather)
-enum { EPI_STORE = 0, EPI_BIAS_TANH = 1, EPI_BIAS_RELU = 2, EPI_POOL = 3, EPI_FC2 = 4, EPI_RELUMASK = 5, EPI_STORE_F32 = 6 };
+enum { EPI_STORE = 0, EPI_BIAS_TANH = 1, EPI_BIAS_RELU = 2, EPI_POOL = 3, EPI_FC2 = 4, EPI_RELUMASK = 5, EPI_STORE_F32 = 6,
+       EPI_STORE_F32T = 7 };   // F32T (ping-pong block only): accumulators held TRANSPOSED (operands swapped in the MFMA), see nt_epilogue_f32t
 
 struct NtParams {
     const u16* A; const u16* B; void* C;
@@ -138,6 +139,33 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x16 (&acc)[TM]
                         reinterpret_cast<u16*>(p.C)[o] = to_elem<ELEM>(f > 0.f ? v * p.scale : 0.f);
                     }
                 }
+            }
+        }
+    }
+}
+
+// f32 output of the 8-wave 256x256 block with the operands SWAPPED in the MFMA (acc = B_frag x A_frag^T): a lane then owns one output
+// ROW (m = lane & 31) and four consecutive COLUMNS per register quad, so the tile leaves as 32 16-byte stores per lane instead of the
+// 128 4-byte stores of the plain C layout (fc1 over window-major rows: 5 GB of f32 products per launch, K = 1024 - the epilogue is
+// as long as the main loop).  Same products, same order of accumulation over k: bit-identical to EPI_STORE_F32.
+__device__ __forceinline__ void nt_epilogue_f32t(const NtParams& p, f32x16 (&acc)[4][2], int m0, int n0, int wr, int wc, int lane) {
+    const int h = lane >> 5, cl = lane & 31;
+    float* out = reinterpret_cast<float*>(p.C);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = m0 + wr * 128 + i * 32 + cl;
+        if (row >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const int col = n0 + wc * 64 + j * 32 + 8 * rq + 4 * h;
+                f32x4 v = {acc[i][j][4 * rq], acc[i][j][4 * rq + 1], acc[i][j][4 * rq + 2], acc[i][j][4 * rq + 3]};
+                if (p.bias) {
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + col);
+                    v += b;
+                }
+                *reinterpret_cast<f32x4*>(out + (long)row * p.ldc + col) = v;
             }
         }
     }

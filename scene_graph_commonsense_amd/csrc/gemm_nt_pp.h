@@ -184,7 +184,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(const NtParams p) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[2 * a + i][j] = mfma32<ELEM>(af[i][ks], bf[j][ks], acc[2 * a + i][j]);
+                for (int j = 0; j < 2; ++j) {
+                    if constexpr (EPI == EPI_STORE_F32T) acc[2 * a + i][j] = mfma32<ELEM>(bf[j][ks], af[i][ks], acc[2 * a + i][j]);
+                    else acc[2 * a + i][j] = mfma32<ELEM>(af[i][ks], bf[j][ks], acc[2 * a + i][j]);
+                }
         SGC_PP_BARRIER();
     };
     // end of a load section: counted wait for the half tiles the NEXT phase reads, retire this phase's reads, barrier
@@ -223,7 +226,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(const NtParams p) {
     if constexpr (EPI == EPI_STORE && !ACG) {         // (gathered rows are scattered: the generic epilogue)
         if (p.epi_lds) { nt_epilogue_store16<ELEM>(p, acc, m0, n0, wr, wc, lane, wid, smem); return; }
     }
-    if constexpr (ACG) nt_epilogue<ELEM, EPI, 4, 2, true>(p, acc, m0, n0, wr, wc, lane, Mlim);
+    if constexpr (EPI == EPI_STORE_F32T) { static_assert(!ACG, "transposed f32 tile: plain rows only"); nt_epilogue_f32t(p, acc, m0, n0, wr, wc, lane); }
+    else if constexpr (ACG) nt_epilogue<ELEM, EPI, 4, 2, true>(p, acc, m0, n0, wr, wc, lane, Mlim);
     else nt_epilogue<ELEM, EPI, 4, 2>(p, acc, m0, n0, wr, wc, lane);
 }
 

@@ -1145,6 +1145,7 @@ int sgc_fc1_windows_gemm(const void* ywm, const void* w1p, const int* tile_group
     NtParams p{};
     p.A = (const u16*)ywm; p.B = (const u16*)w1p; p.C = owm; p.M = rows; p.N = 4096; p.K = 1024;
     p.lda = 1024; p.ldb = 65536; p.ldc = 4096; p.tile_group = tile_group; p.group_stride = 1024;
+    if (sgc_tuning().f32_swap) return launch_gemm_nt_pp<ELEM_F16, EPI_STORE_F32T>(p, (hipStream_t)stream);
     return launch_gemm_nt_pp<ELEM_F16, EPI_STORE_F32>(p, (hipStream_t)stream);
 }
 int sgc_fc1_integral(const float* owm, const int* goff, int n_pseudo, float* S, void* stream) {
