@@ -7,6 +7,6 @@ run() {
     env "$VAR=$1" python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-sensitivity "${@:2}" 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); k=d['kernels_ms']
-print('%-24s %7.2f ms/step  %8.0f pairs/s   fc1 f/d/w %.2f %.2f %.2f  conv3 f/d/w %.2f %.2f %.2f' % ('$VAR=$1', d['ms_per_step'], d['value'], k['fc1_fwd'], k['fc1_dgrad'], k['fc1_wgrad'], k['conv3_fwd'], k['conv3_dgrad'], k['conv3_wgrad']))"
+print('%-24s %7.2f ms/step  %8.0f pairs/s  ' % ('$VAR=$1', d['ms_per_step'], d['value']) + '  '.join('%s %.2f' % (n, k[n]) for n in ('conv3_fwd_windows', 'fc1_fwd_windows', 'fc1_fwd_assemble', 'expand_dense') if n in k))"
 }
 for rep in $(seq $REPS); do run "$A" "$@"; run "$B" "$@"; done
