@@ -37,6 +37,23 @@ int sgc_dbg_gemm_nt_abl(int abl, const void* A, const void* B, void* C, int M, i
     return SGC_ERR_ARG;
 }
 
+// tools/fc1_windows_microbench.py: the grouped fc1 product over window-major rows (sgc_fc1_windows_gemm) with the weight layout and the
+// epilogue as parameters.  mode 0: f32 tile in the MFMA's C layout (4-byte stores), 1: transposed tile (16-byte stores), 2: the same
+// without its stores (C ignored), 3: f16 output through the LDS-staged epilogue.
+int sgc_dbg_fc1_windows_gemm(const void* ywm, const void* w, const int* tile_group, void* owm, int rows, long ldb, long group_stride,
+                             int mode, void* stream) {
+    if (rows <= 0 || (rows & 255)) return SGC_ERR_ARG;
+    NtParams p{};
+    p.A = (const u16*)ywm; p.B = (const u16*)w; p.C = mode == 2 ? nullptr : owm; p.M = rows; p.N = 4096; p.K = 1024;
+    p.lda = 1024; p.ldb = ldb; p.ldc = 4096; p.tile_group = tile_group; p.group_stride = group_stride;
+    switch (mode) {
+        case 0: return launch_gemm_nt_pp<ELEM_F16, EPI_STORE_F32>(p, (hipStream_t)stream);
+        case 1: case 2: return launch_gemm_nt_pp<ELEM_F16, EPI_STORE_F32T>(p, (hipStream_t)stream);
+        case 3: p.epi_lds = 1; return launch_gemm_nt_pp<ELEM_F16, EPI_STORE>(p, (hipStream_t)stream);
+    }
+    return SGC_ERR_ARG;
+}
+
 // A: zero-padded channels-last images [n_img][S+2][S+2][Cin]; B: [N][Cin/64][9][64]; C: [n_img*S*S][N] window-major rows
 int sgc_dbg_conv_nt(int elem, const void* A, const void* B, void* C, int n_img, int lgS, int Cin, int N,
                     const float* bias, void* stream) {

@@ -151,6 +151,7 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x16 (&acc)[TM]
 __device__ __forceinline__ void nt_epilogue_f32t(const NtParams& p, f32x16 (&acc)[4][2], int m0, int n0, int wr, int wc, int lane) {
     const int h = lane >> 5, cl = lane & 31;
     float* out = reinterpret_cast<float*>(p.C);
+    if (!out) return;                                  // tools/fc1_windows_microbench.py: the launch without its stores
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int row = m0 + wr * 128 + i * 32 + cl;
