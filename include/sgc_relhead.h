@@ -184,13 +184,15 @@ int sgc_windows_col2im_objects(const void* col, const int* bbox, int n_obj, int 
  * [2*n_obj pseudo-pair rows][X entries of window w in pair order][zero rows up to a multiple of 256]; goff [65] = group offsets.
  *   sgc_conv3_relu_pool_wm          sgc_conv3_relu_pool of the pseudo-pairs, y / y_bf16 rows written at goff[w] + pseudo-pair
  *   sgc_conv3_relu_pool_windows_wm  ... of the X windows, y / y_bf16 of entry e written at dest[e] (argmax at gather[e] as before)
- *   sgc_fc1_windows_gemm            owm [rows][4096] f32 = ywm [rows][1024] * (columns g*1024.. of w1p)^T, g = tile_group[row/256]
+ *   sgc_fc1_products_pitch          row pitch of owm in floats (4096 + padding: a power-of-two pitch slows the product's stores)
+ *   sgc_fc1_windows_gemm            owm [rows][pitch] f32 (columns 0..4095) = ywm [rows][1024] * (columns g*1024.. of w1p)^T, g = tile_group[row/256]
  *   sgc_fc1_integral                S [n_pseudo][9][9][4096] = 2-D inclusive prefix sums (zero border) of the pseudo rows of owm
  *   sgc_fc1_assemble                h1[p] = dropout(relu(b + S_i[all] - S_i[R_j] + S'_j[R_j] - S'_j[X_p] + sum_{e in X_p} owm[dest[e]])) */
 int sgc_conv3_relu_pool_wm(const void* z_pad, const void* w3r, const float* b3, const int* goff, void* ywm, unsigned char* argmax,
                            void* ywm_bf16, int n_pairs, void* stream);
 int sgc_conv3_relu_pool_windows_wm(const void* z_pad, const void* w3r, const float* b3, const int* gather, const int* gather_n,
                                    const int* dest, int max_entries, void* ywm, unsigned char* argmax, void* ywm_bf16, void* stream);
+int sgc_fc1_products_pitch(void);
 int sgc_fc1_windows_gemm(const void* ywm, const void* w1p, const int* tile_group, float* owm, int rows, void* stream);
 int sgc_fc1_integral(const float* owm, const int* goff, int n_pseudo, float* S, void* stream);
 int sgc_fc1_assemble(const float* S, const float* owm, const int* bbox, const int* sub_idx, const int* obj_idx, const int* count_incl,
@@ -406,7 +408,7 @@ int sgc_match_boxes_top2(const float* pred_box, const int* pred_ptr, const float
 /* ----------------------------------------------------------------------------------------------- test hooks (raw GEMM engines) */
 int sgc_dbg_gemm_nt(int elem, const void* A, const void* B, void* C, int M, int N, int K, long lda, long ldb, long ldc, const float* bias, void* stream);
 int sgc_dbg_gemm_nt_abl(int abl, const void* A, const void* B, void* C, int M, int N, int K, void* stream);
-int sgc_dbg_fc1_windows_gemm(const void* ywm, const void* w, const int* tile_group, void* owm, int rows, long ldb, long group_stride, int mode, void* stream);
+int sgc_dbg_fc1_windows_gemm(const void* ywm, const void* w, const int* tile_group, void* owm, int rows, long ldb, long group_stride, long ldc, int mode, int stagger, int phases, void* stream);
 int sgc_dbg_conv_nt(int elem, const void* A, const void* B, void* C, int n_img, int lgS, int Cin, int N, const float* bias, void* stream);
 int sgc_dbg_gemm_tn(int elem, const void* A, const void* B, float* C, int M, int N, int K, long lda, long ldb, int splits, int* slabs, void* stream);
 int sgc_dbg_conv_tn(int elem, const void* A, const void* B, float* C, int M, int n_img, int lgS, int Cin, int splits, int* slabs, void* stream);

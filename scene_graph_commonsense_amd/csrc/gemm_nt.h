@@ -48,6 +48,8 @@ struct NtParams {
     float* raw; int raw_first;                      // AMODE_CONV_GATHER + EPI_POOL: the accumulators (no bias / ReLU / pooling) of the entries
                                                     // e >= raw_first also go to raw[(e - raw_first) * 4 + pixel][ldc] (linear pairs, kernels_shared.hip)
     const int* tile_group; long group_stride;       // gemm_nt_pp_kernel: M tile t multiplies with B + tile_group[t] * group_stride
+    int stagger, stagger_phases;                    // gemm_nt_pp_kernel: the blocks of the FIRST generation (one per CU) start (id/8 % phases) * stagger
+                                                    // sleep units (~4 us) late, so that the CUs' store phases do not coincide (0: off)
 };
 
 template <int ELEM>

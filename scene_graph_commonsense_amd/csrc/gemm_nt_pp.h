@@ -90,6 +90,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(const NtParams p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wid >> 2, wc = wid & 3;
+    if (p.stagger > 0 && blockIdx.x < 256) {          // equal tiles started together keep every CU's epilogue at the same moment
+        const int late = ((blockIdx.x >> 3) & (p.stagger_phases - 1)) * p.stagger;
+        for (int s = 0; s < late; ++s) __builtin_amdgcn_s_sleep(127);
+    }
     int tm, tn;
     if (p.patch_aligned) {
         if (!xcd_patch_map_aligned(blockIdx.x, p.tiles_m, p.tiles_n, tm, tn)) return;  // padding block (uniform exit)

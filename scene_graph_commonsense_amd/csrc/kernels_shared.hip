@@ -478,7 +478,11 @@ __global__ __launch_bounds__(256) void pair_contract_windows_kernel(const u16* _
 //   S_o  = 2-D inclusive prefix sums of T_o over the 8x8 window grid (9x9 with a zero border)
 //   h_pre[p] = b + S_i[all] - S_i[R_j] + S'_j[R_j] - S'_j[X_p] + sum_{e in X_p} O[dest[e]]          (rectangle sums = 4 look-ups)
 // which is the same sum in a different order (f32 round-off instead of bit equality with the [P, 65536] GEMM).
-__global__ __launch_bounds__(256) void fc1_integral_kernel(const float* __restrict__ owm, const int* __restrict__ goff, int n2,
+// Row pitch of the f32 products owm in floats: 4096 + 256 B.  With the power-of-two pitch every row of a 256 x 256 output tile starts
+// 16 KiB after the previous one and the tile's stores drain 10 % slower (tools/fc1_windows_microbench.py: 3.18 -> 2.86 ms per launch
+// with 16-byte stores; profiles/r03_fc1_windows_microbench*.txt).
+static inline int owm_pitch() { return sgc_tuning().owm_pitch; }     // 4160
+__global__ __launch_bounds__(256) void fc1_integral_kernel(const float* __restrict__ owm, int pitch, const int* __restrict__ goff, int n2,
                                                            float* __restrict__ S) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     const int c = (int)(idx & 4095);
@@ -495,7 +499,7 @@ __global__ __launch_bounds__(256) void fc1_integral_kernel(const float* __restri
         So[(long)((y + 1) * 9) * 4096] = 0.f;
 #pragma unroll
         for (int x = 0; x < 8; ++x) {
-            run += owm[((long)goff[y * 8 + x] + ps) * 4096 + c];
+            run += owm[((long)goff[y * 8 + x] + ps) * pitch + c];
             col[x] += run;
             So[(long)((y + 1) * 9 + x + 1) * 4096] = col[x];
         }
@@ -520,7 +524,7 @@ __device__ __forceinline__ void rect_acc(float (&acc)[16], const float* __restri
 
 // h1[p] = dropout(relu(h_pre[p])) as above; one workgroup per pair, thread t owns channels 16t .. 16t+15
 // (reference model.py:148-149: fc1 -> ReLU -> dropout; the keep bit is the one sgc_fc1_relu uses: hash(seed, p*4096 + c))
-__global__ __launch_bounds__(256) void fc1_assemble_kernel(const float* __restrict__ S, const float* __restrict__ owm,
+__global__ __launch_bounds__(256) void fc1_assemble_kernel(const float* __restrict__ S, const float* __restrict__ owm, int pitch,
                                                            const int* __restrict__ bbox, const int* __restrict__ sub,
                                                            const int* __restrict__ obj, const int* __restrict__ incl,
                                                            const int* __restrict__ dest, int n_obj, const float* __restrict__ bias,
@@ -545,7 +549,7 @@ __global__ __launch_bounds__(256) void fc1_assemble_kernel(const float* __restri
     }
     const int e0 = p ? incl[p - 1] : 0, e1 = incl[p];
     for (int e = e0; e < e1; ++e) {
-        const float* o = owm + (long)dest[e] * 4096 + c0;
+        const float* o = owm + (long)dest[e] * pitch + c0;
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
             const float4 t = reinterpret_cast<const float4*>(o)[v];
@@ -1138,19 +1142,20 @@ int sgc_conv3_relu_pool_windows_wm_raw(const void* z_pad, const void* w3r, const
     p.gather = gather; p.gather_n = gather_n; p.dest = dest; p.raw = raw; p.raw_first = raw_first;
     return launch_gemm_nt_pp_conv_gather<ELEM_F16, EPI_POOL>(p, (hipStream_t)stream);
 }
-// owm [rows][4096] f32 = ywm [rows][1024] f16 * w1p[:, g*1024 .. +1024]^T, g = tile_group[row / 256]  (rows a multiple of 256)
+int sgc_fc1_products_pitch(void) { return owm_pitch(); }
+// owm [rows][pitch] f32 (columns 0..4095) = ywm [rows][1024] f16 * w1p[:, g*1024 .. +1024]^T, g = tile_group[row / 256]  (rows a multiple of 256)
 int sgc_fc1_windows_gemm(const void* ywm, const void* w1p, const int* tile_group, float* owm, int rows, void* stream) {
     if (rows <= 0) return SGC_OK;
     if (rows & 255) return SGC_ERR_ARG;
     NtParams p{};
     p.A = (const u16*)ywm; p.B = (const u16*)w1p; p.C = owm; p.M = rows; p.N = 4096; p.K = 1024;
-    p.lda = 1024; p.ldb = 65536; p.ldc = 4096; p.tile_group = tile_group; p.group_stride = 1024;
+    p.lda = 1024; p.ldb = 65536; p.ldc = owm_pitch(); p.tile_group = tile_group; p.group_stride = 1024;
     if (sgc_tuning().f32_swap) return launch_gemm_nt_pp<ELEM_F16, EPI_STORE_F32T>(p, (hipStream_t)stream);
     return launch_gemm_nt_pp<ELEM_F16, EPI_STORE_F32>(p, (hipStream_t)stream);
 }
 int sgc_fc1_integral(const float* owm, const int* goff, int n_pseudo, float* S, void* stream) {
     if (n_pseudo <= 0) return SGC_OK;
-    SGC_LAUNCH(fc1_integral_kernel, dim3((unsigned)(((long)n_pseudo * 4096 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, owm, goff,
+    SGC_LAUNCH(fc1_integral_kernel, dim3((unsigned)(((long)n_pseudo * 4096 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, owm, owm_pitch(), goff,
                n_pseudo, S);
     SGC_CHECK_LAUNCH();
     return SGC_OK;
@@ -1159,7 +1164,7 @@ int sgc_fc1_assemble(const float* S, const float* owm, const int* bbox, const in
                      const int* dest, int n_obj, const float* bias, int drop_enable, unsigned drop_seed, void* h1, int n_pairs,
                      void* stream) {
     if (n_pairs <= 0) return SGC_OK;
-    SGC_LAUNCH(fc1_assemble_kernel, dim3(n_pairs), dim3(256), 0, (hipStream_t)stream, S, owm, bbox, sub_idx, obj_idx, count_incl, dest,
+    SGC_LAUNCH(fc1_assemble_kernel, dim3(n_pairs), dim3(256), 0, (hipStream_t)stream, S, owm, owm_pitch(), bbox, sub_idx, obj_idx, count_incl, dest,
                n_obj, bias, drop_enable, drop_seed, 2.f, (u16*)h1);
     SGC_CHECK_LAUNCH();
     return SGC_OK;

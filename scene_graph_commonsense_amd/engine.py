@@ -557,7 +557,7 @@ class RelHeadEngine:
     def fc1_shared(self, wm, ywm, bbox, sub_idx, obj_idx, incl, P, n_obj, h1, dropout, seed):
         """fc1 + ReLU (+ dropout) from the window-major rows: grouped GEMM, per-object 2-D prefix sums, per-pair assembly."""
         lib, sc = self.lib, self.scratch
-        owm = sc.get("owm", wm["rows"] * 4096, torch.float32)
+        owm = sc.get("owm", wm["rows"] * int(lib.sgc_fc1_products_pitch()), torch.float32)
         self._timed("fc1_fwd_windows", lambda: _lib.check(lib.sgc_fc1_windows_gemm(
             _lib.ptr(ywm), _lib.ptr(self.w["w1p"]), _lib.ptr(wm["tile_group"]), _lib.ptr(owm), wm["rows"], self._st()), "sgc_fc1_windows_gemm"))
         S = sc.get("fc1_S", wm["n2"] * 81 * 4096, torch.float32)

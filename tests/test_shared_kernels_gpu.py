@@ -125,10 +125,10 @@ def test_fc1_prefix_sums_and_per_object_gradient_sums():
     goff, _ = window_major_layout(np.zeros(64, dtype=np.int64), n2)
     goff_d = torch.from_numpy(goff).to(DEV)
     rows = int(goff[64])
-    owm = torch.randn(rows, 4096, device=DEV)
+    owm = torch.randn(rows, int(lib.sgc_fc1_products_pitch()), device=DEV)       # padded row pitch; columns 0..4095 are the products
     S = torch.full((n2, 9, 9, 4096), float("nan"), device=DEV)
     L.check(lib.sgc_fc1_integral(L.ptr(owm), L.ptr(goff_d), n2, L.ptr(S), L.stream_ptr()), "integral")
-    T = torch.stack([owm[int(goff[w]):int(goff[w]) + n2] for w in range(64)], dim=1).view(n2, 8, 8, 4096)
+    T = torch.stack([owm[int(goff[w]):int(goff[w]) + n2, :4096] for w in range(64)], dim=1).view(n2, 8, 8, 4096)
     want = torch.zeros(n2, 9, 9, 4096, device=DEV)
     want[:, 1:, 1:] = T.cumsum(1).cumsum(2)
     assert torch.allclose(S, want, atol=1e-4, rtol=1e-5)

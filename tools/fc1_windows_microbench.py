@@ -24,20 +24,22 @@ ywm = (torch.rand(rows, 1024, device=dev) * 2 - 1).half()
 w_rows = (torch.rand(4096, 65536, device=dev) * 0.06 - 0.03).half()                       # the product's layout
 w_slab = w_rows.view(4096, 64, 1024).permute(1, 0, 2).contiguous()                       # [group][4096][1024]
 tg = torch.arange(64, device=dev, dtype=torch.int32).repeat_interleave(rpg // 256).contiguous()
-o32 = torch.empty(rows, 4096, dtype=torch.float32, device=dev)
-o16 = torch.empty(rows, 4096, dtype=torch.float16, device=dev)
+LDC = int(os.environ.get("MB_LDC", "4096"))          # row pitch of the products in elements (4096: the product's; e.g. 4160 = + 256 B)
+STAG, PHASES = [int(x) for x in os.environ.get("MB_STAGGER", "0,1").split(",")]     # sleep units (~4 us) per phase step, phases (power of 2)
+o32 = torch.empty(rows, LDC, dtype=torch.float32, device=dev)
+o16 = torch.empty(rows, LDC, dtype=torch.float16, device=dev)
 flop = 2.0 * rows * 1024 * 4096
 modes = {0: "f32, 4-byte stores", 1: "f32, 16-byte stores", 2: "no stores", 3: "f16 output (LDS-staged)"}
 layouts = {"rows [4096][65536]": (w_rows, 65536, 1024), "slabs [64][4096][1024]": (w_slab, 1024, 4096 * 1024)}
 L = ctypes.c_long
-print("# %d rows (%d per window group), %.2f TFLOP, %.2f GB of f32 products" % (rows, rpg, flop / 1e12, rows * 4096 * 4 / 1e9))
+print("# %d rows (%d per window group), %.2f TFLOP, %.2f GB of f32 products, row pitch %d elements, stagger %d x %d phases" % (rows, rpg, flop / 1e12, rows * 4096 * 4 / 1e9, LDC, STAG, PHASES))
 ref = None
 for rep in range(2):
     for lname, (w, ldb, gs) in layouts.items():
         for mode, mname in modes.items():
             out = o16 if mode == 3 else o32
             def run():
-                _lib.check(lib.sgc_dbg_fc1_windows_gemm(_lib.ptr(ywm), _lib.ptr(w), _lib.ptr(tg), _lib.ptr(out), rows, L(ldb), L(gs), mode,
+                _lib.check(lib.sgc_dbg_fc1_windows_gemm(_lib.ptr(ywm), _lib.ptr(w), _lib.ptr(tg), _lib.ptr(out), rows, L(ldb), L(gs), L(LDC), mode, STAG, PHASES,
                                                         _lib.stream_ptr()), "sgc_dbg_fc1_windows_gemm")
             run(); run()
             torch.cuda.synchronize()
@@ -52,10 +54,10 @@ for rep in range(2):
             if rep == 0 and mode in (0, 1):
                 g = 37
                 want = ywm[g * rpg:g * rpg + 256].float() @ w_rows[:, g * 1024:(g + 1) * 1024].float().t()
-                got = o32[g * rpg:g * rpg + 256]
+                got = o32[g * rpg:g * rpg + 256, :4096]
                 note = "  max rel err %.1e" % float((got - want).abs().max() / want.abs().max())
                 if ref is None:
-                    ref = o32.clone()
+                    ref = o32[:, :4096].clone()
                 else:
-                    note += ", bit-identical to the first variant: %s" % bool(torch.equal(ref, o32))
+                    note += ", bit-identical to the first variant: %s" % bool(torch.equal(ref, o32[:, :4096]))
             print("%-24s %-26s %7.3f ms  %7.1f TFLOP/s%s" % (lname, mname, ms, flop / ms / 1e9, note), flush=True)
