@@ -51,6 +51,8 @@ int sgc_dbg_fc1_windows_gemm(const void* ywm, const void* w, const int* tile_gro
         case 0: return launch_gemm_nt_pp<ELEM_F16, EPI_STORE_F32>(p, (hipStream_t)stream);
         case 1: case 2: return launch_gemm_nt_pp<ELEM_F16, EPI_STORE_F32T>(p, (hipStream_t)stream);
         case 3: p.epi_lds = 1; return launch_gemm_nt_pp<ELEM_F16, EPI_STORE>(p, (hipStream_t)stream);
+        case 11: p.nt_store = 8; return launch_gemm_nt_pp<ELEM_F16, EPI_STORE_F32T>(p, (hipStream_t)stream);      // tile-contiguous output
+        case 4: case 5: case 6: case 7: p.nt_store = mode - 3; return launch_gemm_nt_pp<ELEM_F16, EPI_STORE_F32T>(p, (hipStream_t)stream);   // 1 with nt / sc1 / sc0 sc1 / sc0 sc1 nt
     }
     return SGC_ERR_ARG;
 }

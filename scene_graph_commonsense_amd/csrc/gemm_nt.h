@@ -48,6 +48,7 @@ struct NtParams {
     float* raw; int raw_first;                      // AMODE_CONV_GATHER + EPI_POOL: the accumulators (no bias / ReLU / pooling) of the entries
                                                     // e >= raw_first also go to raw[(e - raw_first) * 4 + pixel][ldc] (linear pairs, kernels_shared.hip)
     const int* tile_group; long group_stride;       // gemm_nt_pp_kernel: M tile t multiplies with B + tile_group[t] * group_stride
+    int nt_store;                                   // nt_epilogue_f32t / nt_epilogue_store16: non-temporal stores (tools/fc1_windows_microbench.py)
     int stagger, stagger_phases;                    // gemm_nt_pp_kernel: the blocks of the FIRST generation (one per CU) start (id/8 % phases) * stagger
                                                     // sleep units (~4 us) late, so that the CUs' store phases do not coincide (0: off)
 };
@@ -168,7 +169,15 @@ __device__ __forceinline__ void nt_epilogue_f32t(const NtParams& p, f32x16 (&acc
                     const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + col);
                     v += b;
                 }
-                *reinterpret_cast<f32x4*>(out + (long)row * p.ldc + col) = v;
+                f32x4* dst = reinterpret_cast<f32x4*>(out + (long)row * p.ldc + col);
+                if (p.nt_store == 8)      // experiment: every 256 x 256 tile stored as ONE contiguous 256 KiB block (page locality of the stores)
+                    dst = reinterpret_cast<f32x4*>(out + (((long)(m0 >> 8) * p.tiles_n + (n0 >> 8)) << 16) + ((row - m0) << 8) + (col - n0));
+                // cache-policy bits of the store (experiment): 1 nt, 2 sc1, 3 sc0 sc1, 4 sc0 sc1 nt
+                if (p.nt_store == 1) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(dst), "v"(v) : "memory");
+                else if (p.nt_store == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory");
+                else if (p.nt_store == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(v) : "memory");
+                else if (p.nt_store == 4) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(dst), "v"(v) : "memory");
+                else *dst = v;
             }
         }
     }
@@ -244,7 +253,10 @@ __device__ __forceinline__ void nt_epilogue_store16(const NtParams& p, f32x16 (&
         const int rowl = it * 8 + rsub;
         const uint4 v = *reinterpret_cast<const uint4*>(reg + rowl * 144 + c8 * 16);
         const int row = m0 + wr * 128 + rowl;
-        if (row < p.M) *reinterpret_cast<uint4*>(out + (long)row * p.ldc + n0 + wc * 64 + c8 * 8) = v;
+        if (row < p.M) {
+            uint4* dst = reinterpret_cast<uint4*>(out + (long)row * p.ldc + n0 + wc * 64 + c8 * 8);
+            *dst = v;
+        }
     }
 }
 

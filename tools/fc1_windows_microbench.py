@@ -29,7 +29,9 @@ STAG, PHASES = [int(x) for x in os.environ.get("MB_STAGGER", "0,1").split(",")] 
 o32 = torch.empty(rows, LDC, dtype=torch.float32, device=dev)
 o16 = torch.empty(rows, LDC, dtype=torch.float16, device=dev)
 flop = 2.0 * rows * 1024 * 4096
-modes = {0: "f32, 4-byte stores", 1: "f32, 16-byte stores", 2: "no stores", 3: "f16 output (LDS-staged)"}
+modes = {0: "f32, 4-byte stores", 1: "f32, 16-byte stores", 2: "no stores", 3: "f16 output (LDS-staged)", 4: "f32, 16-byte stores nt",
+         5: "f32, 16-byte stores sc1", 6: "f32, 16-byte stores sc0 sc1", 7: "f32, 16-byte stores sc0 sc1 nt",
+         11: "f32, tile-contiguous output"}
 layouts = {"rows [4096][65536]": (w_rows, 65536, 1024), "slabs [64][4096][1024]": (w_slab, 1024, 4096 * 1024)}
 L = ctypes.c_long
 print("# %d rows (%d per window group), %.2f TFLOP, %.2f GB of f32 products, row pitch %d elements, stagger %d x %d phases" % (rows, rpg, flop / 1e12, rows * 4096 * 4 / 1e9, LDC, STAG, PHASES))
@@ -51,7 +53,7 @@ for rep in range(2):
             torch.cuda.synchronize()
             ms = a.elapsed_time(b) / 5
             note = ""
-            if rep == 0 and mode in (0, 1):
+            if rep == 0 and mode in (0, 1, 4, 5, 6, 7):
                 g = 37
                 want = ywm[g * rpg:g * rpg + 256].float() @ w_rows[:, g * 1024:(g + 1) * 1024].float().t()
                 got = o32[g * rpg:g * rpg + 256, :4096]
