@@ -41,12 +41,12 @@ int sgc_dbg_gemm_nt_abl(int abl, const void* A, const void* B, void* C, int M, i
 // epilogue as parameters.  mode 0: f32 tile in the MFMA's C layout (4-byte stores), 1: transposed tile (16-byte stores), 2: the same
 // without its stores (C ignored), 3: f16 output through the LDS-staged epilogue.
 int sgc_dbg_fc1_windows_gemm(const void* ywm, const void* w, const int* tile_group, void* owm, int rows, long ldb, long group_stride,
-                             long ldc, int mode, int stagger, int phases, void* stream) {
+                             long ldc, int mode, int stagger, int phases, unsigned long long* clk, void* stream) {
     if (rows <= 0 || (rows & 255)) return SGC_ERR_ARG;
     NtParams p{};
     p.A = (const u16*)ywm; p.B = (const u16*)w; p.C = mode == 2 ? nullptr : owm; p.M = rows; p.N = 4096; p.K = 1024;
     p.lda = 1024; p.ldb = ldb; p.ldc = ldc; p.tile_group = tile_group; p.group_stride = group_stride;
-    p.stagger = stagger; p.stagger_phases = phases;
+    p.stagger = stagger; p.stagger_phases = phases; p.clk = clk;
     switch (mode) {
         case 0: return launch_gemm_nt_pp<ELEM_F16, EPI_STORE_F32>(p, (hipStream_t)stream);
         case 1: case 2: return launch_gemm_nt_pp<ELEM_F16, EPI_STORE_F32T>(p, (hipStream_t)stream);

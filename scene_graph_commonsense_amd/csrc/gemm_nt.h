@@ -49,6 +49,7 @@ struct NtParams {
                                                     // e >= raw_first also go to raw[(e - raw_first) * 4 + pixel][ldc] (linear pairs, kernels_shared.hip)
     const int* tile_group; long group_stride;       // gemm_nt_pp_kernel: M tile t multiplies with B + tile_group[t] * group_stride
     int nt_store;                                   // nt_epilogue_f32t / nt_epilogue_store16: non-temporal stores (tools/fc1_windows_microbench.py)
+    unsigned long long* clk;                        // gemm_nt_pp_kernel (tools/fc1_windows_microbench.py): per-block wall clocks summed: [0] main loop, [1] epilogue, [2] blocks
     int stagger, stagger_phases;                    // gemm_nt_pp_kernel: the blocks of the FIRST generation (one per CU) start (id/8 % phases) * stagger
                                                     // sleep units (~4 us) late, so that the CUs' store phases do not coincide (0: off)
 };

@@ -94,6 +94,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(const NtParams p) {
         const int late = ((blockIdx.x >> 3) & (p.stagger_phases - 1)) * p.stagger;
         for (int s = 0; s < late; ++s) __builtin_amdgcn_s_sleep(127);
     }
+    const unsigned long long clk0 = p.clk ? wall_clock64() : 0ULL;
     int tm, tn;
     if (p.patch_aligned) {
         if (!xcd_patch_map_aligned(blockIdx.x, p.tiles_m, p.tiles_n, tm, tn)) return;  // padding block (uniform exit)
@@ -227,10 +228,20 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(const NtParams p) {
     for (; t < nk; ++t) tile(t, t & 1, std::false_type{});
     if (wr == 0) __builtin_amdgcn_s_barrier();        // re-align the two wave rows
 
+    bool stored = false;
     if constexpr (EPI == EPI_STORE && !ACG) {         // (gathered rows are scattered: the generic epilogue)
-        if (p.epi_lds) { nt_epilogue_store16<ELEM>(p, acc, m0, n0, wr, wc, lane, wid, smem); return; }
+        if (p.epi_lds) { nt_epilogue_store16<ELEM>(p, acc, m0, n0, wr, wc, lane, wid, smem); stored = true; }
     }
-    if constexpr (EPI == EPI_STORE_F32T) { static_assert(!ACG, "transposed f32 tile: plain rows only"); nt_epilogue_f32t(p, acc, m0, n0, wr, wc, lane); }
+    if (stored) {
+    } else if constexpr (EPI == EPI_STORE_F32T) {
+        static_assert(!ACG, "transposed f32 tile: plain rows only");
+        const unsigned long long clk1 = p.clk ? wall_clock64() : 0ULL;
+        nt_epilogue_f32t(p, acc, m0, n0, wr, wc, lane);
+        if (p.clk && tid == 0) {                      // (wall clock: 100 MHz) time to ISSUE the stores, not to complete them
+            const unsigned long long clk2 = wall_clock64();
+            atomicAdd(p.clk, clk1 - clk0); atomicAdd(p.clk + 1, clk2 - clk1); atomicAdd(p.clk + 2, 1ULL);
+        }
+    }
     else if constexpr (ACG) nt_epilogue<ELEM, EPI, 4, 2, true>(p, acc, m0, n0, wr, wc, lane, Mlim);
     else nt_epilogue<ELEM, EPI, 4, 2>(p, acc, m0, n0, wr, wc, lane);
 }

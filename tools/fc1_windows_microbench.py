@@ -25,6 +25,7 @@ w_rows = (torch.rand(4096, 65536, device=dev) * 0.06 - 0.03).half()             
 w_slab = w_rows.view(4096, 64, 1024).permute(1, 0, 2).contiguous()                       # [group][4096][1024]
 tg = torch.arange(64, device=dev, dtype=torch.int32).repeat_interleave(rpg // 256).contiguous()
 LDC = int(os.environ.get("MB_LDC", "4096"))          # row pitch of the products in elements (4096: the product's; e.g. 4160 = + 256 B)
+MODES = [int(x) for x in os.environ.get("MB_MODES", "").split(",") if x]
 STAG, PHASES = [int(x) for x in os.environ.get("MB_STAGGER", "0,1").split(",")]     # sleep units (~4 us) per phase step, phases (power of 2)
 o32 = torch.empty(rows, LDC, dtype=torch.float32, device=dev)
 o16 = torch.empty(rows, LDC, dtype=torch.float16, device=dev)
@@ -36,15 +37,19 @@ layouts = {"rows [4096][65536]": (w_rows, 65536, 1024), "slabs [64][4096][1024]"
 L = ctypes.c_long
 print("# %d rows (%d per window group), %.2f TFLOP, %.2f GB of f32 products, row pitch %d elements, stagger %d x %d phases" % (rows, rpg, flop / 1e12, rows * 4096 * 4 / 1e9, LDC, STAG, PHASES))
 ref = None
+clk = torch.zeros(4, dtype=torch.int64, device=dev)        # per-block wall clocks (100 MHz): main loop, store issue, blocks
 for rep in range(2):
     for lname, (w, ldb, gs) in layouts.items():
         for mode, mname in modes.items():
+            if MODES and mode not in MODES:
+                continue
             out = o16 if mode == 3 else o32
             def run():
-                _lib.check(lib.sgc_dbg_fc1_windows_gemm(_lib.ptr(ywm), _lib.ptr(w), _lib.ptr(tg), _lib.ptr(out), rows, L(ldb), L(gs), L(LDC), mode, STAG, PHASES,
+                _lib.check(lib.sgc_dbg_fc1_windows_gemm(_lib.ptr(ywm), _lib.ptr(w), _lib.ptr(tg), _lib.ptr(out), rows, L(ldb), L(gs), L(LDC), mode, STAG, PHASES, _lib.ptr(clk),
                                                         _lib.stream_ptr()), "sgc_dbg_fc1_windows_gemm")
             run(); run()
             torch.cuda.synchronize()
+            clk.zero_()
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
             for _ in range(5):
@@ -62,4 +67,7 @@ for rep in range(2):
                     ref = o32[:, :4096].clone()
                 else:
                     note += ", bit-identical to the first variant: %s" % bool(torch.equal(ref, o32[:, :4096]))
-            print("%-24s %-26s %7.3f ms  %7.1f TFLOP/s%s" % (lname, mname, ms, flop / ms / 1e9, note), flush=True)
+            c = clk.tolist()
+            per = "  per tile: main loop %.1f us, store issue %.1f us, x %.1f tiles per CU = %.2f ms" % (
+                c[0] / c[2] / 100.0, c[1] / c[2] / 100.0, c[2] / 5 / 256.0, (c[0] + c[1]) / 5 / 256.0 / 1e5) if c[2] else ""
+            print("%-24s %-26s %7.3f ms  %7.1f TFLOP/s%s%s" % (lname, mname, ms, flop / ms / 1e9, per, note), flush=True)
