@@ -264,7 +264,8 @@ def run_rank(args):
     reducer = sgd_dist.GradReducer(world)
     if world > 1 and args.dp_mode == "sharded" and not args.torch_sgd:
         # one object is both: reduce-scatter of the gradients, SGD on this rank's shard, all-gather of the updated parameters
-        opt = reducer = sgd_dist.ShardedSGD(model.named_parameters(), world, rank, lr=1e-5, momentum=0.9, weight_decay=1e-4)
+        opt = reducer = sgd_dist.ShardedSGD(model.named_parameters(), world, rank, lr=1e-5, momentum=0.9, weight_decay=1e-4,
+                                            defer_gather=True).attach(model)
     eng = model.engine()
 
     def barrier():

@@ -145,8 +145,9 @@ class ShardedSGD:
     ``step``).  ``fc1.weight`` (97 % of the bytes) is cut into ``buckets`` row blocks that are reduce-scattered / gathered as
     separate collectives, so the optimizer works on the first block while the last is on the wire.  The f32 master parameters
     stay REPLICATED and bit-identical on every rank (checkpoints, ``state_dict`` and the 16-bit re-cast work as before).
-    Not done: gathering 16-bit compute copies instead of f32 (halves the all-gather, but every rank would hold stale masters
-    outside its shard), and deferring the wait for fc1's gather until the next forward reaches fc1 (~12 ms later).
+    ``defer_gather=True`` + ``attach(model)``: the wait for fc1.weight's gather moves to the point of the NEXT forward where its
+    16-bit copies are made (right before fc1, ~12 ms into the step).  Not done: gathering 16-bit compute copies instead of f32
+    (halves the all-gather, but every rank would hold stale masters outside its shard).
 
     Interface: ``hook`` / ``finish_grads`` (what ``model.training_step(reducer=...)`` calls; ``owns_grads`` tells it not to
     write ``param.grad`` - no rank holds the full mean gradient), ``zero_grad`` / ``step`` / ``param_groups`` (what the training
@@ -156,10 +157,16 @@ class ShardedSGD:
     owns_grads = True
 
     def __init__(self, named_params, world: int = 1, rank: int = 0, lr: float = 1e-3, momentum: float = 0.0, weight_decay: float = 0.0,
-                 big=("fc1.weight",), buckets: int = 8, update_fn=None, group=None, force_collectives: bool = False):
+                 big=("fc1.weight",), buckets: int = 8, update_fn=None, group=None, force_collectives: bool = False,
+                 defer_gather: bool = False):
         self.named = [(n, p) for n, p in named_params]
         self.world, self.rank, self.group = int(world), int(rank), group
         self.collective = self.world > 1 or bool(force_collectives)   # forced: a one-rank RCCL group still runs every collective (tests)
+        # deferred: ``step`` returns while the all-gathers of the big parameters are still on the wire; whoever reads those parameters
+        # next calls ``wait_gathers`` first - the classifier does (``attach``: the 16-bit copies of fc1.weight are made right before fc1
+        # runs, ``engine.Weights``), so the gather overlaps the next forward up to fc1.  Anything else that reads the parameters on the
+        # compute stream (checkpoints, ``state_dict``) must call ``wait_gathers()`` itself; ``torch.cuda.synchronize()`` also suffices.
+        self.defer_gather = bool(defer_gather)
         self.param_groups = [dict(lr=lr, momentum=momentum, weight_decay=weight_decay, params=[p for _, p in self.named])]
         self.update = update_fn or _hip_sgd_update
         self.big = [n for n, p in self.named if n in set(big) and p.numel() % (self.world * 4) == 0]
@@ -182,7 +189,7 @@ class ShardedSGD:
         self.pieces["__small__"] = [_Piece("__small__", self.rank * sl, sl, 0, self.small_pad)] if self.small else []
         self.pending: List = []            # (work, shard tensor, piece) reduce-scatters in flight
         self.hooked = set()
-        self.gathers: List = []            # (work, keep-alive) all-gathers in flight
+        self.gathers: List = []            # (work, keep-alive, is a big parameter's) all-gathers in flight
         self._small_flat = None
         self._keep: List = []
         self.exposed_events: List = []     # (start, end) event pairs around every wait on the compute stream
@@ -298,12 +305,21 @@ class ShardedSGD:
         for _, p in self.named:
             p.grad = None
 
-    def wait_gathers(self):
-        """Block the compute stream until every parameter all-gather of the last ``step`` has landed (called before the weights
-        are read: ``model.refresh_weights``)."""
-        for work, _ in self.gathers:
-            self._wait(work)
-        self.gathers.clear()
+    def attach(self, model):
+        """Let ``model`` (a classifier of ``model.py``) wait for this optimizer's parameter gathers before it reads ``fc1.weight``."""
+        model.__dict__["weight_sync"] = self.wait_gathers
+        return self
+
+    def wait_gathers(self, small_only: bool = False):
+        """Block the compute stream until the parameter all-gathers of the last ``step`` have landed (``small_only``: only the
+        flat bucket of the small parameters - what ``step`` itself waits for with ``defer_gather``)."""
+        keep = []
+        for work, src, big in self.gathers:
+            if small_only and big:
+                keep.append((work, src, big))
+            else:
+                self._wait(work)
+        self.gathers[:] = keep
         if self._small_flat is not None:
             off = 0
             with torch.no_grad():
@@ -333,7 +349,7 @@ class ShardedSGD:
                 pc.first = False
                 if self.collective:
                     src = mine.clone()        # a copy of the shard (1/W of the block): no aliasing of a collective's input and output
-                    self.gathers.append((self._all_gather(flat[pc.bucket_off:pc.bucket_off + pc.bucket_len], src), src))
+                    self.gathers.append((self._all_gather(flat[pc.bucket_off:pc.bucket_off + pc.bucket_len], src), src, True))
         # ---- small parameters: one flat bucket
         if self.small and self.pieces["__small__"][0].acc is not None:
             pc = self.pieces["__small__"][0]
@@ -350,9 +366,11 @@ class ShardedSGD:
             pc.first = False
             if self.collective:
                 src = mine.clone()
-                self.gathers.append((self._all_gather(flat, src), src))
+                self.gathers.append((self._all_gather(flat, src), src, False))
             self._small_flat = flat
         for _, p in self.named:               # parameters change behind autograd's back: version-based caches must notice
             torch.autograd.graph.increment_version(p)
-        self.wait_gathers()                   # the classifier re-derives its 16-bit copies right after: gathers must have landed
+        # the classifier re-derives its 16-bit copies right after: the small parameters' gather must have landed; fc1.weight's may
+        # stay in flight until its copies are made (``defer_gather`` + ``attach``)
+        self.wait_gathers(small_only=self.defer_gather)
         return None

@@ -49,6 +49,28 @@ class PairOutputs:
     cand_pred: torch.Tensor                 # [P, 3] int32 / [P, 1]
 
 
+class Weights(dict):
+    """The 16-bit compute copies of the parameters.  An entry can be DEFERRED: ``defer(key, make)`` registers the function that
+    builds it and the first ``w[key]`` of the step runs it.  The two copies of ``fc1.weight`` (97 % of the parameter bytes) are made
+    this way, right before the first kernel that reads them: with ``distributed.ShardedSGD(defer_gather=True)`` the all-gather of
+    the updated ``fc1.weight`` is still on the wire when the next step starts and ``make`` first waits for it, so the gather
+    overlaps everything the forward does before fc1 (flatten, conv1, conv2, conv3: ~12 of 48 ms at the benchmark's size)."""
+
+    def __init__(self):
+        super().__init__()
+        self.deferred = {}
+
+    def defer(self, key, make):
+        self.deferred[key] = make
+        dict.pop(self, key, None)
+
+    def __getitem__(self, key):
+        make = self.deferred.pop(key, None)
+        if make is not None:
+            dict.__setitem__(self, key, make())
+        return dict.__getitem__(self, key)
+
+
 class Workspace:
     """Grow-only cache of device buffers keyed by name (no allocation inside the steady-state step)."""
 
@@ -218,7 +240,7 @@ class RelHeadEngine:
         self.lib = _lib.load()
         self.ws = Workspace(self.device)          # buffers a training context keeps until its backward has run
         self.scratch = self.ws                    # transient buffers; a child engine shares its parent's (see ``child``)
-        self.w: Dict[str, torch.Tensor] = {}
+        self.w: Dict[str, torch.Tensor] = Weights()
         self.T = (1.0, 1.0, 1.0)
         self.timers = None          # optional {name: [(start_event, end_event), ...]} filled by bench.py
 
@@ -245,8 +267,9 @@ class RelHeadEngine:
         return r
 
     # ------------------------------------------------------------------ weights
-    def load_weights(self, sd: Dict[str, torch.Tensor]):
-        """Build the 16-bit compute copies (layouts of csrc/kernels_fwd.hip) from the f32 master weights."""
+    def load_weights(self, sd: Dict[str, torch.Tensor], fc1_sync=None):
+        """Build the 16-bit compute copies (layouts of csrc/kernels_fwd.hip) from the f32 master weights.  ``fc1_sync``: called
+        before ``fc1.weight`` is read (``Weights``: that copy is made at its first use in the step)."""
         cfg, dev = self.cfg, self.device
         g = lambda k: sd[k].detach().to(dev, torch.float32)
         w = self.w
@@ -261,8 +284,12 @@ class RelHeadEngine:
         w["b2"] = g("conv2_1.bias").contiguous()
         w["w3r"] = conv_k_layout(g("conv3_1.weight")).half().contiguous()
         w["b3"] = g("conv3_1.bias").contiguous()
-        w1 = g("fc1.weight").contiguous()
-        w["w1p"] = self._transpose_cast(w1, "w1p", torch.float16, 0, 4096, 16, 65536, 4096, 64, 65536, 64, 1024)
+        def make_w1p():
+            if fc1_sync is not None:
+                fc1_sync()
+            with torch.no_grad():
+                return self._transpose_cast(g("fc1.weight").contiguous(), "w1p", torch.float16, 0, 4096, 16, 65536, 4096, 64, 65536, 64, 1024)
+        w.defer("w1p", make_w1p)
         w["bf1"] = g("fc1.bias").contiguous()
         fc2 = g("fc2.weight")
         w["fc2_full"] = fc2
@@ -557,9 +584,10 @@ class RelHeadEngine:
     def fc1_shared(self, wm, ywm, bbox, sub_idx, obj_idx, incl, P, n_obj, h1, dropout, seed):
         """fc1 + ReLU (+ dropout) from the window-major rows: grouped GEMM, per-object 2-D prefix sums, per-pair assembly."""
         lib, sc = self.lib, self.scratch
+        w1p = self.w["w1p"]                          # deferred copy: made here (after the wait for fc1.weight's all-gather, if one is in flight)
         owm = sc.get("owm", wm["rows"] * int(lib.sgc_fc1_products_pitch()), torch.float32)
         self._timed("fc1_fwd_windows", lambda: _lib.check(lib.sgc_fc1_windows_gemm(
-            _lib.ptr(ywm), _lib.ptr(self.w["w1p"]), _lib.ptr(wm["tile_group"]), _lib.ptr(owm), wm["rows"], self._st()), "sgc_fc1_windows_gemm"))
+            _lib.ptr(ywm), _lib.ptr(w1p), _lib.ptr(wm["tile_group"]), _lib.ptr(owm), wm["rows"], self._st()), "sgc_fc1_windows_gemm"))
         S = sc.get("fc1_S", wm["n2"] * 81 * 4096, torch.float32)
         self._timed("fc1_fwd_integral", lambda: _lib.check(lib.sgc_fc1_integral(_lib.ptr(owm), _lib.ptr(wm["goff"]), wm["n2"], _lib.ptr(S), self._st()),
                                                            "sgc_fc1_integral"))
@@ -689,7 +717,8 @@ class RelHeadEngine:
                 self._timed("conv3_fwd", lambda: _lib.check(lib.sgc_conv3_relu_pool(_lib.ptr(z), _lib.ptr(self.w["w3r"]), _lib.ptr(self.w["b3"]),
                                                                                    _lib.ptr(y), _lib.ptr(am), _lib.ptr(None), P, self._st()),
                                                             "sgc_conv3_relu_pool"))
-            self._timed("fc1_fwd", lambda: _lib.check(lib.sgc_fc1_relu(_lib.ptr(y), _lib.ptr(self.w["w1p"]), _lib.ptr(self.w["bf1"]), _lib.ptr(h1), P, 65536,
+            w1p = self.w["w1p"]                               # deferred copy (Weights): made here, outside the timed launch
+            self._timed("fc1_fwd", lambda: _lib.check(lib.sgc_fc1_relu(_lib.ptr(y), _lib.ptr(w1p), _lib.ptr(self.w["bf1"]), _lib.ptr(h1), P, 65536,
                                                                        int(train), ctypes.c_uint(seeds[0]), self._st()), "sgc_fc1_relu"))
         p = ws.get("p", Ppad * 512, torch.float32)
         self._timed("fc2_fwd", lambda: _lib.check(lib.sgc_fc2_labels_relu(_lib.ptr(h1), _lib.ptr(self.w["w2m"]), _lib.ptr(self.w["bf2"]), _lib.ptr(lsub),
@@ -779,14 +808,20 @@ class RelHeadEngine:
         return full
 
     # ====================================================================== training (forward + backward)
-    def prep_bwd_weights(self, sd):
+    def prep_bwd_weights(self, sd, fc1_sync=None):
         """bf16 transposed / flipped weight copies for the data-gradient GEMMs."""
         dev = self.device
         g = lambda k: sd[k].detach().to(dev, torch.float32)
         w = self.w
         w["w2mT"] = w["fc2_full"][:, :4096].t().contiguous().to(torch.bfloat16)
-        w["w1pT"] = self._transpose_cast(g("fc1.weight").contiguous(), "w1pT", torch.bfloat16, 1, 64, 1024, 64 * 65536, 64, 65536,
-                                         64, 4096, 1024 * 4096)
+
+        def make_w1pT():
+            if fc1_sync is not None:
+                fc1_sync()
+            with torch.no_grad():
+                return self._transpose_cast(g("fc1.weight").contiguous(), "w1pT", torch.bfloat16, 1, 64, 1024, 64 * 65536, 64, 65536,
+                                            64, 4096, 1024 * 4096)
+        w.defer("w1pT", make_w1pT)
         w["wd3"] = conv_k_layout(g("conv3_1.weight").flip(2, 3).permute(1, 0, 2, 3)).to(torch.bfloat16).contiguous()
         # [(tap, c_in)][c_out]: second operand of the column form of the data gradient over pair-specific windows
         w["w3col"] = g("conv3_1.weight").permute(2, 3, 1, 0).reshape(9 * 512, 1024).to(torch.bfloat16).contiguous()
@@ -880,7 +915,8 @@ class RelHeadEngine:
                 self._timed("conv3_fwd", lambda: _lib.check(lib.sgc_conv3_relu_pool(_lib.ptr(z), _lib.ptr(self.w["w3r"]), _lib.ptr(self.w["b3"]),
                                                                                    _lib.ptr(y), _lib.ptr(am), _lib.ptr(y_bf), P, self._st()),
                                                             "sgc_conv3_relu_pool"))
-            self._timed("fc1_fwd", lambda: _lib.check(lib.sgc_fc1_relu(_lib.ptr(y), _lib.ptr(self.w["w1p"]), _lib.ptr(self.w["bf1"]), _lib.ptr(h1), P, 65536,
+            w1p = self.w["w1p"]                               # deferred copy (Weights): made here, outside the timed launch
+            self._timed("fc1_fwd", lambda: _lib.check(lib.sgc_fc1_relu(_lib.ptr(y), _lib.ptr(w1p), _lib.ptr(self.w["bf1"]), _lib.ptr(h1), P, 65536,
                                                                        int(dropout), ctypes.c_uint(seeds[0]), self._st()), "sgc_fc1_relu"))
             ctx.y, ctx.y_bf = y, y_bf
         p = ws.get("p", Ppad * 512, torch.float32)
@@ -1081,7 +1117,8 @@ class RelHeadEngine:
                                                         "sgc_fc1_wgrad"))
             self._fc1_finish_wgrad(dW1p, dh1, Ppad, grads, grad_hook)
         dy = ws.get("dy", Ppad * 65536, torch.bfloat16)
-        self._timed("fc1_dgrad", lambda: _lib.check(lib.sgc_fc1_dgrad(_lib.ptr(dh1), _lib.ptr(w["w1pT"]), _lib.ptr(dy), P, 65536, st()), "sgc_fc1_dgrad"))
+        w1pT = w["w1pT"]                               # deferred copy (Weights): made here, outside the timed launch
+        self._timed("fc1_dgrad", lambda: _lib.check(lib.sgc_fc1_dgrad(_lib.ptr(dh1), _lib.ptr(w1pT), _lib.ptr(dy), P, 65536, st()), "sgc_fc1_dgrad"))
         return dy
 
     def _fc1_backward_rows(self, ctx, dh1, sub_csr, obj_csr, side, grads, grad_hook):
@@ -1106,7 +1143,8 @@ class RelHeadEngine:
                 self._fc1_finish_wgrad(dW1p, dh1, ctx.Ppad, grads, grad_hook)
 
         def dgrad():
-            self._timed("fc1_dgrad", lambda: _lib.check(lib.sgc_fc1_windows_dgrad(_lib.ptr(gwm), _lib.ptr(w["w1pT"]), _lib.ptr(wm["tile_group"]),
+            w1pT = w["w1pT"]                               # deferred copy (Weights): made here, outside the timed launch
+            self._timed("fc1_dgrad", lambda: _lib.check(lib.sgc_fc1_windows_dgrad(_lib.ptr(gwm), _lib.ptr(w1pT), _lib.ptr(wm["tile_group"]),
                                                                                   _lib.ptr(dy), wm["rows"], st()), "sgc_fc1_windows_dgrad"))
         # GEMM beside GEMM buys nothing on this chip (two ping-pong GEMMs on two streams: 13.5 ms against 13.4 back to back) while an
         # HBM-bound kernel beside a GEMM hides ~40 % of its time (profiles/r03_overlap_microbench.txt).  ``TUNING.gemms_apart``: the

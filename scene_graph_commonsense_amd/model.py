@@ -149,10 +149,11 @@ class _RelationBase(nn.Module):
         v = (self._version(), backward)
         if self._weights_version is None or self._weights_version[0] != v[0] or (backward and not self._weights_version[1]):
             sd = {k: p for k, p in self.named_parameters()}
+            sync = self.__dict__.get("weight_sync")      # distributed.ShardedSGD.attach: fc1.weight's all-gather may still be in flight
             with torch.no_grad():
-                eng.load_weights(sd)
+                eng.load_weights(sd, fc1_sync=sync)
                 if backward:
-                    eng.prep_bwd_weights(sd)
+                    eng.prep_bwd_weights(sd, fc1_sync=sync)
             self._weights_version = v
         return eng
 
@@ -162,6 +163,7 @@ class _RelationBase(nn.Module):
         eng = self.refresh_weights(backward=True)
         if k == 0:
             return eng
+        eng.w["w1p"], eng.w["w1pT"]                    # deferred copies: made on the caller's stream, before the lanes' streams read them
         lanes = self.__dict__.setdefault("_lane_engines", {})
         if k not in lanes or lanes[k].device != eng.device:
             lanes[k] = RelHeadEngine(self.head_config(), eng.device)

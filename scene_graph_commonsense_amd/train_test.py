@@ -255,7 +255,7 @@ def training(gpu, args, train_subset, test_subset):
     if world_size > 1 and T.get("dp_mode", "sharded") == "sharded":
         # reduce-scatter of the gradients + SGD on this rank's shard + all-gather of the parameters: reducer and optimizer in one
         optimizer = reducer = ShardedSGD(relation_classifier.named_parameters(), world_size, rank, lr=T["learning_rate"], momentum=0.9,
-                                         weight_decay=T["weight_decay"])
+                                         weight_decay=T["weight_decay"], defer_gather=True).attach(relation_classifier)
     else:
         optimizer = FusedSGD(relation_classifier.parameters(), lr=T["learning_rate"], momentum=0.9, weight_decay=T["weight_decay"])
         reducer = GradReducer(world_size)
@@ -330,6 +330,8 @@ def training(gpu, args, train_subset, test_subset):
             # connectivity and commonsense as 0.)
             running_losses.zero_(); running_contrast.zero_()
             stats[0] = 0; stats[1] = 0; stats[3] = 0
+        if hasattr(optimizer, "wait_gathers"):
+            optimizer.wait_gathers()                         # deferred all-gather of fc1.weight: land it before the parameters are read
         if rank == 0:
             path = checkpoint_name(args, epoch, cs_mode)[0]
             print("Saving model to %s..." % path)

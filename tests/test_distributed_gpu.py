@@ -84,7 +84,8 @@ def _sharded_worker(rank, world, port, q):
         model.load_state_dict(sd)
         model.eval()                                                               # dropout off: both modes see the same step
         if mode == "sharded":
-            opt = red = D.ShardedSGD(model.named_parameters(), world, rank, lr=1e-5, momentum=0.9, weight_decay=1e-4)
+            opt = red = D.ShardedSGD(model.named_parameters(), world, rank, lr=1e-5, momentum=0.9, weight_decay=1e-4,
+                                     defer_gather=True).attach(model)      # fc1.weight's gather is waited for where fc1's copies are made
         else:
             opt, red = FusedSGD(model.parameters(), lr=1e-5, momentum=0.9, weight_decay=1e-4), D.GradReducer(world)
         train_minibatch(model, batch, opt, reducer=red)                            # step 1
@@ -154,7 +155,8 @@ def _rccl_worker(port, q):
         model.load_state_dict(sd)
         model.eval()
         if mode == "sharded":
-            opt = red = D.ShardedSGD(model.named_parameters(), 1, 0, lr=1e-5, momentum=0.9, weight_decay=1e-4, force_collectives=True)
+            opt = red = D.ShardedSGD(model.named_parameters(), 1, 0, lr=1e-5, momentum=0.9, weight_decay=1e-4, force_collectives=True,
+                                     defer_gather=True).attach(model)      # the gather of step k is in flight when step k+1 starts
         else:
             opt = FusedSGD(model.parameters(), lr=1e-5, momentum=0.9, weight_decay=1e-4)
             red = D.GradReducer(1, force_collectives=True) if mode == "allreduce" else None

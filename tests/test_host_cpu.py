@@ -464,7 +464,7 @@ def _torch_sgd_update(p, g, m, lr, momentum, weight_decay, first):
     p.sub_(lr * m)
 
 
-def _sharded_worker(rank, world, port, q):
+def _sharded_worker(rank, world, port, q, defer=False):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     from scene_graph_commonsense_amd import distributed as D
@@ -474,7 +474,7 @@ def _sharded_worker(rank, world, port, q):
     params = [(n, torch.nn.Parameter(torch.randn(s, generator=g))) for n, s in shapes]
     ref = [(n, torch.nn.Parameter(p.detach().clone())) for n, p in params]
     ref_opt = torch.optim.SGD([p for _, p in ref], lr=0.05, momentum=0.9, weight_decay=1e-3)
-    opt = D.ShardedSGD(params, w, r, lr=0.05, momentum=0.9, weight_decay=1e-3, buckets=4, update_fn=_torch_sgd_update)
+    opt = D.ShardedSGD(params, w, r, lr=0.05, momentum=0.9, weight_decay=1e-3, buckets=4, update_fn=_torch_sgd_update, defer_gather=defer)
     assert len(opt.pieces["fc1.weight"]) == 4 and opt.pieces["fc1.weight"][1].length == 64 * 128 // 4 // w
     assert opt.small_pad % (4 * w) == 0 and opt.small_pad >= 15 + 7 + 65
     worst = 0.0
@@ -499,6 +499,14 @@ def _sharded_worker(rank, world, port, q):
         v0 = [p._version for _, p in params]
         opt.step(); ref_opt.step()
         assert all(p._version > v for (_, p), v in zip(params, v0))
+        if defer:
+            # the small parameters are final when step() returns; fc1.weight's gathers may still be in flight until a reader waits
+            for (n, p), (_, q_) in zip(params, ref):
+                if n != "fc1.weight":
+                    worst = max(worst, float((p.detach() - q_.detach()).abs().max()))
+            assert all(big for _, _, big in opt.gathers)
+            opt.wait_gathers()
+        assert not opt.gathers
         for (n, p), (_, q_) in zip(params, ref):
             worst = max(worst, float((p.detach() - q_.detach()).abs().max()))
     # the momentum state is sharded: this rank holds 1/world of every bucket
@@ -508,9 +516,11 @@ def _sharded_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_sharded_sgd_reduce_scatter_update_all_gather_gloo_world2():
+@pytest.mark.parametrize("defer", [False, True])
+def test_sharded_sgd_reduce_scatter_update_all_gather_gloo_world2(defer):
     """distributed.ShardedSGD under gloo, world 2: four steps (early hook or not, gradient accumulation, lr change) leave EVERY
-    rank with the parameters a single torch.optim.SGD gets from the mean gradients; optimizer state is 1/world per rank."""
+    rank with the parameters a single torch.optim.SGD gets from the mean gradients; optimizer state is 1/world per rank.
+    ``defer``: the all-gather of the big parameter is waited for by its next reader, not by ``step``."""
     import socket
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
@@ -518,7 +528,7 @@ def test_sharded_sgd_reduce_scatter_update_all_gather_gloo_world2():
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, q, defer)) for r in range(2)]
     [p.start() for p in procs]
     res = sorted((q.get(timeout=180) for _ in range(2)), key=lambda t: t[0])
     [p.join(60) for p in procs]
