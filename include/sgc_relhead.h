@@ -159,6 +159,15 @@ int sgc_windows_wgrad_gather(const void* dy3x, const void* z_pad_bf16, const int
 int sgc_windows_dgrad_cols(const void* dy3x, const void* w3col, void* col, int rows, void* stream);
 int sgc_windows_col2im(const void* col, const int* bbox, const int* sub_idx, const int* obj_idx, const int* count_incl, int n_pairs,
                        void* dz, void* stream);
+/* The same data gradient in PATCH form (the step's default): patch [entries][16][512] bf16 = gradient of the 4 x 4 input patch (pixels
+ * 2wy-1 .. 2wy+2, 2wx-1 .. 2wx+2) of every listed window, summed over the taps inside the GEMM (K = 1024 x the 1 / 2 / 4 (own pixel,
+ * tap) combinations that reach a patch pixel); w3patch as engine.prep_bwd_weights lays it out.  sgc_windows_patch_sum[_objects]: dz of a
+ * pixel = sum of the patches of the <= 2 x 2 windows of the pair's rectangle that cover it (same output as sgc_windows_col2im[_objects];
+ * reference: the autograd of model.py:144-146's conv3). */
+int sgc_windows_dgrad_patches(const void* dy3x, const void* w3patch, void* patch, int entries, void* stream);
+int sgc_windows_patch_sum(const void* patch, const int* bbox, const int* sub_idx, const int* obj_idx, const int* count_incl, int n_pairs,
+                          void* dz, void* stream);
+int sgc_windows_patch_sum_objects(const void* patch, const int* bbox, int n_obj, int n_real_pairs, const int* count_incl, void* dz, void* stream);
 int sgc_pair_contract_windows(const void* dz, const unsigned char* amz, const int* ptr, const int* list, const int* pixel_rect,
                               const int* img_ptr, int role, int n_real_pairs, int n_obj, int n_img, int bg_maps, void* dU_pad, void* stream);
 /* Second level of the same sharing: a per-object map equals the all-background map outside R_o, so a pseudo-pair is computed only

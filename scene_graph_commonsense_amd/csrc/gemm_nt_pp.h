@@ -83,7 +83,13 @@ __device__ __forceinline__ bool xcd_patch_map_aligned(int id, int tiles_m, int t
 // gemm_nt.h: row m = pixel m&3 of window gather[m>>2] = image*(S/2)^2 + window, *gather_n entries, p.M only bounds the launch).  The rows of one
 // tile come from a few consecutive images (the list is sorted), so their byte offsets from the tile's first image fit the 32-bit
 // per-lane offset of the buffer load; the K step (64-channel chunk, tap) is a wave-uniform byte offset.
-template <int ELEM, int EPI, int ABL = 0, int ACG = 0>
+// SEG = 1: the data gradient of conv3 over listed windows in PATCH form (csrc/kernels_shared.hip, sgc_windows_dgrad_patches).  Row m is
+// a listed window; the virtual N tile tn = (patch pixel pp = 4*py + px of the window's 4x4 input patch, N half): the gradient of that
+// patch pixel is the sum over the (own pixel q, tap t) combinations with q + t = pp - 1, 2 or 4 of them - of dy[4m + q][:1024] x
+// W_t, i.e. a product with K = 1024 x combinations whose A row is made of SEGMENTS (rows 4m + q_c of dy) and whose B is the matching
+// stack of tap matrices (prepared per pp, contiguous).  Against the column form (rows 4m + q, N = 9 x 512, K = 1024) the same
+// multiply-adds leave 16 instead of 36 rows of 512 values per window, and the 9-tap sum of col2im happens in the accumulators.
+template <int ELEM, int EPI, int ABL = 0, int ACG = 0, int SEG = 0>
 __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(const NtParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int HT = 16384;                        // half-tile bytes; slot = parity*4 + kind, kind 0 A0, 1 B0, 2 B1, 3 A1
@@ -101,7 +107,19 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(const NtParams p) {
     } else {
         xcd_patch_map(blockIdx.x, p.tiles_m, p.tiles_n, tm, tn);
     }
-    const int m0 = tm * 256, n0 = tn * 256;
+    const int m0 = tm * 256;
+    int n0 = tn * 256, n_tile = tn, Kloc = p.K, seg_py = 0, seg_px = 0, seg_ny = 1, seg_nx = 1;
+    long ldb = p.ldb, b_off = 0;
+    if constexpr (SEG) {
+        const int pp = tn >> 1;
+        n_tile = tn & 1;
+        seg_py = pp >> 2; seg_px = pp & 3;
+        auto cnt1 = [](int c) { return (c == 0 || c == 3) ? 1 : 2; };
+        seg_ny = cnt1(seg_py); seg_nx = cnt1(seg_px);
+        Kloc = seg_ny * seg_nx * 1024;
+        ldb = Kloc;
+        for (int j = 0; j < pp; ++j) b_off += 512L * 1024 * (cnt1(j >> 2) * cnt1(j & 3));     // B_pp follows B_0 .. B_pp-1
+    }
     int Mlim = p.M;
     long img0 = 0;
     if constexpr (ACG) {
@@ -115,7 +133,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(const NtParams p) {
     // ---- staging sources: wave w writes LDS rows (2w+q)*8 .. +7 of every half tile (q = 0,1), 8 lanes per 128-B row
     const int lrow = lane >> 3, cpos = lane & 7;
     const u16* const a_blk = ACG ? p.A + img0 * img_elems : p.A + (long)m0 * p.lda;
-    const u16* const b_blk = p.B + (long)n0 * p.ldb + (p.tile_group ? (long)p.tile_group[tm] * p.group_stride : 0L);
+    const u16* const b_blk = p.B + b_off + (long)(n_tile * 256) * ldb + (p.tile_group ? (long)p.tile_group[tm] * p.group_stride : 0L);
     int voff[4][2];                                  // byte offsets from a_blk / b_blk
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -133,7 +151,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(const NtParams p) {
                 voff[h ? 3 : 0][q] = (int)((m * p.lda + chunk) * 2);
             }
             const int n = (r >> 5) * 64 + h * 32 + (r & 31);
-            voff[1 + h][q] = (int)((n * p.ldb + chunk) * 2);
+            voff[1 + h][q] = (int)((n * ldb + chunk) * 2);
         }
     }
     auto stage = [&](int kind, int t) __attribute__((always_inline)) {
@@ -146,6 +164,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(const NtParams p) {
                 const int cc = t / 9, tap = t - cc * 9;
                 const int ky = tap / 3, kx = tap - 3 * ky;
                 soff = ((ky * SP + kx) * p.Cin + (cc << 6)) * 2;
+            }
+        }
+        if constexpr (SEG) {
+            if (kind == 0 || kind == 3) {            // K tile t: combination c = t / 16 -> own pixel (qy, qx) of the window, channels (t % 16) * 64
+                const int c = t >> 4;
+                const int cy = seg_nx == 2 ? (c >> 1) : c, cx = seg_nx == 2 ? (c & 1) : 0;
+                const int qy = seg_ny == 1 ? (seg_py == 3) : cy, qx = seg_nx == 1 ? (seg_px == 3) : cx;
+                soff = ((qy * 2 + qx) * 1024 + ((t & 15) << 6)) * 2;
             }
         }
         buf_load_lds16(g, voff[kind][0], soff, base);
@@ -203,7 +229,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(const NtParams p) {
         SGC_PP_BARRIER();                                      \
     } while (0)
 
-    const int nk = p.K >> 6;
+    const int nk = Kloc >> 6;
     // ---- prologue: ring order is [A0 B0 B1](t) in phase Y(t-2), A1(t) in phase X(t-1)
     stage(0, 0); stage(1, 0); stage(2, 0); stage(3, 0);
     if (nk > 1) { stage(0, 1); stage(1, 1); stage(2, 1); SGC_WAIT_VM(8); } else SGC_WAIT_VM(0);
@@ -258,6 +284,22 @@ static int launch_gemm_nt_pp_conv_gather(NtParams p, hipStream_t stream) {
     auto kern = gemm_nt_pp_kernel<ELEM, EPI, 0, 1>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     SGC_LAUNCH(kern, dim3((unsigned)(al ? xcd_patch_grid(p.tiles_m, p.tiles_n) : p.tiles_m * p.tiles_n)), dim3(512), LDS, stream, p);
+    SGC_CHECK_LAUNCH();
+    return SGC_OK;
+}
+
+// SEG form (see gemm_nt_pp_kernel): M = listed windows, virtual N = 16 patch pixels x 512 channels, bf16 output through the LDS epilogue
+template <int ELEM>
+static int launch_gemm_nt_pp_seg(NtParams p, hipStream_t stream) {
+    constexpr int LDS = EPI_LDS_BYTES;
+    p.tiles_m = (p.M + 255) / 256;
+    p.tiles_n = 32;
+    p.epi_lds = 1;
+    auto kern = gemm_nt_pp_kernel<ELEM, EPI_STORE, 0, 0, 1>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    const int grid_aligned = xcd_patch_grid(p.tiles_m, p.tiles_n), nb = p.tiles_m * p.tiles_n;
+    p.patch_aligned = (nb >= 1024 && (nb & 255) != 0 && grid_aligned * 10 <= nb * 11) ? 1 : 0;
+    SGC_LAUNCH(kern, dim3((unsigned)(p.patch_aligned ? grid_aligned : nb)), dim3(512), LDS, stream, p);
     SGC_CHECK_LAUNCH();
     return SGC_OK;
 }

@@ -369,6 +369,61 @@ __global__ __launch_bounds__(256) void windows_col2im_kernel(const u16* __restri
     col2im_rect(col, x, e0, p, dz);
 }
 
+// PATCH form of the same sum (sgc_windows_dgrad_patches): patch[16 e + 4 py + px][512] is already the 9-tap sum for pixel
+// (2 wy - 1 + py, 2 wx - 1 + px) over the own pixels of window e; dz of a pixel adds the patches of the (at most 2 x 2) windows of
+// the pair's rectangle whose 4 x 4 input patch covers it.
+__device__ __forceinline__ void patch_sum_rect(const u16* __restrict__ patch, const WRect& x, int off, long p, u16* __restrict__ dz) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (x.x1 <= x.x0) return;
+    const int wdt = x.x1 - x.x0;
+    const int Y0 = max(2 * x.y0 - 1, 0), Y1 = min(2 * x.y1 + 1, 16), X0 = max(2 * x.x0 - 1, 0), X1 = min(2 * x.x1 + 1, 16);
+    const int nx = X1 - X0, n = (Y1 - Y0) * nx;
+    for (int t = wv; t < n; t += 4) {
+        const int y = Y0 + t / nx, xx = X0 + t % nx;
+        float acc[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int wy = ((y + 1) >> 1) - a;                 // windows whose patch rows 2 wy - 1 .. 2 wy + 2 contain y
+            if (wy < x.y0 || wy >= x.y1) continue;
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int wx = ((xx + 1) >> 1) - b;
+                if (wx < x.x0 || wx >= x.x1) continue;
+                const long row = 16L * (off + (wy - x.y0) * wdt + (wx - x.x0)) + (y - 2 * wy + 1) * 4 + (xx - 2 * wx + 1);
+                const uint4 v = *reinterpret_cast<const uint4*>(patch + row * 512 + lane * 8);
+                const u16* vh = reinterpret_cast<const u16*>(&v);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc[k] += bf16_bits_to_f32(vh[k]);
+            }
+        }
+        uint4 ov;
+        u16* oh = reinterpret_cast<u16*>(&ov);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) oh[k] = f32_to_bf16_bits(acc[k]);
+        const int m3 = 4 * ((y >> 1) * 8 + (xx >> 1)) + (y & 1) * 2 + (xx & 1);
+        *reinterpret_cast<uint4*>(dz + (p * 256 + m3) * 512 + lane * 8) = ov;
+    }
+}
+
+__global__ __launch_bounds__(256) void windows_patch_sum_kernel(const u16* __restrict__ patch, const int* __restrict__ bbox,
+                                                                const int* __restrict__ sub, const int* __restrict__ obj,
+                                                                const int* __restrict__ incl, u16* __restrict__ dz) {
+    const int p = blockIdx.x;
+    const int e0 = p ? incl[p - 1] : 0;
+    if (incl[p] == e0) return;                 // no entries of its own in this list (no X window, or a linear pair: no dz either)
+    const WRect x = pair_windows(object_windows(bbox + 4 * sub[p]), object_windows(bbox + 4 * obj[p]));
+    patch_sum_rect(patch, x, e0, p, dz);
+}
+
+__global__ __launch_bounds__(256) void windows_patch_sum_objects_kernel(const u16* __restrict__ patch, const int* __restrict__ bbox, int n_obj,
+                                                                        int n_real, const int* __restrict__ incl, u16* __restrict__ dz) {
+    const int ps = blockIdx.x, pair = n_real + ps;
+    const WRect x = object_windows(bbox + 4 * (ps >= n_obj ? ps - n_obj : ps));
+    patch_sum_rect(patch, x, pair ? incl[pair - 1] : 0, pair, dz);
+}
+
 // the same for the window-list entries of the pseudo-pairs (pair index n_real + ps, windows R_o)
 __global__ __launch_bounds__(256) void windows_col2im_objects_kernel(const u16* __restrict__ col, const int* __restrict__ bbox, int n_obj,
                                                                      int n_real, const int* __restrict__ incl, u16* __restrict__ dz) {
@@ -1089,6 +1144,32 @@ int sgc_windows_dgrad_cols(const void* dy3x, const void* w3col, void* col, int r
     p.A = (const u16*)dy3x; p.B = (const u16*)w3col; p.C = col; p.M = rows; p.N = 9 * 512; p.K = 1024;
     p.lda = 1024; p.ldb = 1024; p.ldc = 9 * 512;
     return launch_gemm_nt<ELEM_BF16, AMODE_PLAIN, EPI_STORE>(p, (hipStream_t)stream);
+}
+
+// patch [entries][16][512] bf16: gradient of the 4 x 4 input patch of every listed window (entries = list length, padded freely);
+// w3patch: for pp = 4 py + px in order, [512 c_in][combinations x 1024 c_out] bf16 with the combinations (own pixel q, tap t), q + t = pp,
+// ordered (qy, ky) major, (qx, kx) minor, q ascending (engine.prep_bwd_weights)
+int sgc_windows_dgrad_patches(const void* dy3x, const void* w3patch, void* patch, int entries, void* stream) {
+    if (entries <= 0) return SGC_OK;
+    NtParams p{};
+    p.A = (const u16*)dy3x; p.B = (const u16*)w3patch; p.C = patch; p.M = entries; p.N = 16 * 512; p.K = 4096;
+    p.lda = 4 * 1024; p.ldb = 0; p.ldc = 16 * 512;
+    return launch_gemm_nt_pp_seg<ELEM_BF16>(p, (hipStream_t)stream);
+}
+int sgc_windows_patch_sum(const void* patch, const int* bbox, const int* sub_idx, const int* obj_idx, const int* count_incl, int n_pairs,
+                          void* dz, void* stream) {
+    if (n_pairs <= 0) return SGC_OK;
+    SGC_LAUNCH(windows_patch_sum_kernel, dim3(n_pairs), dim3(256), 0, (hipStream_t)stream, (const u16*)patch, bbox, sub_idx, obj_idx,
+               count_incl, (u16*)dz);
+    SGC_CHECK_LAUNCH();
+    return SGC_OK;
+}
+int sgc_windows_patch_sum_objects(const void* patch, const int* bbox, int n_obj, int n_real, const int* count_incl, void* dz, void* stream) {
+    if (n_obj <= 0) return SGC_OK;
+    SGC_LAUNCH(windows_patch_sum_objects_kernel, dim3(2 * n_obj), dim3(256), 0, (hipStream_t)stream, (const u16*)patch, bbox, n_obj, n_real,
+               count_incl, (u16*)dz);
+    SGC_CHECK_LAUNCH();
+    return SGC_OK;
 }
 
 int sgc_windows_col2im(const void* col, const int* bbox, const int* sub_idx, const int* obj_idx, const int* count_incl, int n_pairs,

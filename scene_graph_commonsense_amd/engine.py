@@ -174,6 +174,7 @@ class Tuning:
     gemms_apart: bool = True          # two-stream backward: keep the big GEMMs of the two chains from running side by side
     shared_linear: bool = True        # pairs whose regions of influence on the 16-grid are disjoint: X windows combined, not convolved
     shared_conv2: bool = True         # conv2 halves computed on the objects' own regions, the rest copied from the image's background half
+    patch_dgrad: bool = True          # conv3 data gradient over the listed windows in patch form (16 rows per window; off: 36 columns + col2im)
 
     @classmethod
     def from_env(cls):
@@ -184,7 +185,8 @@ class Tuning:
                    bwd_streams=os.environ.get("SGC_BWD_STREAMS", "1") != "0",
                    gemms_apart=os.environ.get("SGC_GEMMS_APART", "1") != "0",
                    shared_linear=lvl >= 3 and os.environ.get("SGC_SHARED_LINEAR", "1") != "0",
-                   shared_conv2=lvl >= 1 and os.environ.get("SGC_SHARED_CONV2", "1") != "0")
+                   shared_conv2=lvl >= 1 and os.environ.get("SGC_SHARED_CONV2", "1") != "0",
+                   patch_dgrad=os.environ.get("SGC_PATCH_DGRAD", "1") != "0")
 
 
 TUNING = Tuning.from_env()
@@ -825,6 +827,12 @@ class RelHeadEngine:
         w["wd3"] = conv_k_layout(g("conv3_1.weight").flip(2, 3).permute(1, 0, 2, 3)).to(torch.bfloat16).contiguous()
         # [(tap, c_in)][c_out]: second operand of the column form of the data gradient over pair-specific windows
         w["w3col"] = g("conv3_1.weight").permute(2, 3, 1, 0).reshape(9 * 512, 1024).to(torch.bfloat16).contiguous()
+        # patch form of the same data gradient (sgc_windows_dgrad_patches): for every pixel pp = (py, px) of a window's 4 x 4 input patch
+        # the tap matrices of the (own pixel q, tap k) combinations with q + k = pp, stacked along K: [512 c_in][combinations x 1024 c_out]
+        w3 = g("conv3_1.weight")
+        opts = lambda c: [(0, 0)] if c == 0 else ([(1, 2)] if c == 3 else [(0, c), (1, c - 1)])
+        w["w3patch"] = torch.cat([torch.cat([w3[:, :, ky, kx].t() for _, ky in opts(py) for _, kx in opts(px)], dim=1).reshape(-1)
+                                  for py in range(4) for px in range(4)]).to(torch.bfloat16).contiguous()
         c2 = g("conv2_1.weight")
         w["wd2"] = torch.stack([conv_k_layout(c2[:, r * 128:(r + 1) * 128].flip(2, 3).permute(1, 0, 2, 3))
                                 for r in (0, 1)]).to(torch.bfloat16).contiguous()
@@ -1304,7 +1312,21 @@ class RelHeadEngine:
         else:
             self._timed("conv3_dgrad_objects", lambda: _lib.check(lib.sgc_conv3_dgrad(
                 _lib.ptr(dy3_bg), _lib.ptr(w["wd3"]), _lib.ptr(dz_maps), n_maps, st()), "sgc_conv3_dgrad"))
-        if Epad:
+        if Epad and TUNING.patch_dgrad:
+            # PATCH form: the 16 pixels of every listed window's input patch leave the GEMM already summed over the taps (K = 1024 x
+            # 1 / 2 / 4 per output element instead of 1024: 3.7 instead of 8.4 GB of stores per launch at the benchmark's size, and
+            # the sum over a pair's windows reads 16 instead of 36 rows per window)
+            patch = ws.get("xpatch", Epad * 16 * 512, torch.bfloat16)
+            self._timed("conv3_dgrad_windows", lambda: _lib.check(lib.sgc_windows_dgrad_patches(_lib.ptr(dy3x), _lib.ptr(w["w3patch"]), _lib.ptr(patch), Epad, st()),
+                                                                  "sgc_windows_dgrad_patches"))
+            if TUNING.gemms_apart:
+                wgrad_windows()                      # side stream: after the data-gradient GEMM, beside the patch sums / the contraction
+            self._timed("col2im_windows", lambda: (
+                _lib.check(lib.sgc_windows_patch_sum(_lib.ptr(patch), _lib.ptr(ctx.bbox), _lib.ptr(ctx.sub_idx), _lib.ptr(ctx.obj_idx), _lib.ptr(sh["incl"]),
+                                                     P, _lib.ptr(dz), st()), "sgc_windows_patch_sum"),
+                _lib.check(lib.sgc_windows_patch_sum_objects(_lib.ptr(patch), _lib.ptr(ctx.bbox), n_obj, P, _lib.ptr(sh["incl"]), _lib.ptr(dz), st()),
+                           "sgc_windows_patch_sum_objects") if objects else None))
+        elif Epad:
             col = ws.get("xcol", Epad * 4 * 9 * 512, torch.bfloat16)
             self._timed("conv3_dgrad_windows", lambda: _lib.check(lib.sgc_windows_dgrad_cols(_lib.ptr(dy3x), _lib.ptr(w["w3col"]), _lib.ptr(col), Epad * 4, st()),
                                                                   "sgc_windows_dgrad_cols"))

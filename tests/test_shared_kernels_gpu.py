@@ -209,3 +209,65 @@ def test_second_level_rows_and_their_gradient():
             if not ins(o)[w]:
                 want[int(obj_img[o]) * 64 + w] += dywm[int(goff[w]) + ps].float()
     assert torch.allclose(dy_bg.float(), want, atol=0.05, rtol=1e-2)
+
+
+def test_patch_form_of_the_conv3_data_gradient_equals_the_transposed_convolution():
+    """``sgc_windows_dgrad_patches`` + ``sgc_windows_patch_sum`` (16 patch pixels per listed window, the taps summed inside the
+    GEMM) against the f32 transposed convolution of the un-pooled gradient (reference: autograd of model.py:144-146's conv3 on the
+    pair's own pixels), and against the column form + col2im the step used before."""
+    L, lib = _lib()
+    rng = np.random.default_rng(5)
+    pl = _plan(rng, n=7)
+    P, E = pl["P"], int(pl["incl"][-1])
+    Epad = (E + 63) // 64 * 64
+    g = pl["gather"][:E].long()
+    pair, w = (g >> 6), (g & 63)
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    w3 = torch.randn(1024, 512, 3, 3, device=DEV, generator=gen) * 0.02
+    dy3x = torch.zeros(Epad * 4, 1024, device=DEV)
+    dy3x[:E * 4] = torch.randn(E * 4, 1024, device=DEV, generator=gen) * (torch.rand(E * 4, 1024, device=DEV, generator=gen) < 0.25)
+    dy3x = dy3x.bfloat16()
+    # weights in the two layouts of engine.prep_bwd_weights
+    opts = lambda c: [(0, 0)] if c == 0 else ([(1, 2)] if c == 3 else [(0, c), (1, c - 1)])
+    w3patch = torch.cat([torch.cat([w3[:, :, ky, kx].t() for _, ky in opts(py) for _, kx in opts(px)], dim=1).reshape(-1)
+                         for py in range(4) for px in range(4)]).bfloat16().contiguous()
+    w3col = w3.permute(2, 3, 1, 0).reshape(9 * 512, 1024).bfloat16().contiguous()
+    patch = torch.full((Epad * 16, 512), float("nan"), device=DEV).bfloat16()
+    L.check(lib.sgc_windows_dgrad_patches(L.ptr(dy3x), L.ptr(w3patch), L.ptr(patch), Epad, L.stream_ptr()), "dgrad_patches")
+    # ---- every patch pixel against f32: patch[e][py][px] = sum_{q + k = (py, px)} dy3x[4e + q] @ W[:, :, ky, kx]
+    wb = w3.bfloat16().float()
+    dyf = dy3x.float().view(Epad, 4, 1024)
+    want = torch.zeros(Epad, 4, 4, 512, device=DEV)
+    for q in range(4):
+        for ky in range(3):
+            for kx in range(3):
+                want[:, (q >> 1) + ky, (q & 1) + kx] += dyf[:, q] @ wb[:, :, ky, kx]
+    got = patch.float().view(Epad, 4, 4, 512)
+    scale = float(want.abs().max())
+    assert float((got - want).abs().max()) <= 1e-2 * scale                       # one bf16 rounding of an f32 sum
+    assert float(got[E:].abs().max()) == 0.0                                     # entries behind the list: zero rows in, zero rows out
+    # ---- the sum over a pair's windows against the column form + col2im on the same operands
+    dz_p = torch.full((P * 256, 512), float("nan"), device=DEV).bfloat16()
+    L.check(lib.sgc_windows_patch_sum(L.ptr(patch), L.ptr(pl["bb_d"]), L.ptr(pl["sub_d"]), L.ptr(pl["obj_d"]), L.ptr(pl["incl"]), P, L.ptr(dz_p),
+                                      L.stream_ptr()), "patch_sum")
+    col = torch.empty(Epad * 4, 9 * 512, device=DEV).bfloat16()
+    L.check(lib.sgc_windows_dgrad_cols(L.ptr(dy3x), L.ptr(w3col), L.ptr(col), Epad * 4, L.stream_ptr()), "dgrad_cols")
+    dz_c = torch.full((P * 256, 512), float("nan"), device=DEV).bfloat16()
+    L.check(lib.sgc_windows_col2im(L.ptr(col), L.ptr(pl["bb_d"]), L.ptr(pl["sub_d"]), L.ptr(pl["obj_d"]), L.ptr(pl["incl"]), P, L.ptr(dz_c),
+                                   L.stream_ptr()), "col2im")
+    a, b = dz_p.float(), dz_c.float()
+    assert torch.equal(torch.isnan(a), torch.isnan(b))                            # the same pixels are written
+    live = ~torch.isnan(a)
+    assert live.any()
+    # f32 reference of the whole thing: scatter the exact patches
+    acc = torch.zeros(P, 18, 18, 512, device=DEV)
+    for py in range(4):
+        for px in range(4):
+            acc.index_put_((pair, 2 * (w >> 3) + py, 2 * (w & 7) + px), want[:E, py, px], accumulate=True)
+    m3 = torch.arange(256, device=DEV)
+    Y, X = 2 * ((m3 >> 2) >> 3) + ((m3 & 3) >> 1), 2 * ((m3 >> 2) & 7) + (m3 & 1)
+    ref = acc[:, Y + 1, X + 1].reshape(P * 256, 512)     # padded frame: patch pixel py of window wy is row 2 wy + py, image pixel y is row y + 1
+    s2 = float(ref[live].abs().max())
+    assert float((a[live] - ref[live]).abs().max()) <= 2e-2 * s2
+    assert float((b[live] - ref[live]).abs().max()) <= 4e-2 * s2                  # the column form rounds nine terms to bf16 before adding
+    assert float((a[live] - ref[live]).abs().mean()) <= float((b[live] - ref[live]).abs().mean())   # the patch form is the more accurate one
