@@ -111,7 +111,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(const NtParams p) {
     int n0 = tn * 256, n_tile = tn, Kloc = p.K, seg_py = 0, seg_px = 0, seg_ny = 1, seg_nx = 1;
     long ldb = p.ldb, b_off = 0;
     if constexpr (SEG) {
-        const int pp = tn >> 1;
+        // virtual N tiles in the order centre (4 combinations, K = 4096) | top, bottom edge | left, right edge (2) | corners (1): the 32 blocks
+        // of an XCD patch (4 M tiles x 8 virtual N tiles) then have the same K and read the same segments of the same rows at the same
+        // time, as the blocks of a plain product do (pp in natural order: 9.4 ms per launch against 7.9 for the column form)
+        const int pp = (int)((0xfc30b784ed21a965ULL >> (4 * (tn >> 1))) & 15);
         n_tile = tn & 1;
         seg_py = pp >> 2; seg_px = pp & 3;
         auto cnt1 = [](int c) { return (c == 0 || c == 3) ? 1 : 2; };
