@@ -116,6 +116,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(const NtParams p) {
         // time, as the blocks of a plain product do (pp in natural order: 9.4 ms per launch against 7.9 for the column form)
         const int pp = (int)((0xfc30b784ed21a965ULL >> (4 * (tn >> 1))) & 15);
         n_tile = tn & 1;
+        n0 = pp * 512 + n_tile * 256;                  // output columns: patch pixel pp, channel half
         seg_py = pp >> 2; seg_px = pp & 3;
         auto cnt1 = [](int c) { return (c == 0 || c == 3) ? 1 : 2; };
         seg_ny = cnt1(seg_py); seg_nx = cnt1(seg_px);
