@@ -418,6 +418,7 @@ int sgc_match_boxes_top2(const float* pred_box, const int* pred_ptr, const float
 int sgc_dbg_gemm_nt(int elem, const void* A, const void* B, void* C, int M, int N, int K, long lda, long ldb, long ldc, const float* bias, void* stream);
 int sgc_dbg_gemm_nt_abl(int abl, const void* A, const void* B, void* C, int M, int N, int K, void* stream);
 int sgc_dbg_fc1_windows_gemm(const void* ywm, const void* w, const int* tile_group, void* owm, int rows, long ldb, long group_stride, long ldc, int mode, int stagger, int phases, unsigned long long* clk, void* stream);
+int sgc_dbg_dgrad_patches(const void* dy3x, const void* w3patch, void* patch, int entries, long lda, long seg_stride, int bpad, int order, void* stream);
 int sgc_dbg_conv_nt(int elem, const void* A, const void* B, void* C, int n_img, int lgS, int Cin, int N, const float* bias, void* stream);
 int sgc_dbg_gemm_tn(int elem, const void* A, const void* B, float* C, int M, int N, int K, long lda, long ldb, int splits, int* slabs, void* stream);
 int sgc_dbg_conv_tn(int elem, const void* A, const void* B, float* C, int M, int n_img, int lgS, int Cin, int splits, int* slabs, void* stream);

@@ -57,6 +57,16 @@ int sgc_dbg_fc1_windows_gemm(const void* ywm, const void* w, const int* tile_gro
     return SGC_ERR_ARG;
 }
 
+// tools/dgrad_patch_microbench.py: sgc_windows_dgrad_patches with the layouts as parameters (lda / seg_stride: elements between the
+// windows / between the own pixels of a window in dy3x; bpad: padding of B_pp's rows; order: 1 = virtual N tiles by combination class)
+int sgc_dbg_dgrad_patches(const void* dy3x, const void* w3patch, void* patch, int entries, long lda, long seg_stride, int bpad, int order,
+                          void* stream) {
+    NtParams p{};
+    p.A = (const u16*)dy3x; p.B = (const u16*)w3patch; p.C = patch; p.M = entries; p.N = 16 * 512; p.K = 4096;
+    p.lda = lda; p.ldb = 0; p.ldc = 16 * 512; p.seg_stride = seg_stride; p.seg_bpad = bpad; p.seg_order = order;
+    return launch_gemm_nt_pp_seg<ELEM_BF16>(p, (hipStream_t)stream);
+}
+
 // A: zero-padded channels-last images [n_img][S+2][S+2][Cin]; B: [N][Cin/64][9][64]; C: [n_img*S*S][N] window-major rows
 int sgc_dbg_conv_nt(int elem, const void* A, const void* B, void* C, int n_img, int lgS, int Cin, int N,
                     const float* bias, void* stream) {

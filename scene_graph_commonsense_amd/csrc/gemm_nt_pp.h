@@ -114,15 +114,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(const NtParams p) {
         // virtual N tiles in the order centre (4 combinations, K = 4096) | top, bottom edge | left, right edge (2) | corners (1): the 32 blocks
         // of an XCD patch (4 M tiles x 8 virtual N tiles) then have the same K and read the same segments of the same rows at the same
         // time, as the blocks of a plain product do (pp in natural order: 9.4 ms per launch against 7.9 for the column form)
-        const int pp = (int)((0xfc30b784ed21a965ULL >> (4 * (tn >> 1))) & 15);
+        const int pp = p.seg_order ? (int)((0xfc30b784ed21a965ULL >> (4 * (tn >> 1))) & 15) : (tn >> 1);
         n_tile = tn & 1;
         n0 = pp * 512 + n_tile * 256;                  // output columns: patch pixel pp, channel half
         seg_py = pp >> 2; seg_px = pp & 3;
         auto cnt1 = [](int c) { return (c == 0 || c == 3) ? 1 : 2; };
         seg_ny = cnt1(seg_py); seg_nx = cnt1(seg_px);
         Kloc = seg_ny * seg_nx * 1024;
-        ldb = Kloc;
-        for (int j = 0; j < pp; ++j) b_off += 512L * 1024 * (cnt1(j >> 2) * cnt1(j & 3));     // B_pp follows B_0 .. B_pp-1
+        ldb = Kloc + p.seg_bpad;                       // rows of B_pp padded: a power-of-two row stride keeps a tile's rows on few channels
+        for (int j = 0; j < pp; ++j) b_off += 512L * (1024 * (cnt1(j >> 2) * cnt1(j & 3)) + p.seg_bpad);     // B_pp follows B_0 .. B_pp-1
     }
     int Mlim = p.M;
     long img0 = 0;
@@ -175,7 +175,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(const NtParams p) {
                 const int c = t >> 4;
                 const int cy = seg_nx == 2 ? (c >> 1) : c, cx = seg_nx == 2 ? (c & 1) : 0;
                 const int qy = seg_ny == 1 ? (seg_py == 3) : cy, qx = seg_nx == 1 ? (seg_px == 3) : cx;
-                soff = ((qy * 2 + qx) * 1024 + ((t & 15) << 6)) * 2;
+                g = a_blk + (long)(qy * 2 + qx) * p.seg_stride;       // wave-uniform: goes into the buffer descriptor
+                soff = (t & 15) << 7;
             }
         }
         buf_load_lds16(g, voff[kind][0], soff, base);

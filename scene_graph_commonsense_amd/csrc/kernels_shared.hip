@@ -1153,7 +1153,7 @@ int sgc_windows_dgrad_patches(const void* dy3x, const void* w3patch, void* patch
     if (entries <= 0) return SGC_OK;
     NtParams p{};
     p.A = (const u16*)dy3x; p.B = (const u16*)w3patch; p.C = patch; p.M = entries; p.N = 16 * 512; p.K = 4096;
-    p.lda = 4 * 1024; p.ldb = 0; p.ldc = 16 * 512;
+    p.lda = 4 * 1024; p.ldb = 0; p.ldc = 16 * 512; p.seg_stride = 1024; p.seg_bpad = 0; p.seg_order = 0;
     return launch_gemm_nt_pp_seg<ELEM_BF16>(p, (hipStream_t)stream);
 }
 int sgc_windows_patch_sum(const void* patch, const int* bbox, const int* sub_idx, const int* obj_idx, const int* count_incl, int n_pairs,

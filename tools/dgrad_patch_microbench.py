@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""conv3 data gradient over listed windows: the column form (rows = window pixels, N = 9 x 512, K = 1024) against the patch form
+(rows = windows, 16 patch pixels x 512, K = 1024 x 1 / 2 / 4) with the layouts of its operands as parameters (GPU box).
+
+    python tools/dgrad_patch_microbench.py [entries]        (default 228096: the benchmark's list of convolved windows)
+"""
+import ctypes
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from scene_graph_commonsense_amd import _lib
+
+lib = _lib.load()
+E = (int(sys.argv[1]) if len(sys.argv) > 1 else 228096) // 256 * 256
+dev = "cuda"
+g = torch.Generator(device=dev).manual_seed(0)
+w3 = torch.randn(1024, 512, 3, 3, device=dev, generator=g) * 0.02
+dy = (torch.randn(E, 4, 1024, device=dev, generator=g) * (torch.rand(E, 4, 1024, device=dev, generator=g) < 0.25)).bfloat16()   # 1 of 4 routes live
+dy_q = dy.permute(1, 0, 2).contiguous()                       # [4][E][1024]: own-pixel-major
+opts = lambda c: [(0, 0)] if c == 0 else ([(1, 2)] if c == 3 else [(0, c), (1, c - 1)])
+
+
+def w3patch(pad):
+    mats = []
+    for py in range(4):
+        for px in range(4):
+            m = torch.cat([w3[:, :, ky, kx].t() for _, ky in opts(py) for _, kx in opts(px)], dim=1)      # [512][K]
+            if pad:
+                m = torch.cat([m, torch.zeros(512, pad, device=dev)], dim=1)
+            mats.append(m.reshape(-1))
+    return torch.cat(mats).bfloat16().contiguous()
+
+
+w3col = w3.permute(2, 3, 1, 0).reshape(9 * 512, 1024).bfloat16().contiguous()
+col = torch.empty(E * 4, 9 * 512, dtype=torch.bfloat16, device=dev)
+patch = torch.empty(E * 16, 512, dtype=torch.bfloat16, device=dev)
+L = ctypes.c_long
+flop = 2.0 * E * 4 * 1024 * 9 * 512
+
+
+def timed(fn, name):
+    fn(); fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(4):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / 4
+    print("%-64s %7.3f ms  %7.1f TFLOP/s" % (name, ms, flop / ms / 1e9), flush=True)
+
+
+print("# %d listed windows, %.2f TFLOP; column form stores %.2f GB, patch form %.2f GB" % (E, flop / 1e12, E * 4 * 4608 * 2 / 1e9, E * 16 * 512 * 2 / 1e9))
+ref = None
+for rep in range(2):
+    timed(lambda: _lib.check(lib.sgc_windows_dgrad_cols(_lib.ptr(dy), _lib.ptr(w3col), _lib.ptr(col), E * 4, _lib.stream_ptr()), "cols"), "column form")
+    for lay, (A, lda, ss) in {"window-major dy3x": (dy, 4096, 1024), "own-pixel-major dy3x": (dy_q, 1024, E * 1024)}.items():
+        for pad in (0, 64):
+            B = w3patch(pad)
+            for order in (0, 1):
+                timed(lambda: _lib.check(lib.sgc_dbg_dgrad_patches(_lib.ptr(A), _lib.ptr(B), _lib.ptr(patch), E, L(lda), L(ss), pad, order,
+                                                                   _lib.stream_ptr()), "patches"),
+                      "patch form, %s, B rows +%d, %s order" % (lay, pad, "class" if order else "natural"))
+                if rep == 0:
+                    if ref is None:
+                        ref = patch.clone()
+                    else:
+                        assert torch.equal(ref, patch), "variants disagree"
