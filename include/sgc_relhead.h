@@ -159,11 +159,13 @@ int sgc_windows_wgrad_gather(const void* dy3x, const void* z_pad_bf16, const int
 int sgc_windows_dgrad_cols(const void* dy3x, const void* w3col, void* col, int rows, void* stream);
 int sgc_windows_col2im(const void* col, const int* bbox, const int* sub_idx, const int* obj_idx, const int* count_incl, int n_pairs,
                        void* dz, void* stream);
-/* The same data gradient in PATCH form (the step's default): patch [entries][16][512] bf16 = gradient of the 4 x 4 input patch (pixels
- * 2wy-1 .. 2wy+2, 2wx-1 .. 2wx+2) of every listed window, summed over the taps inside the GEMM (K = 1024 x the 1 / 2 / 4 (own pixel,
- * tap) combinations that reach a patch pixel); w3patch as engine.prep_bwd_weights lays it out.  sgc_windows_patch_sum[_objects]: dz of a
- * pixel = sum of the patches of the <= 2 x 2 windows of the pair's rectangle that cover it (same output as sgc_windows_col2im[_objects];
+/* The same data gradient in PATCH form (the step's default): patch [entries][slots][512] bf16, slots = sgc_windows_patch_slots() = 20:
+ * the gradient of the 4 x 4 input patch (pixels 2wy-1 .. 2wy+2, 2wx-1 .. 2wx+2) of every listed window, summed over the taps inside the
+ * GEMM (K = 1024 x the 1 / 2 / 4 (own pixel, tap) combinations that reach a patch pixel; the four centre pixels as two rows of two
+ * combinations each, so that K <= 2048); w3patch as engine.prep_bwd_weights lays it out.  sgc_windows_patch_sum[_objects]: dz of a
+ * pixel = sum of the rows of the <= 2 x 2 windows of the pair's rectangle that cover it (same output as sgc_windows_col2im[_objects];
  * reference: the autograd of model.py:144-146's conv3). */
+int sgc_windows_patch_slots(void);
 int sgc_windows_dgrad_patches(const void* dy3x, const void* w3patch, void* patch, int entries, void* stream);
 int sgc_windows_patch_sum(const void* patch, const int* bbox, const int* sub_idx, const int* obj_idx, const int* count_incl, int n_pairs,
                           void* dz, void* stream);
@@ -418,7 +420,7 @@ int sgc_match_boxes_top2(const float* pred_box, const int* pred_ptr, const float
 int sgc_dbg_gemm_nt(int elem, const void* A, const void* B, void* C, int M, int N, int K, long lda, long ldb, long ldc, const float* bias, void* stream);
 int sgc_dbg_gemm_nt_abl(int abl, const void* A, const void* B, void* C, int M, int N, int K, void* stream);
 int sgc_dbg_fc1_windows_gemm(const void* ywm, const void* w, const int* tile_group, void* owm, int rows, long ldb, long group_stride, long ldc, int mode, int stagger, int phases, unsigned long long* clk, void* stream);
-int sgc_dbg_dgrad_patches(const void* dy3x, const void* w3patch, void* patch, int entries, long lda, long seg_stride, int bpad, int order, void* stream);
+int sgc_dbg_dgrad_patches(const void* dy3x, const void* w3patch, void* patch, int entries, long lda, long seg_stride, int bpad, int split, void* stream);
 int sgc_dbg_conv_nt(int elem, const void* A, const void* B, void* C, int n_img, int lgS, int Cin, int N, const float* bias, void* stream);
 int sgc_dbg_gemm_tn(int elem, const void* A, const void* B, float* C, int M, int N, int K, long lda, long ldb, int splits, int* slabs, void* stream);
 int sgc_dbg_conv_tn(int elem, const void* A, const void* B, float* C, int M, int n_img, int lgS, int Cin, int splits, int* slabs, void* stream);

@@ -58,12 +58,12 @@ int sgc_dbg_fc1_windows_gemm(const void* ywm, const void* w, const int* tile_gro
 }
 
 // tools/dgrad_patch_microbench.py: sgc_windows_dgrad_patches with the layouts as parameters (lda / seg_stride: elements between the
-// windows / between the own pixels of a window in dy3x; bpad: padding of B_pp's rows; order: 1 = virtual N tiles by combination class)
-int sgc_dbg_dgrad_patches(const void* dy3x, const void* w3patch, void* patch, int entries, long lda, long seg_stride, int bpad, int order,
+// windows / between the own pixels of a window in dy3x; bpad: padding of B_pp's rows; split: 1 = the centre pixels in two slots of two combinations)
+int sgc_dbg_dgrad_patches(const void* dy3x, const void* w3patch, void* patch, int entries, long lda, long seg_stride, int bpad, int split,
                           void* stream) {
     NtParams p{};
-    p.A = (const u16*)dy3x; p.B = (const u16*)w3patch; p.C = patch; p.M = entries; p.N = 16 * 512; p.K = 4096;
-    p.lda = lda; p.ldb = 0; p.ldc = 16 * 512; p.seg_stride = seg_stride; p.seg_bpad = bpad; p.seg_order = order;
+    p.A = (const u16*)dy3x; p.B = (const u16*)w3patch; p.C = patch; p.M = entries; p.N = (split ? 20 : 16) * 512; p.K = 4096;
+    p.lda = lda; p.ldb = 0; p.ldc = p.N; p.seg_stride = seg_stride; p.seg_bpad = bpad; p.seg_split = split;
     return launch_gemm_nt_pp_seg<ELEM_BF16>(p, (hipStream_t)stream);
 }
 

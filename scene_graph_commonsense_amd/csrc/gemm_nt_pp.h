@@ -108,21 +108,36 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(const NtParams p) {
         xcd_patch_map(blockIdx.x, p.tiles_m, p.tiles_n, tm, tn);
     }
     const int m0 = tm * 256;
-    int n0 = tn * 256, n_tile = tn, Kloc = p.K, seg_py = 0, seg_px = 0, seg_ny = 1, seg_nx = 1;
+    int n0 = tn * 256, n_tile = tn, Kloc = p.K, seg_py = 0, seg_px = 0, seg_ny = 1, seg_nx = 1, seg_c0 = 0;
     long ldb = p.ldb, b_off = 0;
     if constexpr (SEG) {
-        // virtual N tiles in the order centre (4 combinations, K = 4096) | top, bottom edge | left, right edge (2) | corners (1): the 32 blocks
-        // of an XCD patch (4 M tiles x 8 virtual N tiles) then have the same K and read the same segments of the same rows at the same
-        // time, as the blocks of a plain product do (pp in natural order: 9.4 ms per launch against 7.9 for the column form)
-        const int pp = p.seg_order ? (int)((0xfc30b784ed21a965ULL >> (4 * (tn >> 1))) & 15) : (tn >> 1);
+        // virtual N tile = (slot, channel half).  Slots are the 16 patch pixels pp in natural order; with p.seg_split the four centre pixels
+        // (4 combinations, K = 4096) take TWO slots of 2 combinations each, summed by the reader (windows_patch_sum): the blocks of an XCD
+        // patch share their A and B tiles through the L2 only while they stay at the same K step, and blocks of 64 K steps drift apart
+        // (measured: slots ordered by class, i.e. whole patches of K = 4096 blocks, 10.9 ms per launch against 8.6 in natural order).
+        const int slot = tn >> 1;
+        int pp = 0, part = 0;
+        if (p.seg_split) {
+            int acc = 0;
+            for (pp = 0; pp < 16; ++pp) {
+                const int wdt = (((pp >> 2) == 1 || (pp >> 2) == 2) && ((pp & 3) == 1 || (pp & 3) == 2)) ? 2 : 1;
+                if (slot < acc + wdt) { part = slot - acc; break; }
+                acc += wdt;
+            }
+        } else {
+            pp = slot;
+        }
         n_tile = tn & 1;
-        n0 = pp * 512 + n_tile * 256;                  // output columns: patch pixel pp, channel half
+        n0 = slot * 512 + n_tile * 256;                // output columns: slot, channel half
         seg_py = pp >> 2; seg_px = pp & 3;
         auto cnt1 = [](int c) { return (c == 0 || c == 3) ? 1 : 2; };
         seg_ny = cnt1(seg_py); seg_nx = cnt1(seg_px);
-        Kloc = seg_ny * seg_nx * 1024;
-        ldb = Kloc + p.seg_bpad;                       // rows of B_pp padded: a power-of-two row stride keeps a tile's rows on few channels
+        const int ncomb = seg_ny * seg_nx;
+        seg_c0 = (p.seg_split && ncomb == 4) ? 2 * part : 0;
+        Kloc = ((p.seg_split && ncomb == 4) ? 2 : ncomb) * 1024;
+        ldb = ncomb * 1024 + p.seg_bpad;               // row of B_pp: all combinations of pp (+ padding)
         for (int j = 0; j < pp; ++j) b_off += 512L * (1024 * (cnt1(j >> 2) * cnt1(j & 3)) + p.seg_bpad);     // B_pp follows B_0 .. B_pp-1
+        b_off += seg_c0 * 1024;
     }
     int Mlim = p.M;
     long img0 = 0;
@@ -172,7 +187,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(const NtParams p) {
         }
         if constexpr (SEG) {
             if (kind == 0 || kind == 3) {            // K tile t: combination c = t / 16 -> own pixel (qy, qx) of the window, channels (t % 16) * 64
-                const int c = t >> 4;
+                const int c = seg_c0 + (t >> 4);
                 const int cy = seg_nx == 2 ? (c >> 1) : c, cx = seg_nx == 2 ? (c & 1) : 0;
                 const int qy = seg_ny == 1 ? (seg_py == 3) : cy, qx = seg_nx == 1 ? (seg_px == 3) : cx;
                 g = a_blk + (long)(qy * 2 + qx) * p.seg_stride;       // wave-uniform: goes into the buffer descriptor
@@ -298,7 +313,7 @@ template <int ELEM>
 static int launch_gemm_nt_pp_seg(NtParams p, hipStream_t stream) {
     constexpr int LDS = EPI_LDS_BYTES;
     p.tiles_m = (p.M + 255) / 256;
-    p.tiles_n = 32;
+    p.tiles_n = p.N / 256;                          // 32 or, with the centre pixels split, 40
     p.epi_lds = 1;
     auto kern = gemm_nt_pp_kernel<ELEM, EPI_STORE, 0, 0, 1>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);

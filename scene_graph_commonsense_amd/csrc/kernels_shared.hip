@@ -369,9 +369,11 @@ __global__ __launch_bounds__(256) void windows_col2im_kernel(const u16* __restri
     col2im_rect(col, x, e0, p, dz);
 }
 
-// PATCH form of the same sum (sgc_windows_dgrad_patches): patch[16 e + 4 py + px][512] is already the 9-tap sum for pixel
-// (2 wy - 1 + py, 2 wx - 1 + px) over the own pixels of window e; dz of a pixel adds the patches of the (at most 2 x 2) windows of
-// the pair's rectangle whose 4 x 4 input patch covers it.
+// PATCH form of the same sum (sgc_windows_dgrad_patches): the PATCH_SLOTS = 20 rows of window e hold the 9-tap sums for the 16 pixels
+// (2 wy - 1 + py, 2 wx - 1 + px) of its input patch over its own pixels - pp = 4 py + px in natural order, the four centre pixels in
+// two consecutive rows (two of their four (own pixel, tap) combinations each: the product keeps K <= 2048, see gemm_nt_pp_kernel<SEG>);
+// dz of a pixel adds the rows of the (at most 2 x 2) windows of the pair's rectangle whose patch covers it.
+constexpr int PATCH_SLOTS = 20;
 __device__ __forceinline__ void patch_sum_rect(const u16* __restrict__ patch, const WRect& x, int off, long p, u16* __restrict__ dz) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (x.x1 <= x.x0) return;
@@ -391,11 +393,19 @@ __device__ __forceinline__ void patch_sum_rect(const u16* __restrict__ patch, co
             for (int b = 0; b < 2; ++b) {
                 const int wx = ((xx + 1) >> 1) - b;
                 if (wx < x.x0 || wx >= x.x1) continue;
-                const long row = 16L * (off + (wy - x.y0) * wdt + (wx - x.x0)) + (y - 2 * wy + 1) * 4 + (xx - 2 * wx + 1);
+                const int py = y - 2 * wy + 1, px = xx - 2 * wx + 1, pp = py * 4 + px;
+                const bool centre = (py == 1 || py == 2) && (px == 1 || px == 2);          // two slots (two of the four combinations each)
+                const long row = (long)PATCH_SLOTS * (off + (wy - x.y0) * wdt + (wx - x.x0)) + pp + (pp > 5) + (pp > 6) + (pp > 9) + (pp > 10);
                 const uint4 v = *reinterpret_cast<const uint4*>(patch + row * 512 + lane * 8);
                 const u16* vh = reinterpret_cast<const u16*>(&v);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) acc[k] += bf16_bits_to_f32(vh[k]);
+                if (centre) {
+                    const uint4 v2 = *reinterpret_cast<const uint4*>(patch + (row + 1) * 512 + lane * 8);
+                    const u16* vh2 = reinterpret_cast<const u16*>(&v2);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) acc[k] += bf16_bits_to_f32(vh2[k]);
+                }
             }
         }
         uint4 ov;
@@ -1146,14 +1156,15 @@ int sgc_windows_dgrad_cols(const void* dy3x, const void* w3col, void* col, int r
     return launch_gemm_nt<ELEM_BF16, AMODE_PLAIN, EPI_STORE>(p, (hipStream_t)stream);
 }
 
-// patch [entries][16][512] bf16: gradient of the 4 x 4 input patch of every listed window (entries = list length, padded freely);
+int sgc_windows_patch_slots(void) { return PATCH_SLOTS; }
+// patch [entries][PATCH_SLOTS][512] bf16: gradient of the 4 x 4 input patch of every listed window (entries = list length, padded freely);
 // w3patch: for pp = 4 py + px in order, [512 c_in][combinations x 1024 c_out] bf16 with the combinations (own pixel q, tap t), q + t = pp,
 // ordered (qy, ky) major, (qx, kx) minor, q ascending (engine.prep_bwd_weights)
 int sgc_windows_dgrad_patches(const void* dy3x, const void* w3patch, void* patch, int entries, void* stream) {
     if (entries <= 0) return SGC_OK;
     NtParams p{};
-    p.A = (const u16*)dy3x; p.B = (const u16*)w3patch; p.C = patch; p.M = entries; p.N = 16 * 512; p.K = 4096;
-    p.lda = 4 * 1024; p.ldb = 0; p.ldc = 16 * 512; p.seg_stride = 1024; p.seg_bpad = 0; p.seg_order = 0;
+    p.A = (const u16*)dy3x; p.B = (const u16*)w3patch; p.C = patch; p.M = entries; p.N = PATCH_SLOTS * 512; p.K = 4096;
+    p.lda = 4 * 1024; p.ldb = 0; p.ldc = PATCH_SLOTS * 512; p.seg_stride = 1024; p.seg_bpad = 0; p.seg_split = 1;
     return launch_gemm_nt_pp_seg<ELEM_BF16>(p, (hipStream_t)stream);
 }
 int sgc_windows_patch_sum(const void* patch, const int* bbox, const int* sub_idx, const int* obj_idx, const int* count_incl, int n_pairs,

@@ -1314,9 +1314,9 @@ class RelHeadEngine:
                 _lib.ptr(dy3_bg), _lib.ptr(w["wd3"]), _lib.ptr(dz_maps), n_maps, st()), "sgc_conv3_dgrad"))
         if Epad and TUNING.patch_dgrad:
             # PATCH form: the 16 pixels of every listed window's input patch leave the GEMM already summed over the taps (K = 1024 x
-            # 1 / 2 / 4 per output element instead of 1024: 3.7 instead of 8.4 GB of stores per launch at the benchmark's size, and
-            # the sum over a pair's windows reads 16 instead of 36 rows per window)
-            patch = ws.get("xpatch", Epad * 16 * 512, torch.bfloat16)
+            # 1 / 2 per output element instead of 1024: 4.7 instead of 8.4 GB of stores per launch at the benchmark's size, and the
+            # sum over a pair's windows reads 20 instead of 36 rows per window)
+            patch = ws.get("xpatch", Epad * int(lib.sgc_windows_patch_slots()) * 512, torch.bfloat16)
             self._timed("conv3_dgrad_windows", lambda: _lib.check(lib.sgc_windows_dgrad_patches(_lib.ptr(dy3x), _lib.ptr(w["w3patch"]), _lib.ptr(patch), Epad, st()),
                                                                   "sgc_windows_dgrad_patches"))
             if TUNING.gemms_apart:

@@ -58,15 +58,22 @@ print("# %d listed windows, %.2f TFLOP; column form stores %.2f GB, patch form %
 ref = None
 for rep in range(2):
     timed(lambda: _lib.check(lib.sgc_windows_dgrad_cols(_lib.ptr(dy), _lib.ptr(w3col), _lib.ptr(col), E * 4, _lib.stream_ptr()), "cols"), "column form")
-    for lay, (A, lda, ss) in {"window-major dy3x": (dy, 4096, 1024), "own-pixel-major dy3x": (dy_q, 1024, E * 1024)}.items():
-        for pad in (0, 64):
-            B = w3patch(pad)
-            for order in (0, 1):
-                timed(lambda: _lib.check(lib.sgc_dbg_dgrad_patches(_lib.ptr(A), _lib.ptr(B), _lib.ptr(patch), E, L(lda), L(ss), pad, order,
-                                                                   _lib.stream_ptr()), "patches"),
-                      "patch form, %s, B rows +%d, %s order" % (lay, pad, "class" if order else "natural"))
-                if rep == 0:
-                    if ref is None:
-                        ref = patch.clone()
-                    else:
-                        assert torch.equal(ref, patch), "variants disagree"
+    B = w3patch(0)
+    for split in (0, 1):
+        out = torch.empty(E * (20 if split else 16), 512, dtype=torch.bfloat16, device=dev)
+        timed(lambda: _lib.check(lib.sgc_dbg_dgrad_patches(_lib.ptr(dy), _lib.ptr(B), _lib.ptr(out), E, L(4096), L(1024), 0, split,
+                                                           _lib.stream_ptr()), "patches"),
+              "patch form%s" % (", centre pixels in two slots (K <= 2048)" if split else " (K = 1024 / 2048 / 4096)"))
+        if rep == 0:
+            o = out.float().view(E, -1, 512)
+            if split:                                      # fold the two slots of the centre pixels
+                idx, k = [], 0
+                for pp in range(16):
+                    c = (pp >> 2) in (1, 2) and (pp & 3) in (1, 2)
+                    idx.append((k, k + 1) if c else (k,))
+                    k += 2 if c else 1
+                o = torch.stack([sum(o[:, j] for j in t) for t in idx], dim=1)
+            if ref is None:
+                ref = o
+            else:
+                print("    max |split - unsplit| / max |unsplit| = %.2e" % float((o - ref).abs().max() / ref.abs().max()))
