@@ -13,7 +13,7 @@
 #include "common.h"
 #include "gemm_nt.h"
 
-enum { BMODE_PLAIN = 0, BMODE_CONV = 1, BMODE_GATHER = 2 };   // GATHER (ping-pong block only): conv rows from a window list, see TnParams::gather
+enum { BMODE_PLAIN = 0, BMODE_CONV = 1, BMODE_GATHER = 2, BMODE_PATCH = 3 };   // GATHER / PATCH (ping-pong block only): conv rows from a window list / from per-window 4x4 patches, see TnParams
 
 struct TnParams {
     const u16* A; const u16* B; float* C;
@@ -29,6 +29,9 @@ struct TnParams {
                                  // [img][18][18][Cin] (csrc/kernels_shared.hip): the conv weight gradient over LISTED windows with no
                                  // im2col buffer.  A k block of 4 rows is one window, so the row base is wave-uniform (scalar load
                                  // of the list entry) and only the pixel / tap / column part is per lane.
+                                 // BMODE_PATCH: B = [windows][16 pixels of the window's 4 x 4 input patch][Cin] (sgc_windows_im2patch);
+                                 // contraction row r = own pixel r&3 of window r>>2, its value for tap (ky, kx) is patch pixel
+                                 // (qy + ky, qx + kx): 16 instead of the 36 rows per window of the im2col form, fixed per-lane offsets.
     const int* goff;             // ping-pong block, grouped form: block -> (group g, tile); the contraction runs over rows goff[g] .. goff[g+1]
                                  // (multiples of 64) and the result goes to columns g*N .. of C (no split-K, splits = number of groups)
 };
@@ -268,6 +271,11 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(const TnParams p) {
                 const int ky = tap / 3, kx = tap - 3 * ky;
                 // pixel kr of the window + tap + column; the window's own offset is added per K tile (stage)
                 b = (long)(((kr >> 1) + ky) * 18 + (kr & 1) + kx) * p.Cin + (col - tap_raw * p.Cin);
+            } else if constexpr (BMODE == BMODE_PATCH) {
+                const int tap_raw = col / p.Cin;
+                const int tap = tap_raw > 8 ? 8 : tap_raw;
+                const int ky = tap / 3, kx = tap - 3 * ky;
+                b = (long)((kl >> 2) * 16 + ((kr >> 1) + ky) * 4 + (kr & 1) + kx) * p.Cin + (col - tap_raw * p.Cin);
             } else {
                 b = (long)kl * p.ldb + col;
             }
@@ -283,7 +291,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(const TnParams p) {
             if constexpr (ACONV) toff = conv_row_base(kt * 64, p.lgS, p.CinA); else toff = (long)kt * 64 * p.lda;
             g = p.A + toff;                          // wave-uniform: goes into the buffer descriptor
         } else {
-            if constexpr (BMODE == BMODE_CONV) toff = conv_row_base(kt * 64, p.lgS, p.Cin); else toff = (long)kt * 64 * p.ldb;
+            if constexpr (BMODE == BMODE_CONV) toff = conv_row_base(kt * 64, p.lgS, p.Cin);
+            else if constexpr (BMODE == BMODE_PATCH) toff = (long)kt * 16 * 16 * p.Cin;        // 16 windows per K tile, 16 patch pixels each
+            else toff = (long)kt * 64 * p.ldb;
             g = p.B + toff;                          // (BMODE_GATHER: replaced below by the window's own base)
         }
         if constexpr (BMODE == BMODE_GATHER) {

@@ -324,6 +324,31 @@ __global__ __launch_bounds__(256) void windows_im2col_kernel(const u16* __restri
     }
 }
 
+// zpatch[e][4 py + px][512] = z_pad_bf16[pair][2 wy + py][2 wx + px][:]: the 4 x 4 input patch of every listed window (padded
+// coordinates), the second operand of the weight-gradient product in its PATCH form (gemm_tn.h: BMODE_PATCH) - 16 rows per window
+// instead of the 36 of the im2col form.  One wavefront per (entry, patch row).
+__global__ __launch_bounds__(256) void windows_im2patch_kernel(const u16* __restrict__ zbf, const int* __restrict__ gather,
+                                                               const int* __restrict__ gather_n, long n_rows, u16* __restrict__ zpatch) {
+    const int lane = threadIdx.x & 63;
+    const int E = *gather_n;
+    for (long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6); row < n_rows; row += (long)gridDim.x * 4) {
+        const int e = (int)(row >> 2), py = (int)(row & 3);
+        uint4 v[4];
+        if (e < E) {
+            const int g = gather[e];
+            const int pair = g >> 6, w = g & 63;
+            const u16* src = zbf + (((long)pair * 18 + 2 * (w >> 3) + py) * 18 + 2 * (w & 7)) * 512 + lane * 8;
+#pragma unroll
+            for (int px = 0; px < 4; ++px) v[px] = *reinterpret_cast<const uint4*>(src + px * 512);
+        } else {
+#pragma unroll
+            for (int px = 0; px < 4; ++px) v[px] = make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int px = 0; px < 4; ++px) *reinterpret_cast<uint4*>(zpatch + (row * 4 + px) * 512 + lane * 8) = v[px];
+    }
+}
+
 // dz[pair][pixel] = sum over the taps of col[row of the source pixel][tap]: the scatter half of the transposed convolution, written
 // as a gather so that every dz row has one writer.  Only the pixels within one pixel of the pair's X windows exist; one workgroup
 // per pair.
@@ -1145,6 +1170,26 @@ int sgc_windows_wgrad(const void* dy3x, const void* zcol, float* slabs, int rows
     p.A = (const u16*)dy3x; p.B = (const u16*)zcol; p.C = slabs; p.M = 1024; p.N = 9 * 512; p.K = rows;
     p.lda = 1024; p.ldb = 9 * 512; p.ldc = 9 * 512; p.slab_stride = 1024L * 9 * 512;
     return launch_gemm_tn<ELEM_BF16, BMODE_PLAIN>(p, splits, n_slabs, (hipStream_t)stream);
+}
+
+// PATCH form of the two calls above: zpatch [entries_pad][16][512] bf16 (entries behind the list: zero rows), then
+// slabs [splits][1024][9*512] f32 = sum_rows dy3x[row][n] * zpatch[window of the row][its pixel + tap][c]
+int sgc_windows_im2patch(const void* z_pad_bf16, const int* gather, const int* gather_n, int entries_pad, void* zpatch, void* stream) {
+    if (entries_pad <= 0) return SGC_OK;
+    const long rows = (long)entries_pad * 4;
+    SGC_LAUNCH(windows_im2patch_kernel, dim3(grid_cap(rows, 4, 262144)), dim3(256), 0, (hipStream_t)stream, (const u16*)z_pad_bf16,
+               gather, gather_n, rows, (u16*)zpatch);
+    SGC_CHECK_LAUNCH();
+    return SGC_OK;
+}
+int sgc_windows_wgrad_patch(const void* dy3x, const void* zpatch, float* slabs, int rows, int splits, int* n_slabs, void* stream) {
+    if (rows <= 0) { if (n_slabs) *n_slabs = 0; return SGC_OK; }
+    if (rows & 63) return SGC_ERR_ARG;
+    TnParams p{};
+    p.A = (const u16*)dy3x; p.B = (const u16*)zpatch; p.C = slabs; p.M = 1024; p.N = 9 * 512; p.K = rows; p.Cin = 512;
+    p.lda = 1024; p.ldb = 0; p.ldc = 9 * 512; p.slab_stride = 1024L * 9 * 512;
+    if (splits <= 0) splits = tn_auto_splits((p.M / 256) * (p.N / 256), p.K >> 6);
+    return launch_gemm_tn_pp<ELEM_BF16, BMODE_PATCH, 0>(p, splits, n_slabs, (hipStream_t)stream);
 }
 
 // col [rows][9*512] bf16 = dy3x [rows][1024] * w3col[(tap, c)][1024]^T

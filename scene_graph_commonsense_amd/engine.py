@@ -174,7 +174,8 @@ class Tuning:
     gemms_apart: bool = True          # two-stream backward: keep the big GEMMs of the two chains from running side by side
     shared_linear: bool = True        # pairs whose regions of influence on the 16-grid are disjoint: X windows combined, not convolved
     shared_conv2: bool = True         # conv2 halves computed on the objects' own regions, the rest copied from the image's background half
-    patch_dgrad: bool = True          # conv3 data gradient over the listed windows in patch form (16 rows per window; off: 36 columns + col2im)
+    patch_dgrad: bool = True          # conv3 data gradient over the listed windows in patch form (20 rows per window; off: 36 columns + col2im)
+    patch_wgrad: bool = True          # conv3 weight gradient over the listed windows from 4 x 4 patches (16 rows per window; off: im2col, 36)
 
     @classmethod
     def from_env(cls):
@@ -186,7 +187,8 @@ class Tuning:
                    gemms_apart=os.environ.get("SGC_GEMMS_APART", "1") != "0",
                    shared_linear=lvl >= 3 and os.environ.get("SGC_SHARED_LINEAR", "1") != "0",
                    shared_conv2=lvl >= 1 and os.environ.get("SGC_SHARED_CONV2", "1") != "0",
-                   patch_dgrad=os.environ.get("SGC_PATCH_DGRAD", "1") != "0")
+                   patch_dgrad=os.environ.get("SGC_PATCH_DGRAD", "1") != "0",
+                   patch_wgrad=os.environ.get("SGC_PATCH_WGRAD", "1") != "0")
 
 
 TUNING = Tuning.from_env()
@@ -1287,9 +1289,15 @@ class RelHeadEngine:
                 # im2col + plain ping-pong TN GEMM.  (Rows of z gathered by the window list inside the GEMM block - no column
                 # buffer, sgc_windows_wgrad_gather - measured 11.0 ms against 8.3 + 2.3 ms: the nine shifted re-reads of the z rows
                 # by different N tiles cost more than the im2col pass; kept in the C-ABI, not used by the step.)
-                zcol = ws.get("zcol", Epad * 4 * 9 * 512, torch.bfloat16)
-                self._timed("im2col_windows", lambda: _lib.check(lib.sgc_windows_im2col(_lib.ptr(z_bf), _lib.ptr(gather), _lib.ptr(gn), Epad,
-                                                                                       _lib.ptr(zcol), st()), "sgc_windows_im2col"))
+                if TUNING.patch_wgrad:
+                    # PATCH form: the 16 pixels of every listed window's input patch, read by the product at (own pixel + tap)
+                    zcol = ws.get("zpatch", Epad * 16 * 512, torch.bfloat16)
+                    self._timed("im2col_windows", lambda: _lib.check(lib.sgc_windows_im2patch(_lib.ptr(z_bf), _lib.ptr(gather), _lib.ptr(gn), Epad,
+                                                                                             _lib.ptr(zcol), st()), "sgc_windows_im2patch"))
+                else:
+                    zcol = ws.get("zcol", Epad * 4 * 9 * 512, torch.bfloat16)
+                    self._timed("im2col_windows", lambda: _lib.check(lib.sgc_windows_im2col(_lib.ptr(z_bf), _lib.ptr(gather), _lib.ptr(gn), Epad,
+                                                                                           _lib.ptr(zcol), st()), "sgc_windows_im2col"))
 
         def wgrad_windows():
             # the second big GEMM of the window backward.  With ``TUNING.gemms_apart`` it is enqueued after the data-gradient GEMM
@@ -1298,7 +1306,7 @@ class RelHeadEngine:
             with side():
                 if Epad:
                     slx = sl[slabs_n.value * 1024 * 4608:]
-                    self._timed("conv3_wgrad_windows", lambda: _lib.check(lib.sgc_windows_wgrad(
+                    self._timed("conv3_wgrad_windows", lambda: _lib.check((lib.sgc_windows_wgrad_patch if TUNING.patch_wgrad else lib.sgc_windows_wgrad)(
                         _lib.ptr(dy3x), _lib.ptr(zcol), _lib.ptr(slx), Epad * 4, 0, ctypes.byref(slabs_x), st()), "sgc_windows_wgrad"))
                 dW3r = self._slab_sum(sl, 1024 * 4608, slabs_n.value + slabs_x.value)
                 grads["conv3_1.weight"] = dW3r.view(1024, 3, 3, 512).permute(0, 3, 1, 2).contiguous()

@@ -279,3 +279,40 @@ def test_patch_form_of_the_conv3_data_gradient_equals_the_transposed_convolution
     assert float((a[live] - ref[live]).abs().max()) <= 2e-2 * s2
     assert float((b[live] - ref[live]).abs().max()) <= 4e-2 * s2                  # the column form rounds nine terms to bf16 before adding
     assert float((a[live] - ref[live]).abs().mean()) <= float((b[live] - ref[live]).abs().mean())   # the patch form is the more accurate one
+
+
+def test_patch_form_of_the_conv3_weight_gradient_is_bitwise_the_im2col_form():
+    """``sgc_windows_im2patch`` + ``sgc_windows_wgrad_patch`` (16 patch rows per listed window, read at own pixel + tap) against
+    ``sgc_windows_im2col`` + ``sgc_windows_wgrad`` (36 column rows): the same products in the same order of accumulation."""
+    L, lib = _lib()
+    rng = np.random.default_rng(6)
+    pl = _plan(rng, n=8)
+    P, E = pl["P"], int(pl["incl"][-1])
+    Epad = (E + 63) // 64 * 64
+    gn = pl["incl"][P - 1:]
+    g = pl["gather"][:E].long()
+    gen = torch.Generator(device=DEV).manual_seed(4)
+    z = torch.randn(P, 18, 18, 512, device=DEV, generator=gen).bfloat16()
+    dy3x = torch.zeros(Epad * 4, 1024, device=DEV)
+    dy3x[:E * 4] = torch.randn(E * 4, 1024, device=DEV, generator=gen)
+    dy3x = dy3x.bfloat16()
+    zpatch = torch.full((Epad, 16, 512), float("nan"), device=DEV).bfloat16()
+    L.check(lib.sgc_windows_im2patch(L.ptr(z), L.ptr(pl["gather"]), L.ptr(gn), Epad, L.ptr(zpatch), L.stream_ptr()), "im2patch")
+    pair, w = (g >> 6), (g & 63)
+    for py in range(4):
+        for px in range(4):
+            assert torch.equal(zpatch[:E, py * 4 + px], z[pair, 2 * (w >> 3) + py, 2 * (w & 7) + px])
+    if Epad > E:
+        assert float(zpatch[E:].float().abs().max()) == 0.0
+    zcol = torch.empty(Epad * 4, 9 * 512, device=DEV).bfloat16()
+    L.check(lib.sgc_windows_im2col(L.ptr(z), L.ptr(pl["gather"]), L.ptr(gn), Epad, L.ptr(zcol), L.stream_ptr()), "im2col")
+    out = []
+    for fn, B in ((lib.sgc_windows_wgrad, zcol), (lib.sgc_windows_wgrad_patch, zpatch)):
+        slabs = torch.full((64, 1024, 9 * 512), float("nan"), device=DEV)
+        n = ctypes.c_int(0)
+        L.check(fn(L.ptr(dy3x), L.ptr(B), L.ptr(slabs), Epad * 4, 0, ctypes.byref(n), L.stream_ptr()), "wgrad")
+        out.append(slabs[:n.value].sum(0))
+        assert n.value >= 1
+    assert torch.equal(out[0], out[1])
+    ref = dy3x.float().t() @ zcol.float()
+    assert float((out[1] - ref).abs().max()) <= 2e-3 * float(ref.abs().max())
