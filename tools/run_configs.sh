@@ -12,6 +12,8 @@ ARGS="" run "8x64 default (two-stream backward, GEMMs apart)" SGC_NOOP=1
 ARGS="" run "8x64 SGC_GEMMS_APART=0 (round-2 order)" SGC_GEMMS_APART=0
 ARGS="" run "8x64 SGC_BWD_STREAMS=0 (one stream)" SGC_BWD_STREAMS=0
 ARGS="" run "8x64 default again" SGC_NOOP=1
+ARGS="" run "8x64 column forms of the conv3 window backward (rounds 1-2)" SGC_PATCH_DGRAD=0 SGC_PATCH_WGRAD=0
+ARGS="" run "8x64 SGC_SHARED_LINEAR=0 (every pair convolves its own X windows)" SGC_SHARED_LINEAR=0
 ARGS="" run "8x64 SGC_SHARED_LEVEL=2 (no second level)" SGC_SHARED_LEVEL=2
 ARGS="" run "8x64 SGC_SHARED_LEVEL=1 (fc1 per pair)" SGC_SHARED_LEVEL=1
 ARGS="" run "8x64 SGC_SHARED_LEVEL=0 (everything per pair)" SGC_SHARED_LEVEL=0
