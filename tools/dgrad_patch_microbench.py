@@ -77,3 +77,22 @@ for rep in range(2):
                 ref = o
             else:
                 print("    max |split - unsplit| / max |unsplit| = %.2e" % float((o - ref).abs().max() / ref.abs().max()))
+
+# ---- weight gradient over the same list: im2col form against the patch form, and the number of K splits of the patch form
+z = torch.randn(E // 64, 18, 18, 512, device=dev, generator=g).bfloat16()
+gather = (torch.arange(E, device=dev, dtype=torch.int32) % 64) + (torch.arange(E, device=dev, dtype=torch.int32) // 64) * 64
+gn = torch.tensor([E], device=dev, dtype=torch.int32)
+dy2 = dy.view(E * 4, 1024)
+slabs = torch.empty(64, 1024, 9 * 512, device=dev)
+n = ctypes.c_int(0)
+zcol = torch.empty(E * 4, 9 * 512, dtype=torch.bfloat16, device=dev)
+zpatch = torch.empty(E, 16, 512, dtype=torch.bfloat16, device=dev)
+for rep in range(2):
+    timed(lambda: _lib.check(lib.sgc_windows_im2col(_lib.ptr(z), _lib.ptr(gather), _lib.ptr(gn), E, _lib.ptr(zcol), _lib.stream_ptr()), "im2col"), "im2col (36 rows per window)")
+    timed(lambda: _lib.check(lib.sgc_windows_im2patch(_lib.ptr(z), _lib.ptr(gather), _lib.ptr(gn), E, _lib.ptr(zpatch), _lib.stream_ptr()), "im2patch"), "im2patch (16 rows per window)")
+    timed(lambda: _lib.check(lib.sgc_windows_wgrad(_lib.ptr(dy2), _lib.ptr(zcol), _lib.ptr(slabs), E * 4, 0, ctypes.byref(n), _lib.stream_ptr()), "wgrad"),
+          "weight gradient, im2col form, automatic splits")
+    for sp in (0, 4, 7, 14, 28, 56):
+        timed(lambda: _lib.check(lib.sgc_windows_wgrad_patch(_lib.ptr(dy2), _lib.ptr(zpatch), _lib.ptr(slabs), E * 4, sp, ctypes.byref(n), _lib.stream_ptr()), "wgrad"),
+              "weight gradient, patch form, %s" % ("automatic splits" if sp == 0 else "%d splits" % sp))
+        print("    -> %d slabs" % n.value)
