@@ -152,19 +152,19 @@ class TrainContext:
 @dataclass
 class Tuning:
     """The switches of the product path, in ONE place, read once at import.  Defaults are the measured best.
-    Environment (seven documented variables; tests and tools flip the fields directly, e.g. ``with engine.tuning(shared_fc1=False)``):
+    Environment (four documented variables; tests and tools flip the fields directly, e.g. ``with engine.tuning(shared_fc1=False)``):
 
       SGC_SHARED_LEVEL         0 per-pair kernels | 1 conv3 over shared windows | 2 + fc1 over the same windows | 3 (default) + the
-                               per-object maps shared with the image's background map (second level)
-      SGC_SHARED_BWD           0: per-pair backward under a shared forward (A/B of the backward alone)
+                               per-object maps shared with the image's background map (second level) and the linear pairs
       SGC_SHARED_MAX_FRACTION  share of pair-specific windows above which a scene goes to the per-pair kernels (default 0.5:
                                profiles/r03_box_sweep.txt - the step time crosses near 0.65 but the workspace reaches 170 GB at 0.5)
       SGC_BWD_STREAMS          0: weight-gradient chain on the caller's stream (single-stream profiles, tools/collect_profiles.sh)
-      SGC_GEMMS_APART          0: round 2's order of the two-stream backward (data- and weight-gradient GEMM of a layer side by side)
-      SGC_SHARED_LINEAR        0: every pair convolves its own X windows (off: the sixth identity of csrc/kernels_shared.hip)
-      SGC_SHARED_CONV2         0: conv2 halves computed on whole object maps
+      SGC_TUNING               "field=value,field=value": any field below by name (A/B tools: tools/ab_env.sh SGC_TUNING gemms_apart=1
+                               gemms_apart=0), e.g. shared_bwd=0 (per-pair backward under a shared forward), gemms_apart=0 (round 2's order
+                               of the two backward chains), shared_linear=0, shared_conv2=0, patch_dgrad=0 / patch_wgrad=0 (the column
+                               forms of the conv3 window backward: im2col / col2im)
     Decided and no longer switchable: sparse-MFMA conv3 weight gradient, un-pool fused into the conv3 data gradient, im2col + plain
-    GEMM (not the gathered TN block) for the weight gradient over the listed windows."""
+    GEMM (not the gathered TN block) for the column form of the weight gradient over the listed windows."""
     shared_conv3: bool = True
     shared_fc1: bool = True
     shared_objects: bool = True
@@ -180,15 +180,16 @@ class Tuning:
     @classmethod
     def from_env(cls):
         lvl = int(os.environ.get("SGC_SHARED_LEVEL", "3"))
-        return cls(shared_conv3=lvl >= 1, shared_fc1=lvl >= 2, shared_objects=lvl >= 3,
-                   shared_bwd=os.environ.get("SGC_SHARED_BWD", "1") != "0",
-                   shared_max_fraction=float(os.environ.get("SGC_SHARED_MAX_FRACTION", "0.5")),
-                   bwd_streams=os.environ.get("SGC_BWD_STREAMS", "1") != "0",
-                   gemms_apart=os.environ.get("SGC_GEMMS_APART", "1") != "0",
-                   shared_linear=lvl >= 3 and os.environ.get("SGC_SHARED_LINEAR", "1") != "0",
-                   shared_conv2=lvl >= 1 and os.environ.get("SGC_SHARED_CONV2", "1") != "0",
-                   patch_dgrad=os.environ.get("SGC_PATCH_DGRAD", "1") != "0",
-                   patch_wgrad=os.environ.get("SGC_PATCH_WGRAD", "1") != "0")
+        t = cls(shared_conv3=lvl >= 1, shared_fc1=lvl >= 2, shared_objects=lvl >= 3, shared_linear=lvl >= 3, shared_conv2=lvl >= 1,
+                shared_max_fraction=float(os.environ.get("SGC_SHARED_MAX_FRACTION", "0.5")),
+                bwd_streams=os.environ.get("SGC_BWD_STREAMS", "1") != "0")
+        for item in filter(None, os.environ.get("SGC_TUNING", "").split(",")):
+            k, _, v = item.partition("=")
+            k = k.strip()
+            if k not in cls.__dataclass_fields__:
+                raise ValueError("SGC_TUNING: unknown field %r (fields: %s)" % (k, ", ".join(cls.__dataclass_fields__)))
+            setattr(t, k, float(v) if k == "shared_max_fraction" else v.strip() not in ("0", "false", "False", ""))
+        return t
 
 
 TUNING = Tuning.from_env()

@@ -9,11 +9,11 @@ d=json.loads(sys.stdin.read())
 print('%-62s %8.2f ms/step  %9.0f pairs/s  frac %.3f  step_frac %s  peak %.1f GB' % ('$label', d['ms_per_step'], d['value'], (d['roofline'] or {}).get('frac', 0) if d['roofline'] else 0, (d['roofline'] or {}).get('step_frac'), d['peak_memory_gb']))"
 }
 ARGS="" run "8x64 default (two-stream backward, GEMMs apart)" SGC_NOOP=1
-ARGS="" run "8x64 SGC_GEMMS_APART=0 (round-2 order)" SGC_GEMMS_APART=0
+ARGS="" run "8x64 SGC_TUNING=gemms_apart=0 (round-2 order)" SGC_TUNING=gemms_apart=0
 ARGS="" run "8x64 SGC_BWD_STREAMS=0 (one stream)" SGC_BWD_STREAMS=0
 ARGS="" run "8x64 default again" SGC_NOOP=1
-ARGS="" run "8x64 column forms of the conv3 window backward (rounds 1-2)" SGC_PATCH_DGRAD=0 SGC_PATCH_WGRAD=0
-ARGS="" run "8x64 SGC_SHARED_LINEAR=0 (every pair convolves its own X windows)" SGC_SHARED_LINEAR=0
+ARGS="" run "8x64 column forms of the conv3 window backward (rounds 1-2)" SGC_TUNING=patch_dgrad=0,patch_wgrad=0
+ARGS="" run "8x64 SGC_TUNING=shared_linear=0 (every pair convolves its own X windows)" SGC_TUNING=shared_linear=0
 ARGS="" run "8x64 SGC_SHARED_LEVEL=2 (no second level)" SGC_SHARED_LEVEL=2
 ARGS="" run "8x64 SGC_SHARED_LEVEL=1 (fc1 per pair)" SGC_SHARED_LEVEL=1
 ARGS="" run "8x64 SGC_SHARED_LEVEL=0 (everything per pair)" SGC_SHARED_LEVEL=0
