@@ -160,6 +160,7 @@ int sgc_windows_wgrad_gather(const void* dy3x, const void* z_pad_bf16, const int
  * patch of every listed window (zero rows behind the list), read by the weight-gradient product at (own pixel + tap) - 16 instead of 36
  * rows per window (reference: the autograd of model.py:144-146's conv3 w.r.t. its weight). */
 int sgc_windows_im2patch(const void* z_pad_bf16, const int* gather, const int* gather_n, int entries_pad, void* zpatch, void* stream);
+int sgc_windows_im2patch_f16(const void* z_pad_f16, const int* gather, const int* gather_n, int entries_pad, void* zpatch, void* stream);   /* source: the forward's f16 maps */
 int sgc_windows_wgrad_patch(const void* dy3x, const void* zpatch, float* slabs, int rows, int splits, int* n_slabs, void* stream);
 int sgc_windows_dgrad_cols(const void* dy3x, const void* w3col, void* col, int rows, void* stream);
 int sgc_windows_col2im(const void* col, const int* bbox, const int* sub_idx, const int* obj_idx, const int* count_incl, int n_pairs,

@@ -327,6 +327,16 @@ __global__ __launch_bounds__(256) void windows_im2col_kernel(const u16* __restri
 // zpatch[e][4 py + px][512] = z_pad_bf16[pair][2 wy + py][2 wx + px][:]: the 4 x 4 input patch of every listed window (padded
 // coordinates), the second operand of the weight-gradient product in its PATCH form (gemm_tn.h: BMODE_PATCH) - 16 rows per window
 // instead of the 36 of the im2col form.  One wavefront per (entry, patch row).
+// SRC_F16: the source map is the forward's f16 z (no bf16 copy of the real pairs is kept); values are converted on the way.
+__device__ __forceinline__ uint4 f16x8_to_bf16x8(uint4 v) {
+    const u16* h = reinterpret_cast<const u16*>(&v);
+    uint4 o;
+    unsigned* od = reinterpret_cast<unsigned*>(&o);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) od[k] = f32x2_to_bf16x2_bits(f16_bits_to_f32(h[2 * k]), f16_bits_to_f32(h[2 * k + 1]));
+    return o;
+}
+template <bool SRC_F16>
 __global__ __launch_bounds__(256) void windows_im2patch_kernel(const u16* __restrict__ zbf, const int* __restrict__ gather,
                                                                const int* __restrict__ gather_n, long n_rows, u16* __restrict__ zpatch) {
     const int lane = threadIdx.x & 63;
@@ -345,7 +355,7 @@ __global__ __launch_bounds__(256) void windows_im2patch_kernel(const u16* __rest
             for (int px = 0; px < 4; ++px) v[px] = make_uint4(0, 0, 0, 0);
         }
 #pragma unroll
-        for (int px = 0; px < 4; ++px) *reinterpret_cast<uint4*>(zpatch + (row * 4 + px) * 512 + lane * 8) = v[px];
+        for (int px = 0; px < 4; ++px) *reinterpret_cast<uint4*>(zpatch + (row * 4 + px) * 512 + lane * 8) = SRC_F16 ? f16x8_to_bf16x8(v[px]) : v[px];
     }
 }
 
@@ -1177,7 +1187,16 @@ int sgc_windows_wgrad(const void* dy3x, const void* zcol, float* slabs, int rows
 int sgc_windows_im2patch(const void* z_pad_bf16, const int* gather, const int* gather_n, int entries_pad, void* zpatch, void* stream) {
     if (entries_pad <= 0) return SGC_OK;
     const long rows = (long)entries_pad * 4;
-    SGC_LAUNCH(windows_im2patch_kernel, dim3(grid_cap(rows, 4, 262144)), dim3(256), 0, (hipStream_t)stream, (const u16*)z_pad_bf16,
+    SGC_LAUNCH(windows_im2patch_kernel<false>, dim3(grid_cap(rows, 4, 262144)), dim3(256), 0, (hipStream_t)stream, (const u16*)z_pad_bf16,
+               gather, gather_n, rows, (u16*)zpatch);
+    SGC_CHECK_LAUNCH();
+    return SGC_OK;
+}
+// the same from the forward's f16 maps (values rounded f16 -> bf16 on the way): no bf16 copy of the real pairs' z is needed
+int sgc_windows_im2patch_f16(const void* z_pad_f16, const int* gather, const int* gather_n, int entries_pad, void* zpatch, void* stream) {
+    if (entries_pad <= 0) return SGC_OK;
+    const long rows = (long)entries_pad * 4;
+    SGC_LAUNCH(windows_im2patch_kernel<true>, dim3(grid_cap(rows, 4, 262144)), dim3(256), 0, (hipStream_t)stream, (const u16*)z_pad_f16,
                gather, gather_n, rows, (u16*)zpatch);
     SGC_CHECK_LAUNCH();
     return SGC_OK;

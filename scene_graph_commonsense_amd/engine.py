@@ -626,7 +626,7 @@ class RelHeadEngine:
                        "sgc_pair_expand")
         else:
             _lib.check(lib.sgc_pair_expand_train(_lib.ptr(U), _lib.ptr(V), _lib.ptr(ps_sub), _lib.ptr(ps_obj), _lib.ptr(zt),
-                                                 _lib.ptr(keep[0][P * 18 * 18 * 512:]), _lib.ptr(keep[1][P * 256 * 256:]), n_tail, self._st()),
+                                                 _lib.ptr(keep[0][(P - keep[2]) * 18 * 18 * 512:]), _lib.ptr(keep[1][P * 256 * 256:]), n_tail, self._st()),
                        "sgc_pair_expand_train")
         gather, incl = plan["gather"], plan["incl"]
         out = dict(plan, n2=n2, wm=wm)
@@ -900,9 +900,14 @@ class RelHeadEngine:
                                 objects=wm_mode and shared_objects_enabled(), obj_img=obj_img) if share else None
         Pt = P + (2 * ctx.n_obj + ctx.n_img if share else 0)         # pseudo-pairs and background maps live behind the real pairs
         z = sc.get("z_pad", Pt * 18 * 18 * 512, torch.float16)
-        z_bf = ws.get("z_pad_bf", Pt * 18 * 18 * 512, torch.bfloat16)
+        # bf16 copy of z for the weight gradients.  With the shared backward in its patch form the real pairs' copy is never read: the
+        # patch gather converts the f16 rows it gathers (sgc_windows_im2patch_f16), so the expansion writes 1 KB less per pixel and
+        # only the pseudo-pairs / background maps behind the real pairs get a bf16 map (``z_bf_base`` = pair index of the buffer's first map)
+        ctx.z_bf_base = P if (narrow and TUNING.patch_wgrad and dense is not None and 0 < dense[2] <= 150) else 0
+        z_bf = ws.get("z_pad_bf", (Pt - ctx.z_bf_base) * 18 * 18 * 512, torch.bfloat16)
         amz = ws.get("amz", Pt * 256 * 256, torch.uint8)             # two 4-bit routing codes per byte
-        self.expand(ctx.uv[0], ctx.uv[1], sub_idx, obj_idx, P, z, z_bf, amz, dense=dense, pixrect=plan["pixrect"] if narrow else None)
+        self.expand(ctx.uv[0], ctx.uv[1], sub_idx, obj_idx, P, z, None if ctx.z_bf_base else z_bf, amz, dense=dense,
+                    pixrect=plan["pixrect"] if narrow else None)
         ctx.z_bf = z_bf
         am = ws.get("argmax", Pt * 65536, torch.uint8)              # conv3 routing codes (shared path: only the rows of listed windows)
         h1 = ws.get("h1", Ppad * 4096, torch.float16)
@@ -912,7 +917,7 @@ class RelHeadEngine:
             wm = self.window_major_rows(plan, P, 2 * ctx.n_obj)
             ywm = sc.get("ywm", wm["rows"] * 1024, torch.float16)
             ywm_bf = ws.get("ywm_bf", wm["rows"] * 1024, torch.bfloat16)
-            ctx.shared = self.conv3_shared(plan, z, ctx.uv[0], ctx.uv[1], bbox, obj_img, sub_idx, obj_idx, P, ywm, am, ywm_bf, keep=(z_bf, amz), wm=wm)
+            ctx.shared = self.conv3_shared(plan, z, ctx.uv[0], ctx.uv[1], bbox, obj_img, sub_idx, obj_idx, P, ywm, am, ywm_bf, keep=(z_bf, amz, ctx.z_bf_base), wm=wm)
             ctx.shared["ywm_bf"] = ywm_bf
             self.fc1_shared(wm, ywm, bbox, sub_idx, obj_idx, plan.get("incl_all", plan["incl"]), P, ctx.n_obj, h1, dropout, seeds[0])
         else:
@@ -921,7 +926,7 @@ class RelHeadEngine:
             if Ppad > P:
                 Workspace._zero(y_bf[P * 65536:])
             if share:
-                ctx.shared = self.conv3_shared(plan, z, ctx.uv[0], ctx.uv[1], bbox, obj_img, sub_idx, obj_idx, P, y, am, y_bf, keep=(z_bf, amz))
+                ctx.shared = self.conv3_shared(plan, z, ctx.uv[0], ctx.uv[1], bbox, obj_img, sub_idx, obj_idx, P, y, am, y_bf, keep=(z_bf, amz, ctx.z_bf_base))
             else:
                 self._timed("conv3_fwd", lambda: _lib.check(lib.sgc_conv3_relu_pool(_lib.ptr(z), _lib.ptr(self.w["w3r"]), _lib.ptr(self.w["b3"]),
                                                                                    _lib.ptr(y), _lib.ptr(am), _lib.ptr(y_bf), P, self._st()),
@@ -1182,6 +1187,9 @@ class RelHeadEngine:
         bpart = ws.get("b3_part", 2048 * 1024, torch.float32)
         nparts = ctypes.c_int(0)
         z_bf = ctx.z_bf
+        if getattr(ctx, "z_bf_base", 0):
+            raise RuntimeError("the per-pair conv3 backward needs the bf16 copy of z that this forward did not write "
+                               "(TUNING changed between forward and backward)")
         pack_a = ws.get("w3_pack_a", P * 4 * 1024 * 64, torch.uint8)
         pack_i = ws.get("w3_pack_i", P * 4 * 1024 * 8, torch.uint8)
         self._timed("unpool", lambda: _lib.check(lib.sgc_unpool_relu_bwd_pack(
@@ -1237,7 +1245,8 @@ class RelHeadEngine:
             am_maps = sh["am_ps"]
         dest = wm["dest_conv"] if wm is not None else None
         lin = sh.get("lin") if objects else None
-        z_bf_maps = z_bf[map0 * 18 * 18 * 512:]
+        zb0 = getattr(ctx, "z_bf_base", 0)
+        z_bf_maps = z_bf[(map0 - zb0) * 18 * 18 * 512:]
         dz_maps = dz[map0 * 256 * 512:]
         bpart = ws.get("b3_part", 2048 * 1024, torch.float32)
         bpart_x = ws.get("b3_part_x", 1024 * 1024, torch.float32)
@@ -1293,9 +1302,15 @@ class RelHeadEngine:
                 if TUNING.patch_wgrad:
                     # PATCH form: the 16 pixels of every listed window's input patch, read by the product at (own pixel + tap)
                     zcol = ws.get("zpatch", Epad * 16 * 512, torch.bfloat16)
-                    self._timed("im2col_windows", lambda: _lib.check(lib.sgc_windows_im2patch(_lib.ptr(z_bf), _lib.ptr(gather), _lib.ptr(gn), Epad,
-                                                                                             _lib.ptr(zcol), st()), "sgc_windows_im2patch"))
+                    if zb0:        # no bf16 copy of the real pairs' z: gather the f16 rows of the forward and convert
+                        self._timed("im2col_windows", lambda: _lib.check(lib.sgc_windows_im2patch_f16(_lib.ptr(ctx.z), _lib.ptr(gather), _lib.ptr(gn), Epad,
+                                                                                                     _lib.ptr(zcol), st()), "sgc_windows_im2patch_f16"))
+                    else:
+                        self._timed("im2col_windows", lambda: _lib.check(lib.sgc_windows_im2patch(_lib.ptr(z_bf), _lib.ptr(gather), _lib.ptr(gn), Epad,
+                                                                                                 _lib.ptr(zcol), st()), "sgc_windows_im2patch"))
                 else:
+                    if zb0:
+                        raise RuntimeError("the im2col form needs the bf16 copy of z that this forward did not write (TUNING changed between forward and backward)")
                     zcol = ws.get("zcol", Epad * 4 * 9 * 512, torch.bfloat16)
                     self._timed("im2col_windows", lambda: _lib.check(lib.sgc_windows_im2col(_lib.ptr(z_bf), _lib.ptr(gather), _lib.ptr(gn), Epad,
                                                                                            _lib.ptr(zcol), st()), "sgc_windows_im2col"))
