@@ -27,8 +27,8 @@ from .pairs import DeviceScene, flatten_scene, match_target_sgd, pair_targets_fa
 # Bytes per pair / per pair-specific window / per object, measured with tools/mem_report.py (+15 % margin in ``plan_image_groups``):
 _COST = {
     # (per pair, per X window, per pair on the per-pair kernels, per object)
-    True: (1.25e6, 0.09e6, 2.7e6, 8.0e6),           # training: z f16 + bf16 + routing codes + dz, patch forms of the backward (16 + 20 rows of 1 KB
-                                                    # per convolved window; the column forms of rounds 1-2: 0.125e6)
+    True: (0.95e6, 0.09e6, 2.7e6, 8.0e6),           # training: z f16 + routing codes + dz (no bf16 copy of the pairs' z: -0.33e6), patch forms of
+                                                    # the backward (16 + 20 rows of 1 KB per convolved window; the column forms of rounds 1-2: 0.125e6)
     False: (0.40e6, 0.03e6, 0.60e6, 3.0e6),         # evaluation: z f16, window-major rows, f32 fc1 products
 }
 

@@ -52,7 +52,7 @@ def main():
         scene = flatten_scene(cfg, batch, dev)
         P = scene.n_pairs
         frac = scene.shared_windows / (64.0 * P)
-        est_gb = (1.25e6 * P + 0.09e6 * scene.shared_windows) * 1.15 / 1e9
+        est_gb = (0.95e6 * P + 0.09e6 * scene.shared_windows) * 1.15 / 1e9
         row = []
         for mode in ("shared", "pairs"):
             if mode == "shared" and est_gb > args.max_gb:
