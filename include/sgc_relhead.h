@@ -50,11 +50,6 @@ int sgc_pair_expand_dense(const void* U, const void* V, const int* img_ptr, cons
  * expansion is read only next to its pair-specific windows; NULL = every pixel. */
 int sgc_pair_expand_dense_windows(const void* U, const void* V, const int* img_ptr, const int* pid, int pid_ld, int n_img, int max_n,
                                   void* z_pad_f16, void* z_pad_bf16, unsigned char* amz, const int* pixel_rect, void* stream);
-/* ... obj_rect [objects] (or NULL): packed pixel rectangles that contain every pair rectangle of the object (the pseudo-pair (o, bg) of
- * sgc_shared_objects_count): subjects and object tiles that miss a pixel are skipped without a look at their pairs */
-int sgc_pair_expand_dense_windows_rects(const void* U, const void* V, const int* img_ptr, const int* pid, int pid_ld, int n_img, int max_n,
-                                        void* z_pad_f16, void* z_pad_bf16, unsigned char* amz, const int* pixel_rect, const int* obj_rect,
-                                        void* stream);
 
 /* y [n_pairs*64][1024] f16 (+ argmax u8, may be NULL; + y_bf16, the same values rounded to bf16 for the fc1 weight gradient, may be
  * NULL) = maxpool2(relu(conv3x3(z_pad, w3r[1024][8][9][64]) + b3))   (model.py:145-146) */

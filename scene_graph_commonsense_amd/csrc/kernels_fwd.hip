@@ -108,25 +108,13 @@ constexpr int EXPAND_JT = 16;
 __global__ __launch_bounds__(512) void pair_expand_dense_kernel(const u16* __restrict__ U, const u16* __restrict__ V,
                                                                 const int* __restrict__ img_ptr, const int* __restrict__ pid,
                                                                 int pid_ld, u16* __restrict__ z, u16* __restrict__ zb,
-                                                                unsigned char* __restrict__ amz, const int* __restrict__ pixrect,
-                                                                const int* __restrict__ obj_rect) {
+                                                                unsigned char* __restrict__ amz, const int* __restrict__ pixrect) {
     __shared__ __attribute__((aligned(16))) char sv[EXPAND_JT * 4096];
-    __shared__ int srect[160];
     const int W = blockIdx.x, jt = blockIdx.y, img = blockIdx.z;
     const int o0 = img_ptr[img], n = img_ptr[img + 1] - o0;
     const int j0 = jt * EXPAND_JT;
     if (j0 >= n) return;
     const int nj = min(EXPAND_JT, n - j0);
-    const int Y = W >> 4, X = W & 15;
-    // obj_rect [objects]: packed pixel rectangle outside which NO pair of the object needs a pixel (the pixels within one of its
-    // windows R_o; sgc_shared_objects_count).  A pair's rectangle lies inside both objects': a block whose 16 objects all miss the
-    // pixel has nothing to write, and a subject that misses it is skipped without a look at its pairs (two dependent loads each).
-    if (obj_rect) {
-        bool any = false;
-        for (int jj = 0; jj < nj; ++jj) any = any || in_pixel_rect(obj_rect[o0 + j0 + jj], Y, X);       // uniform
-        if (!any) return;
-        for (int k = threadIdx.x; k < n; k += 512) srect[k] = obj_rect[o0 + k];
-    }
     // stage V: object jj -> 4 pixels x 1 KiB, contiguous in global memory (window-major pixel order)
     for (int it = threadIdx.x; it < nj * 256; it += 512) {
         const int jj = it >> 8, part = it & 255;
@@ -136,24 +124,17 @@ __global__ __launch_bounds__(512) void pair_expand_dense_kernel(const u16* __res
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int Y = W >> 4, X = W & 15;
     const long zoff = ((long)(Y + 1) * 18 + X + 1) * 512 + lane * 8;
     const long aoff = (long)W * 256 + lane * 4;
-    // the subjects of this wave (i = wid + 8 k) that need the pixel at all, as a bit mask over k (n <= 150: k < 19)
-    unsigned rel = 0;
-    for (int k = 0; wid + 8 * k < n; ++k)
-        if (!obj_rect || in_pixel_rect(srect[wid + 8 * k], Y, X)) rel |= 1u << k;
-    if (!rel) return;                                   // (after the block's only barrier)
     // the U quad of the wave's NEXT subject is requested before the current one is expanded: the 16-object store loop covers its latency
     uint4 unext[4];
-    {
-        const int i = wid + 8 * (__ffs(rel) - 1);
+    if (wid < n) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            unext[q] = *reinterpret_cast<const uint4*>(U + ((long)(o0 + i) * 1024 + 4 * W + q) * 512 + lane * 8);
+            unext[q] = *reinterpret_cast<const uint4*>(U + ((long)(o0 + wid) * 1024 + 4 * W + q) * 512 + lane * 8);
     }
-    while (rel) {
-        const int i = wid + 8 * (__ffs(rel) - 1);
-        rel &= rel - 1;
+    for (int i = wid; i < n; i += 8) {
         float uf[4][8];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -161,11 +142,10 @@ __global__ __launch_bounds__(512) void pair_expand_dense_kernel(const u16* __res
 #pragma unroll
             for (int k = 0; k < 8; ++k) uf[q][k] = f16_bits_to_f32(ah[k]);
         }
-        if (rel) {
-            const int inext = wid + 8 * (__ffs(rel) - 1);
+        if (i + 8 < n) {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                unext[q] = *reinterpret_cast<const uint4*>(U + ((long)(o0 + inext) * 1024 + 4 * W + q) * 512 + lane * 8);
+                unext[q] = *reinterpret_cast<const uint4*>(U + ((long)(o0 + i + 8) * 1024 + 4 * W + q) * 512 + lane * 8);
         }
         const int* prow = pid + (long)(o0 + i) * pid_ld + j0;
         // lane jj looks up pair jj of the tile: not requested (diagonal) or - with pixrect - a pair that does not need this pixel
@@ -370,19 +350,14 @@ int sgc_pair_expand(const void* U, const void* V, const int* sub_idx, const int*
 // Dense form of the expansion: every ordered pair (i, j) of every image, pair index looked up in pid[n_obj][pid_ld]
 // (-1 = skip).  img_ptr [n_img+1] object ranges; max_n = largest object count of an image (<= 150).
 // Any of z_pad_f16 / z_pad_bf16 / amz may be NULL.
-int sgc_pair_expand_dense_windows_rects(const void* U, const void* V, const int* img_ptr, const int* pid, int pid_ld, int n_img, int max_n,
-                                        void* z_pad_f16, void* z_pad_bf16, unsigned char* amz, const int* pixel_rect, const int* obj_rect,
-                                        void* stream) {
+int sgc_pair_expand_dense_windows(const void* U, const void* V, const int* img_ptr, const int* pid, int pid_ld, int n_img, int max_n,
+                                  void* z_pad_f16, void* z_pad_bf16, unsigned char* amz, const int* pixel_rect, void* stream) {
     if (max_n > 150 || max_n < 1) return SGC_ERR_ARG;
     if (n_img <= 0) return SGC_OK;
     SGC_LAUNCH(pair_expand_dense_kernel, dim3(256, (max_n + EXPAND_JT - 1) / EXPAND_JT, n_img), dim3(512), 0, (hipStream_t)stream,
-               (const u16*)U, (const u16*)V, img_ptr, pid, pid_ld, (u16*)z_pad_f16, (u16*)z_pad_bf16, amz, pixel_rect, pixel_rect ? obj_rect : nullptr);
+               (const u16*)U, (const u16*)V, img_ptr, pid, pid_ld, (u16*)z_pad_f16, (u16*)z_pad_bf16, amz, pixel_rect);
     SGC_CHECK_LAUNCH();
     return SGC_OK;
-}
-int sgc_pair_expand_dense_windows(const void* U, const void* V, const int* img_ptr, const int* pid, int pid_ld, int n_img, int max_n,
-                                  void* z_pad_f16, void* z_pad_bf16, unsigned char* amz, const int* pixel_rect, void* stream) {
-    return sgc_pair_expand_dense_windows_rects(U, V, img_ptr, pid, pid_ld, n_img, max_n, z_pad_f16, z_pad_bf16, amz, pixel_rect, nullptr, stream);
 }
 int sgc_pair_expand_dense(const void* U, const void* V, const int* img_ptr, const int* pid, int pid_ld, int n_img, int max_n,
                           void* z_pad_f16, void* z_pad_bf16, unsigned char* amz, void* stream) {

@@ -430,17 +430,16 @@ class RelHeadEngine:
             res[r] = uv
         return res
 
-    def expand(self, U, V, sub_idx, obj_idx, P, z, z_bf=None, amz=None, dense=None, pixrect=None, obj_rect=None):
+    def expand(self, U, V, sub_idx, obj_idx, P, z, z_bf=None, amz=None, dense=None, pixrect=None):
         """Pair expansion: dense LDS-staged kernel when the pair list is "all ordered pairs of every image"
         (dense = (img_ptr, pid, max_n)), generic pair-list kernel otherwise.  ``pixrect`` ([P] packed rectangles from
-        ``shared_plan``): only the pixels conv3 over shared windows reads are written (dense kernel only); ``obj_rect`` ([objects]
-        packed rectangles that contain every rectangle of the object's pairs): subjects / object tiles that miss a pixel are skipped."""
+        ``shared_plan``): only the pixels conv3 over shared windows reads are written (dense kernel only)."""
         lib = self.lib
         if dense is not None and 0 < dense[2] <= 150:
             img_ptr, pid, max_n = dense
-            self._timed("expand_dense", lambda: _lib.check(lib.sgc_pair_expand_dense_windows_rects(
+            self._timed("expand_dense", lambda: _lib.check(lib.sgc_pair_expand_dense_windows(
                 _lib.ptr(U), _lib.ptr(V), _lib.ptr(img_ptr), _lib.ptr(pid), int(pid.shape[1]), int(img_ptr.shape[0]) - 1, max_n,
-                _lib.ptr(z), _lib.ptr(z_bf), _lib.ptr(amz), _lib.ptr(pixrect), _lib.ptr(obj_rect), self._st()), "sgc_pair_expand_dense_windows_rects"))
+                _lib.ptr(z), _lib.ptr(z_bf), _lib.ptr(amz), _lib.ptr(pixrect), self._st()), "sgc_pair_expand_dense_windows"))
         elif z_bf is None and amz is None:
             self._timed("expand", lambda: _lib.check(lib.sgc_pair_expand(_lib.ptr(U), _lib.ptr(V), _lib.ptr(sub_idx), _lib.ptr(obj_idx),
                                                                        _lib.ptr(z), P, ELEM_F16, self._st()), "sgc_pair_expand"))
@@ -450,15 +449,6 @@ class RelHeadEngine:
                 self._st()), "sgc_pair_expand_train"))
 
     FULL_PIXRECT = (16 << 5) | (16 << 15)          # packed pixel rectangle covering the whole 16x16 map
-
-    @staticmethod
-    def _object_rects(plan, P):
-        """The pixel rectangles of the pseudo-pairs (o, bg) of a second-level plan = the pixels within one of the object's windows R_o:
-        every rectangle of a pair of o lies inside (pixels of R_i ∩ R_j ± 1 ⊆ pixels of R_i ± 1).  None without the second level (the
-        pseudo-pairs' rectangles are then the whole map)."""
-        if plan is None or not plan.get("objects") or plan["pixrect"].shape[0] <= P:
-            return None
-        return plan["pixrect"][P:]
 
     def shared_plan(self, bbox, sub_idx, obj_idx, P, bound=None, keep=False, n_obj=0, n_img=0, objects=False, obj_img=None):
         """The window list of a pair list (``csrc/kernels_shared.hip``).  Pair index space: [P real pairs][2*n_obj pseudo-pairs
@@ -715,8 +705,7 @@ class RelHeadEngine:
                                     objects=wm_mode and shared_objects_enabled(), obj_img=shared[1])
             Pt = P + 2 * n_obj + n_img
         z = ws.get("z_pad", Pt * 18 * 18 * 512, torch.float16)     # border stays zero: only interiors are written
-        self.expand(U, V, sub_idx, obj_idx, P, z, dense=dense, pixrect=None if plan is None else plan["pixrect"],
-                    obj_rect=self._object_rects(plan, P))
+        self.expand(U, V, sub_idx, obj_idx, P, z, dense=dense, pixrect=None if plan is None else plan["pixrect"])
         am = ws.get("argmax", Pt * 65536, torch.uint8) if keep_argmax else None
         h1 = ws.get("h1", Ppad * 4096, torch.float16)
         if shared is not None and wm_mode:
@@ -918,7 +907,7 @@ class RelHeadEngine:
         z_bf = ws.get("z_pad_bf", (Pt - ctx.z_bf_base) * 18 * 18 * 512, torch.bfloat16)
         amz = ws.get("amz", Pt * 256 * 256, torch.uint8)             # two 4-bit routing codes per byte
         self.expand(ctx.uv[0], ctx.uv[1], sub_idx, obj_idx, P, z, None if ctx.z_bf_base else z_bf, amz, dense=dense,
-                    pixrect=plan["pixrect"] if narrow else None, obj_rect=self._object_rects(plan, P) if narrow else None)
+                    pixrect=plan["pixrect"] if narrow else None)
         ctx.z_bf = z_bf
         am = ws.get("argmax", Pt * 65536, torch.uint8)              # conv3 routing codes (shared path: only the rows of listed windows)
         h1 = ws.get("h1", Ppad * 4096, torch.float16)
