@@ -4,7 +4,7 @@ The reference's per-step loop handles any object count (``evaluate.py:375-444``:
 images per minibatch in BASELINE.json configs[2]); the fused pass needs workspace proportional to the ordered pairs.  A minibatch
 that does not fit a workspace budget is run in consecutive image groups.  Checked here:
 
-* training: a 16 x 48 step under a budget that forces >= 3 groups equals the one-pass step (loss, every gradient, outputs,
+* training: a 16 x 48 step under a budget (18 GB) that forces >= 3 groups equals the one-pass step (loss, every gradient, outputs,
   connectivity counters) up to f32 summation order - dropout off, because the keep bit is indexed by the position in the pass;
 * capacity: a 24 x 64 step (96 768 ordered pairs, ~230 GB as one pass) runs in <= 40 GB groups;
 * configs[2] as ONE pass: pixels -> DETR-101 stand-in (random weights, ``detr.py``) -> HIP object front-end (soft-max, top-2
@@ -38,7 +38,7 @@ def test_chunked_training_step_equals_the_one_pass_step():
     model = _model(cfg)
     batch = make_scene_batch(cfg, [48] * 12 + [30, 17, 2, 48], seed=41, connect_frac=0.04)      # ragged tail, one pair-less-ish image
     res = []
-    for budget in (1e15, 30 * GB):
+    for budget in (1e15, 18 * GB):
         model.zero_grad(set_to_none=True)
         loss = train_minibatch(model, batch, None, workspace_budget=budget, lambda_connectivity=0.15)
         torch.cuda.synchronize()
