@@ -35,7 +35,6 @@ struct SgcTuning {
     int tn_patch = 1;        // SGC_TN_PATCH: per-XCD 4x8 patches for TN grids with >= 8 M tiles
     int gather_pp = 1;       // SGC_GATHER_PP: ping-pong block for the gathered conv3 forward
     int owm_pitch = 4160;    // SGC_OWM_PITCH: row pitch (floats) of fc1's f32 products over the window-major rows; 4096 + 256 B (a power of two is 10 % slower)
-    int contract_lds = 1;    // SGC_CONTRACT_LDS: pair contraction over the shared windows accumulates its routed sums with ds_add_f32 (0: in registers, 12 VALU ops per value)
     int f32_swap = 1;        // SGC_F32_SWAP: f32 products of fc1 over the window-major rows leave as 16-byte stores (operands swapped in the MFMA)
 };
 inline const SgcTuning& sgc_tuning() {
@@ -49,7 +48,7 @@ inline const SgcTuning& sgc_tuning() {
         v.nt_aligned = rd("SGC_NT_ALIGNED", v.nt_aligned); v.halo_walk = rd("SGC_HALO_WALK", v.halo_walk);
         v.tn_xcd = rd("SGC_TN_XCD", v.tn_xcd);             v.tn_patch = rd("SGC_TN_PATCH", v.tn_patch);
         v.gather_pp = rd("SGC_GATHER_PP", v.gather_pp);    v.f32_swap = rd("SGC_F32_SWAP", v.f32_swap);
-        v.owm_pitch = rd("SGC_OWM_PITCH", v.owm_pitch);    v.contract_lds = rd("SGC_CONTRACT_LDS", v.contract_lds);
+        v.owm_pitch = rd("SGC_OWM_PITCH", v.owm_pitch);
 #endif
         return v;
     }();

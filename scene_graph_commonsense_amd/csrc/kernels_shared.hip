@@ -481,22 +481,12 @@ __global__ __launch_bounds__(256) void windows_col2im_objects_kernel(const u16* 
 // (Y, X) only if the pixel lies within one pixel of its X windows (elsewhere dz does not exist); every object also has its
 // pseudo-pair (o, bg) / (bg, o) at pair index n_real + o / n_real + n_obj + o, and the background object of image b (index
 // n_obj + b) collects the other side of the pseudo-pairs of that image's objects.
-template <bool LDSACC>
 __global__ __launch_bounds__(256) void pair_contract_windows_kernel(const u16* __restrict__ dz, const unsigned char* __restrict__ amz,
                                                                     const int* __restrict__ ptr, const int* __restrict__ list,
                                                                     const int* __restrict__ pixrect, const int* __restrict__ img_ptr,
                                                                     int role, int n_real, int n_obj, int bg_maps, u16* __restrict__ dU,
                                                                     long n_items) {
     const int lane = threadIdx.x & 63;
-    // LDSACC: the routed sums acc[code][channel] live in the wave's own LDS slab and every gradient value is ONE ds_add_f32 at
-    // [its routing code][k][lane] (code 4 = no route: a dummy row) instead of four compare / select / add triples - the kernel was bound
-    // by its vector arithmetic (120 operations per lane and live pair), not by bytes.  Same additions in the same order: bit-identical.
-    __shared__ float sacc[LDSACC ? 4 * 5 * 512 : 1];
-    float* const wacc = sacc + (LDSACC ? (threadIdx.x >> 6) * (5 * 512) : 0);
-    if constexpr (LDSACC) {
-#pragma unroll
-        for (int j = 0; j < 40; ++j) wacc[j * 64 + lane] = 0.f;
-    }
     for (long it = (long)blockIdx.x * 4 + (threadIdx.x >> 6); it < n_items; it += (long)gridDim.x * 4) {
         const int o = (int)(it >> 8), W = (int)(it & 255);
         const int Y = W >> 4, X = W & 15;
@@ -523,12 +513,8 @@ __global__ __launch_bounds__(256) void pair_contract_windows_kernel(const u16* _
                     for (int k = 0; k < 8; ++k) {
                         const float v = bf16_bits_to_f32(gh[k]);
                         const unsigned code = (a[u] >> (4 * k)) & 15u;
-                        if constexpr (LDSACC) {
-                            (void)__hip_atomic_fetch_add(wacc + (min(code, 4u) * 8 + k) * 64 + lane, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                        } else {
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) acc[q][k] += (code == (unsigned)q) ? v : 0.f;
-                        }
+                        for (int q = 0; q < 4; ++q) acc[q][k] += (code == (unsigned)q) ? v : 0.f;
                     }
                 }
         };
@@ -570,15 +556,6 @@ __global__ __launch_bounds__(256) void pair_contract_windows_kernel(const u16* _
                 vp[0] = (long)n_real + 2 * n_obj + (o - n_obj);
                 add4(vp, 1);
             }
-        }
-        if constexpr (LDSACC) {                          // collect the sums and clear the slab for the next (object, pixel)
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    acc[q][k] = wacc[(q * 8 + k) * 64 + lane];
-                    wacc[(q * 8 + k) * 64 + lane] = 0.f;
-                }
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -1284,12 +1261,8 @@ int sgc_pair_contract_windows(const void* dz, const unsigned char* amz, const in
                               void* stream) {
     if (n_obj <= 0) return SGC_OK;
     const long items = (long)(n_obj + n_img) * 256;
-    if (sgc_tuning().contract_lds)
-        SGC_LAUNCH(pair_contract_windows_kernel<true>, dim3(grid_cap(items, 4, 262144)), dim3(256), 0, (hipStream_t)stream, (const u16*)dz, amz,
-                   ptr, list, pixel_rect, img_ptr, role, n_real_pairs, n_obj, bg_maps, (u16*)dU_pad, items);
-    else
-        SGC_LAUNCH(pair_contract_windows_kernel<false>, dim3(grid_cap(items, 4, 262144)), dim3(256), 0, (hipStream_t)stream, (const u16*)dz, amz,
-                   ptr, list, pixel_rect, img_ptr, role, n_real_pairs, n_obj, bg_maps, (u16*)dU_pad, items);
+    SGC_LAUNCH(pair_contract_windows_kernel, dim3(grid_cap(items, 4, 262144)), dim3(256), 0, (hipStream_t)stream, (const u16*)dz, amz,
+               ptr, list, pixel_rect, img_ptr, role, n_real_pairs, n_obj, bg_maps, (u16*)dU_pad, items);
     SGC_CHECK_LAUNCH();
     return SGC_OK;
 }
