@@ -556,3 +556,34 @@ def test_sharded_sgd_world1_is_plain_sgd():
         opt.step(); ro.step()
     for (_, p), q_ in zip(params, ref):
         assert float((p.detach() - q_.detach()).abs().max()) <= 1e-6
+
+
+def test_tuning_environment_variables(monkeypatch):
+    """``engine.Tuning.from_env``: the three plain variables and the ``SGC_TUNING`` field list; unknown fields are an error."""
+    from scene_graph_commonsense_amd.engine import Tuning
+    for k in ("SGC_SHARED_LEVEL", "SGC_SHARED_MAX_FRACTION", "SGC_BWD_STREAMS", "SGC_TUNING"):
+        monkeypatch.delenv(k, raising=False)
+    t = Tuning.from_env()
+    assert t == Tuning() and t.patch_dgrad and t.patch_wgrad and t.shared_linear and t.gemms_apart
+    monkeypatch.setenv("SGC_SHARED_LEVEL", "2")
+    monkeypatch.setenv("SGC_BWD_STREAMS", "0")
+    monkeypatch.setenv("SGC_TUNING", "gemms_apart=0, patch_dgrad=0,shared_max_fraction=0.25")
+    t = Tuning.from_env()
+    assert (t.shared_conv3, t.shared_fc1, t.shared_objects, t.shared_linear) == (True, True, False, False)
+    assert not t.bwd_streams and not t.gemms_apart and not t.patch_dgrad and t.patch_wgrad and t.shared_max_fraction == 0.25
+    monkeypatch.setenv("SGC_TUNING", "no_such_field=1")
+    with pytest.raises(ValueError):
+        Tuning.from_env()
+
+
+def test_deferred_weight_entries_are_made_at_first_use():
+    """``engine.Weights``: a deferred entry is built by the first ``w[key]`` (after the registered sync), once."""
+    from scene_graph_commonsense_amd.engine import Weights
+    calls = []
+    w = Weights()
+    w["a"] = 1
+    w.defer("b", lambda: calls.append("made") or 2)
+    assert w["a"] == 1 and calls == []
+    assert w["b"] == 2 and w["b"] == 2 and calls == ["made"]
+    w.defer("b", lambda: calls.append("again") or 3)          # the next weight version replaces the entry
+    assert w["b"] == 3 and calls == ["made", "again"]
