@@ -63,7 +63,7 @@ int sgc_dbg_dgrad_patches(const void* dy3x, const void* w3patch, void* patch, in
                           void* stream) {
     NtParams p{};
     p.A = (const u16*)dy3x; p.B = (const u16*)w3patch; p.C = patch; p.M = entries; p.N = (split ? 20 : 16) * 512; p.K = 4096;
-    p.lda = lda; p.ldb = 0; p.ldc = p.N; p.seg_stride = seg_stride; p.seg_bpad = bpad; p.seg_split = split;
+    p.lda = lda; p.ldb = 0; p.ldc = p.N; p.seg_stride = seg_stride; p.seg_bpad = bpad & 0xffff; p.patch_gn = bpad >> 16; p.seg_split = split;      // (bpad: low 16 bits = padding, high bits = patch width in virtual N tiles, 0 = default)
     return launch_gemm_nt_pp_seg<ELEM_BF16>(p, (hipStream_t)stream);
 }
 

@@ -50,7 +50,7 @@ struct NtParams {
     const int* tile_group; long group_stride;       // gemm_nt_pp_kernel: M tile t multiplies with B + tile_group[t] * group_stride
     int nt_store;                                   // nt_epilogue_f32t / nt_epilogue_store16: non-temporal stores (tools/fc1_windows_microbench.py)
     unsigned long long* clk;                        // gemm_nt_pp_kernel (tools/fc1_windows_microbench.py): per-block wall clocks summed: [0] main loop, [1] epilogue, [2] blocks
-    long seg_stride; int seg_bpad, seg_split;                  // gemm_nt_pp_kernel<SEG>: elements between the segments (own pixels q) of a row of A; padding of B_pp's rows
+    long seg_stride; int seg_bpad, seg_split, patch_gn;                  // gemm_nt_pp_kernel<SEG>: elements between the segments (own pixels q) of a row of A; padding of B_pp's rows
     int stagger, stagger_phases;                    // gemm_nt_pp_kernel: the blocks of the FIRST generation (one per CU) start (id/8 % phases) * stagger
                                                     // sleep units (~4 us) late, so that the CUs' store phases do not coincide (0: off)
 };

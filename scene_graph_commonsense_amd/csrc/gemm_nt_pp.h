@@ -47,10 +47,10 @@ __device__ __forceinline__ void buf_load_lds16(const void* base, int voff, int s
 
 // XCD-aware tile walk: block id -> XCD id%8 (hardware round-robin); each XCD walks a contiguous range of the tile
 // sequence in 4(M) x 8(N) patches, so the 32 blocks resident on one XCD share 4 A panels and 8 B panels through its L2.
-__device__ __forceinline__ void xcd_patch_map(int id, int tiles_m, int tiles_n, int& tm, int& tn) {
+__device__ __forceinline__ void xcd_patch_map(int id, int tiles_m, int tiles_n, int& tm, int& tn, int gm = 4, int gn = 8) {
     const int nb = tiles_m * tiles_n, q = nb >> 3, r = nb & 7, x = id & 7;
     const int lin = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (id >> 3);
-    supertile_map_g(lin, tiles_m, tiles_n, 4, 8, tm, tn);
+    supertile_map_g(lin, tiles_m, tiles_n, gm, gn, tm, tn);
 }
 
 // Patch-aligned form used by the NT block: the tile grid is cut into GM x GN = 32-tile patches (4 x 8; narrower grids 8x4, 16x2,
@@ -104,6 +104,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(const NtParams p) {
     int tm, tn;
     if (p.patch_aligned) {
         if (!xcd_patch_map_aligned(blockIdx.x, p.tiles_m, p.tiles_n, tm, tn)) return;  // padding block (uniform exit)
+    } else if (SEG && p.patch_gn > 0) {
+        xcd_patch_map(blockIdx.x, p.tiles_m, p.tiles_n, tm, tn, 32 / p.patch_gn, p.patch_gn);      // tools/dgrad_patch_microbench.py: patch shape
     } else {
         xcd_patch_map(blockIdx.x, p.tiles_m, p.tiles_n, tm, tn);
     }
@@ -318,7 +320,7 @@ static int launch_gemm_nt_pp_seg(NtParams p, hipStream_t stream) {
     auto kern = gemm_nt_pp_kernel<ELEM, EPI_STORE, 0, 0, 1>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     const int grid_aligned = xcd_patch_grid(p.tiles_m, p.tiles_n), nb = p.tiles_m * p.tiles_n;
-    p.patch_aligned = (nb >= 1024 && (nb & 255) != 0 && grid_aligned * 10 <= nb * 11) ? 1 : 0;
+    p.patch_aligned = (p.patch_gn == 0 && nb >= 1024 && (nb & 255) != 0 && grid_aligned * 10 <= nb * 11) ? 1 : 0;
     SGC_LAUNCH(kern, dim3((unsigned)(p.patch_aligned ? grid_aligned : nb)), dim3(512), LDS, stream, p);
     SGC_CHECK_LAUNCH();
     return SGC_OK;

@@ -59,6 +59,10 @@ ref = None
 for rep in range(2):
     timed(lambda: _lib.check(lib.sgc_windows_dgrad_cols(_lib.ptr(dy), _lib.ptr(w3col), _lib.ptr(col), E * 4, _lib.stream_ptr()), "cols"), "column form")
     B = w3patch(0)
+    out20 = torch.empty(E * 20, 512, dtype=torch.bfloat16, device=dev)
+    for gn in (1, 2, 4, 8, 16, 32):          # XCD patch = (32 / gn) M tiles x gn virtual N tiles, unaligned walk
+        timed(lambda: _lib.check(lib.sgc_dbg_dgrad_patches(_lib.ptr(dy), _lib.ptr(B), _lib.ptr(out20), E, L(4096), L(1024), gn << 16, 1,
+                                                           _lib.stream_ptr()), "patches"), "patch form, K <= 2048, XCD patches of %d x %d tiles" % (32 // gn, gn))
     for split in (0, 1):
         out = torch.empty(E * (20 if split else 16), 512, dtype=torch.bfloat16, device=dev)
         timed(lambda: _lib.check(lib.sgc_dbg_dgrad_patches(_lib.ptr(dy), _lib.ptr(B), _lib.ptr(out), E, L(4096), L(1024), 0, split,
