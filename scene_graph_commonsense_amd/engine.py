@@ -705,12 +705,14 @@ class RelHeadEngine:
                                     objects=wm_mode and shared_objects_enabled(), obj_img=shared[1])
             Pt = P + 2 * n_obj + n_img
         z = ws.get("z_pad", Pt * 18 * 18 * 512, torch.float16)     # border stays zero: only interiors are written
+        # the row plan (a sort, a dozen small launches, four blocking host-to-device copies) goes BEFORE the pair expansion: its
+        # launches are then behind the host when the 1.4 ms expansion kernel starts, instead of leaving the GPU idle between them
+        wm = self.window_major_rows(plan, P, 2 * n_obj) if shared is not None and wm_mode else None
         self.expand(U, V, sub_idx, obj_idx, P, z, dense=dense, pixrect=None if plan is None else plan["pixrect"])
         am = ws.get("argmax", Pt * 65536, torch.uint8) if keep_argmax else None
         h1 = ws.get("h1", Ppad * 4096, torch.float16)
         if shared is not None and wm_mode:
             # conv3 and fc1 over shared windows: the rows fc1 multiplies are written window-major, y [P, 65536] never exists
-            wm = self.window_major_rows(plan, P, 2 * n_obj)
             ywm = ws.get("ywm", wm["rows"] * 1024, torch.float16)
             self.conv3_shared(plan, z, U, V, shared[0], shared[1], sub_idx, obj_idx, P, ywm, am, None, wm=wm)
             self.fc1_shared(wm, ywm, shared[0], sub_idx, obj_idx, plan.get("incl_all", plan["incl"]), P, n_obj, h1, train, seeds[0])
@@ -906,6 +908,7 @@ class RelHeadEngine:
         ctx.z_bf_base = P if (narrow and TUNING.patch_wgrad and dense is not None and 0 < dense[2] <= 150) else 0
         z_bf = ws.get("z_pad_bf", (Pt - ctx.z_bf_base) * 18 * 18 * 512, torch.bfloat16)
         amz = ws.get("amz", Pt * 256 * 256, torch.uint8)             # two 4-bit routing codes per byte
+        wm = self.window_major_rows(plan, P, 2 * ctx.n_obj) if wm_mode else None     # before the expansion: see forward_pairs
         self.expand(ctx.uv[0], ctx.uv[1], sub_idx, obj_idx, P, z, None if ctx.z_bf_base else z_bf, amz, dense=dense,
                     pixrect=plan["pixrect"] if narrow else None)
         ctx.z_bf = z_bf
@@ -914,7 +917,6 @@ class RelHeadEngine:
         ctx.shared, ctx.y, ctx.y_bf = None, None, None
         if wm_mode:
             # conv3 and fc1 over shared windows: y and its bf16 copy exist only as the window-major rows fc1 multiplies
-            wm = self.window_major_rows(plan, P, 2 * ctx.n_obj)
             ywm = sc.get("ywm", wm["rows"] * 1024, torch.float16)
             ywm_bf = ws.get("ywm_bf", wm["rows"] * 1024, torch.bfloat16)
             ctx.shared = self.conv3_shared(plan, z, ctx.uv[0], ctx.uv[1], bbox, obj_img, sub_idx, obj_idx, P, ywm, am, ywm_bf, keep=(z_bf, amz, ctx.z_bf_base), wm=wm)
