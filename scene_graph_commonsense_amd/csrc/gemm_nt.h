@@ -172,14 +172,16 @@ __device__ __forceinline__ void nt_epilogue_f32t(const NtParams& p, f32x16 (&acc
                     v += b;
                 }
                 f32x4* dst = reinterpret_cast<f32x4*>(out + (long)row * p.ldc + col);
-                if (p.nt_store == 8)      // experiment: every 256 x 256 tile stored as ONE contiguous 256 KiB block (page locality of the stores)
+#ifdef SGC_EXPERIMENTS      // tools/fc1_windows_microbench.py: tile-contiguous output, cache-policy bits of the store (1 nt, 2 sc1, 3 sc0 sc1, 4 sc0 sc1 nt)
+                if (p.nt_store == 8)
                     dst = reinterpret_cast<f32x4*>(out + (((long)(m0 >> 8) * p.tiles_n + (n0 >> 8)) << 16) + ((row - m0) << 8) + (col - n0));
-                // cache-policy bits of the store (experiment): 1 nt, 2 sc1, 3 sc0 sc1, 4 sc0 sc1 nt
                 if (p.nt_store == 1) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(dst), "v"(v) : "memory");
                 else if (p.nt_store == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory");
                 else if (p.nt_store == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(v) : "memory");
                 else if (p.nt_store == 4) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(dst), "v"(v) : "memory");
-                else *dst = v;
+                else
+#endif
+                *dst = v;
             }
         }
     }

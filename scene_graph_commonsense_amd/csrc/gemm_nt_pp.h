@@ -96,11 +96,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(const NtParams p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wid >> 2, wc = wid & 3;
+#ifdef SGC_EXPERIMENTS      // tools/fc1_windows_microbench.py: staggered first generation of blocks, per-block wall clocks
     if (p.stagger > 0 && blockIdx.x < 256) {          // equal tiles started together keep every CU's epilogue at the same moment
         const int late = ((blockIdx.x >> 3) & (p.stagger_phases - 1)) * p.stagger;
         for (int s = 0; s < late; ++s) __builtin_amdgcn_s_sleep(127);
     }
     const unsigned long long clk0 = p.clk ? wall_clock64() : 0ULL;
+#endif
     int tm, tn;
     if (p.patch_aligned) {
         if (!xcd_patch_map_aligned(blockIdx.x, p.tiles_m, p.tiles_n, tm, tn)) return;  // padding block (uniform exit)
@@ -283,12 +285,16 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(const NtParams p) {
     if (stored) {
     } else if constexpr (EPI == EPI_STORE_F32T) {
         static_assert(!ACG, "transposed f32 tile: plain rows only");
+#ifdef SGC_EXPERIMENTS
         const unsigned long long clk1 = p.clk ? wall_clock64() : 0ULL;
+#endif
         nt_epilogue_f32t(p, acc, m0, n0, wr, wc, lane);
+#ifdef SGC_EXPERIMENTS
         if (p.clk && tid == 0) {                      // (wall clock: 100 MHz) time to ISSUE the stores, not to complete them
             const unsigned long long clk2 = wall_clock64();
             atomicAdd(p.clk, clk1 - clk0); atomicAdd(p.clk + 1, clk2 - clk1); atomicAdd(p.clk + 2, 1ULL);
         }
+#endif
     }
     else if constexpr (ACG) nt_epilogue<ELEM, EPI, 4, 2, true>(p, acc, m0, n0, wr, wc, lane, Mlim);
     else nt_epilogue<ELEM, EPI, 4, 2>(p, acc, m0, n0, wr, wc, lane);

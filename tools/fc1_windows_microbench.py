@@ -6,6 +6,9 @@ stores / no stores / f16 output) and the weight layout (the product's [4096][(wi
 against one contiguous [4096][1024] slab per window group).  Random f16 operands.
 
     python tools/fc1_windows_microbench.py [rows_per_group]      (default 4736 = 303 104 rows)
+
+The store-policy / tile-contiguous / stagger / wall-clock variants are compiled only into a library built with SGC_EXPERIMENTS=1
+(``SGC_EXPERIMENTS=1 python -m scene_graph_commonsense_amd.build --force``); the product library runs them as the plain variant.
 """
 import ctypes
 import os
