@@ -176,7 +176,6 @@ class Tuning:
     shared_conv2: bool = True         # conv2 halves computed on the objects' own regions, the rest copied from the image's background half
     patch_dgrad: bool = True          # conv3 data gradient over the listed windows in patch form (20 rows per window; off: 36 columns + col2im)
     patch_wgrad: bool = True          # conv3 weight gradient over the listed windows from 4 x 4 patches (16 rows per window; off: im2col, 36)
-    early_fc1_update: bool = True     # train_minibatch + FusedSGD: fc1.weight's SGD update runs from the backward, as soon as its gradient is complete
 
     @classmethod
     def from_env(cls):
@@ -1130,14 +1129,13 @@ class RelHeadEngine:
     def _fc1_backward_pairs(self, ctx, dh1, side, grads, grad_hook):
         """fc1 backward as two [pairs, 65536] GEMMs; returns dy [Ppad*64, 1024] (pair-major pooled gradient)."""
         lib, w, ws, st, P, Ppad = self.lib, self.w, self.scratch, self._st, ctx.P, ctx.Ppad
-        w1pT = w["w1pT"]                               # deferred copy (Weights): made here, outside the timed launch - and BEFORE the
-                                                       # weight-gradient chain, whose hook may already update the f32 master (train_minibatch)
         with side():
             dW1p = ws.get("dW1p", 4096 * 65536, torch.float32)
             self._timed("fc1_wgrad", lambda: _lib.check(lib.sgc_fc1_wgrad(_lib.ptr(dh1), _lib.ptr(ctx.y_bf), _lib.ptr(dW1p), Ppad, 65536, st()),
                                                         "sgc_fc1_wgrad"))
             self._fc1_finish_wgrad(dW1p, dh1, Ppad, grads, grad_hook)
         dy = ws.get("dy", Ppad * 65536, torch.bfloat16)
+        w1pT = w["w1pT"]                               # deferred copy (Weights): made here, outside the timed launch
         self._timed("fc1_dgrad", lambda: _lib.check(lib.sgc_fc1_dgrad(_lib.ptr(dh1), _lib.ptr(w1pT), _lib.ptr(dy), P, 65536, st()), "sgc_fc1_dgrad"))
         return dy
 
@@ -1154,7 +1152,6 @@ class RelHeadEngine:
             _lib.check(lib.sgc_fc1_xrows(_lib.ptr(dh1), _lib.ptr(sh.get("gather_all", sh["gather"])), _lib.ptr(wm["dest"]), wm["E"], _lib.ptr(wm["goff"]),
                                          _lib.ptr(wm["gend"]), _lib.ptr(gwm), _lib.ptr(sh["ywm_bf"]), st()), "sgc_fc1_xrows")))
         dy = ws.get("dywm", wm["rows"] * 1024, torch.bfloat16)
-        w1pT = w["w1pT"]        # deferred copy (Weights): made BEFORE the weight-gradient chain, whose hook may already update the f32 master
 
         def wgrad():
             with side():
@@ -1164,6 +1161,7 @@ class RelHeadEngine:
                 self._fc1_finish_wgrad(dW1p, dh1, ctx.Ppad, grads, grad_hook)
 
         def dgrad():
+            w1pT = w["w1pT"]                               # deferred copy (Weights): made here, outside the timed launch
             self._timed("fc1_dgrad", lambda: _lib.check(lib.sgc_fc1_windows_dgrad(_lib.ptr(gwm), _lib.ptr(w1pT), _lib.ptr(wm["tile_group"]),
                                                                                   _lib.ptr(dy), wm["rows"], st()), "sgc_fc1_windows_dgrad"))
         # GEMM beside GEMM buys nothing on this chip (two ping-pong GEMMs on two streams: 13.5 ms against 13.4 back to back) while an

@@ -21,40 +21,6 @@ class FusedSGD(torch.optim.Optimizer):
             raise ValueError("lr, momentum and weight_decay must be non-negative")
         super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay))
         self._lib = _lib.load()
-        self._early = set()          # ids of the parameters ``update_now`` has already stepped since the last ``step`` / ``zero_grad``
-
-    def _update(self, p, g, group):
-        f = ctypes.c_float
-        if p.dtype != torch.float32 or not p.is_cuda or not p.is_contiguous():
-            raise RuntimeError("FusedSGD handles contiguous f32 parameters on the GPU (the HIP path has no fallback)")
-        g = g if g.is_contiguous() else g.contiguous()
-        st = self.state[p]
-        first = "momentum_buffer" not in st
-        if first:
-            st["momentum_buffer"] = torch.empty_like(p, memory_format=torch.contiguous_format)
-        _lib.check(self._lib.sgc_sgd_momentum_step(_lib.ptr(p), _lib.ptr(g), _lib.ptr(st["momentum_buffer"]),
-                                                   ctypes.c_long(p.numel()), f(group["lr"]), f(group["momentum"]),
-                                                   f(group["weight_decay"]), int(first), _lib.stream_ptr()),
-                   "sgc_sgd_momentum_step")
-        # the kernel wrote p behind autograd's back: bump its version counter (the classifier re-derives its 16-bit weight
-        # copies when a parameter's version changes, and autograd's saved-tensor checks rely on it too)
-        torch.autograd.graph.increment_version(p)
-
-    @torch.no_grad()
-    def update_now(self, p, grad):
-        """Step ONE parameter right away, on the current stream, with ``grad`` as its whole gradient of this step; the next
-        ``step()`` skips it.  ``pair_loop.train_minibatch`` calls this from the backward as soon as fc1.weight's gradient (97 % of
-        the optimizer's bytes) is complete, so that its update runs beside the rest of the backward instead of after it."""
-        for group in self.param_groups:
-            if any(q is p for q in group["params"]):
-                self._update(p, grad, group)
-                self._early.add(id(p))
-                return
-        raise ValueError("update_now: not a parameter of this optimizer")
-
-    def zero_grad(self, set_to_none: bool = True):
-        self._early.clear()
-        return super().zero_grad(set_to_none=set_to_none)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -62,10 +28,23 @@ class FusedSGD(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        f = ctypes.c_float
         for group in self.param_groups:
             for p in group["params"]:
-                if p.grad is None or id(p) in self._early:
+                if p.grad is None:
                     continue
-                self._update(p, p.grad, group)
-        self._early.clear()
+                if p.dtype != torch.float32 or not p.is_cuda or not p.is_contiguous():
+                    raise RuntimeError("FusedSGD handles contiguous f32 parameters on the GPU (the HIP path has no fallback)")
+                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                st = self.state[p]
+                first = "momentum_buffer" not in st
+                if first:
+                    st["momentum_buffer"] = torch.empty_like(p, memory_format=torch.contiguous_format)
+                _lib.check(self._lib.sgc_sgd_momentum_step(_lib.ptr(p), _lib.ptr(g), _lib.ptr(st["momentum_buffer"]),
+                                                           ctypes.c_long(p.numel()), f(group["lr"]), f(group["momentum"]),
+                                                           f(group["weight_decay"]), int(first), _lib.stream_ptr()),
+                           "sgc_sgd_momentum_step")
+                # the kernel wrote p behind autograd's back: bump its version counter (the classifier re-derives its 16-bit weight
+                # copies when a parameter's version changes, and autograd's saved-tensor checks rely on it too)
+                torch.autograd.graph.increment_version(p)
         return loss

@@ -14,7 +14,6 @@ import numpy as np
 import torch
 
 from . import _lib
-from .engine import TUNING
 from .pairs import DeviceScene, flatten_scene, match_target_sgd, pair_targets_fast
 
 
@@ -326,17 +325,7 @@ def train_minibatch(model, batch, optimizer=None, reducer=None, scene: Optional[
     if scene is None:
         scene = flatten_scene(cfg, batch, dev)
     if len(groups) == 1:
-        hook = None
-        if reducer is None and optimizer is not None and hasattr(optimizer, "update_now") and TUNING.early_fc1_update:
-            # fc1.weight's gradient is complete a third into the backward: its SGD update (97 % of the optimizer's bytes) runs right
-            # there, on the weight-gradient chain's stream, beside the conv3 / conv2 backward instead of after it.  (Nothing reads
-            # the f32 master of fc1.weight between that point and the next forward: its bf16 copy for the data gradient is made first.)
-            fc1 = model.fc1.weight
-
-            def hook(name, grad):
-                if name == "fc1.weight" and fc1.grad is None:
-                    optimizer.update_now(fc1, grad.view_as(fc1))
-        loss = model.training_step(scene, batch.relationships, batch.subj_or_obj, reducer=reducer, grad_hook=hook, **loss_kw)
+        loss = model.training_step(scene, batch.relationships, batch.subj_or_obj, reducer=reducer, **loss_kw)
     else:
         loss = _train_image_groups(model, cfg, batch, scene, groups, reducer, loss_kw, lanes=lanes)
     model.last_scene = scene
