@@ -29,12 +29,13 @@ sys.path.insert(0, REPO)
 
 MFMA_PEAK_TFLOPS = 2500.0      # dense bf16/f16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
+CPU_BASELINE_THREADS = 32      # fastest single-process setting on the GPU box's 256 host threads (profiles/r04_oracle_threads.txt: 8 / 32 / 128 threads = 20 / 30 / 11 pairs/s)
 # conv3 forward over the pair-specific windows: f16 implicit 3x3 GEMM whose rows are gathered from the window list, ReLU + max-pool
 # epilogue (gemm_nt_pp_kernel<ELEM, EPI_POOL, ABL, ACG = 1>: the ping-pong block with gathered conv rows).  With conv3 AND fc1
 # computed over shared windows (csrc/kernels_shared.hip) the three GEMMs over those windows are the longest launches of the step
 # (forward / data gradient / weight gradient, 7.4 / 7.9 / 8.3 ms); the forward one is reported here, the others are in kernels_ms.
 DOMINANT_KERNEL = ("gemm_nt_pp_kernel<0, 3, 0, 1, 0>", "gemm_nt_pp_kernel<0, 3, 0, 1>")      # <ELEM, EPI, ABL, ACG, SEG>; older profiles: four arguments
-PMC_TAGS = ("r03_final6", "r03_final5", "r03_final4")                                     # newest committed counter passes first
+PMC_TAGS = ("r04_final", "r04_mid", "r03_final6", "r03_final5", "r03_final4")             # newest committed profile sets first
 
 
 def parse_args(argv=None):
@@ -109,9 +110,12 @@ def state_plan_total(eng):
 
 
 def pmc_traffic():
-    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (separate FETCH_SIZE
-    and WRITE_SIZE runs, profiles/rNN_final_pmc_{f,w}.csv).  FETCH_SIZE is doubled: gfx950 counts 128-B requests of
-    wide coalesced reads as 64 B (MI355X_MICROARCH.md, HBM section); both counters are KiB."""
+    """(bytes per launch, rocprof average ms per launch, profile tag) of the dominant kernel from the NEWEST committed profile set
+    under profiles/: HBM-side bytes from the separate rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE runs,
+    profiles/<tag>_pmc_{f,w}.csv; FETCH_SIZE is doubled: gfx950 counts 128-B requests of wide coalesced reads as 64 B,
+    MI355X_MICROARCH.md HBM section; both counters are KiB) and the warm-only kernel-trace average of the same set
+    (profiles/<tag>_kernel_stats.csv).  These describe the COMMITTED profile run of ``tag``, not this process: the JSON line names the
+    tag next to them and keeps its own live HIP-event duration apart (``ms_per_launch`` / ``frac`` vs ``frac_rocprof``)."""
     for tag in PMC_TAGS:
         vals = {}
         for suffix, ctr in (("f", "FETCH_SIZE"), ("w", "WRITE_SIZE")):
@@ -122,8 +126,39 @@ def pmc_traffic():
                 if any(k in line for k in DOMINANT_KERNEL) and "," + ctr + "," in line:
                     vals[ctr] = float(line.rsplit(",", 1)[1])
         if len(vals) == 2:
-            return int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024), tag
-    return None, None
+            avg = None
+            ks = os.path.join(REPO, "profiles", "%s_kernel_stats.csv" % tag)
+            if os.path.exists(ks):
+                for line in open(ks):
+                    if any(k in line for k in DOMINANT_KERNEL):
+                        avg = float(line.split(",")[2])          # calls,total_ms,avg_ms,...
+                        break
+            return int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024), avg, tag
+    return None, None, None
+
+
+def expansion_bytes(pixrect, sub, obj, n_obj, bf16_copy):
+    """Algorithmic HBM bytes of one launch of the pair expansion over pixel rectangles (``pair_expand_dense_kernel``, SURVEY 8d's
+    "write every z_ij once, read every U_i / V_j once" restricted to the pixels conv3 over shared windows reads): per live
+    (pair, 16-grid pixel) one 1 KiB channel row of z (f16) + 256 B of routing codes (two 4-bit codes per byte) [+ 1 KiB bf16 copy],
+    and per DISTINCT (object, role, pixel) that some pair needs the four 1 KiB source rows of its 2x2 pooling window (read once;
+    re-reads are served by LDS / L2 and are not algorithmic).  ``pixrect`` packs y0 | y1 << 5 | x0 << 10 | x1 << 15."""
+    import numpy as np
+    r = pixrect.astype(np.int64)
+    y0, y1, x0, x1 = r & 31, (r >> 5) & 31, (r >> 10) & 31, (r >> 15) & 31
+    live = int(((y1 - y0).clip(0) * (x1 - x0).clip(0)).sum())
+    reads = 0
+    ok = (y1 > y0) & (x1 > x0)
+    for idx in (sub, obj):
+        d = np.zeros((n_obj, 18, 18), dtype=np.int32)
+        o = idx[ok].astype(np.int64)
+        np.add.at(d, (o, y0[ok], x0[ok]), 1)
+        np.add.at(d, (o, y1[ok], x0[ok]), -1)
+        np.add.at(d, (o, y0[ok], x1[ok]), -1)
+        np.add.at(d, (o, y1[ok], x1[ok]), 1)
+        cover = d.cumsum(1).cumsum(2)[:, :16, :16] > 0
+        reads += int(cover.sum()) * 4 * 1024
+    return live * (1024 + 256 + (1024 if bf16_copy else 0)) + reads, live
 
 
 def scale_boxes(batch, factor):
@@ -166,29 +201,47 @@ def executed_flops(P, n_img, n_obj, n_x, n_list, shared, forward_only=False, lin
     return f
 
 
-def cpu_baseline(cfg, sd, budget_s=25.0):
-    """The CPU oracle (literal reference restatement) timed on this host: fwd + loss + bwd of the reference's
-    per-step calls (b = 8 images per call), bounded sample, all host cores."""
+def cpu_baseline(cfg, sd, reps=5, steps_per_rep=7, threads=None):
+    """The CPU oracle (literal reference restatement) timed on this host, SURVEY 8d's protocol: f32, fwd + loss + bwd of the
+    reference's per-step calls (b = 8 images per call; the per-call cost does not depend on (g, e)); 2 warm-up calls, then ``reps``
+    timings of ``2 * steps_per_rep`` calls each (>= 64 calls in all), value = pairs per timing / MEDIAN seconds, spread reported.
+    ``threads``: torch intra-op threads (default: the count tools/oracle_threads.py found fastest on this class of host - one
+    b = 8 call does not scale past a few dozen threads - capped by the cores present)."""
+    import numpy as np
     import torch
     from oracle import relhead_oracle as O
     from scene_graph_commonsense_amd.synthetic import make_scene_batch, predicate_counts
-    batch = make_scene_batch(cfg, [6] * 8, seed=123, connect_frac=0.3)
-    w = O.class_weights(predicate_counts(cfg))
-    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
-    t0 = time.time()
-    out = O.run_pair_loop(sdr, batch, cfg, mode="train", weights=w, max_steps=1)
-    out["losses"].backward()
-    one = time.time() - t0                         # warm-up + cost estimate of one (g,e) step = 2 calls of b=8
-    steps = int(max(1, min(16, budget_s / max(one, 1e-3))))
-    for p in sdr.values():
-        p.grad = None
-    t0 = time.time()
-    out = O.run_pair_loop(sdr, batch, cfg, mode="train", weights=w, max_steps=steps)
-    out["losses"].backward()
-    dt = time.time() - t0
-    pairs = sum(len(r["keep"]) for r in out["records"])
-    return {"value": pairs / dt, "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "%d reference calls of b=8 pairs (fwd+loss+bwd, f32, %.1f s)" % (len(out["records"]), dt)}
+    if threads is None:
+        threads = min(os.cpu_count() or 8, CPU_BASELINE_THREADS)
+    prev = torch.get_num_threads()
+    torch.set_num_threads(int(threads))
+    try:
+        batch = make_scene_batch(cfg, [6] * 8, seed=123, connect_frac=0.3)
+        w = O.class_weights(predicate_counts(cfg))
+        sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+
+        def run(steps):
+            for p in sdr.values():
+                p.grad = None
+            t0 = time.time()
+            out = O.run_pair_loop(sdr, batch, cfg, mode="train", weights=w, max_steps=steps)
+            out["losses"].backward()
+            return time.time() - t0, sum(len(r["keep"]) for r in out["records"]), len(out["records"])
+
+        run(1)                                             # warm-up: one (g, e) step = 2 calls
+        times, pairs, calls = [], 0, 0
+        for _ in range(reps):
+            dt, pairs, calls = run(steps_per_rep)
+            times.append(dt)
+        med = float(np.median(times))
+        return {"value": round(pairs / med, 2), "unit": "pairs/s", "cores": int(threads), "kind": "port",
+                "n_calls": calls * reps, "calls_per_timing": calls, "timings": reps, "median_s": round(med, 3),
+                "min_s": round(min(times), 3), "max_s": round(max(times), 3),
+                "sample": "2 warm-up calls, then %d timings of %d reference calls of b=8 pairs each (%d calls; fwd+loss+bwd, f32, "
+                          "%d torch threads of %d host threads); value = %d pairs / median %.2f s (min %.2f, max %.2f)"
+                          % (reps, calls, calls * reps, threads, os.cpu_count() or 0, pairs, med, min(times), max(times))}
+    finally:
+        torch.set_num_threads(prev)
 
 
 def dry_run(args):
@@ -309,11 +362,17 @@ def run_rank(args):
         kern = {name: float(np.mean([a.elapsed_time(b) for a, b in evs])) for name, evs in eng.timers.items()}
         xw = getattr(eng, "_xw", None)
         n_x = int(xw[1][-1]) if xw is not None else 0
+        exp_bytes = None
+        if xw is not None and "expand_dense" in kern and "xw_pixrect" in eng.ws.bufs and not args.forward_only:
+            Pn = scene0.n_pairs
+            exp_bytes = expansion_bytes(eng.ws.bufs["xw_pixrect"][:Pn].cpu().numpy(), scene0.sub_idx.cpu().numpy(), scene0.obj_idx.cpu().numpy(),
+                                        int(scene0.obj_img.shape[0]), bf16_copy="z_pad_bf" in eng.ws.bufs and
+                                        eng.ws.bufs["z_pad_bf"].numel() >= (Pn + 1) * 18 * 18 * 512)
         n_list = (int(state_plan_total(eng)) if state_plan_total(eng) else n_x) if xw is not None else 0
         return dict(dt=dt, loss=None if loss is None else float(loss), first_loss=first_loss, kern=kern, P=scene0.n_pairs,
                     shared=xw is not None, n_x=n_x, n_list=n_list, n_obj=int(scene0.obj_img.shape[0]),
                     linear=getattr(eng, "_xw_linear", None) if xw is not None else None,
-                    exposed_ms=reducer.pop_exposed_ms() / max(steps, 1),
+                    exposed_ms=reducer.pop_exposed_ms() / max(steps, 1), exp_bytes=exp_bytes,
                     peak_gb=torch.cuda.max_memory_allocated(dev) / 1e9)
 
     m = measure(batch, args.steps, args.warmup)
@@ -371,7 +430,7 @@ def run_rank(args):
         roof = None
         if dom in kern and kern[dom] > 0:
             ach = flops[dom] / (kern[dom] * 1e-3) / 1e12
-            traffic, tag = pmc_traffic() if P == 32256 else (None, None)
+            traffic, rocprof_ms, tag = pmc_traffic() if (P == 32256 and args.box_scale == 1.0 and args.dataset == "vg") else (None, None, None)
             roof = {"bound": "mfma", "kernel": "gemm_nt_pp_kernel<f16,relu+pool,conv-gather> (sgc_conv3_relu_pool_windows_wm: %d windows x 4 pixels "
                                                "x 1024 x 4608: the pair-specific windows of the %d per-pair windows + the per-object windows; the "
                                                "rest is shared)" % (n_list, P * 64),
@@ -379,7 +438,24 @@ def run_rank(args):
                     "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                     "traffic_note": "bytes/launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from profiles/%s_pmc_{f,w}.csv "
                                     "(separate rocprofv3 --pmc passes at this workload); algorithmic ~2.9e9 (z next to the windows 1.7 + outputs 1.2 + weights 0.01)" % tag,
-                    "ms_per_launch": round(kern[dom], 3)}
+                    "ms_per_launch": round(kern[dom], 3),
+                    # the two timings of the dominant kernel, kept apart: ``frac`` = this process's HIP events on this box;
+                    # ``frac_rocprof`` = the warm-only rocprofv3 --kernel-trace average of the committed profile set ``profile_tag``
+                    # (the set ``traffic`` comes from; same workload and window list, possibly another box / an older commit)
+                    "profile_tag": tag, "ms_per_launch_rocprof": rocprof_ms,
+                    "frac_rocprof": None if not rocprof_ms else round(flops[dom] / (rocprof_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4)}
+        hbm = None
+        if m.get("exp_bytes") and kern.get("expand_dense", 0) > 0:
+            # north_star names the pair expansion's HBM rate: the longest HBM-bound launch of the forward
+            eb, live = m["exp_bytes"]
+            gbs = eb / (kern["expand_dense"] * 1e-3) / 1e9
+            hbm = {"bound": "hbm", "kernel": "pair_expand_dense_kernel (sgc_pair_expand_dense_windows: z_ij = maxpool2(relu(U_i + V_j)) on the "
+                                             "%d live (pair, pixel) items next to the pair-specific windows, of %d)" % (live, P * 256),
+                   "bytes": int(eb), "ms_per_launch": round(kern["expand_dense"], 3), "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
+                   "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                   "note": "algorithmic bytes: 1 KiB z row + 256 B routing codes per live item, 4 KiB per distinct (object, role, pixel) read "
+                           "once; the launch is bound by its vector arithmetic (~220 f32 operations per lane and item), not by these "
+                           "bytes (DESIGN: measured by dropping 40 % of its stores for -6 % time)"}
         ex = executed_flops(P, args.images, m["n_obj"], n_x, n_list, m["shared"], args.forward_only, linear=m["linear"])
         if roof is not None:
             # whole-step efficiency on EXECUTED matrix flops (the per-pair form SURVEY 8d prices is mostly not executed any more)
@@ -397,6 +473,7 @@ def run_rank(args):
                        "parallelism": "dp%d" % world},
             "loss": None if loss is None else float(loss), "loss_first_step": first_loss,
             "roofline": roof,
+            "hbm": hbm,
             # SURVEY 8d priced the path at 2.996 (fwd) / 8.99 (fwd+bwd) GFLOP per ordered pair, taking conv3 / fc1 per pair as
             # irreducible; with the shared windows most of that is no longer executed, so this is an equivalence, not a rate
             "survey_equivalent_tflops": round(value / max(world, 1) * (2.996e9 if args.forward_only else 8.99e9) / 1e12, 1),

@@ -306,8 +306,16 @@ class ShardedSGD:
             p.grad = None
 
     def attach(self, model):
-        """Let ``model`` (a classifier of ``model.py``) wait for this optimizer's parameter gathers before it reads ``fc1.weight``."""
+        """Let ``model`` (a classifier of ``model.py``) wait for this optimizer's parameter gathers before it reads ``fc1.weight``.
+        With ``defer_gather`` ``step()`` returns while RCCL may still be writing ``fc1.weight``'s storage; the forward's weight-copy
+        refresh waits through ``model.weight_sync``; every OTHER reader on the compute stream goes through ``state_dict()``
+        (checkpoints, EMA snapshots, ``load_state_dict`` round trips), which gets a pre-hook that waits too.  Code that reads
+        ``model.parameters()`` directly between ``step()`` and the next forward must call ``wait_gathers()`` itself."""
         model.__dict__["weight_sync"] = self.wait_gathers
+        if hasattr(model, "register_state_dict_pre_hook") and not getattr(model, "_sgc_gather_hook", False):
+            opt = self
+            model.register_state_dict_pre_hook(lambda module, prefix, keep_vars: opt.wait_gathers())
+            model.__dict__["_sgc_gather_hook"] = True
         return self
 
     def wait_gathers(self, small_only: bool = False):

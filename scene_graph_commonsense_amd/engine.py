@@ -248,6 +248,31 @@ class RelHeadEngine:
         self.w: Dict[str, torch.Tensor] = Weights()
         self.T = (1.0, 1.0, 1.0)
         self.timers = None          # optional {name: [(start_event, end_event), ...]} filled by bench.py
+        self._checks = []           # deferred device-side consistency checks: (event, pinned flag, message), see ``_post_check``
+
+    # ------------------------------------------------------------------ deferred consistency checks
+    def _post_check(self, bad: torch.Tensor, message: str):
+        """``bad`` (device bool/int scalar, non-zero = inconsistent) is copied to pinned memory behind the work enqueued so far and
+        looked at LATER (``verify_checks``: at the next forward, or explicitly) - a host-side ``int(tensor)`` here would stall the
+        launch queue of every training step for a condition that never holds in the drivers' own use."""
+        flag = torch.zeros(1, dtype=torch.int32).pin_memory()
+        flag.copy_(bad.reshape(1).to(torch.int32), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._checks.append((ev, flag, message))
+
+    def verify_checks(self, block: bool = False):
+        """Raise if a posted check failed (``block``: wait for the pending ones first)."""
+        keep = []
+        for ev, flag, message in self._checks:
+            if block:
+                ev.synchronize()
+            if not ev.query():
+                keep.append((ev, flag, message))
+            elif int(flag[0]) != 0:
+                del self._checks[:]
+                raise RuntimeError(message)
+        self._checks[:] = keep
 
     def child(self) -> "RelHeadEngine":
         """An engine that shares this one's weights and transient scratch but owns the buffers of its training context: the
@@ -255,6 +280,7 @@ class RelHeadEngine:
         (``train_test.py:189-276``: one classifier call per direction-step, one backward per minibatch)."""
         c = RelHeadEngine.__new__(RelHeadEngine)
         c.cfg, c.device, c.lib, c.w, c.T, c.timers = self.cfg, self.device, self.lib, self.w, self.T, None
+        c._checks = self._checks
         c.head_rows = getattr(self, "head_rows", None)
         c.ws, c.scratch = Workspace(self.device), self.scratch
         c._side_stream = getattr(self, "_side_stream", None)
@@ -518,6 +544,12 @@ class RelHeadEngine:
         cnt[1, P:P + n2] = cnt[0, P:P + n2]
         incl = torch.cumsum(cnt, 1, dtype=torch.int32)                          # [3][Pt]: all / conv / linear
         incl_all, incl_c, incl_l = incl[0].contiguous(), incl[1].contiguous(), incl[2].contiguous()
+        # the host's counts size every buffer and list below; they are TRUSTED (no read-back) but checked: the device's own counts of
+        # the boxes / pair lists actually passed must equal them (a scene whose boxes were edited after ``flatten_scene`` would
+        # otherwise misplace rows silently).  Looked at by ``verify_checks`` at the next forward.
+        self._post_check((incl_all[P - 1] != e_all) | (incl_l[P - 1] != e_lin) | ((incl_all[Pt - 1] - incl_all[P - 1]) != e_obj),
+                         "shared-window plan: the scene's host-side window counts (windows=%d, linear_windows=%d, object_windows=%d) do not "
+                         "match the boxes / pair lists on the device - was the scene modified after flatten_scene()?" % (e_all, e_lin, e_obj))
         e_c = e_all - e_lin
         gather_all = own.get("xw_gather_all", e_all + e_obj + 64, torch.int32)
         gather_c = own.get("xw_gather", e_c + e_obj + 64, torch.int32)
@@ -759,6 +791,7 @@ class RelHeadEngine:
         ``select`` ([P] bool / uint8 device tensor): run the per-pair trunk (expansion, conv3, fc1, fc2, head) ONLY for the selected
         pairs and scatter the results into full-size outputs; the other pairs get confidence -inf (exactly what the overlap filter
         gives them in the evaluator, ``evaluator.py:131-134``), prediction 0, zero log-probs and hidden vectors."""
+        self.verify_checks()
         a_img = self.image_maps(image_feature, image_depth)
         share = shared_conv3_enabled(shared_windows, int(sub_idx.shape[0]))
         uv = self.object_halves(a_img, obj_img, bbox, with_bg=share,
@@ -872,6 +905,7 @@ class RelHeadEngine:
         row k of each is the subject / object crop of pair k, with labels ``cats`` / ``cats_obj``; every crop is its own
         "image" with one full-size box."""
         lib, ws, sc = self.lib, self.ws, self.scratch
+        self.verify_checks()
         ctx = TrainContext()
         ctx.n_obj = int(obj_img.shape[0])
         ctx.P = P = int(sub_idx.shape[0])
@@ -1406,15 +1440,18 @@ class RelHeadEngine:
         return Chain()
 
 
-    def commonsense_coefficients(self, ctx: "TrainContext", bitmaps, step: torch.Tensor, n_steps: int, scat: torch.Tensor,
+    def commonsense_coefficients(self, cand_pred: torch.Tensor, bitmaps, step: torch.Tensor, n_steps: int, scat: torch.Tensor,
                                  ocat: torch.Tensor, lambda_commonsense=1.0, lambda_weak=0.1, lambda_strong=10.0):
         """Per-candidate coefficients of the train_cs penalty (train_utils.py:36-62 + the running-sum step weights of
-        train_test.py:219-233): kappa = (T - t) * lambda_cs * (lambda_weak * weak / #weak_t + lambda_strong * strong / #strong_t)."""
-        P = ctx.P
-        nc = int(ctx.out.cand_pred.shape[1])
+        train_test.py:219-233): kappa = (T - t) * lambda_cs * (lambda_weak * weak / #weak_t + lambda_strong * strong / #strong_t).
+        ``cand_pred`` [P, n_cand] int32: the forward's per-super-category predicates of ALL pairs of the minibatch (the per-step
+        counts couple its images; image groups hand over the gathered rows)."""
+        P = int(cand_pred.shape[0])
+        nc = int(cand_pred.shape[1])
+        cand_pred = cand_pred.contiguous()
         weak = torch.empty(P, nc, dtype=torch.float32, device=self.device)
         strong = torch.empty(P, nc, dtype=torch.float32, device=self.device)
-        _lib.check(self.lib.sgc_commonsense_flags(_lib.ptr(scat), _lib.ptr(ocat), _lib.ptr(ctx.out.cand_pred), P, nc,
+        _lib.check(self.lib.sgc_commonsense_flags(_lib.ptr(scat), _lib.ptr(ocat), _lib.ptr(cand_pred), P, nc,
                                                   _lib.ptr(bitmaps.aligned), _lib.ptr(bitmaps.violated), bitmaps.C, bitmaps.R,
                                                   _lib.ptr(weak), _lib.ptr(strong), self._st()), "sgc_commonsense_flags")
         cw = torch.zeros(n_steps, device=self.device).index_add_(0, step, weak.sum(1))        # tiny host-side glue

@@ -214,12 +214,37 @@ class _RelationBase(nn.Module):
         return eng.loss_coefficients_device(scene.step_ptr, scene.n_steps, scene.directed, self._class_weight_device(class_weight, eng.device),
                                             lambda_connectivity, lambda_not_connected)
 
+    def zero_gradient_step(self, reducer=None):
+        """The step of a rank that has NOTHING to score (no image with two objects, or a minibatch whose samples the loader dropped):
+        zero loss, zero gradients - but with ``reducer`` over more than one rank it still takes part in this step's collectives, in
+        the same order, with zeros: the other ranks reduce their gradients now, and a rank that skipped them would pair its NEXT
+        step's all-reduce with the peers' current one (or leave them waiting for ever)."""
+        dev = next(self.parameters()).device
+        if reducer is not None and reducer.world > 1:
+            zeros = {n: torch.zeros_like(p) for n, p in self.named_parameters()}
+            if "fc1.weight" in zeros:
+                reducer.hook("fc1.weight", zeros["fc1.weight"])
+            reducer.finish_grads(zeros)           # "zeros" now holds the mean of the OTHER ranks' gradients: apply it like they do
+            if not getattr(reducer, "owns_grads", False):
+                for n, p in self.named_parameters():
+                    if p.grad is None:
+                        p.grad = zeros[n]
+                    else:
+                        p.grad.add_(zeros[n])
+        if not getattr(reducer, "owns_grads", False):
+            for p in self.parameters():
+                if p.grad is None:
+                    p.grad = torch.zeros_like(p)
+        self.last_outputs = None
+        self.last_connectivity_stats = None
+        return torch.zeros((), device=dev)
+
     def training_step(self, scene: DeviceScene, relationships=None, subj_or_obj=None, directed: Optional[np.ndarray] = None,
                       lambda_connectivity: float = 0.1, lambda_not_connected: float = 1.0, class_weight=None,
                       grad_hook=None, reducer=None, image_feature_aug: Optional[torch.Tensor] = None, lambda_contrast: float = 1.0,
                       commonsense=None, lambda_commonsense: float = 1.0, lambda_cs_weak: float = 0.1,
                       lambda_cs_strong: float = 10.0, loss_coefs=None, grads_out: Optional[Dict[str, torch.Tensor]] = None,
-                      engine: Optional[RelHeadEngine] = None):
+                      engine: Optional[RelHeadEngine] = None, coupled: Optional[dict] = None):
         """Forward + loss + backward over all ordered pairs; gradients land in ``param.grad`` (accumulating like
         autograd).  Loss follows ``train_test.py:189-258`` / ``train_utils.py:64-157`` (hierarchical NLL, BCE on
         connectivity, running-sum step weights).  With ``image_feature_aug`` (DETR features of the colour-jittered view,
@@ -232,7 +257,13 @@ class _RelationBase(nn.Module):
         coefficients of THIS scene's pairs taken from the whole minibatch's (per-step means and running-sum weights couple the
         images of a minibatch, the gradients are additive over images once the coefficients are fixed), and a dict the step's
         gradients are summed into instead of ``param.grad`` (no reduction here: the caller reduces the sum once).  ``engine``: run on
-        this engine (``lane_engine``: same weights, own workspace) instead of the module's - image groups on concurrent streams."""
+        this engine (``lane_engine``: same weights, own workspace) instead of the module's - image groups on concurrent streams.
+        ``coupled`` (image groups with the contrastive / commonsense terms, which couple ALL pairs of a minibatch through the
+        forward - ``pair_loop._train_image_groups`` runs every group's forward first, ``coupled_forward``, then the minibatch-level
+        pieces, then this step per group): dict(seeds=(main, aug) - the dropout seeds of the group's first forward, so that this
+        pass reproduces it bit for bit -, cs_coef [P, n_cand] or None - this group's rows of the minibatch's commonsense
+        coefficients -, contrast=(dF_main [M, 512], dF_aug [M, 512]) or None - this group's rows of the SupCon feature gradient,
+        M = its connected pairs in pair order).  The loss returned then lacks the contrastive term (the caller adds it once)."""
         if reducer is not None:
             grad_hook = reducer.hook
         cfg = self.head_config()
@@ -244,26 +275,7 @@ class _RelationBase(nn.Module):
             self.last_connectivity_stats = None
             return torch.zeros((), device=dev)
         if P == 0:                                 # no image with two objects: nothing to score, zero loss and gradients
-            if reducer is not None and reducer.world > 1:
-                # the other ranks reduce this step's gradients: take part in the same collectives, in the same order, with
-                # zeros (a rank that skipped them would pair its NEXT step's all-reduce with the peers' current one)
-                zeros = {n: torch.zeros_like(p) for n, p in self.named_parameters()}
-                if "fc1.weight" in zeros:
-                    reducer.hook("fc1.weight", zeros["fc1.weight"])
-                reducer.finish_grads(zeros)           # "zeros" now holds the mean of the OTHER ranks' gradients: apply it like they do
-                if not getattr(reducer, "owns_grads", False):
-                    for n, p in self.named_parameters():
-                        if p.grad is None:
-                            p.grad = zeros[n]
-                        else:
-                            p.grad.add_(zeros[n])
-            if not getattr(reducer, "owns_grads", False):
-                for p in self.parameters():
-                    if p.grad is None:
-                        p.grad = torch.zeros_like(p)
-            self.last_outputs = None
-            self.last_connectivity_stats = None
-            return torch.zeros((), device=dev)
+            return self.zero_gradient_step(reducer)
         # directed target per pair on the device: an explicit array wins, else what flatten_scene derived from the batch's
         # relationships / subj_or_obj lists (sgc_scene_tables), else derive it from the lists given here
         if torch.is_tensor(directed):
@@ -279,27 +291,26 @@ class _RelationBase(nn.Module):
                              "or pass them (or a directed array) here")
         cw_d = self._class_weight_device(class_weight, dev)
         if loss_coefs is not None:
-            if image_feature_aug is not None or commonsense is not None:
-                raise NotImplementedError("externally supplied loss coefficients (image-group chunking) cover the hierarchical / "
-                                          "connectivity loss only: the contrastive and commonsense terms couple all pairs of a minibatch")
+            if (image_feature_aug is not None or commonsense is not None) and coupled is None:
+                raise ValueError("externally supplied loss coefficients (image-group chunking) with the contrastive / commonsense terms "
+                                 "need the minibatch-level pieces too: pass coupled=... (pair_loop._train_image_groups does)")
             coefs_d = tuple(c.contiguous() for c in loss_coefs)
         else:
             coefs_d = eng.loss_coefficients_device(scene.step_ptr, scene.n_steps, directed_d, cw_d, lambda_connectivity,
                                                    lambda_not_connected)
         sub_csr, obj_csr, img_ptr = scene.sub_csr, scene.obj_csr, scene.img_ptr
         with torch.no_grad():
+            seeds_main = coupled["seeds"][0] if coupled is not None else (self._next_seeds() if self.training else (0, 0))
             ctx = eng.train_forward(scene.image_feature, scene.image_depth, scene.obj_img, scene.bbox, scene.cats,
                                     scene.super_mh, scene.sub_idx, scene.obj_idx,
-                                    seeds=self._next_seeds() if self.training else (0, 0), dropout=self.training,
+                                    seeds=seeds_main, dropout=self.training,
                                     dense=_dense(scene), shared_windows=_shared_hint(scene))
             cs_coef = None
-            if commonsense is not None:
-                from .commonsense import TripletBitmaps
-                if getattr(self, "_cs_bitmaps", None) is None or self._cs_bitmaps[0] is not commonsense:
-                    self._cs_bitmaps = (commonsense, TripletBitmaps(commonsense[0], commonsense[1], cfg.num_classes,
-                                                                    cfg.num_relations, dev))
-                cs_coef = eng.commonsense_coefficients(ctx, self._cs_bitmaps[1], scene.step.long(), scene.n_steps,
-                                                       scene.cats[scene.sub_idx.long()], scene.cats[scene.obj_idx.long()],
+            if coupled is not None:
+                cs_coef = None if coupled.get("cs_coef") is None else coupled["cs_coef"].contiguous()
+            elif commonsense is not None:
+                cs_coef = eng.commonsense_coefficients(ctx.out.cand_pred, self._commonsense_bitmaps(commonsense, dev), scene.step.long(),
+                                                       scene.n_steps, scene.cats[scene.sub_idx.long()], scene.cats[scene.obj_idx.long()],
                                                        lambda_commonsense, lambda_cs_weak, lambda_cs_strong)
             dp_main = None
             extra = None
@@ -308,8 +319,19 @@ class _RelationBase(nn.Module):
                 # connected pairs selected on the device; the only host synchronisation is their count (the augmented trunk's sizes)
                 conn_idx = torch.nonzero(directed_d >= 0).flatten()
             if image_feature_aug is not None and int(conn_idx.numel()) > 0:
-                extra = self._contrast_forward(eng, scene, image_feature_aug, conn_idx, directed_d, ctx, lambda_contrast)
-                loss_c, dp_main = extra["loss"], extra["dp_main"]
+                extra = self._contrast_trunk(eng, scene, image_feature_aug, conn_idx,
+                                             coupled["seeds"][1] if coupled is not None else (self._next_seeds() if self.training else (0, 0)))
+                M = extra["M"]
+                if coupled is not None:                    # the minibatch's SupCon gradient rows of this group's connected pairs
+                    dF_main, extra["dp_aug"] = (t.contiguous() for t in coupled["contrast"])
+                    assert int(dF_main.shape[0]) == M and int(extra["dp_aug"].shape[0]) == M
+                else:
+                    feats = torch.cat((ctx.p[:P * 512].view(P, 512)[conn_idx], extra["ctx"].p[:M * 512].view(M, 512)), dim=0).contiguous()
+                    lam2 = float(lambda_contrast) * float(lambda_contrast)
+                    loss_c, dF = eng.supcon_loss(feats, directed_d[conn_idx].to(torch.int32).contiguous(), grad_scale=lam2)
+                    dF_main, extra["dp_aug"] = dF[:M], dF[M:].contiguous()
+                dp_main = torch.zeros(P, 512, dtype=torch.float32, device=dev)
+                dp_main[conn_idx] = dF_main
             loss, grads = eng.train_backward(ctx, coefs_d, sub_csr, obj_csr, img_ptr,
                                              grad_hook=grad_hook if extra is None else None, dp_extra=dp_main,
                                              cs_coef=cs_coef)
@@ -321,9 +343,10 @@ class _RelationBase(nn.Module):
                     grads[k] = grads[k] + grads_a[k].view_as(grads[k])
                 if grad_hook is not None:
                     grad_hook("fc1.weight", grads["fc1.weight"])
-                if not bool(torch.isnan(loss_c)):
-                    loss = loss + lambda_contrast * lambda_contrast * loss_c      # lambda applied twice (train_test.py:270-273)
-                self.last_contrast_loss = loss_c
+                if loss_c is not None:
+                    if not bool(torch.isnan(loss_c)):
+                        loss = loss + lambda_contrast * lambda_contrast * loss_c      # lambda applied twice (train_test.py:270-273)
+                    self.last_contrast_loss = loss_c
             if grads_out is not None:
                 for name, p in self.named_parameters():
                     g = grads[name].view_as(p)
@@ -348,8 +371,16 @@ class _RelationBase(nn.Module):
         self.last_outputs = ctx.out
         return loss
 
-    def _contrast_forward(self, eng, scene, image_feature_aug, conn_idx, directed, ctx, lambda_contrast):
-        """Augmented-view trunk for the connected pairs + SupConLossHierar; returns what the two backward passes need."""
+    def _commonsense_bitmaps(self, commonsense, dev):
+        from .commonsense import TripletBitmaps
+        cfg = self.head_config()
+        if getattr(self, "_cs_bitmaps", None) is None or self._cs_bitmaps[0] is not commonsense:
+            self._cs_bitmaps = (commonsense, TripletBitmaps(commonsense[0], commonsense[1], cfg.num_classes, cfg.num_relations, dev))
+        return self._cs_bitmaps[1]
+
+    def _contrast_trunk(self, eng, scene, image_feature_aug, conn_idx, seeds):
+        """Augmented-view trunk (``train_test.py:154,196,204``) for the connected pairs only: its context, pair lists and the zero
+        loss coefficients of its backward pass (the SupCon gradient enters through ``dp_extra``)."""
         from .engine import RelHeadEngine
         dev = eng.device
         if getattr(self, "_engine_aug", None) is None or self._engine_aug.device != dev:
@@ -357,26 +388,44 @@ class _RelationBase(nn.Module):
         eng_a = self._engine_aug
         eng_a.w, eng_a.T, eng_a.head_rows = eng.w, eng.T, eng.head_rows          # shared weights, own workspace
         M = int(conn_idx.numel())
-        cidx = conn_idx
-        sub_a = scene.sub_idx[cidx].contiguous()
-        obj_a = scene.obj_idx[cidx].contiguous()
+        sub_a = scene.sub_idx[conn_idx].contiguous()
+        obj_a = scene.obj_idx[conn_idx].contiguous()
         ctx_a = eng_a.train_forward(image_feature_aug.to(dev, torch.float32).contiguous(), scene.image_depth, scene.obj_img,
-                                    scene.bbox, scene.cats, scene.super_mh, sub_a, obj_a,
-                                    seeds=self._next_seeds() if self.training else (0, 0), dropout=self.training)
-        P = scene.n_pairs
-        feats = torch.cat((ctx.p[:P * 512].view(P, 512)[cidx], ctx_a.p[:M * 512].view(M, 512)), dim=0).contiguous()
-        labels = directed[cidx].to(torch.int32).contiguous()
-        lam2 = float(lambda_contrast) * float(lambda_contrast)
-        loss_c, dF = eng.supcon_loss(feats, labels, grad_scale=lam2)
-        dp_main = torch.zeros(P, 512, dtype=torch.float32, device=dev)
-        dp_main[cidx] = dF[:M]
+                                    scene.bbox, scene.cats, scene.super_mh, sub_a, obj_a, seeds=seeds, dropout=self.training)
         n_obj = int(scene.obj_img.shape[0])
         zeros = torch.zeros(M, dtype=torch.float32, device=dev)
         coefs = (torch.full((M,), -1, dtype=torch.int32, device=dev), zeros, zeros, zeros, zeros)
-        sub_csr = _csr_by_device(sub_a, n_obj)
-        obj_csr = _csr_by_device(obj_a, n_obj)
-        return dict(engine=eng_a, ctx=ctx_a, loss=loss_c, dp_main=dp_main, dp_aug=dF[M:].contiguous(), coefs=coefs,
-                    sub_csr=sub_csr, obj_csr=obj_csr)
+        return dict(engine=eng_a, ctx=ctx_a, M=M, coefs=coefs, sub_csr=_csr_by_device(sub_a, n_obj), obj_csr=_csr_by_device(obj_a, n_obj))
+
+    def coupled_forward(self, scene: DeviceScene, image_feature_aug: Optional[torch.Tensor] = None, want_candidates: bool = False,
+                        engine: Optional[RelHeadEngine] = None):
+        """First pass of an image group whose minibatch carries the contrastive / commonsense terms (``pair_loop._train_image_groups``):
+        the training-mode forward only.  Returns dict(seeds=(main, aug) - to be handed back to ``training_step(coupled=...)`` so that
+        the second pass draws the same dropout masks -, cand_pred [P, n_cand] (with ``want_candidates``: what the commonsense flags
+        read), conn_idx [M] connected pairs in pair order, hidden / hidden_aug [M, 512]: the rows SupConLossHierar reads)."""
+        eng = engine if engine is not None else self.refresh_weights(backward=True)
+        if scene.directed is None:
+            raise ValueError("the scene carries no relation targets")
+        P = scene.n_pairs
+        seeds = (self._next_seeds() if self.training else (0, 0), self._next_seeds() if (self.training and image_feature_aug is not None) else (0, 0))
+        out = dict(seeds=seeds, cand_pred=None, conn_idx=None, hidden=None, hidden_aug=None)
+        if P == 0:
+            return out
+        with torch.no_grad():
+            ctx = eng.train_forward(scene.image_feature, scene.image_depth, scene.obj_img, scene.bbox, scene.cats, scene.super_mh,
+                                    scene.sub_idx, scene.obj_idx, seeds=seeds[0], dropout=self.training, dense=_dense(scene),
+                                    shared_windows=_shared_hint(scene))
+            if want_candidates:
+                out["cand_pred"] = ctx.out.cand_pred.clone()
+            if image_feature_aug is not None:
+                conn_idx = torch.nonzero(scene.directed >= 0).flatten()
+                M = int(conn_idx.numel())
+                out["conn_idx"] = conn_idx
+                if M > 0:
+                    out["hidden"] = ctx.p[:P * 512].view(P, 512)[conn_idx].clone()
+                    ctx_a = self._contrast_trunk(eng, scene, image_feature_aug, conn_idx, seeds[1])["ctx"]
+                    out["hidden_aug"] = ctx_a.p[:M * 512].view(M, 512).clone()
+        return out
 
     # ------------------------------------------------------------------ reference per-step call
     def _step_call(self, h_sub, h_obj, c1, c2, s1, s2):

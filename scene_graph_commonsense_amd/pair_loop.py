@@ -3,7 +3,7 @@
 ``evaluate_minibatch`` is what ``train_test.py:373-437`` + ``train_utils.py:160-196`` do for one minibatch: score
 every ordered pair, apply the overlap filter (a step in which no image's two boxes overlap is skipped entirely -
 no candidates and no targets), and feed the Recall@K evaluators in the reference's candidate order.
-``train_minibatch`` is ``train_test.py:174-277`` (pass ``image_feature_aug`` for the contrastive term; no commonsense term).
+``train_minibatch`` is ``train_test.py:174-277`` (pass ``image_feature_aug`` for the contrastive term, ``commonsense`` for train_cs).
 """
 from __future__ import annotations
 
@@ -344,17 +344,84 @@ def _lane_stream(dev, k):
     return _LANE_STREAMS[key]
 
 
+def _coupled_terms(model, cfg, batch, scene: DeviceScene, groups, subs, aug, commonsense, lam):
+    """The minibatch-level pieces of the contrastive (``train_test.py:260-273``, ``sup_contrast/losses.py:85-181``) and commonsense
+    (``train_utils.py:36-62``) terms for a minibatch that runs in image groups.  Both couple all pairs through the FORWARD: the
+    SupCon loss reads the hidden rows of every connected pair of the minibatch (two views), the commonsense penalty's per-step
+    means count the flagged candidates of every image in the step.  So every group's training-mode forward runs first
+    (``model.coupled_forward``; nothing but [M, 512] rows and [P, n_cand] predicates is kept), the loss and its feature gradient /
+    the per-candidate coefficients are computed ONCE for the minibatch, and the groups' second pass (same dropout seeds: the same
+    forward bit for bit) gets its rows of them.  Costs one extra forward per group - the price of not holding every group's
+    workspace at once.  Returns (per-group ``coupled`` dicts, contrastive loss tensor or None)."""
+    dev = scene.bbox.device
+    eng = model.refresh_weights(backward=True)
+    P = scene.n_pairs
+    nc = 3 if cfg.hierarchical else 1
+    cand_full = torch.zeros(P, nc, dtype=torch.int32, device=dev) if commonsense is not None else None
+    conn_full = torch.nonzero(scene.directed >= 0).flatten() if aug is not None else None
+    M = int(conn_full.numel()) if conn_full is not None else 0
+    feats = torch.zeros(2 * M, 512, dtype=torch.float32, device=dev) if M > 0 else None
+    per_group = []
+    for (a, b), (rows, sub) in zip(groups, subs):
+        if sub is None:
+            per_group.append(None)
+            continue
+        st = model.coupled_forward(sub, None if aug is None else aug[a:b], want_candidates=commonsense is not None)
+        pos = None
+        if cand_full is not None:
+            cand_full[rows] = st["cand_pred"]
+        if aug is not None and st["conn_idx"] is not None and int(st["conn_idx"].numel()) > 0:
+            pos = torch.searchsorted(conn_full, rows[st["conn_idx"]])       # this group's connected pairs in the minibatch's list
+            feats[pos] = st["hidden"]
+            feats[M + pos] = st["hidden_aug"]
+        per_group.append(dict(seeds=st["seeds"], pos=pos))
+    cs_full = None
+    if commonsense is not None:
+        cs_full = eng.commonsense_coefficients(cand_full, model._commonsense_bitmaps(commonsense, dev), scene.step.long(), scene.n_steps,
+                                               scene.cats[scene.sub_idx.long()], scene.cats[scene.obj_idx.long()],
+                                               lam["lambda_commonsense"], lam["lambda_cs_weak"], lam["lambda_cs_strong"])
+    loss_c, dF = None, None
+    if M > 0:
+        lam2 = float(lam["lambda_contrast"]) ** 2
+        loss_c, dF = eng.supcon_loss(feats, scene.directed[conn_full].to(torch.int32).contiguous(), grad_scale=lam2)
+    out = []
+    for (rows, sub), g in zip(subs, per_group):
+        if g is None:
+            out.append(None)
+            continue
+        out.append(dict(seeds=g["seeds"], cs_coef=None if cs_full is None else cs_full[rows],
+                        contrast=None if (dF is None or g["pos"] is None) else (dF[g["pos"]], dF[M + g["pos"]])))
+    return out, loss_c
+
+
 def _train_image_groups(model, cfg, batch, scene: DeviceScene, groups, reducer, loss_kw, lanes: int = 1):
     from .engine import PairOutputs
     dev = scene.bbox.device
     kw = dict(loss_kw)
-    if kw.get("image_feature_aug") is not None or kw.get("commonsense") is not None:
-        raise NotImplementedError("this minibatch needs %d image groups (workspace budget); the contrastive and commonsense terms couple "
-                                  "all pairs of a minibatch and are not chunked - lower the batch size or raise the budget" % len(groups))
-    for k_ in ("image_feature_aug", "commonsense", "lambda_contrast", "lambda_commonsense", "lambda_cs_weak", "lambda_cs_strong"):
-        kw.pop(k_, None)
+    aug, commonsense = kw.pop("image_feature_aug", None), kw.pop("commonsense", None)
+    lam = dict(lambda_contrast=kw.pop("lambda_contrast", 1.0), lambda_commonsense=kw.pop("lambda_commonsense", 1.0),
+               lambda_cs_weak=kw.pop("lambda_cs_weak", 0.1), lambda_cs_strong=kw.pop("lambda_cs_strong", 10.0))
+    coupled_terms = aug is not None or commonsense is not None
+    if coupled_terms:
+        lanes = 1                                   # two passes per group on the module's own engine
+        if scene.directed is None:
+            raise ValueError("the contrastive / commonsense terms need relation targets in the scene")
     coefs = model.minibatch_loss_coefficients(scene, kw.pop("class_weight", None), kw.pop("lambda_connectivity", 0.1),
                                               kw.pop("lambda_not_connected", 1.0))
+    subs = []
+    for a, b in groups:
+        rows = _group_rows(scene, a, b)
+        if rows.numel() == 0:
+            subs.append((rows, None))
+            continue
+        sub_b = slice_batch(batch, a, b)
+        sub = flatten_scene(cfg, sub_b, dev)
+        assert sub.n_pairs == int(rows.numel())
+        sub._batch = sub_b
+        subs.append((rows, sub))
+    coupled, loss_c = (None, None)
+    if coupled_terms:
+        coupled, loss_c = _coupled_terms(model, cfg, batch, scene, groups, subs, aug, commonsense, lam)
     P = scene.n_pairs
     nc = 3 if cfg.hierarchical else 1
     full = PairOutputs(torch.zeros(P, cfg.num_relations, device=dev), torch.zeros(P, 3, device=dev) if cfg.hierarchical else None,
@@ -370,15 +437,16 @@ def _train_image_groups(model, cfg, batch, scene: DeviceScene, groups, reducer, 
     for gi, (a, b) in enumerate(groups):
         ln = lane[gi % lanes]
         with torch.cuda.stream(ln["stream"]):
-            rows = _group_rows(scene, a, b)
-            if rows.numel() == 0:
+            rows, sub = subs[gi]
+            if sub is None:
                 continue
-            sub_b = slice_batch(batch, a, b)
-            sub = flatten_scene(cfg, sub_b, dev)
-            assert sub.n_pairs == int(rows.numel())
+            sub_b = sub._batch
+            extra = {}
+            if coupled is not None:
+                extra = dict(coupled=coupled[gi], image_feature_aug=None if aug is None else aug[a:b])
             ln["loss"] = ln["loss"] + model.training_step(sub, sub_b.relationships, sub_b.subj_or_obj,
                                                           loss_coefs=tuple(c[rows] for c in coefs), grads_out=ln["acc"],
-                                                          engine=ln["engine"], **kw)
+                                                          engine=ln["engine"] if coupled is None else None, **extra, **kw)
             out = model.last_outputs
             full.relation[rows] = out.relation
             if full.super_relation is not None:
@@ -400,6 +468,13 @@ def _train_image_groups(model, cfg, batch, scene: DeviceScene, groups, reducer, 
             else:
                 acc[name] = g
         stats, loss = stats + ln["stats"], loss + ln["loss"]
+    if loss_c is not None:
+        if not bool(torch.isnan(loss_c)):
+            loss = loss + float(lam["lambda_contrast"]) ** 2 * loss_c          # lambda applied twice (train_test.py:270-273)
+        model.last_contrast_loss = loss_c
+    for name, p in model.named_parameters():          # no group had a pair: a zero gradient, not a missing one
+        if name not in acc:
+            acc[name] = torch.zeros_like(p)
     # the minibatch's gradient = the sum over its image groups: mean-reduce it across ranks once, then accumulate like autograd
     if reducer is not None:
         if "fc1.weight" in acc:

@@ -34,16 +34,28 @@ def _lowbias32(x: np.ndarray) -> np.ndarray:
 
 
 def hash_uniform(seed: int, n: int, lo: float = -1.0, hi: float = 1.0) -> np.ndarray:
-    """``n`` float32 values in ``[lo, hi)``; element ``i`` depends only on ``(seed, i)``."""
+    """``n`` float32 values in ``[lo, hi)``; element ``i`` depends only on ``(seed, i)``.  Large arrays (fc1.weight: 268 M
+    values) are filled chunk by chunk on a few threads (the numpy kernels release the GIL): same values, a fraction of the time."""
     out = np.empty(n, dtype=np.float32)
     salt = np.uint32((seed * 0x9E3779B1 + 0x7F4A7C15) & 0xFFFFFFFF)
-    for s in range(0, n, _CHUNK):
+
+    def fill(s):
         e = min(n, s + _CHUNK)
         idx = np.arange(s, e, dtype=np.uint32)
         h = _lowbias32(idx ^ salt)
         h = _lowbias32(h + salt)
         u = (h >> np.uint32(8)).astype(np.float32) * np.float32(1.0 / (1 << 24))
         out[s:e] = np.float32(lo) + u * np.float32(hi - lo)
+
+    starts = range(0, n, _CHUNK)
+    if len(starts) >= 4:
+        import os
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 4, len(starts))) as pool:
+            list(pool.map(fill, starts))
+    else:
+        for s in starts:
+            fill(s)
     return out
 
 
@@ -162,24 +174,38 @@ def param_shapes(cfg: HeadConfig) -> Dict[str, Tuple[int, ...]]:
     return shapes
 
 
+_SD_CACHE: Dict[tuple, Dict[str, torch.Tensor]] = {}
+_SD_CACHE_MAX = 3
+
+
 def make_state_dict(cfg: HeadConfig, seed: int = 0, head_gain: float = 1.0,
                     trunk_gain: float = 1.0) -> Dict[str, torch.Tensor]:
     """Random-init weights scaled like PyTorch's default (uniform ±1/sqrt(fan_in)).
 
     ``head_gain`` multiplies the fc3_*/fc4/fc5 weights so the log-softmaxes are not nearly
     uniform (a trained head has O(1..10) logits); ``trunk_gain`` multiplies conv/fc weights.
+    The last few results are cached (the test suites rebuild the same 1.1 GB dictionaries dozens of times); every call returns
+    fresh clones, so callers may modify what they get.
     """
-    sd: Dict[str, torch.Tensor] = {}
-    for k, (name, shape) in enumerate(sorted(param_shapes(cfg).items())):
-        base = name.rsplit(".", 1)[0]
-        wshape = param_shapes(cfg)[base + ".weight"]
-        fan_in = int(np.prod(wshape[1:]))
-        bound = 1.0 / math.sqrt(fan_in)
-        gain = head_gain if base.startswith(("fc3", "fc4", "fc5")) else trunk_gain
-        n = int(np.prod(shape))
-        v = hash_uniform(seed * 131 + k, n, -bound * gain, bound * gain)
-        sd[name] = torch.from_numpy(v.reshape(shape))
-    return sd
+    key = (tuple(sorted(cfg.__dict__.items())), int(seed), float(head_gain), float(trunk_gain))
+    hit = _SD_CACHE.get(key)
+    if hit is None:
+        hit = {}
+        for k, (name, shape) in enumerate(sorted(param_shapes(cfg).items())):
+            base = name.rsplit(".", 1)[0]
+            wshape = param_shapes(cfg)[base + ".weight"]
+            fan_in = int(np.prod(wshape[1:]))
+            bound = 1.0 / math.sqrt(fan_in)
+            gain = head_gain if base.startswith(("fc3", "fc4", "fc5")) else trunk_gain
+            n = int(np.prod(shape))
+            v = hash_uniform(seed * 131 + k, n, -bound * gain, bound * gain)
+            hit[name] = torch.from_numpy(v.reshape(shape))
+        while len(_SD_CACHE) >= _SD_CACHE_MAX:
+            _SD_CACHE.pop(next(iter(_SD_CACHE)))
+        _SD_CACHE[key] = hit
+    else:
+        _SD_CACHE[key] = _SD_CACHE.pop(key)            # most recently used last
+    return {k: v.clone() for k, v in hit.items()}
 
 
 @dataclass

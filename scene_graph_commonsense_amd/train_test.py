@@ -282,7 +282,16 @@ def training(gpu, args, train_subset, test_subset):
             try:
                 batch, feature_aug, annot_path = _to_batch(args, data, detr, rank, with_aug=True)
             except EmptyMinibatch:
-                continue                                     # a minibatch whose samples were all dropped by the loader
+                # a minibatch whose samples were all dropped by the loader.  The reference just skips it - and with more than one
+                # rank leaves the others waiting in DDP's all-reduce; here the rank still takes part in the step's collectives
+                # (zero gradients), applies the same update as its peers and joins the print_freq barrier.
+                if world_size > 1:
+                    optimizer.zero_grad(set_to_none=True)
+                    relation_classifier.zero_gradient_step(reducer)
+                    optimizer.step()
+                    if batch_count % T["print_freq"] == 0 or batch_count + 1 == len(train_loader):
+                        dist.barrier()
+                continue
             Recall.load_annotation_paths(annot_path)
             # the reference rescales lr inside its graph_iter loop and steps once per minibatch: the value in force at
             # optimizer.step() is the one of the LAST graph_iter, whose keep_in_batch are the images with the most objects

@@ -12,6 +12,36 @@ GOLDEN = os.path.join(REPO, "tests", "golden")
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "slow: full-size CPU oracle cases (tens of seconds)")
+    config.addinivalue_line("markers", "oracle_launch: device step that feeds a background CPU-oracle job (ordered first)")
+    config.addinivalue_line("markers", "oracle_join: asserts on a background CPU-oracle job (ordered last)")
+    config.addinivalue_line("markers", "oracle_jobs(kind): the test uses jobs of tests/oracle_pool.py that can start when collection ends")
+
+
+@pytest.hookimpl(trylast=True)
+def pytest_collection_modifyitems(config, items):
+    """The long CPU-oracle computations of the GPU suite run as background jobs (tests/oracle_pool.py).  Tests that produce what a
+    job needs from the device run first, tests that wait for a job run last (stable otherwise), and the jobs that need nothing
+    from the device are submitted right here - before the first test - for the cases that were actually selected."""
+    rank = lambda it: 0 if it.get_closest_marker("oracle_launch") else (2 if it.get_closest_marker("oracle_join") else 1)
+    items.sort(key=rank)
+    kinds = {}
+    for it in items:
+        m = it.get_closest_marker("oracle_jobs")
+        if m is not None:
+            kinds.setdefault(m.args[0], set()).add(it.callspec.params.get("name") if hasattr(it, "callspec") else None)
+    if not kinds or config.option.collectonly:
+        return
+    if "sampled" in kinds:
+        from tests import sampled_case
+        sampled_case.prelaunch(sorted(n for n in kinds["sampled"] if n))
+    if "trajectory" in kinds:
+        from tests import trajectory_case
+        trajectory_case.prelaunch(sorted(n for n in kinds["trajectory"] if n))
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if "tests.oracle_pool" in sys.modules:
+        sys.modules["tests.oracle_pool"].shutdown()
 
 
 @pytest.fixture(scope="session")

@@ -1,0 +1,103 @@
+"""One CPU-oracle job in its own process (TEST INFRASTRUCTURE: the checker's side of the GPU parity tests).
+
+``python -m tests.oracle_worker <job dir>`` reads ``job.pt`` (a small spec: every input is regenerated from seeds, exactly as the
+test that submitted the job generates it), runs the f32 oracle (``oracle/relhead_oracle.py``) and writes ``out.pt`` (+ one file
+per step for trajectories).  The process never touches a GPU (the pool hides the devices).  Job kinds:
+
+* ``sampled``     - the reference loop restricted to the given (graph_iter, edge_iter) steps of a full-size minibatch, loss with the
+                    running-sum quirk over those steps, ``backward()``: records + loss + every parameter gradient.  ``routes``: a
+                    file with the device's own pool / ReLU routes of those pairs, injected into the oracle's graph.
+* ``trajectory``  - K SGD steps (momentum, weight decay as ``train_test.py:100``) on a golden case with the kernels' dropout masks:
+                    per step the loss and every parameter's update, written as ``step_<k>.pt`` as soon as the step is done.
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+
+def _sampled(spec, out_dir):
+    from oracle import relhead_oracle as O
+    from scene_graph_commonsense_amd.synthetic import HeadConfig, make_scene_batch, make_state_dict, predicate_counts
+    cfg = HeadConfig(**spec["cfg_kw"])
+    sd = make_state_dict(cfg, seed=spec["sd_seed"], head_gain=spec["head_gain"])
+    batch = make_scene_batch(cfg, spec["nobj"], seed=spec["batch_seed"], connect_frac=spec["connect_frac"])
+    steps = {tuple(s) for s in spec["steps"]}
+    routes = torch.load(spec["routes"]) if spec.get("routes") else None
+    sizes = spec.get("call_sizes")                        # rows per record, record order (needed to slice the route tables)
+    start = np.concatenate([[0], np.cumsum(sizes)]) if sizes is not None else None
+
+    def hook(t, b):
+        if routes is None:
+            return {}
+        r0 = int(start[t])
+        assert int(start[t + 1]) - r0 == b
+        return {"routes": {k: v[r0:r0 + b] for k, v in routes.items()}}
+
+    backward = spec.get("backward", True)
+    sdr = {k: v.clone().requires_grad_(backward) for k, v in sd.items()}
+    t0 = time.time()
+    with torch.set_grad_enabled(backward):
+        ref = O.run_pair_loop(sdr, batch, cfg, mode="train", weights=O.class_weights(predicate_counts(cfg)),
+                              step_filter=lambda g, e: (g, e) in steps, call_hook=hook)
+    t_fwd = time.time() - t0
+    grads = None
+    if backward:
+        ref["losses"].backward()
+        grads = {k: p.grad for k, p in sdr.items()}
+    recs = [{k: r[k] for k in ("g", "e", "first", "keep", "relation", "super_relation", "connectivity", "hidden")} for r in ref["records"]]
+    torch.save(dict(records=recs, loss=float(ref["losses"].detach()), grads=grads, seconds=(t_fwd, time.time() - t0),
+                    threads=torch.get_num_threads()), os.path.join(out_dir, "out.pt.tmp"))
+    os.replace(os.path.join(out_dir, "out.pt.tmp"), os.path.join(out_dir, "out.pt"))
+
+
+def _trajectory(spec, out_dir):
+    from oracle import relhead_oracle as O
+    from scene_graph_commonsense_amd.pairs import enumerate_pairs
+    from scene_graph_commonsense_amd.synthetic import dropout_keep_mask, predicate_counts
+    from tests.golden_cases import load_case
+    cfg, sd, batch, _ = load_case(spec["case"])
+    names = spec["names"]
+    nobj = [int(b.shape[0]) for b in batch.bbox]
+    pidx = enumerate_pairs(nobj)
+    start = np.concatenate([[0], np.cumsum(pidx.call_sizes)])
+    sdr = {k_: v.clone().requires_grad_(True) for k_, v in sd.items()}
+    opt = torch.optim.SGD([sdr[n] for n in names], lr=spec["lr"], momentum=spec["momentum"], weight_decay=spec["weight_decay"])
+    weights = O.class_weights(predicate_counts(cfg))
+    ds = spec["dropout_seed"]
+    losses = []
+    for k in range(spec["K"]):
+        s1 = (ds * 2654435761 + 2 * (k + 1)) & 0xFFFFFFFF              # model._next_seeds of training step k + 1
+        s2 = (ds * 2654435761 + 2 * (k + 1) + 1) & 0xFFFFFFFF
+
+        def hook(t, b, s1=s1, s2=s2):
+            r0 = int(start[t])
+            return dict(drop1=torch.from_numpy(dropout_keep_mask(s1, b, 4096, r0)).float() * 2,
+                        drop2=torch.from_numpy(dropout_keep_mask(s2, b, 512, r0)).float() * 2)
+
+        before = {n: sdr[n].detach().clone() for n in names}
+        out = O.run_pair_loop(sdr, batch, cfg, mode="train", weights=weights, call_hook=hook)
+        opt.zero_grad(set_to_none=True)
+        out["losses"].backward()
+        opt.step()
+        losses.append(float(out["losses"].detach()))
+        upd = {n: (sdr[n].detach() - before[n]) for n in names}
+        tmp = os.path.join(out_dir, "step_%d.pt.tmp" % k)
+        torch.save(dict(loss=losses[-1], update=upd), tmp)
+        os.replace(tmp, os.path.join(out_dir, "step_%d.pt" % k))
+    torch.save(dict(losses=losses), os.path.join(out_dir, "out.pt.tmp"))
+    os.replace(os.path.join(out_dir, "out.pt.tmp"), os.path.join(out_dir, "out.pt"))
+
+
+def main(out_dir):
+    spec = torch.load(os.path.join(out_dir, "job.pt"))
+    if spec.get("threads"):
+        torch.set_num_threads(int(spec["threads"]))
+    {"sampled": _sampled, "trajectory": _trajectory}[spec["kind"]](spec, out_dir)
+
+
+if __name__ == "__main__":
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    main(sys.argv[1])

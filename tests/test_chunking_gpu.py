@@ -60,6 +60,51 @@ def test_chunked_training_step_equals_the_one_pass_step():
         assert e <= 2e-4, (n, e)
 
 
+@pytest.mark.parametrize("terms", ["contrast", "commonsense", "both"])
+def test_chunked_step_with_minibatch_coupled_terms_equals_the_one_pass_step(terms):
+    """the contrastive term (``train_test.py:260-273``: SupConLossHierar over the hidden rows of EVERY connected
+    pair of the minibatch) and the commonsense penalty (``train_utils.py:36-62``: per-step means over every image of the step) couple
+    the image groups through the forward.  Chunked = every group's forward first, the minibatch-level pieces once, then forward +
+    backward per group with its rows of them; must equal the one-pass step (dropout off: keep bits are indexed by pass position)."""
+    from scene_graph_commonsense_amd.pair_loop import train_minibatch
+    from scene_graph_commonsense_amd.synthetic import HeadConfig, hash_normal, make_scene_batch
+    from tests.golden_cases import GOLDEN
+    cfg = HeadConfig()
+    model = _model(cfg)
+    batch = make_scene_batch(cfg, [48] * 12 + [30, 17, 2, 48], seed=41, connect_frac=0.04)
+    kw = {}
+    if terms in ("contrast", "both"):
+        f = batch.image_feature
+        kw["image_feature_aug"] = (0.9 * f + 0.3 * torch.from_numpy(hash_normal(4242, f.numel()).reshape(f.shape))).cuda()
+        kw["lambda_contrast"] = 0.7
+    if terms in ("commonsense", "both"):
+        fx = os.path.join(GOLDEN, "ref_fixtures") + os.sep
+        kw["commonsense"] = (list(torch.load(fx + "commonsense_aligned_triplets.pt").keys()),
+                             list(torch.load(fx + "commonsense_violated_triplets.pt").keys()))
+        kw["lambda_commonsense"] = 0.5
+    res = []
+    for budget in (1e15, 18 * GB):
+        model.zero_grad(set_to_none=True)
+        model.last_contrast_loss = None
+        loss = train_minibatch(model, batch, None, workspace_budget=budget, lambda_connectivity=0.15, **kw)
+        torch.cuda.synchronize()
+        res.append(dict(loss=float(loss), groups=list(model.last_image_groups), grads={n: p.grad.clone() for n, p in model.named_parameters()},
+                        rel=model.last_outputs.relation.clone(), hidden=model.last_outputs.hidden.clone(),
+                        contrast=None if model.last_contrast_loss is None else float(model.last_contrast_loss)))
+    one, many = res
+    print(terms, "groups", many["groups"], "loss", one["loss"], many["loss"], "contrastive", one["contrast"], many["contrast"])
+    assert len(one["groups"]) == 1 and len(many["groups"]) >= 3
+    assert abs(one["loss"] - many["loss"]) <= 1e-5 * abs(one["loss"])
+    if "image_feature_aug" in kw:
+        assert one["contrast"] is not None and abs(one["contrast"] - many["contrast"]) <= 1e-6 * abs(one["contrast"])
+    assert torch.equal(one["rel"], many["rel"]) and torch.equal(one["hidden"], many["hidden"])
+    worst = {n: float((one["grads"][n].double() - many["grads"][n].double()).norm() / one["grads"][n].double().norm().clamp(min=1e-30))
+             for n in one["grads"]}
+    print({k: "%.1e" % v for k, v in worst.items()})
+    for n, e in worst.items():
+        assert e <= 2e-4, (n, e)
+
+
 def test_24x64_training_step_runs_in_40gb_groups():
     from scene_graph_commonsense_amd.optim import FusedSGD
     from scene_graph_commonsense_amd.pair_loop import train_minibatch

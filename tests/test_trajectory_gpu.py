@@ -9,40 +9,35 @@ that leaves TRAINING: K optimisation steps through the product entry points (``p
 
 Bars: the loss curves agree within 1e-2 relative at EVERY step, and the weight update of every parameter tensor (w_k+1 - w_k,
 i.e. lr x momentum buffer) has cosine >= 0.99 with the oracle's at every step, its norm within 10 %.  At the reference's learning
-rate (``config.yaml:51``; half of it for the VG case, see ``LR``) the running-sum loss falls by tens of percent over the K steps
-(asserted: the run must train, otherwise nothing is tested).
+rate (``config.yaml:51``; the VG case also at half of it, see ``tests/trajectory_case.py``) the running-sum loss falls by tens of
+percent over the K steps (asserted: the run must train, otherwise nothing is tested).
+
+The oracle's K steps run as a job of ``tests/oracle_pool.py`` (a process beside the GPU tests, started when collection ends: it
+needs nothing from the device); the test streams its per-step updates as they are written.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
 
+from tests import oracle_pool
 from tests.golden_cases import load_case
+from tests.trajectory_case import CASES, DROPOUT_SEED, MOMENTUM, WEIGHT_DECAY, job_name, job_spec, param_names
 
 pytestmark = pytest.mark.gpu
 
-K = 10
-MOMENTUM, WEIGHT_DECAY = 0.9, 1e-4
-# oiv6_full: the reference's learning rate (config.yaml:51).  vg_full: half of it - at 1e-5 the ORACLE's own loss overshoots at step 9
-# (332 -> 412 -> 284) and from there the two runs separate beyond the bar (device 421 vs 412 at step 9, update cosines 0.95-0.98),
-# while steps 1-8 agree to <= 6e-3: an unstable step amplifies any difference, whatever its source.  At 5e-6 the oracle's loss
-# falls monotonically 643 -> 353 in 10 steps.
-LR = {"vg_full": 5e-6, "oiv6_full": 1e-5}
 
-
-def _seeds(dropout_seed, step):
-    return ((dropout_seed * 2654435761 + 2 * step) & 0xFFFFFFFF, (dropout_seed * 2654435761 + 2 * step + 1) & 0xFFFFFFFF)
-
-
-@pytest.mark.parametrize("name", ["vg_full", "oiv6_full"])
+@pytest.mark.oracle_join
+@pytest.mark.oracle_jobs("trajectory")
+@pytest.mark.parametrize("name", list(CASES))
 def test_training_trajectory_matches_f32_oracle(name):
-    from oracle import relhead_oracle as O
     from scene_graph_commonsense_amd.model import BayesianRelationClassifier
     from scene_graph_commonsense_amd.optim import FusedSGD
     from scene_graph_commonsense_amd.pair_loop import train_minibatch
-    from scene_graph_commonsense_amd.pairs import enumerate_pairs
-    from scene_graph_commonsense_amd.synthetic import dropout_keep_mask, predicate_counts
-    cfg, sd, batch, _ = load_case(name)
-    lr = LR[name]
+    case, lr, K = CASES[name]
+    cfg, sd, batch, _ = load_case(case)
+    oracle_pool.submit(job_name(name), job_spec(name))          # no-op when collection pre-launched it
 
     # ---- device: the product path
     model = BayesianRelationClassifier(cfg.args(), num_classes=cfg.num_classes, num_super_classes=cfg.num_super_classes,
@@ -50,9 +45,10 @@ def test_training_trajectory_matches_f32_oracle(name):
                                        num_semantic=cfg.num_semantic).cuda()
     model.load_state_dict(sd)
     model.train()
-    assert model._step == 0
+    assert model._step == 0 and model.dropout_seed == DROPOUT_SEED
     opt = FusedSGD(model.parameters(), lr=lr, momentum=MOMENTUM, weight_decay=WEIGHT_DECAY)
     names = [n for n, _ in model.named_parameters()]
+    assert names == param_names(case)
     dev_losses, dev_updates = [], []
     prev = {n: p.detach().clone() for n, p in model.named_parameters()}
     for k in range(K):
@@ -67,30 +63,15 @@ def test_training_trajectory_matches_f32_oracle(name):
     torch.cuda.synchronize()
     assert model._step == K
 
-    # ---- oracle: f32 on the CPU, same dropout masks
-    nobj = [int(b.shape[0]) for b in batch.bbox]
-    pidx = enumerate_pairs(nobj)
-    start = np.concatenate([[0], np.cumsum(pidx.call_sizes)])
-    sdr = {k_: v.clone().requires_grad_(True) for k_, v in sd.items()}
-    ref_opt = torch.optim.SGD([sdr[n] for n in names], lr=lr, momentum=MOMENTUM, weight_decay=WEIGHT_DECAY)
-    weights = O.class_weights(predicate_counts(cfg))
+    # ---- oracle: f32 on the CPU, same dropout masks (tests/oracle_worker.py:_trajectory), one file per step
     ref_losses, worst_cos, worst_norm = [], {n: 1.0 for n in names}, {n: 0.0 for n in names}
     for k in range(K):
-        s1, s2 = _seeds(model.dropout_seed, k + 1)
-
-        def hook(t, b, s1=s1, s2=s2):
-            r0 = int(start[t])
-            return dict(drop1=torch.from_numpy(dropout_keep_mask(s1, b, 4096, r0)).float() * 2,
-                        drop2=torch.from_numpy(dropout_keep_mask(s2, b, 512, r0)).float() * 2)
-
-        before = {n: sdr[n].detach().clone() for n in names}
-        out = O.run_pair_loop(sdr, batch, cfg, mode="train", weights=weights, call_hook=hook)
-        ref_opt.zero_grad(set_to_none=True)
-        out["losses"].backward()
-        ref_opt.step()
-        ref_losses.append(float(out["losses"].detach()))
+        path = oracle_pool.wait_file(job_name(name), "step_%d.pt" % k)
+        step = torch.load(path)
+        os.remove(path)
+        ref_losses.append(step["loss"])
         for n in names:
-            r = (sdr[n].detach() - before[n])
+            r = step["update"][n]
             d = dev_updates[k][n]
             if d.is_cuda:
                 r = r.cuda()
@@ -105,6 +86,8 @@ def test_training_trajectory_matches_f32_oracle(name):
             worst_norm[n] = max(worst_norm[n], abs(na - nb) / nb)
         dev_updates[k] = None
         print("step %d loss device %.4f oracle %.4f" % (k + 1, dev_losses[k], ref_losses[k]))
+    oracle_pool.result(job_name(name))
+    oracle_pool.release(job_name(name))
     print({n: "%.4f" % c for n, c in worst_cos.items()})
     for k in range(K):
         assert abs(dev_losses[k] - ref_losses[k]) <= 1e-2 * abs(ref_losses[k]), (k, dev_losses[k], ref_losses[k])

@@ -4,8 +4,10 @@ import numpy as np
 import torch
 
 
-def run_train_gpu(cfg, sd, batch, dropout=False, seeds=(0, 0), keep_ctx=False):
-    """(loss, grads {name: f32 cpu}, ctx, scene) of ``RelHeadEngine.train_forward`` + ``train_backward``."""
+def run_train_gpu(cfg, sd, batch, dropout=False, seeds=(0, 0), keep_ctx=False, coefs=None, route_rows=None):
+    """(loss, grads {name: f32 cpu}, routes, scene) of ``RelHeadEngine.train_forward`` + ``train_backward``.
+    ``coefs``: per-pair loss coefficients (tgt, a, b, c, y) instead of the whole minibatch's (sampled steps of a full-size
+    minibatch: zero outside them); ``route_rows``: the pairs whose routes are returned (default: all)."""
     from scene_graph_commonsense_amd.engine import RelHeadEngine, csr_by, loss_coefficients
     from scene_graph_commonsense_amd.model import _shared_hint          # the host's window counts: the organisation the product path takes
     from scene_graph_commonsense_amd.pairs import flatten_scene, pair_targets
@@ -16,10 +18,11 @@ def run_train_gpu(cfg, sd, batch, dropout=False, seeds=(0, 0), keep_ctx=False):
     eng.prep_bwd_weights(sd)
     sc = flatten_scene(cfg, batch, dev)
     pidx = sc.pidx
-    directed, _ = pair_targets(batch.relationships, batch.subj_or_obj, pidx)
-    counts = predicate_counts(cfg).numpy()
-    cw = 1 - counts / counts.sum()
-    coefs = loss_coefficients(cfg, pidx.step, len(pidx.call_sizes), directed, cw)
+    if coefs is None:
+        directed, _ = pair_targets(batch.relationships, batch.subj_or_obj, pidx)
+        counts = predicate_counts(cfg).numpy()
+        cw = 1 - counts / counts.sum()
+        coefs = loss_coefficients(cfg, pidx.step, len(pidx.call_sizes), directed, cw)
     coefs_d = tuple(torch.from_numpy(c).to(dev) for c in coefs)
     n_obj = int(sc.obj_img.shape[0])
     sub_csr = tuple(torch.from_numpy(a).to(dev) for a in csr_by(pidx.sub, n_obj))
@@ -27,30 +30,34 @@ def run_train_gpu(cfg, sd, batch, dropout=False, seeds=(0, 0), keep_ctx=False):
     img_ptr = torch.from_numpy(pidx.obj_offset.astype(np.int32)).to(dev)
     ctx = eng.train_forward(sc.image_feature, sc.image_depth, sc.obj_img, sc.bbox, sc.cats, sc.super_mh, sc.sub_idx, sc.obj_idx,
                             dropout=dropout, seeds=seeds, dense=(sc.img_ptr, sc.pid, sc.max_n), shared_windows=_shared_hint(sc))
-    routes = device_routes(ctx) if keep_ctx else None
+    routes = device_routes(ctx, route_rows) if keep_ctx else None
     loss, grads = eng.train_backward(ctx, coefs_d, sub_csr, obj_csr, img_ptr)
     torch.cuda.synchronize()
     return float(loss), {k: v.float().cpu() for k, v in grads.items()}, routes, sc
 
 
-def device_routes(ctx):
+def device_routes(ctx, rows=None):
     """The routing decisions the device's backward follows, in the oracle's layouts (CPU tensors, one row per ordered pair):
     pool2 [P,512,16,16] / pool3 [P,1024,8,8] window codes (dy*2+dx, 4 = killed by the ReLU), relu1 [P,4096] / relu2 [P,512]
     pass masks (an element the dropout removed reads as "not passed": the injected dropout mask zeroes it anyway).
     With conv3 / fc1 over shared windows (``csrc/kernels_shared.hip``) a pair's own codes exist only next to its pair-specific
     windows; everywhere else its gradient flows through the pseudo-pair (subject, background) or (background, object), whose
-    codes are what the reference's graph has there too (identical inputs), so the full per-pair tables are put together from them."""
+    codes are what the reference's graph has there too (identical inputs), so the full per-pair tables are put together from them.
+    ``rows`` (int array of pair indices): tables of those pairs only, in that order (full-size minibatches: the sampled steps)."""
     P = ctx.P
+    sel = np.arange(P) if rows is None else np.asarray(rows, dtype=np.int64)
+    sel_d = torch.from_numpy(sel).to(ctx.h1.device)
+    n = len(sel)
     sh = getattr(ctx, "shared", None)
     unpack = lambda a: torch.stack((a & 15, a >> 4), dim=3).reshape(a.shape[0], 256, 512)      # channel 2k low nibble, 2k+1 high
     if sh is None:
-        codes = unpack(ctx.amz[:P * 256 * 256].view(P, 256, 256).cpu())
-        am3 = ctx.am[:P * 65536].view(P, 64, 1024).cpu()
+        codes = unpack(ctx.amz[:P * 256 * 256].view(P, 256, 256)[sel_d].cpu())
+        am3 = ctx.am[:P * 65536].view(P, 64, 1024)[sel_d].cpu()
     else:
         from scene_graph_commonsense_amd.pairs import object_window_rects
         n_obj, n2 = ctx.n_obj, sh["n2"]
-        allc = unpack(ctx.amz[:(P + n2) * 256 * 256].view(P + n2, 256, 256).cpu())
-        real, pseudo = allc[:P], allc[P:]
+        real = unpack(ctx.amz[:P * 256 * 256].view(P, 256, 256)[sel_d].cpu())
+        pseudo = unpack(ctx.amz[P * 256 * 256:(P + n2) * 256 * 256].view(n2, 256, 256).cpu())
         bb = ctx.bbox.cpu().numpy()
         sub, obj = ctx.sub_idx.cpu().numpy(), ctx.obj_idx.cpu().numpy()
         pr = sh["pixrect"].cpu().numpy()
@@ -62,12 +69,12 @@ def device_routes(ctx):
             if x1 > x0 and y1 > y0:
                 lx, hx, ly, hy = max(x0 - 1, 0), min(x1 + 1, 32), max(y0 - 1, 0), min(y1 + 1, 32)
                 d16[o, ly >> 1:(hy + 1) >> 1, lx >> 1:(hx + 1) >> 1] = True
-        am_real = ctx.am[:P * 65536].view(P, 64, 1024).cpu()
+        am_real = ctx.am[:P * 65536].view(P, 64, 1024)[sel_d].cpu()
         am_ps = sh["am_ps"][:n2 * 65536].view(n2, 64, 1024).cpu()
-        codes = torch.empty(P, 256, 512, dtype=real.dtype)
-        am3 = torch.empty(P, 64, 1024, dtype=am_real.dtype)
+        codes = torch.empty(n, 256, 512, dtype=real.dtype)
+        am3 = torch.empty(n, 64, 1024, dtype=am_real.dtype)
         wy, wx = np.divmod(np.arange(64), 8)
-        for p in range(P):
+        for k, p in enumerate(sel):
             i, j = int(sub[p]), int(obj[p])
             r = int(pr[p])
             own = np.zeros((16, 16), dtype=bool)
@@ -75,19 +82,19 @@ def device_routes(ctx):
             assert not (d16[i] & d16[j] & ~own).any()                 # pair-specific pixels lie inside what the pair computed itself
             from_j = torch.from_numpy((~own & d16[j]).reshape(256))
             from_i = torch.from_numpy((~own & ~d16[j]).reshape(256))
-            codes[p] = real[p]
-            codes[p][from_i] = pseudo[i][from_i]
-            codes[p][from_j] = pseudo[n_obj + j][from_j]
+            codes[k] = real[k]
+            codes[k][from_i] = pseudo[i][from_i]
+            codes[k][from_j] = pseudo[n_obj + j][from_j]
             in_i = (wx >= R[i, 0]) & (wx < R[i, 1]) & (wy >= R[i, 2]) & (wy < R[i, 3])
             in_j = (wx >= R[j, 0]) & (wx < R[j, 1]) & (wy >= R[j, 2]) & (wy < R[j, 3])
-            am3[p] = am_real[p]
-            am3[p][torch.from_numpy(~in_j)] = am_ps[i][torch.from_numpy(~in_j)]
-            sel = torch.from_numpy(in_j & ~in_i)
-            am3[p][sel] = am_ps[n_obj + j][sel]
-    pool2 = codes.permute(0, 2, 1).reshape(P, 512, 16, 16).contiguous()
-    pool3 = am3.permute(0, 2, 1).reshape(P, 1024, 8, 8).contiguous()
-    relu1 = (ctx.h1[:P * 4096].view(P, 4096) != 0).float().cpu()
-    relu2 = (ctx.p[:P * 512].view(P, 512) != 0).float().cpu()
+            am3[k] = am_real[k]
+            am3[k][torch.from_numpy(~in_j)] = am_ps[i][torch.from_numpy(~in_j)]
+            s_ = torch.from_numpy(in_j & ~in_i)
+            am3[k][s_] = am_ps[n_obj + j][s_]
+    pool2 = codes.permute(0, 2, 1).reshape(n, 512, 16, 16).contiguous()
+    pool3 = am3.permute(0, 2, 1).reshape(n, 1024, 8, 8).contiguous()
+    relu1 = (ctx.h1[:P * 4096].view(P, 4096)[sel_d] != 0).float().cpu()
+    relu2 = (ctx.p[:P * 512].view(P, 512)[sel_d] != 0).float().cpu()
     return dict(pool2=pool2, pool3=pool3, relu1=relu1, relu2=relu2)
 
 

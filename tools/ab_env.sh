@@ -2,7 +2,7 @@
 # Alternated A/B of ONE environment switch inside one box (box-to-box spread exceeds most effects):
 #   bash tools/ab_env.sh VAR A B [reps] [extra bench.py arguments...]
 # C-library switches (csrc/common.h:SgcTuning) need a library built with SGC_EXPERIMENTS=1; engine.TUNING switches work on the product library.
-VAR=$1; A=$2; B=$3; REPS=${4:-2}; shift 4 2>/dev/null
+VAR=$1; A=$2; B=$3; REPS=${4:-2}; shift $(( $# < 4 ? $# : 4 ))
 run() {
     env "$VAR=$1" python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-sensitivity "${@:2}" 2>/dev/null | python -c "
 import json,sys
