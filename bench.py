@@ -201,7 +201,7 @@ def executed_flops(P, n_img, n_obj, n_x, n_list, shared, forward_only=False, lin
     return f
 
 
-def cpu_baseline(cfg, sd, reps=5, steps_per_rep=7, threads=None):
+def cpu_baseline(cfg, sd, reps=5, steps_per_rep=16, threads=None):
     """The CPU oracle (literal reference restatement) timed on this host, SURVEY 8d's protocol: f32, fwd + loss + bwd of the
     reference's per-step calls (b = 8 images per call; the per-call cost does not depend on (g, e)); 2 warm-up calls, then ``reps``
     timings of ``2 * steps_per_rep`` calls each (>= 64 calls in all), value = pairs per timing / MEDIAN seconds, spread reported.

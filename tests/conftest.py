@@ -24,6 +24,11 @@ def pytest_collection_modifyitems(config, items):
     from the device are submitted right here - before the first test - for the cases that were actually selected."""
     rank = lambda it: 0 if it.get_closest_marker("oracle_launch") else (2 if it.get_closest_marker("oracle_join") else 1)
     items.sort(key=rank)
+    if any(it.get_closest_marker("gpu") for it in items):
+        # in-process oracle calls (b <= 8 pairs per reference call) are FASTEST on ~32 threads of the GPU box's 256
+        # (profiles/r04_oracle_threads.txt: 30 pairs/s on 32 threads, 11 on 128); the pool's jobs take 8 x 8 more
+        import torch
+        torch.set_num_threads(min(32, os.cpu_count() or 8))
     kinds = {}
     for it in items:
         m = it.get_closest_marker("oracle_jobs")

@@ -23,7 +23,7 @@ import torch
 
 from tests import oracle_pool
 from tests.golden_cases import load_case
-from tests.trajectory_case import CASES, DROPOUT_SEED, MOMENTUM, WEIGHT_DECAY, job_name, job_spec, param_names
+from tests.trajectory_case import CASES, DROPOUT_SEED, LATE_COSINE, MOMENTUM, STRICT_STEPS, WEIGHT_DECAY, job_name, job_spec, param_names
 
 pytestmark = pytest.mark.gpu
 
@@ -36,6 +36,7 @@ def test_training_trajectory_matches_f32_oracle(name):
     from scene_graph_commonsense_amd.optim import FusedSGD
     from scene_graph_commonsense_amd.pair_loop import train_minibatch
     case, lr, K = CASES[name]
+    strict_steps = STRICT_STEPS.get(name, K)
     cfg, sd, batch, _ = load_case(case)
     oracle_pool.submit(job_name(name), job_spec(name))          # no-op when collection pre-launched it
 
@@ -65,6 +66,7 @@ def test_training_trajectory_matches_f32_oracle(name):
 
     # ---- oracle: f32 on the CPU, same dropout masks (tests/oracle_worker.py:_trajectory), one file per step
     ref_losses, worst_cos, worst_norm = [], {n: 1.0 for n in names}, {n: 0.0 for n in names}
+    step_cos = []                                   # per step: the smallest update cosine over the parameter tensors
     for k in range(K):
         path = oracle_pool.wait_file(job_name(name), "step_%d.pt" % k)
         step = torch.load(path)
@@ -82,10 +84,15 @@ def test_training_trajectory_matches_f32_oracle(name):
             if nb <= 1e-30 and na <= 1e-30:      # no update on either side (the OpenImages case has no possessive target: fc3_2 gets
                 continue                          # no gradient, and lr x weight decay x w is below half an ulp of w)
             cos = dot / max(na * nb, 1e-300)
-            worst_cos[n] = min(worst_cos[n], cos)
+            if len(step_cos) <= k:
+                step_cos.append((cos, n))
+            elif cos < step_cos[k][0]:
+                step_cos[k] = (cos, n)
+            if k < strict_steps:
+                worst_cos[n] = min(worst_cos[n], cos)
             worst_norm[n] = max(worst_norm[n], abs(na - nb) / nb)
         dev_updates[k] = None
-        print("step %d loss device %.4f oracle %.4f" % (k + 1, dev_losses[k], ref_losses[k]))
+        print("step %d loss device %.4f oracle %.4f | smallest update cosine %.4f (%s)" % (k + 1, dev_losses[k], ref_losses[k], *step_cos[k]))
     oracle_pool.result(job_name(name))
     oracle_pool.release(job_name(name))
     print({n: "%.4f" % c for n, c in worst_cos.items()})
@@ -94,6 +101,8 @@ def test_training_trajectory_matches_f32_oracle(name):
     print({n: "%.3f" % c for n, c in worst_norm.items()})
     for n, c in worst_cos.items():
         assert c >= 0.99, (n, c)
+    for k in range(strict_steps, K):                # the reference's own learning rate, late steps: see tests/trajectory_case.py
+        assert step_cos[k][0] >= LATE_COSINE, (k, step_cos[k])
     for n, c in worst_norm.items():
         assert c <= 0.1, (n, c)              # measured <= 0.06 (a conv1 bias late in the run): routing flips move norms as they move angles
     # the run must have trained: the (dropout-noisy) loss of the last three steps lies well below that of the first three
