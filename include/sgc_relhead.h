@@ -10,7 +10,8 @@
  *   - layouts are channels-last.  Pixel rows of conv outputs are "window-major": row m of an SxS map is
  *     m = 4*(py*(S/2)+px) + (dy*2+dx), i.e. the four pixels of a 2x2 pooling window are adjacent.
  * Sizes are specialised to the reference defaults hidden_dim=128 (D), feature_size=32 (F): C = 2D+1 = 257 input
- * channels zero-padded to XC=384, conv2 512 ch, conv3 1024 ch, fc1 65536->4096, fc2 ->512.
+ * channels zero-padded to XC=384, conv2 512 ch, conv3 1024 ch, fc1 65536->4096, fc2 ->512 (other sizes: the sgc_generic_* trunk
+ * at the end of this file).
  * The Python binding is scene_graph_commonsense_amd/_lib.py (ctypes); INTEGRATION.md shows the call sites.
  */
 #ifndef SGC_RELHEAD_H
@@ -421,6 +422,38 @@ int sgc_nms_per_class(const int* cand_cat, const float* cand_conf, const float* 
  * prediction index.  top_idx / top_iou [n_tgt][2] (image-local prediction indices, -1 / -1.0 when the image has < 2 predictions). */
 int sgc_match_boxes_top2(const float* pred_box, const int* pred_ptr, const float* tgt_box, const int* tgt_ptr, int n_img, int max_tgt,
                          int feature_size, int* top_idx, float* top_iou, void* stream);
+
+/* ----------------------------------------------------------------------------------------------- generic-size trunk
+ * model.py:110-111 constructs BayesianRelationClassifier(args, input_dim, feature_size, ...) with ANY sizes; the tiled kernels above are
+ * specialised to input_dim = 128, feature_size = 32 (every shipped configuration, main.py:49-85).  These entry points run the trunk
+ * (model.py:138-150) for every OTHER size in plain f32, per pair, literally (csrc/kernels_generic.hip); fc2 / head / loss and their
+ * backward are size-independent and stay on the kernels above.  C = input_dim, F = feature_size (a multiple of 4).  All tensors f32
+ * channels-last unless stated; img / box: [2][n_pairs] image index and [2][n_pairs][4] slice-normalised (x0,x1,y0,y1) of the subject
+ * (side 0) and object (side 1) of every pair; feat / depth: NCHW with per-image element strides (the minibatch's tensors, or the
+ * pre-masked [b,2C+1,F,F] crops of forward() with depth = feat + 2C*F*F). */
+
+/* a [n_pairs][F*F][2C] = cat(tanh(conv1_1(feat*mask_s, depth*mask_s)), tanh(conv1_2(... mask_o)))   (train_test.py:164-169,194-195,
+ * model.py:139-141).  w1 [2][C][2C+1], b1 [2][C]: conv1_1 / conv1_2 in the reference's layout. */
+int sgc_generic_conv1_tanh(const float* feat, const float* depth, long stride_feat, long stride_depth, const int* img, const int* box,
+                           const float* w1, const float* b1, int n_pairs, int C, int F, float* a, void* stream);
+/* out [n_pairs][(S/2)^2][Cout] = maxpool2(relu(conv3x3(in [n_pairs][S*S][Cin], w [Cout][Cin][3][3], padding 1) + b)); code: one byte per
+ * output, dy*2+dx of the first maximum, 4 = no positive value   (model.py:142-144 conv2_1, :145-147 conv3_1). */
+int sgc_generic_conv3x3_relu_pool(const float* in, const float* w, const float* b, int n_pairs, int S, int Cin, int Cout, float* out,
+                                  unsigned char* code, void* stream);
+/* Backward of the above from the pooled gradient dout: dpre [n_pairs][S*S][Cout] scratch (un-pooled), din (may be NULL), dw [Cout][Cin][3][3],
+ * db [Cout]; fixed summation order, no atomics. */
+int sgc_generic_conv3x3_bwd(const float* in, const float* w, const float* dout, const unsigned char* code, int n_pairs, int S, int Cin, int Cout,
+                            float* dpre, float* din, float* dw, float* db, void* stream);
+/* h1 [n_pairs][4096] f16 = dropout(relu(fc1(flatten_NCHW(y))))   (model.py:148-149; y [n_pairs][Q][C8], Q = (F/4)^2, C8 = 8C; w1 [4096][C8*Q] in
+ * the reference's column order c*Q + q; dropout keep bit = the hash of common.h:dropout_keep over p*4096 + n, x2). */
+int sgc_generic_fc1_relu(const float* y, const float* w1, const float* b1, int n_pairs, int Q, int C8, int dropout, unsigned seed, void* h1,
+                         void* stream);
+/* dh1 [n_pairs][4096] bf16 (gradient wrt fc1's pre-activation, as sgc_fc2_dgrad leaves it) -> dy, dw1 [4096][C8*Q], db1 [4096]. */
+int sgc_generic_fc1_bwd(const void* dh1, const float* y, const float* w1, int n_pairs, int Q, int C8, float* dy, float* dw1, float* db1,
+                        void* stream);
+/* da (gradient wrt a, overwritten with the gradient wrt conv1's pre-activation) -> dw1 [2][C][2C+1], db1 [2][C]. */
+int sgc_generic_conv1_bwd(const float* feat, const float* depth, long stride_feat, long stride_depth, const int* img, const int* box, const float* a,
+                          float* da, int n_pairs, int C, int F, float* dw1, float* db1, void* stream);
 
 /* ----------------------------------------------------------------------------------------------- test hooks (raw GEMM engines) */
 int sgc_dbg_gemm_nt(int elem, const void* A, const void* B, void* C, int M, int N, int K, long lda, long ldb, long ldc, const float* bias, void* stream);

@@ -232,14 +232,28 @@ def shared_conv3_enabled(hint=None, n_pairs=0) -> bool:
     return True
 
 
+def make_engine(cfg: HeadConfig, device="cuda:0") -> "RelHeadEngine":
+    """The engine for ``cfg``: the tiled MFMA kernels for the reference's sizes (hidden_dim 128, feature_size 32 - every shipped
+    configuration), the generic f32 trunk (``engine_generic.GenericTrunkEngine``) for any other ``input_dim`` / ``feature_size`` the
+    reference's constructor accepts (``model.py:110-111``)."""
+    if cfg.hidden_dim == 128 and cfg.feature_size == 32:
+        return RelHeadEngine(cfg, device)
+    from .engine_generic import GenericTrunkEngine
+    return GenericTrunkEngine(cfg, device)
+
+
 class RelHeadEngine:
     """Forward and backward of the relation head over explicit pair lists (one instance = one GPU, one workspace)."""
 
-    def __init__(self, cfg: HeadConfig, device="cuda:0"):
+    def _check_sizes(self, cfg: HeadConfig):
         if cfg.hidden_dim != 128 or cfg.feature_size != 32:
-            raise NotImplementedError("the gfx950 kernels are specialised to hidden_dim=128, feature_size=32")
+            raise NotImplementedError("the tiled gfx950 kernels are specialised to hidden_dim=128, feature_size=32; other sizes run on "
+                                      "engine_generic.GenericTrunkEngine (engine.make_engine picks it)")
         if cfg.num_relations + 4 > 64:
             raise NotImplementedError("head kernel holds one output row per wavefront lane (<= 60 relations)")
+
+    def __init__(self, cfg: HeadConfig, device="cuda:0"):
+        self._check_sizes(cfg)
         self.cfg = cfg
         self.device = torch.device(device)
         self.lib = _lib.load()
@@ -278,7 +292,7 @@ class RelHeadEngine:
         """An engine that shares this one's weights and transient scratch but owns the buffers of its training context: the
         per-step ``forward()`` of the drop-in modules keeps many contexts alive until ``losses.backward()``
         (``train_test.py:189-276``: one classifier call per direction-step, one backward per minibatch)."""
-        c = RelHeadEngine.__new__(RelHeadEngine)
+        c = type(self).__new__(type(self))
         c.cfg, c.device, c.lib, c.w, c.T, c.timers = self.cfg, self.device, self.lib, self.w, self.T, None
         c._checks = self._checks
         c.head_rows = getattr(self, "head_rows", None)
@@ -304,6 +318,11 @@ class RelHeadEngine:
         cfg, dev = self.cfg, self.device
         g = lambda k: sd[k].detach().to(dev, torch.float32)
         w = self.w
+        self._load_trunk_weights(sd, g, fc1_sync)
+        self._load_head_weights(sd, g)
+
+    def _load_trunk_weights(self, sd, g, fc1_sync):
+        w = self.w
         w1r = self.ws.get("w1r", 2 * 128 * XC, torch.float16).view(2, 128, XC)     # created zeroed; the channel padding stays zero
         w1r[0, :, :257] = g("conv1_1.weight").view(128, 257).half()
         w1r[1, :, :257] = g("conv1_2.weight").view(128, 257).half()
@@ -322,6 +341,10 @@ class RelHeadEngine:
                 return self._transpose_cast(g("fc1.weight").contiguous(), "w1p", torch.float16, 0, 4096, 16, 65536, 4096, 64, 65536, 64, 1024)
         w.defer("w1p", make_w1p)
         w["bf1"] = g("fc1.bias").contiguous()
+
+    def _load_head_weights(self, sd, g):
+        """fc2 and the head: independent of hidden_dim / feature_size (fc1 always ends in 4096 features)."""
+        cfg, w = self.cfg, self.w
         fc2 = g("fc2.weight")
         w["fc2_full"] = fc2
         w["w2m"] = fc2[:, :4096].half().contiguous()
@@ -847,6 +870,22 @@ class RelHeadEngine:
         full.cand_pred[idx] = out.cand_pred
         return full
 
+    def compat_forward(self, hs, ho, c1, c2, mh1, mh2, train=False, seeds=(0, 0)) -> PairOutputs:
+        """The reference's per-step call on PRE-MASKED inputs (``model.py:170``): row k of ``hs`` / ``ho`` [b,257,32,32] is the subject /
+        object crop of pair k (inference: no context is kept)."""
+        dev = self.device
+        b = int(hs.shape[0])
+        a_s = self.image_maps(hs, None, roles=(0,), tag="cs")
+        a_o = self.image_maps(ho, None, roles=(1,), tag="co")
+        F = self.cfg.feature_size
+        full = torch.tensor([[0, F, 0, F]], dtype=torch.int32, device=dev).repeat(b, 1).contiguous()
+        ids = torch.arange(b, dtype=torch.int32, device=dev)
+        U = self.object_halves({0: a_s[0]}, ids, full, roles=(0,))[0]
+        V = self.object_halves({1: a_o[1]}, ids, full, roles=(1,))[1]
+        lsub, _ = self.label_vectors(c1, mh1)
+        _, lobj = self.label_vectors(c2, mh2)
+        return self.pair_trunk(U, V, ids, ids, lsub, lobj, train=train, seeds=seeds)
+
     # ====================================================================== training (forward + backward)
     def prep_bwd_weights(self, sd, fc1_sync=None):
         """bf16 transposed / flipped weight copies for the data-gradient GEMMs."""
@@ -854,6 +893,10 @@ class RelHeadEngine:
         g = lambda k: sd[k].detach().to(dev, torch.float32)
         w = self.w
         w["w2mT"] = w["fc2_full"][:, :4096].t().contiguous().to(torch.bfloat16)
+        self._prep_bwd_trunk_weights(sd, g, fc1_sync)
+
+    def _prep_bwd_trunk_weights(self, sd, g, fc1_sync):
+        w = self.w
 
         def make_w1pT():
             if fc1_sync is not None:
@@ -1081,6 +1124,11 @@ class RelHeadEngine:
             Workspace._zero(dh1[P * 4096:])
         self._timed("fc2_dgrad", lambda: _lib.check(lib.sgc_fc2_dgrad(_lib.ptr(dpre), _lib.ptr(w["w2mT"]), _lib.ptr(ctx.h1), _lib.ptr(dh1), P, f(scale), st()),
                    "sgc_fc2_dgrad"))
+
+        if getattr(ctx, "generic", None) is not None:        # sizes other than 128 / 32: the f32 per-pair trunk (engine_generic.py)
+            self._generic_trunk_backward(ctx, dh1, grads, side)
+            side.join()
+            return loss, grads
 
         # ---- fc1
         if getattr(ctx, "shared", None) is not None and ctx.shared.get("wm") is not None:

@@ -19,7 +19,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from .engine import PairOutputs, RelHeadEngine
+from .engine import PairOutputs, RelHeadEngine, make_engine
 from .pairs import DeviceScene, pair_targets_fast, super_multihot
 from .synthetic import HeadConfig, predicate_counts
 
@@ -68,7 +68,7 @@ class _PairStepFunction(torch.autograd.Function):
         b = int(h_sub.shape[0])
         hs = h_sub.detach().to(dev, torch.float32).contiguous()
         ho = h_obj.detach().to(dev, torch.float32).contiguous()
-        full = torch.tensor([[0, 32, 0, 32]], dtype=torch.int32, device=dev).repeat(b, 1).contiguous()
+        full = torch.tensor([[0, cfg.feature_size, 0, cfg.feature_size]], dtype=torch.int32, device=dev).repeat(b, 1).contiguous()
         ids = torch.arange(b, dtype=torch.int32, device=dev)
         mh1 = mh2 = None
         if s1 is not None and cfg.dataset == "vg":
@@ -135,7 +135,7 @@ class _RelationBase(nn.Module):
             raise RuntimeError("the relation head runs only on a GPU through its HIP kernels (no CPU fallback); "
                                "move the module to a cuda device")
         if self._engine is None or self._engine.device != dev:
-            self._engine = RelHeadEngine(self.head_config(), dev)
+            self._engine = make_engine(self.head_config(), dev)
             self._engine.T = (float(getattr(self, "T1", 1)), float(getattr(self, "T2", 1)), float(getattr(self, "T3", 1)))
             self._weights_version = None
         return self._engine
@@ -166,7 +166,7 @@ class _RelationBase(nn.Module):
         eng.w["w1p"], eng.w["w1pT"]                    # deferred copies: made on the caller's stream, before the lanes' streams read them
         lanes = self.__dict__.setdefault("_lane_engines", {})
         if k not in lanes or lanes[k].device != eng.device:
-            lanes[k] = RelHeadEngine(self.head_config(), eng.device)
+            lanes[k] = make_engine(self.head_config(), eng.device)
         lane = lanes[k]
         lane.w, lane.T, lane.head_rows = eng.w, eng.T, eng.head_rows
         return lane
@@ -381,10 +381,9 @@ class _RelationBase(nn.Module):
     def _contrast_trunk(self, eng, scene, image_feature_aug, conn_idx, seeds):
         """Augmented-view trunk (``train_test.py:154,196,204``) for the connected pairs only: its context, pair lists and the zero
         loss coefficients of its backward pass (the SupCon gradient enters through ``dp_extra``)."""
-        from .engine import RelHeadEngine
         dev = eng.device
         if getattr(self, "_engine_aug", None) is None or self._engine_aug.device != dev:
-            self._engine_aug = RelHeadEngine(self.head_config(), dev)
+            self._engine_aug = make_engine(self.head_config(), dev)
         eng_a = self._engine_aug
         eng_a.w, eng_a.T, eng_a.head_rows = eng.w, eng.T, eng.head_rows          # shared weights, own workspace
         M = int(conn_idx.numel())
@@ -449,20 +448,12 @@ class _RelationBase(nn.Module):
         with torch.no_grad():
             hs = h_sub.to(dev, torch.float32).contiguous()
             ho = h_obj.to(dev, torch.float32).contiguous()
-            a_s = eng.image_maps(hs, None, roles=(0,), tag="cs")
-            a_o = eng.image_maps(ho, None, roles=(1,), tag="co")
-            full = torch.tensor([[0, 32, 0, 32]], dtype=torch.int32, device=dev).repeat(b, 1).contiguous()
-            ids = torch.arange(b, dtype=torch.int32, device=dev)
-            U = eng.object_halves({0: a_s[0]}, ids, full, roles=(0,))[0]
-            V = eng.object_halves({1: a_o[1]}, ids, full, roles=(1,))[1]
             mh1 = mh2 = None
             if s1 is not None:
                 mh1 = torch.from_numpy(super_multihot([list(s1)], cfg.num_super_classes)).to(dev)
                 mh2 = torch.from_numpy(super_multihot([list(s2)], cfg.num_super_classes)).to(dev)
-            lsub, _ = eng.label_vectors(c1.to(dev).long(), mh1)
-            _, lobj = eng.label_vectors(c2.to(dev).long(), mh2)
             seeds = self._next_seeds() if self.training else (0, 0)
-            return eng.pair_trunk(U, V, ids, ids, lsub, lobj, train=self.training, seeds=seeds)
+            return eng.compat_forward(hs, ho, c1.to(dev).long(), c2.to(dev).long(), mh1, mh2, train=self.training, seeds=seeds)
 
 
 class BayesianRelationClassifier(_RelationBase):

@@ -44,6 +44,20 @@ def pytest_collection_modifyitems(config, items):
         trajectory_case.prelaunch(sorted(n for n in kinds["trajectory"] if n))
 
 
+_T0 = None
+
+
+def pytest_runtest_logreport(report):
+    """``SGC_TEST_CLOCK=1``: wall-clock offset of every test's end (where does a slow suite spend its time - tests/README)."""
+    global _T0
+    if os.environ.get("SGC_TEST_CLOCK") != "1" or report.when != "call":
+        return
+    import time
+    if _T0 is None:
+        _T0 = time.time() - report.duration
+    print("\n[clock] %7.1f s  %6.1f s  %s" % (time.time() - _T0, report.duration, report.nodeid), flush=True)
+
+
 def pytest_sessionfinish(session, exitstatus):
     if "tests.oracle_pool" in sys.modules:
         sys.modules["tests.oracle_pool"].shutdown()

@@ -10,7 +10,19 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, q):
+def _detection_shaped_batch(cfg, rank):
+    """BASELINE.json configs[3] per rank: 8 images, ragged object lists of detector size (12-30 objects), FLOAT boxes as the SGDET
+    front-end produces them (``evaluate.py:332``: x0, x1, y0, y1 on the grid, truncated by ``int()`` when the masks are built)."""
+    from scene_graph_commonsense_amd.synthetic import hash_uniform, make_scene_batch
+    nobj = [18 + rank, 25, 12, 30 - rank, 22, 16, 27, 20]
+    batch = make_scene_batch(cfg, nobj, seed=300 + rank, connect_frac=0.05)
+    for k, b in enumerate(batch.bbox):
+        jit = torch.from_numpy(hash_uniform(977 * rank + k, b.numel(), 0.0, 0.95).reshape(b.shape))
+        batch.bbox[k] = torch.minimum(b.float() + jit, torch.tensor(32.0))
+    return batch
+
+
+def _worker(rank, world, port, q, shape="small"):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
     from scene_graph_commonsense_amd import distributed as D
@@ -23,8 +35,8 @@ def _worker(rank, world, port, q):
     model = BayesianRelationClassifier(cfg.args()).cuda()
     model.load_state_dict(make_state_dict(cfg, seed=5, head_gain=4.0))
     model.eval()
-    batch = make_scene_batch(cfg, (3, 2), seed=100 + rank, connect_frac=0.6)      # every rank its own images
-    train_minibatch(model, batch)                                                 # local gradients
+    batch = make_scene_batch(cfg, (3, 2), seed=100 + rank, connect_frac=0.6) if shape == "small" else _detection_shaped_batch(cfg, rank)
+    train_minibatch(model, batch)                                                 # local gradients (every rank its own images)
     local = {n: p.grad.clone() for n, p in model.named_parameters()}
     model.zero_grad(set_to_none=True)
     train_minibatch(model, batch, reducer=D.GradReducer(world))                   # reduced gradients
@@ -47,7 +59,10 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_ranks_mean_gradients_on_one_gpu():
+@pytest.mark.parametrize("shape", ["small", "configs3_sgdet_8_images_per_rank"])
+def test_two_ranks_mean_gradients_on_one_gpu(shape):
+    """``configs3...``: BASELINE.json configs[3]'s shape per rank (8 images of detector-sized ragged object lists with float boxes,
+    gradients reduced across the ranks) - two of its eight ranks, sharing this box's one GPU over gloo."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -55,7 +70,7 @@ def test_two_ranks_mean_gradients_on_one_gpu():
     with socket.socket() as sk:                       # a port the OS knows to be free right now
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, shape)) for r in range(2)]
     [p.start() for p in procs]
     res = sorted(q.get(timeout=600) for _ in range(2))
     [p.join(120) for p in procs]
