@@ -244,13 +244,21 @@ def run_pair_loop(sd: Dict[str, Tensor], batch, cfg, mode: str = "eval", evaluat
                   weights: Optional[Tensor] = None, lambda_connectivity: float = 0.1,
                   lambda_not_connected: float = 1.0, overlap_filtering: Optional[bool] = None,
                   max_steps: Optional[int] = None, step_filter=None, image_feature_aug: Optional[Tensor] = None,
-                  lambda_contrast: float = 1.0, commonsense=None, lambda_commonsense: float = 1.0, call_hook=None):
+                  lambda_contrast: float = 1.0, commonsense=None, lambda_commonsense: float = 1.0, call_hook=None,
+                  step_loss_hook=None):
     """The reference's nested (graph_iter, edge_iter) x 2-direction loop.
 
     ``call_hook(t, b)`` (tests only): for the t-th classifier call (0-based, direction-steps in loop order, b rows) returns a
     dict with any of ``drop1`` [b,4096] / ``drop2`` [b,512] (dropout masks of ``model.py:120-121,149,175`` injected instead
     of drawn - how the training-mode device path is compared), ``routes`` (see ``conv_trunk``) and ``routes_aug`` (the same for
     the augmented view of the contrastive branch; only the rows of connected pairs matter).
+
+    ``step_loss_hook(k, own)`` (tests only, memory): instead of the literal running sums - ``losses += run_rel + lambda_c * run_conn``
+    after every direction-step, which keeps the autograd graph of EVERY call alive until the final ``backward()`` (17 GB for 128 calls
+    of b = 8) - the k-th direction-step's OWN loss ``own = lr_ + lambda_c * lc_ (+ lambda_cs * cs_)`` is handed to the caller, who
+    weights it by the number of running-sum additions it takes part in (T - k for T direction-steps in all) and back-propagates it at
+    once.  The same total and the same gradients (``tests/test_oracle_golden.py`` holds the two forms against each other); ``losses``
+    is then None.
 
     mode 'eval' mirrors ``testing()`` (overlap filter on, steps with no overlapping image skipped),
     mode 'train' mirrors ``training()`` (iou_mask all ones, loss with the running-sum quirk; dropout
@@ -327,11 +335,15 @@ def run_pair_loop(sd: Dict[str, Tensor], batch, cfg, mode: str = "eval", evaluat
                 if mode == "train":
                     lr_, lc_, connected, _ = direction_step_loss(relation, sup, conn, rel_row, dir_row, first, weights, ng,
                                                                  npos, hier, lambda_not_connected)
-                    run_rel = run_rel + lr_
-                    run_conn = run_conn + lc_
-                    if commonsense is not None:
-                        run_cs = run_cs + commonsense_step_loss(relation, cs, co, commonsense[0], commonsense[1], ng, npos, hier)
-                    losses = losses + run_rel + lambda_connectivity * run_conn + lambda_commonsense * run_cs
+                    cs_ = commonsense_step_loss(relation, cs, co, commonsense[0], commonsense[1], ng, npos, hier) if commonsense is not None else 0.0
+                    if step_loss_hook is not None:
+                        step_loss_hook(len(records), lr_ + lambda_connectivity * lc_ + lambda_commonsense * cs_)
+                    else:
+                        run_rel = run_rel + lr_
+                        run_conn = run_conn + lc_
+                        if commonsense is not None:
+                            run_cs = run_cs + cs_
+                        losses = losses + run_rel + lambda_connectivity * run_conn + lambda_commonsense * run_cs
                     if contrast and len(connected) > 0:
                         hsa, hoa = (h_graph_aug, h_edge_aug) if first else (h_edge_aug, h_graph_aug)
                         ra = inj.get("routes_aug")          # test hook: the device's routing of the augmented trunk (rows of this call)
@@ -361,7 +373,7 @@ def run_pair_loop(sd: Dict[str, Tensor], batch, cfg, mode: str = "eval", evaluat
         temp = supcon_hierar_loss(feats, labs)
         loss_contrast = 0.0 if torch.isnan(temp) else lambda_contrast * temp
         losses = losses + lambda_contrast * loss_contrast          # lambda applied twice, as in train_test.py:270-273
-    return dict(records=records, losses=losses if mode == "train" else None, loss_contrast=loss_contrast)
+    return dict(records=records, losses=losses if (mode == "train" and step_loss_hook is None) else None, loss_contrast=loss_contrast)
 
 
 # --------------------------------------------------------------------------- SGDET (predicted objects)

@@ -38,15 +38,24 @@ def _sampled(spec, out_dir):
 
     backward = spec.get("backward", True)
     sdr = {k: v.clone().requires_grad_(backward) for k, v in sd.items()}
+    T = 2 * len(steps)                                   # direction-steps of the restricted loop
+    total = [0.0]
+
+    def own_loss(k, own):
+        # the running-sum quirk gives direction-step k the weight T - k; back-propagated at once, so that one call's graph is alive
+        # at a time (oracle.run_pair_loop: step_loss_hook)
+        if backward:
+            ((T - k) * own).backward()
+        total[0] += (T - k) * float(own.detach())
+
     t0 = time.time()
     with torch.set_grad_enabled(backward):
         ref = O.run_pair_loop(sdr, batch, cfg, mode="train", weights=O.class_weights(predicate_counts(cfg)),
-                              step_filter=lambda g, e: (g, e) in steps, call_hook=hook)
+                              step_filter=lambda g, e: (g, e) in steps, call_hook=hook, step_loss_hook=own_loss)
+    assert len(ref["records"]) == T
     t_fwd = time.time() - t0
-    grads = None
-    if backward:
-        ref["losses"].backward()
-        grads = {k: p.grad for k, p in sdr.items()}
+    grads = {k: p.grad for k, p in sdr.items()} if backward else None
+    ref["losses"] = torch.tensor(total[0])
     recs = [{k: r[k] for k in ("g", "e", "first", "keep", "relation", "super_relation", "connectivity", "hidden")} for r in ref["records"]]
     torch.save(dict(records=recs, loss=float(ref["losses"].detach()), grads=grads, seconds=(t_fwd, time.time() - t0),
                     threads=torch.get_num_threads()), os.path.join(out_dir, "out.pt.tmp"))
@@ -83,7 +92,9 @@ def _trajectory(spec, out_dir):
         out["losses"].backward()
         opt.step()
         losses.append(float(out["losses"].detach()))
+        # big tensors (fc1.weight: 1.07 GB in f32) travel as bf16: a cosine / norm check does not see 2^-9 of independent rounding
         upd = {n: (sdr[n].detach() - before[n]) for n in names}
+        upd = {n: (u.to(torch.bfloat16) if u.numel() > (1 << 22) else u) for n, u in upd.items()}
         tmp = os.path.join(out_dir, "step_%d.pt.tmp" % k)
         torch.save(dict(loss=losses[-1], update=upd), tmp)
         os.replace(tmp, os.path.join(out_dir, "step_%d.pt" % k))

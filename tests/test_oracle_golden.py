@@ -200,3 +200,35 @@ def test_oracle_bayes_head_and_aug_forward_match_reference_boundary_golden():
             hs = torch.cat((feat * gm, batch.image_depth * gm), dim=1); ho = torch.cat((feat * em, batch.image_depth * em), dim=1)
             out = O.classifier_forward(sdm, hs, ho, cs, co, ss, so)
             np.testing.assert_allclose(out[5].numpy(), gold[key], rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("with_cs", [False, True])
+def test_streamed_step_losses_equal_the_literal_running_sums(with_cs):
+    """``run_pair_loop(step_loss_hook=...)`` (one call's autograd graph alive at a time: what the full-size sampled-step jobs of
+    ``tests/oracle_worker.py`` use) against the literal running-sum form pinned to the reference above: same loss, same gradients."""
+    import os
+    from tests.golden_cases import GOLDEN
+    cfg, sd, batch, _ = load_case("vg_small")
+    kw = {}
+    if with_cs:
+        fx = os.path.join(GOLDEN, "ref_fixtures") + os.sep
+        kw["commonsense"] = (torch.load(fx + "commonsense_aligned_triplets.pt"), torch.load(fx + "commonsense_violated_triplets.pt"))
+    keep = lambda g, e: (g + e) % 3 != 1                                    # a restricted loop, as the sampled-step jobs run it
+    w = O.class_weights(predicate_counts(cfg))
+    a = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    lit = O.run_pair_loop(a, batch, cfg, mode="train", weights=w, step_filter=keep, **kw)
+    lit["losses"].backward()
+    T = len(lit["records"])
+    b = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    total = [0.0]
+
+    def own(k, loss):
+        ((T - k) * loss).backward()
+        total[0] += (T - k) * float(loss.detach())
+
+    out = O.run_pair_loop(b, batch, cfg, mode="train", weights=w, step_filter=keep, step_loss_hook=own, **kw)
+    assert out["losses"] is None and len(out["records"]) == T
+    np.testing.assert_allclose(total[0], float(lit["losses"]), rtol=1e-5)
+    for k in a:
+        ga, gb = a[k].grad, b[k].grad
+        assert float((ga - gb).norm()) <= 2e-5 * max(float(ga.norm()), 1e-12), k
