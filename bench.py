@@ -216,7 +216,7 @@ def cpu_baseline(cfg, sd, reps=5, steps_per_rep=16, threads=None):
     prev = torch.get_num_threads()
     torch.set_num_threads(int(threads))
     try:
-        batch = make_scene_batch(cfg, [6] * 8, seed=123, connect_frac=0.3)
+        batch = make_scene_batch(cfg, [7] * 8, seed=123, connect_frac=0.3)      # 21 (g, e) steps: room for 16 per timing
         w = O.class_weights(predicate_counts(cfg))
         sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
 

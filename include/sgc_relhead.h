@@ -291,6 +291,21 @@ int sgc_scene_tables(const int* n_per_img, const int* img_ptr, const int* goff, 
                      const int* rel_tri, const float* dir_tri, int* sub_idx, int* obj_idx, int* step, int* image, int* directed,
                      int* raw, int* pid, int* obj_ptr, int* sub_list, int* obj_list, int* obj_img, int* step_ptr, void* stream);
 
+/* Stable bucket placement of a window list - the row plan of conv3 / fc1 over shared windows (no reference counterpart: the reference
+ * computes every window of every pair, model.py:145-148).  codes[e] = pair*64 + window in pair order; key = window (img_key 0) or
+ * obj_img[sub_idx[pair]]*64 + window (img_key 1).  mode 0: out[e] = base[key] + (number of earlier entries with that key);
+ * mode 1: out = the entry indices ordered by key, stable, and seg [n_keys+1] = first position of every key.  Equals a stable sort by
+ * key, bit for bit, without one. */
+int sgc_bucket_place(const int* codes, int n, const int* sub_idx, const int* obj_img, int img_key, int n_keys, const int* base, int* out,
+                     int* seg, int mode, void* stream);
+
+/* Rows of the other entries of the window list in the window-major row space: the per-object entries (codes = (P + pseudo-pair)*64 +
+ * window: dest = goff[window] + pseudo-pair) and the entries of the CONV list (pairs that convolve their own windows; incl_* = inclusive
+ * entry counts over the pair index space of the two lists): dest_conv[e] = dest_all[e - first_conv(pair) + first_all(pair)]. */
+int sgc_window_rows_objects(const int* codes, int n, const int* goff, int n_pairs, int* dest, void* stream);
+int sgc_window_rows_conv(const int* codes_conv, int n, const int* incl_conv, const int* incl_all, const int* dest_all, int* dest_conv,
+                         void* stream);
+
 /* Per-pair loss coefficients (train_utils.py:64-94,116-157; the running sums of train_test.py:219-258 give step t the weight T-t):
  * loss_i = -a*super[st] - b*rel[t] + c*BCE(conn, y); one thread per direction-step, double arithmetic in pair order.
  * class_weight [R] f32 (train_test.py:104-105); hier = 0: one class-weighted cross entropy (model.py:37-102 variant). */

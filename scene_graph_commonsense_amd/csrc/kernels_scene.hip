@@ -233,6 +233,92 @@ __global__ __launch_bounds__(256) void fill_zero_kernel(uint4* __restrict__ p, l
 }
 
 // ------------------------------------------------------------------------------------------------ C ABI
+// ---- stable bucket placement of a window list (the row plan of conv3 / fc1 over shared windows, csrc/kernels_shared.hip) ----------
+// codes[e] = pair*64 + window (list order = pair order).  key(e) = window (img_key = 0) or image(pair)*64 + window (img_key = 1:
+// image = obj_img[sub_idx[pair]]).  One workgroup per key scans the list with ballots: rank_k(e) = number of earlier entries with
+// the same key - what a stable sort by key gives, without the sort (torch.sort + searchsorted + gathers were a dozen small launches
+// per step).  mode 0: out[e] = base[key] + rank (destination row of every entry, window-major row space);
+// mode 1: out[start_k + rank] = e and seg[k] = start_k = number of entries with a smaller key (seg[n_keys] = n): the list ordered by
+// key, stable.  No atomics; every output is written exactly once.
+__global__ __launch_bounds__(1024) void bucket_place_kernel(const int* __restrict__ codes, int n, const int* __restrict__ sub_idx,
+                                                            const int* __restrict__ obj_img, int img_key, int n_keys,
+                                                            const int* __restrict__ base, int* __restrict__ out, int* __restrict__ seg, int mode) {
+    __shared__ int wave_tot[4][16];
+    __shared__ int s_less;
+    const int k = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    auto key_of = [&](int e) {
+        const int c = codes[e];
+        return img_key ? obj_img[sub_idx[c >> 6]] * 64 + (c & 63) : (c & 63);
+    };
+    int start = 0;
+    if (mode == 1) {                      // entries with a smaller key: a first pass over the list
+        int less = 0;
+        for (int e = tid; e < n; e += 1024) less += key_of(e) < k ? 1 : 0;
+        for (int o = 32; o > 0; o >>= 1) less += __shfl_down(less, o, 64);
+        if (tid == 0) s_less = 0;
+        __syncthreads();
+        if (lane == 0 && less) atomicAdd(&s_less, less);          // integer LDS atomics: order-independent
+        __syncthreads();
+        start = s_less;
+        if (tid == 0) {
+            seg[k] = start;
+            if (k == n_keys - 1) seg[n_keys] = n;
+        }
+    } else {
+        start = base[k];
+    }
+    int running = 0;
+    for (int it = 0; it < n; it += 4096) {
+        unsigned long long bal[4];
+        bool m[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int e = it + j * 1024 + tid;
+            m[j] = e < n && key_of(e) == k;
+            bal[j] = __ballot(m[j]);
+            if (lane == 0) wave_tot[j][wid] = __popcll(bal[j]);
+        }
+        __syncthreads();
+        int before = running;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int off = 0, tot = 0;
+#pragma unroll
+            for (int w = 0; w < 16; ++w) {
+                const int t = wave_tot[j][w];
+                off += w < wid ? t : 0;
+                tot += t;
+            }
+            if (m[j]) {
+                const int rank = before + off + __popcll(bal[j] & ((1ull << lane) - 1ull));
+                const int e = it + j * 1024 + tid;
+                if (mode == 0) out[e] = start + rank; else out[start + rank] = e;
+            }
+            before += tot;
+        }
+        running = before;
+        __syncthreads();
+    }
+}
+
+// dest[i] = goff[code & 63] + (code >> 6) - P for the per-object entries of the window list (a pseudo-pair's own windows ARE per-object rows)
+__global__ void window_rows_objects_kernel(const int* __restrict__ codes, int n, const int* __restrict__ goff, int P, int* __restrict__ dest) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int c = codes[i];
+    dest[i] = goff[c & 63] + (c >> 6) - P;
+}
+// rows of the CONV list (pairs that convolve their own windows + per-object entries): the same (pair, window) sits at
+// first(pair, all) + its rank inside the pair's rectangle in the list of ALL X windows
+__global__ void window_rows_conv_kernel(const int* __restrict__ codes_conv, int n, const int* __restrict__ incl_conv, const int* __restrict__ incl_all,
+                                        const int* __restrict__ dest_all, int* __restrict__ dest_conv) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const int pair = codes_conv[e] >> 6;
+    const int fc = pair ? incl_conv[pair - 1] : 0, fa = pair ? incl_all[pair - 1] : 0;
+    dest_conv[e] = dest_all[e - fc + fa];
+}
+
 extern "C" {
 
 int sgc_fill_zero(void* ptr, long nbytes, void* stream) {
@@ -311,6 +397,32 @@ int sgc_slab_sum_ld(const float* in, float* out, int rows, int cols, long ld_out
     const long n = (long)rows * cols;
     const long blocks = (n + 255) / 256 < 65536 ? (n + 255) / 256 : 65536;
     SGC_LAUNCH(slab_sum_ld_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, in, out, rows, cols, ld_out, slabs);
+    SGC_CHECK_LAUNCH();
+    return SGC_OK;
+}
+
+int sgc_bucket_place(const int* codes, int n, const int* sub_idx, const int* obj_img, int img_key, int n_keys, const int* base, int* out,
+                     int* seg, int mode, void* stream) {
+    if (n_keys <= 0 || (mode != 0 && mode != 1) || (mode == 0 && base == nullptr) || (mode == 1 && seg == nullptr)) return SGC_ERR_ARG;
+    if (img_key && (sub_idx == nullptr || obj_img == nullptr)) return SGC_ERR_ARG;
+    SGC_LAUNCH(bucket_place_kernel, dim3(n_keys), dim3(1024), 0, (hipStream_t)stream, codes, n < 0 ? 0 : n, sub_idx, obj_img, img_key, n_keys, base,
+               out, seg, mode);
+    SGC_CHECK_LAUNCH();
+    return SGC_OK;
+}
+
+int sgc_window_rows_objects(const int* codes, int n, const int* goff, int n_pairs, int* dest, void* stream) {
+    if (n <= 0) return SGC_OK;
+    SGC_LAUNCH(window_rows_objects_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, codes, n, goff, n_pairs, dest);
+    SGC_CHECK_LAUNCH();
+    return SGC_OK;
+}
+
+int sgc_window_rows_conv(const int* codes_conv, int n, const int* incl_conv, const int* incl_all, const int* dest_all, int* dest_conv,
+                         void* stream) {
+    if (n <= 0) return SGC_OK;
+    SGC_LAUNCH(window_rows_conv_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, codes_conv, n, incl_conv, incl_all, dest_all,
+               dest_conv);
     SGC_CHECK_LAUNCH();
     return SGC_OK;
 }

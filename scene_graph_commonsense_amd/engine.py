@@ -176,6 +176,7 @@ class Tuning:
     shared_conv2: bool = True         # conv2 halves computed on the objects' own regions, the rest copied from the image's background half
     patch_dgrad: bool = True          # conv3 data gradient over the listed windows in patch form (20 rows per window; off: 36 columns + col2im)
     patch_wgrad: bool = True          # conv3 weight gradient over the listed windows from 4 x 4 patches (16 rows per window; off: im2col, 36)
+    plan_kernels: bool = True         # row plan of the shared windows by placement kernels (off: torch.sort / searchsorted / gathers, rounds 2-3)
 
     @classmethod
     def from_env(cls):
@@ -585,12 +586,20 @@ class RelHeadEngine:
                                                      2, self._st()), "sgc_shared_windows_fill_class")
         for inc, ga in ((incl_all, gather_all), (incl_c, gather_c)):
             _lib.check(lib.sgc_shared_objects_fill(_lib.ptr(bbox), n_obj, P, _lib.ptr(inc), _lib.ptr(ga), self._st()), "sgc_shared_objects_fill")
-        # the linear windows sorted by (image, window) for the background side of the backward (stable: sums in list order)
-        code_l = gather_l[:e_lin].long()
-        keys = obj_img.long()[sub_idx.long()[code_l >> 6]] * 64 + (code_l & 63)
-        skeys, order = torch.sort(keys, stable=True)
-        seg = torch.searchsorted(skeys, torch.arange(64 * n_img + 1, device=dev)).to(torch.int32)
-        lin = dict(gather=gather_l, n=incl_l[P - 1:P].contiguous(), max=e_lin, order=order.to(torch.int32).contiguous(), seg=seg.contiguous(),
+        # the linear windows ordered by (image, window) for the background side of the backward (stable: sums in list order):
+        # one placement kernel instead of sort + searchsorted + gathers (sgc_bucket_place, bit-identical: tests/test_scene_gpu.py)
+        if TUNING.plan_kernels:
+            order = own.get("xw_lin_order", e_lin + 64, torch.int32)
+            seg = own.get("xw_lin_seg", 64 * n_img + 1, torch.int32)
+            _lib.check(lib.sgc_bucket_place(_lib.ptr(gather_l), e_lin, _lib.ptr(sub_idx), _lib.ptr(obj_img), 1, 64 * n_img, None, _lib.ptr(order),
+                                            _lib.ptr(seg), 1, self._st()), "sgc_bucket_place")
+        else:
+            code_l = gather_l[:e_lin].long()
+            keys = obj_img.long()[sub_idx.long()[code_l >> 6]] * 64 + (code_l & 63)
+            skeys, order = torch.sort(keys, stable=True)
+            seg = torch.searchsorted(skeys, torch.arange(64 * n_img + 1, device=dev)).to(torch.int32).contiguous()
+            order = order.to(torch.int32).contiguous()
+        lin = dict(gather=gather_l, n=incl_l[P - 1:P].contiguous(), max=e_lin, order=order, seg=seg,
                    drow=own.get("xw_lin_drow", e_lin + 64, torch.int32))
         self._xw = (gather_all, incl_all[:P])
         self._xw_total = incl_c[Pt - 1:]
@@ -614,31 +623,49 @@ class RelHeadEngine:
             counts = torch.bincount((gather[:E] & 63).long(), minlength=64).cpu().numpy()
         E = int(np.asarray(counts).sum())
         goff, tile_group = window_major_layout(counts, n2)
-        cex = np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(np.int64)
-        goff_d = torch.from_numpy(goff).to(dev)
-        keys = (gather[:E] & 63).long()
-        skeys, order = torch.sort(keys, stable=True)
-        base = torch.from_numpy(goff[:64].astype(np.int64) + n2 - cex).to(dev)
+        # ONE host-to-device copy for the four small tables: group offsets, first X row of every group, group ends, tile -> group
+        gend_h = (goff[:64].astype(np.int64) + n2 + np.asarray(counts, dtype=np.int64)).astype(np.int32)
+        tables = np.concatenate([goff.astype(np.int32), np.zeros(3, dtype=np.int32), (goff[:64].astype(np.int64) + n2).astype(np.int32), gend_h,
+                                 np.asarray(tile_group, dtype=np.int32)])          # 68 + 64 + 64 + tiles: every table 16-byte aligned
+        tab_d = torch.from_numpy(tables).to(dev)
+        goff_d, xbase, gend, tile_group_d = tab_d[:65], tab_d[68:132], tab_d[132:196], tab_d[196:]
         Et = E
         if split:
             Et = plan["entries_all"]
         elif plan.get("objects"):
             Et = plan["entries"] if plan["entries"] is not None else int(plan["n_total"][0])
         dest = torch.empty(max(Et, 1), dtype=torch.int32, device=dev)
-        dest[order] = (base[skeys] + torch.arange(E, device=dev)).int()
-        if Et > E:                                   # the pseudo-pairs' own windows: row goff[w] + ps
+        # row of X entry e = first X row of its window's group + its rank among that window's entries in list order (what a stable sort
+        # by window gives; sgc_bucket_place computes the ranks directly)
+        kern = TUNING.plan_kernels
+        if E > 0 and kern:
+            _lib.check(self.lib.sgc_bucket_place(_lib.ptr(gather), E, None, None, 0, 64, _lib.ptr(xbase), _lib.ptr(dest), None, 0, self._st()),
+                       "sgc_bucket_place")
+        elif E > 0:
+            cex = np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(np.int64)
+            skeys, order = torch.sort((gather[:E] & 63).long(), stable=True)
+            base = torch.from_numpy(goff[:64].astype(np.int64) + n2 - cex).to(dev)
+            dest[order] = (base[skeys] + torch.arange(E, device=dev)).int()
+        if Et > E and kern:                          # the pseudo-pairs' own windows: row goff[w] + ps
+            _lib.check(self.lib.sgc_window_rows_objects(_lib.ptr(gather[E:]), Et - E, _lib.ptr(goff_d), P, _lib.ptr(dest[E:]), self._st()),
+                       "sgc_window_rows_objects")
+        elif Et > E:
             code = gather[E:Et].long()
             dest[E:Et] = (goff_d[:64].long()[code & 63] + (code >> 6) - P).int()
-        gend = torch.from_numpy((goff[:64].astype(np.int64) + n2 + np.asarray(counts, dtype=np.int64)).astype(np.int32)).to(dev)
         dest_conv = dest
         if split:
             # destination of every entry of the CONV list: the same (pair, window) sits at  first(pair, all) + its rank in the pair's
             # rectangle  in the list of all X windows (a pair is in the conv list with all of its windows or with none)
             Ec = plan["entries"]
-            pair_k = (plan["gather"][:Ec] >> 6).long()
-            first = lambda inc: torch.cat([inc.new_zeros(1), inc[:-1]]).long()
-            dest_conv = dest[torch.arange(Ec, device=dev) - first(plan["incl"])[pair_k] + first(plan["incl_all"])[pair_k]].contiguous()
-        return dict(goff=goff_d, goff_host=goff, gend=gend, tile_group=torch.from_numpy(tile_group).to(dev), dest=dest, dest_conv=dest_conv,
+            if kern:
+                dest_conv = torch.empty(max(Ec, 1), dtype=torch.int32, device=dev)
+                _lib.check(self.lib.sgc_window_rows_conv(_lib.ptr(plan["gather"]), Ec, _lib.ptr(plan["incl"]), _lib.ptr(plan["incl_all"]),
+                                                         _lib.ptr(dest), _lib.ptr(dest_conv), self._st()), "sgc_window_rows_conv")
+            else:
+                pair_k = (plan["gather"][:Ec] >> 6).long()
+                first = lambda inc: torch.cat([inc.new_zeros(1), inc[:-1]]).long()
+                dest_conv = dest[torch.arange(Ec, device=dev) - first(plan["incl"])[pair_k] + first(plan["incl_all"])[pair_k]].contiguous()
+        return dict(goff=goff_d, goff_host=goff, gend=gend, tile_group=tile_group_d, dest=dest, dest_conv=dest_conv,
                     rows=int(goff[64]), E=E, E_total=Et, n2=n2)
 
     def fc1_shared(self, wm, ywm, bbox, sub_idx, obj_idx, incl, P, n_obj, h1, dropout, seed):

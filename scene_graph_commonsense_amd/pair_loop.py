@@ -318,7 +318,10 @@ def train_minibatch(model, batch, optimizer=None, reducer=None, scene: Optional[
         optimizer.zero_grad(set_to_none=True)
     lanes = int(streams if streams is not None else getattr(model, "pipeline_streams", 1) or 1)
     chunk_free = loss_kw.get("image_feature_aug") is None and loss_kw.get("commonsense") is None
-    groups = plan_image_groups(cfg, batch, True, _budget(model, workspace_budget))
+    budget = _budget(model, workspace_budget)
+    if loss_kw.get("image_feature_aug") is not None:
+        budget *= 0.85          # the augmented view's trunk for the connected pairs lives in a second engine's workspace
+    groups = plan_image_groups(cfg, batch, True, budget)
     if len(groups) == 1 and lanes > 1 and chunk_free:
         groups = split_balanced([int(b.shape[0]) for b in batch.bbox], lanes)
     model.last_image_groups = groups

@@ -173,3 +173,65 @@ def test_scene_edited_after_flattening_is_detected():
     model.training_step(sc, batch.relationships, batch.subj_or_obj)
     with pytest.raises(RuntimeError, match="flatten_scene"):
         model.engine().verify_checks(block=True)
+
+
+@pytest.mark.parametrize("n,n_img", [(1, 1), (4097, 2), (50000, 8), (237268, 8)])
+def test_bucket_placement_equals_a_stable_sort(n, n_img):
+    """``sgc_bucket_place`` (the row plan of conv3 / fc1 over shared windows: ranks among equal keys in list order) against
+    ``torch.sort(stable=True)`` + ``searchsorted``, both modes, bit for bit."""
+    import ctypes
+    from scene_graph_commonsense_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(n)
+    n_obj, P = 16 * n_img, 3000 * n_img
+    obj_img = torch.sort(torch.randint(0, n_img, (n_obj,), generator=g))[0].int().cuda()
+    sub_idx = torch.randint(0, n_obj, (P,), generator=g).int().cuda()
+    pair = torch.sort(torch.randint(0, P, (n,), generator=g))[0]
+    codes = (pair * 64 + torch.randint(0, 64, (n,), generator=g)).int().cuda()
+    # mode 0: destination = base[window] + rank among the window's entries
+    base = (torch.arange(64) * 1000003 % 999983).int().cuda()
+    out = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    _lib.check(lib.sgc_bucket_place(_lib.ptr(codes), n, None, None, 0, 64, _lib.ptr(base), _lib.ptr(out), None, 0, _lib.stream_ptr()), "sgc_bucket_place")
+    keys = (codes & 63).long()
+    skeys, order = torch.sort(keys, stable=True)
+    first = torch.searchsorted(skeys, torch.arange(64, device="cuda"))
+    ref = torch.empty(n, dtype=torch.int64, device="cuda")
+    ref[order] = base.long()[skeys] + torch.arange(n, device="cuda") - first[skeys]
+    assert torch.equal(out.long(), ref)
+    # mode 1: entries ordered by (image of the pair's subject, window), stable, + segment starts
+    nk = 64 * n_img
+    order1 = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    seg = torch.full((nk + 1,), -1, dtype=torch.int32, device="cuda")
+    _lib.check(lib.sgc_bucket_place(_lib.ptr(codes), n, _lib.ptr(sub_idx), _lib.ptr(obj_img), 1, nk, None, _lib.ptr(order1), _lib.ptr(seg), 1,
+                                    _lib.stream_ptr()), "sgc_bucket_place")
+    keys1 = obj_img.long()[sub_idx.long()[codes.long() >> 6]] * 64 + (codes.long() & 63)
+    sk, ord_ref = torch.sort(keys1, stable=True)
+    seg_ref = torch.searchsorted(sk, torch.arange(nk + 1, device="cuda"))
+    assert torch.equal(order1.long(), ord_ref) and torch.equal(seg.long(), seg_ref)
+
+
+def test_row_plan_by_kernels_equals_the_torch_form_at_benchmark_size():
+    """The window-major row plan of an 8 x 64 scene (237 k pair-specific windows, linear pairs split off) built by the placement
+    kernels (``TUNING.plan_kernels``, the default) against the sort / searchsorted / gather form of rounds 2-3: every table bit for bit."""
+    from scene_graph_commonsense_amd.engine import RelHeadEngine, tuning
+    from scene_graph_commonsense_amd.model import _shared_hint
+    from scene_graph_commonsense_amd.pairs import flatten_scene
+    from scene_graph_commonsense_amd.synthetic import HeadConfig, make_scene_batch
+    cfg = HeadConfig()
+    batch = make_scene_batch(cfg, [64] * 8, seed=1000, connect_frac=0.02)
+    sc = flatten_scene(cfg, batch, "cuda:0")
+    eng = RelHeadEngine(cfg, "cuda:0")
+    P, n_obj, n_img = sc.n_pairs, int(sc.obj_img.shape[0]), 8
+    got = {}
+    for kern in (True, False):
+        with tuning(plan_kernels=kern):
+            plan = eng.shared_plan(sc.bbox, sc.sub_idx, sc.obj_idx, P, _shared_hint(sc), keep=True, n_obj=n_obj, n_img=n_img, objects=True,
+                                   obj_img=sc.obj_img)
+            assert "lin" in plan and plan["lin"]["max"] > 0
+            wm = eng.window_major_rows(plan, P, 2 * n_obj)
+            torch.cuda.synchronize()
+            got[kern] = dict(dest=wm["dest"][:wm["E_total"]].clone(), dest_conv=wm["dest_conv"][:plan["entries"]].clone(), goff=wm["goff"].clone(),
+                             gend=wm["gend"].clone(), tile_group=wm["tile_group"].clone(), order=plan["lin"]["order"][:plan["lin"]["max"]].clone(),
+                             seg=plan["lin"]["seg"].clone())
+    for k in got[True]:
+        assert torch.equal(got[True][k].long(), got[False][k].long()), k

@@ -30,6 +30,6 @@ rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_G
 python3 "$R/tools/pmc_summary.py" "$(find /tmp/prof_m -name '*counter_collection.csv' | head -1)" "$OUT/${TAG}_pmc_m.csv"
 # the bench line comes LAST and reads the counter passes just taken (roofline.traffic is derived from them): shipped defaults again
 unset SGC_BWD_STREAMS
-mkdir -p "$R/profiles" && cp "$OUT"/${TAG}_pmc_*.csv "$R/profiles/" 2>/dev/null
+mkdir -p "$R/profiles" && cp "$OUT"/${TAG}_pmc_*.csv "$OUT"/${TAG}_kernel_stats.csv "$R/profiles/" 2>/dev/null
 cd "$R" && python3 bench.py --steps 5 --warmup 2 2>/dev/null | tail -1 > "$OUT/${TAG}_bench.json"
 ls -la "$OUT"/${TAG}_*
