@@ -373,6 +373,16 @@ int sgc_convert_f16_bf16(const void* in, void* out, long n, void* stream);
  * convert(src[a*sa_s + b*sb_s + i*ss_i + j]) for a < na, b < nb, i,j < 64; out_kind 0 f16, 1 bf16, 2 f32. */
 int sgc_transpose_cast(const float* src, void* dst, int out_kind, int na, int nb, long sa_s, long sb_s, long ss_i, long sa_d,
                        long sb_d, long ds_j, void* stream);
+/* Weight layouts in one launch each (no reference counterpart: the reference's conv / linear ops read the f32 parameters directly;
+ * the 16-bit compute copies here are re-derived after every optimizer step).  dst[dst_off + sum i_k*dst_strides[k]] =
+ * cast(src[src_off + sum i_k*src_strides[k]]) over the ndim <= 5 dimensions dims (the last is the fastest; strides in elements, any
+ * sign - a flipped 3x3 kernel is stride -1 from offset 8); out_kind 0 f16, 1 bf16, 2 f32.  src / dst host arrays are read at call time. */
+int sgc_permute_cast(const float* src, void* dst, int out_kind, int ndim, const int* dims, const long* src_strides, const long* dst_strides,
+                     long src_off, long dst_off, void* stream);
+/* n_seg <= 48 [rows][cols] blocks of one source tensor (shared row / column strides), block s to dst_off[s] with row pitch dst_ld[s]
+ * from src_off[s]: the stacked tap matrices of the patch form of the conv3 data gradient (sgc_windows_dgrad_patches). */
+int sgc_segment_cast(const float* src, void* dst, int out_kind, int rows, int cols, long src_row_stride, long src_col_stride, int n_seg,
+                     const long* dst_off, const long* dst_ld, const long* src_off, void* stream);
 
 int sgc_fc2_dgrad(const void* dpre, const void* w2mT, const void* h1, void* dh1, int n_pairs, float drop_scale, void* stream);
 /* Weight gradients with a `splits` argument write split-K partial sums: slabs [*n_slabs][M][N] f32, reduced by sgc_slab_sum.

@@ -650,6 +650,57 @@ static int launch_head_bwd(const HeadBwdParams& hp, hipStream_t stream) {
     return SGC_OK;
 }
 
+// ---- weight layouts: strided gather + cast (f32 master -> one 16-bit compute copy per launch) ---------------------------------
+// dst element (i0..i4) of shape dims (row-major walk of the OUTPUT, so stores coalesce) at dst_off + sum i_k * dstride[k] gets
+// cast(src[src_off + sum i_k * sstride[k]]); strides in elements, any sign (a flipped 3x3 tap is stride -1 from offset 8).
+// Replaces the torch view / permute / flip / cat / cast chains that rebuilt the conv2 / conv3 / fc2 layouts after every optimizer
+// step (~55 small launches per step); the layouts themselves are unchanged (tests/test_gemm_gpu.py holds both forms bit for bit).
+struct PermuteCastParams {
+    const float* src; void* dst;
+    long src_off, dst_off, total;
+    int dims[5];
+    long sstride[5], dstride[5];
+};
+template <int KIND>   // 0 f16, 1 bf16, 2 f32
+__global__ void permute_cast_kernel(const PermuteCastParams p) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < p.total; i += (long)gridDim.x * blockDim.x) {
+        long r = i, so = p.src_off, d_o = p.dst_off;
+#pragma unroll
+        for (int k = 4; k >= 0; --k) {
+            const long q = r / p.dims[k];
+            const int idx = (int)(r - q * p.dims[k]);
+            r = q;
+            so += idx * p.sstride[k];
+            d_o += idx * p.dstride[k];
+        }
+        const float v = p.src[so];
+        if constexpr (KIND == 0) reinterpret_cast<u16*>(p.dst)[d_o] = f32_to_f16_bits(v);
+        else if constexpr (KIND == 1) reinterpret_cast<u16*>(p.dst)[d_o] = f32_to_bf16_bits(v);
+        else reinterpret_cast<float*>(p.dst)[d_o] = v;
+    }
+}
+// Up to 48 [rows][cols] blocks of ONE source tensor in one launch: block s goes to dst_off[s] with row pitch dst_ld[s] from
+// src_off[s] (row / column strides shared).  The patch form of the conv3 data gradient stacks 36 transposed tap matrices.
+struct SegmentCastParams {
+    const float* src; void* dst;
+    int rows, cols, n_seg;
+    long s_row, s_col;
+    long dst_off[48], dst_ld[48], src_off[48];
+};
+template <int KIND>
+__global__ void segment_cast_kernel(const SegmentCastParams p) {
+    const int s = blockIdx.y;
+    const long n = (long)p.rows * p.cols;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / p.cols), c = (int)(i - (long)r * p.cols);
+        const float v = p.src[p.src_off[s] + r * p.s_row + c * p.s_col];
+        const long d_o = p.dst_off[s] + r * p.dst_ld[s] + c;
+        if constexpr (KIND == 0) reinterpret_cast<u16*>(p.dst)[d_o] = f32_to_f16_bits(v);
+        else if constexpr (KIND == 1) reinterpret_cast<u16*>(p.dst)[d_o] = f32_to_bf16_bits(v);
+        else reinterpret_cast<float*>(p.dst)[d_o] = v;
+    }
+}
+
 extern "C" {
 
 int sgc_head_loss_bwd(const float* rel, const float* sup, const float* conn, const float* p, const int* tgt,
@@ -753,6 +804,42 @@ int sgc_transpose_cast(const float* src, void* dst, int out_kind, int na, int nb
     else if (out_kind == 1) SGC_LAUNCH(transpose_cast_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, src, dst, sa_s, sb_s, ss_i, sa_d, sb_d, ds_j);
     else if (out_kind == 2) SGC_LAUNCH(transpose_cast_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, src, dst, sa_s, sb_s, ss_i, sa_d, sb_d, ds_j);
     else return SGC_ERR_ARG;
+    SGC_CHECK_LAUNCH();
+    return SGC_OK;
+}
+
+int sgc_permute_cast(const float* src, void* dst, int out_kind, int ndim, const int* dims, const long* src_strides, const long* dst_strides,
+                     long src_off, long dst_off, void* stream) {
+    if (ndim < 1 || ndim > 5 || out_kind < 0 || out_kind > 2) return SGC_ERR_ARG;
+    PermuteCastParams p{};
+    p.src = src; p.dst = dst; p.src_off = src_off; p.dst_off = dst_off; p.total = 1;
+    for (int k = 0; k < 5; ++k) { p.dims[k] = 1; p.sstride[k] = 0; p.dstride[k] = 0; }
+    for (int k = 0; k < ndim; ++k) {                     // right-aligned: the last given dimension is the fastest
+        const int d = 5 - ndim + k;
+        if (dims[k] <= 0) return SGC_OK;
+        p.dims[d] = dims[k]; p.sstride[d] = src_strides[k]; p.dstride[d] = dst_strides[k];
+        p.total *= dims[k];
+    }
+    const long blocks = (p.total + 255) / 256 < 4096 ? (p.total + 255) / 256 : 4096;
+    if (out_kind == 0) SGC_LAUNCH(permute_cast_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+    else if (out_kind == 1) SGC_LAUNCH(permute_cast_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+    else SGC_LAUNCH(permute_cast_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+    SGC_CHECK_LAUNCH();
+    return SGC_OK;
+}
+
+int sgc_segment_cast(const float* src, void* dst, int out_kind, int rows, int cols, long src_row_stride, long src_col_stride, int n_seg,
+                     const long* dst_off, const long* dst_ld, const long* src_off, void* stream) {
+    if (n_seg < 0 || n_seg > 48 || out_kind < 0 || out_kind > 2) return SGC_ERR_ARG;
+    if (n_seg == 0 || rows <= 0 || cols <= 0) return SGC_OK;
+    SegmentCastParams p{};
+    p.src = src; p.dst = dst; p.rows = rows; p.cols = cols; p.n_seg = n_seg; p.s_row = src_row_stride; p.s_col = src_col_stride;
+    for (int s = 0; s < n_seg; ++s) { p.dst_off[s] = dst_off[s]; p.dst_ld[s] = dst_ld[s]; p.src_off[s] = src_off[s]; }
+    const long n = (long)rows * cols;
+    const unsigned bx = (unsigned)((n + 255) / 256 < 512 ? (n + 255) / 256 : 512);
+    if (out_kind == 0) SGC_LAUNCH(segment_cast_kernel<0>, dim3(bx, n_seg), dim3(256), 0, (hipStream_t)stream, p);
+    else if (out_kind == 1) SGC_LAUNCH(segment_cast_kernel<1>, dim3(bx, n_seg), dim3(256), 0, (hipStream_t)stream, p);
+    else SGC_LAUNCH(segment_cast_kernel<2>, dim3(bx, n_seg), dim3(256), 0, (hipStream_t)stream, p);
     SGC_CHECK_LAUNCH();
     return SGC_OK;
 }

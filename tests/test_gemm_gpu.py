@@ -284,3 +284,28 @@ def test_conv3_dgrad_with_fused_unpool_equals_materialised_unpool(P):
     else:
         err = (dz_a.float() - dz_b.float()).abs().max() / dz_a.float().abs().max()
         assert float(err) <= 1e-2                               # bf16 outputs of two accumulation orders: at most a rounding step apart
+
+
+@pytest.mark.parametrize("oiv6", [False, True])
+def test_weight_layouts_by_gather_kernels_equal_the_torch_chains(oiv6):
+    """Every 16-bit compute copy of the conv1 / conv2 / conv3 / fc2 weights built by ``sgc_permute_cast`` / ``sgc_segment_cast``
+    (``TUNING.weight_kernels``, the default: one launch per layout) against the torch view / permute / flip / cat / cast chains that
+    define the layouts (rounds 1-3), bit for bit - including the flipped-tap data-gradient forms and the stacked tap matrices of the
+    patch form."""
+    from scene_graph_commonsense_amd.engine import RelHeadEngine, tuning
+    from scene_graph_commonsense_amd.synthetic import HeadConfig, make_state_dict
+    cfg = HeadConfig(dataset="oiv6", num_classes=601, num_super_classes=0, num_geometric=4, num_possessive=2, num_semantic=24) if oiv6 else HeadConfig()
+    sd = {k: v.cuda() for k, v in make_state_dict(cfg, seed=17, head_gain=3.0).items()}
+    got = {}
+    for kern in (True, False):
+        eng = RelHeadEngine(cfg, "cuda:0")
+        with tuning(weight_kernels=kern):
+            eng.load_weights(sd)
+            eng.prep_bwd_weights(sd)
+        torch.cuda.synchronize()
+        got[kern] = {k: eng.w[k].clone() for k in ("w1r", "w2r", "w3r", "w2m", "w2mT", "wd3", "w3col", "w3patch", "wd2", "b1", "cst", "b2", "b3")}
+    for k, a in got[True].items():
+        b = got[False][k]
+        assert a.dtype == b.dtype and a.numel() == b.numel(), k
+        assert torch.equal(a.reshape(-1).view(torch.int16 if a.element_size() == 2 else torch.int32),
+                           b.reshape(-1).view(torch.int16 if b.element_size() == 2 else torch.int32)), k
