@@ -205,6 +205,7 @@ int sgc_windows_col2im_objects(const void* col, const int* bbox, int n_obj, int 
  *   sgc_fc1_products_pitch          row pitch of owm in floats (4096 + padding: a power-of-two pitch slows the product's stores)
  *   sgc_fc1_windows_gemm            owm [rows][pitch] f32 (columns 0..4095) = ywm [rows][1024] * (columns g*1024.. of w1p)^T, g = tile_group[row/256]
  *   sgc_fc1_integral                S [n_pseudo][9][9][4096] = 2-D inclusive prefix sums (zero border) of the pseudo rows of owm
+ *   sgc_fc1_own_rect_sums           own[j] = S'_j[R_j]: the rectangle term of the assembly that depends on one object only
  *   sgc_fc1_assemble                h1[p] = dropout(relu(b + S_i[all] - S_i[R_j] + S'_j[R_j] - S'_j[X_p] + sum_{e in X_p} owm[dest[e]])) */
 int sgc_conv3_relu_pool_wm(const void* z_pad, const void* w3r, const float* b3, const int* goff, void* ywm, unsigned char* argmax,
                            void* ywm_bf16, int n_pairs, void* stream);
@@ -213,9 +214,10 @@ int sgc_conv3_relu_pool_windows_wm(const void* z_pad, const void* w3r, const flo
 int sgc_fc1_products_pitch(void);
 int sgc_fc1_windows_gemm(const void* ywm, const void* w1p, const int* tile_group, float* owm, int rows, void* stream);
 int sgc_fc1_integral(const float* owm, const int* goff, int n_pseudo, float* S, void* stream);
+int sgc_fc1_own_rect_sums(const float* S, const int* bbox, int n_obj, float* own, void* stream);   /* own [n_obj][4096] = S'_j[R_j] */
 int sgc_fc1_assemble(const float* S, const float* owm, const int* bbox, const int* sub_idx, const int* obj_idx, const int* count_incl,
                      const int* dest, int n_obj, const float* bias, int drop_enable, unsigned drop_seed, void* h1, int n_pairs,
-                     void* stream);
+                     const float* own_rect_sums /* may be NULL: the four corner reads per pair */, void* stream);
 
 /* Backward of the shared fc1 (window-major rows; all bf16, f32 sums):
  *   sgc_fc1_gsum           pseudo rows of gwm [rows][4096]: row goff[w] + role*n_obj + o = sum of dh1 over the pairs of object o in that

@@ -178,6 +178,7 @@ class Tuning:
     patch_wgrad: bool = True          # conv3 weight gradient over the listed windows from 4 x 4 patches (16 rows per window; off: im2col, 36)
     plan_kernels: bool = True         # row plan of the shared windows by placement kernels (off: torch.sort / searchsorted / gathers, rounds 2-3)
     weight_kernels: bool = True       # 16-bit weight layouts by one gather + cast launch each (off: torch view / permute / flip / cat chains)
+    fc1_own_sums: bool = True         # fc1 assembly reads S'_j[R_j] pre-summed per object (off: four corner vectors per pair; same bits)
 
     @classmethod
     def from_env(cls):
@@ -715,9 +716,13 @@ class RelHeadEngine:
         S = sc.get("fc1_S", wm["n2"] * 81 * 4096, torch.float32)
         self._timed("fc1_fwd_integral", lambda: _lib.check(lib.sgc_fc1_integral(_lib.ptr(owm), _lib.ptr(wm["goff"]), wm["n2"], _lib.ptr(S), self._st()),
                                                            "sgc_fc1_integral"))
+        own = None
+        if TUNING.fc1_own_sums:            # S'_j[R_j] per object: read once per pair instead of four corners
+            own = sc.get("fc1_own", max(n_obj, 1) * 4096, torch.float32)
+            _lib.check(lib.sgc_fc1_own_rect_sums(_lib.ptr(S), _lib.ptr(bbox), n_obj, _lib.ptr(own), self._st()), "sgc_fc1_own_rect_sums")
         self._timed("fc1_fwd_assemble", lambda: _lib.check(lib.sgc_fc1_assemble(
             _lib.ptr(S), _lib.ptr(owm), _lib.ptr(bbox), _lib.ptr(sub_idx), _lib.ptr(obj_idx), _lib.ptr(incl), _lib.ptr(wm["dest"]), n_obj,
-            _lib.ptr(self.w["bf1"]), int(dropout), ctypes.c_uint(seed), _lib.ptr(h1), P, self._st()), "sgc_fc1_assemble"))
+            _lib.ptr(self.w["bf1"]), int(dropout), ctypes.c_uint(seed), _lib.ptr(h1), P, _lib.ptr(own), self._st()), "sgc_fc1_assemble"))
 
     def conv3_shared(self, plan, z, U, V, bbox, obj_img, sub_idx, obj_idx, P, y, am, y_bf, keep=None, wm=None):
         """conv3 + ReLU + pool with the per-object part computed once per object (``csrc/kernels_shared.hip``): U / V hold

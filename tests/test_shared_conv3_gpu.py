@@ -336,3 +336,27 @@ def test_conv2_halves_on_object_regions_equal_whole_maps_bitwise():
     torch.cuda.synchronize()
     for r in (0, 1):
         assert torch.equal(whole[r].view(torch.int16), parts[r].view(torch.int16)), r
+
+
+def test_fc1_assembly_with_presummed_own_rectangles_keeps_its_bits():
+    """``TUNING.fc1_own_sums`` (default): the rectangle term S'_j[R_j] of the fc1 assembly, which depends on one object only, is summed
+    once per object (``sgc_fc1_own_rect_sums``) and read as one vector per pair instead of four corner vectors - the same expression,
+    so every output of the fused pass is bit-identical to the four-corner form."""
+    from scene_graph_commonsense_amd.engine import tuning
+    from scene_graph_commonsense_amd.model import BayesianRelationClassifier
+    from scene_graph_commonsense_amd.pairs import flatten_scene
+    from scene_graph_commonsense_amd.synthetic import HeadConfig, make_scene_batch, make_state_dict
+    cfg = HeadConfig()
+    model = BayesianRelationClassifier(cfg.args()).cuda()
+    model.load_state_dict(make_state_dict(cfg, seed=5, head_gain=4.0))
+    model.eval()
+    batch = make_scene_batch(cfg, (24, 17, 9), seed=77, connect_frac=0.1, edge_boxes=True)
+    sc = flatten_scene(cfg, batch, "cuda:0")
+    outs = []
+    for on in (True, False):
+        with tuning(fc1_own_sums=on):
+            o = model.forward_pairs(sc)
+            torch.cuda.synchronize()
+            outs.append((o.relation.clone(), o.hidden.clone(), o.connectivity.clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
