@@ -301,6 +301,9 @@ int sgc_scene_tables(const int* n_per_img, const int* img_ptr, const int* goff, 
 int sgc_bucket_place(const int* codes, int n, const int* sub_idx, const int* obj_img, int img_key, int n_keys, const int* base, int* out,
                      int* seg, int mode, void* stream);
 
+/* out [rows][n] = inclusive prefix sums of every row of in (int32; in == out allowed): the entry counts of the window lists. */
+int sgc_scan_rows(const int* in, int* out, int rows, int n, void* stream);
+
 /* Rows of the other entries of the window list in the window-major row space: the per-object entries (codes = (P + pseudo-pair)*64 +
  * window: dest = goff[window] + pseudo-pair) and the entries of the CONV list (pairs that convolve their own windows; incl_* = inclusive
  * entry counts over the pair index space of the two lists): dest_conv[e] = dest_all[e - first_conv(pair) + first_all(pair)]. */

@@ -319,6 +319,43 @@ __global__ void window_rows_conv_kernel(const int* __restrict__ codes_conv, int 
     dest_conv[e] = dest_all[e - fc + fa];
 }
 
+// inclusive prefix sums of every row of an int32 [rows][n] matrix: one 1024-thread workgroup per row walks it in chunks of 4096
+// (torch.cumsum over 3 x 33 k counts took 77 us: its innermost-dim scan runs on a handful of workgroups)
+__global__ __launch_bounds__(1024) void scan_rows_kernel(const int* __restrict__ in, int* __restrict__ out, int n) {
+    __shared__ int wave_tot[16];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int* src = in + (long)blockIdx.x * n;
+    int* dst = out + (long)blockIdx.x * n;
+    int running = 0;
+    for (int base = 0; base < n; base += 4096) {
+        const int e = base + tid * 4;
+        int v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (e + j < n) ? src[e + j] : 0;
+        v[1] += v[0]; v[2] += v[1]; v[3] += v[2];
+        int s = v[3];                                     // inclusive scan of the threads' sums inside the wave
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(s, o, 64);
+            if (lane >= o) s += t;
+        }
+        if (lane == 63) wave_tot[wid] = s;
+        __syncthreads();
+        int off = running;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) off += w < wid ? wave_tot[w] : 0;
+        int total = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) total += wave_tot[w];
+        const int before = off + s - v[3];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (e + j < n) dst[e + j] = before + v[j];
+        running += total;
+        __syncthreads();
+    }
+}
+
 extern "C" {
 
 int sgc_fill_zero(void* ptr, long nbytes, void* stream) {
@@ -423,6 +460,13 @@ int sgc_window_rows_conv(const int* codes_conv, int n, const int* incl_conv, con
     if (n <= 0) return SGC_OK;
     SGC_LAUNCH(window_rows_conv_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, codes_conv, n, incl_conv, incl_all, dest_all,
                dest_conv);
+    SGC_CHECK_LAUNCH();
+    return SGC_OK;
+}
+
+int sgc_scan_rows(const int* in, int* out, int rows, int n, void* stream) {
+    if (rows <= 0 || n <= 0) return SGC_OK;
+    SGC_LAUNCH(scan_rows_kernel, dim3(rows), dim3(1024), 0, (hipStream_t)stream, in, out, n);
     SGC_CHECK_LAUNCH();
     return SGC_OK;
 }

@@ -604,8 +604,13 @@ class RelHeadEngine:
         _lib.check(lib.sgc_shared_objects_count(_lib.ptr(bbox), n_obj, _lib.ptr(cnt[0, P:]), _lib.ptr(pixrect[P:]), self._st()),
                    "sgc_shared_objects_count")
         cnt[1, P:P + n2] = cnt[0, P:P + n2]
-        incl = torch.cumsum(cnt, 1, dtype=torch.int32)                          # [3][Pt]: all / conv / linear
-        incl_all, incl_c, incl_l = incl[0].contiguous(), incl[1].contiguous(), incl[2].contiguous()
+        if TUNING.plan_kernels:
+            incl = own.get("xw_incl3", 3 * Pt, torch.int32).view(3, Pt)         # [3][Pt]: all / conv / linear
+            _lib.check(lib.sgc_scan_rows(_lib.ptr(cnt), _lib.ptr(incl), 3, Pt, self._st()), "sgc_scan_rows")
+            incl_all, incl_c, incl_l = incl[0], incl[1], incl[2]
+        else:
+            incl = torch.cumsum(cnt, 1, dtype=torch.int32)
+            incl_all, incl_c, incl_l = incl[0].contiguous(), incl[1].contiguous(), incl[2].contiguous()
         # the host's counts size every buffer and list below; they are TRUSTED (no read-back) but checked: the device's own counts of
         # the boxes / pair lists actually passed must equal them (a scene whose boxes were edited after ``flatten_scene`` would
         # otherwise misplace rows silently).  Looked at by ``verify_checks`` at the next forward.

@@ -232,6 +232,7 @@ def test_row_plan_by_kernels_equals_the_torch_form_at_benchmark_size():
             torch.cuda.synchronize()
             got[kern] = dict(dest=wm["dest"][:wm["E_total"]].clone(), dest_conv=wm["dest_conv"][:plan["entries"]].clone(), goff=wm["goff"].clone(),
                              gend=wm["gend"].clone(), tile_group=wm["tile_group"].clone(), order=plan["lin"]["order"][:plan["lin"]["max"]].clone(),
-                             seg=plan["lin"]["seg"].clone())
+                             seg=plan["lin"]["seg"].clone(), incl=plan["incl"].clone(), incl_all=plan["incl_all"].clone(),
+                             n_lin=plan["lin"]["n"].clone(), n_total=plan["n_total"].clone())
     for k in got[True]:
         assert torch.equal(got[True][k].long(), got[False][k].long()), k
