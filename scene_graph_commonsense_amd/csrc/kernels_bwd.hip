@@ -701,6 +701,29 @@ __global__ void segment_cast_kernel(const SegmentCastParams p) {
     }
 }
 
+// Up to 32 SMALL tensors in one launch (blockIdx.y = tensor): the relation head has 22 parameter tensors, 18 of them below a million
+// elements (biases, head rows, conv1) - one launch each cost more in launch gaps than in work.  Same update, scalar accesses.
+struct SgdMultiParams {
+    float* w[32]; const float* g[32]; float* m[32];
+    long n[32];
+    float lr, momentum, weight_decay;
+    unsigned first_mask;
+};
+__global__ void sgd_momentum_multi_kernel(const SgdMultiParams p) {
+    const int t = blockIdx.y;
+    float* __restrict__ w = p.w[t];
+    const float* __restrict__ g = p.g[t];
+    float* __restrict__ m = p.m[t];
+    const bool first = (p.first_mask >> t) & 1u;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < p.n[t]; i += (long)gridDim.x * blockDim.x) {
+        const float wi = w[i];
+        const float d = g[i] + p.weight_decay * wi;
+        const float b = first ? d : p.momentum * m[i] + d;
+        m[i] = b;
+        w[i] = wi - p.lr * b;
+    }
+}
+
 extern "C" {
 
 int sgc_head_loss_bwd(const float* rel, const float* sup, const float* conn, const float* p, const int* tgt,
@@ -757,6 +780,23 @@ int sgc_slab_sum(const float* in, float* out, long n, int slabs, int accumulate,
     if (n <= 0) return SGC_OK;
     SGC_LAUNCH(slab_sum_kernel, dim3(grid_for(n, 256, 65536)), dim3(256), 0, (hipStream_t)stream, in, out, n, slabs,
                        accumulate);
+    SGC_CHECK_LAUNCH();
+    return SGC_OK;
+}
+
+int sgc_sgd_momentum_multi(int n_tensors, float* const* w, const float* const* g, float* const* momentum_buf, const long* n, float lr,
+                           float momentum, float weight_decay, unsigned first_mask, void* stream) {
+    if (n_tensors <= 0) return SGC_OK;
+    if (n_tensors > 32) return SGC_ERR_ARG;
+    SgdMultiParams p{};
+    long nmax = 0;
+    for (int t = 0; t < n_tensors; ++t) {
+        p.w[t] = w[t]; p.g[t] = g[t]; p.m[t] = momentum_buf[t]; p.n[t] = n[t];
+        nmax = n[t] > nmax ? n[t] : nmax;
+    }
+    p.lr = lr; p.momentum = momentum; p.weight_decay = weight_decay; p.first_mask = first_mask;
+    const unsigned bx = (unsigned)((nmax + 255) / 256 < 1024 ? ((nmax + 255) / 256 > 0 ? (nmax + 255) / 256 : 1) : 1024);
+    SGC_LAUNCH(sgd_momentum_multi_kernel, dim3(bx, n_tensors), dim3(256), 0, (hipStream_t)stream, p);
     SGC_CHECK_LAUNCH();
     return SGC_OK;
 }
