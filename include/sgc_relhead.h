@@ -301,6 +301,12 @@ int sgc_scene_tables(const int* n_per_img, const int* img_ptr, const int* goff, 
 int sgc_bucket_place(const int* codes, int n, const int* sub_idx, const int* obj_img, int img_key, int n_keys, const int* base, int* out,
                      int* seg, int mode, void* stream);
 
+/* Pair lists of the pseudo-pairs of conv3 over shared windows (csrc/kernels_shared.hip): ps_sub / ps_obj [2 n_obj (+ n_img)] = (o, bg(o)),
+ * (bg(o), o) (, (bg, bg) per image) with bg(o) = n_obj + obj_img[o]; bg_codes [64 n_img] (may be NULL) = window codes of the background
+ * maps, pair index n_pairs + 2 n_obj + image; *bg_n = 64 n_img. */
+int sgc_pseudo_pair_tables(const int* obj_img, int n_obj, int n_img, int n_pairs, int with_bg, int* ps_sub, int* ps_obj, int* bg_codes,
+                           int* bg_n, void* stream);
+
 /* out [rows][n] = inclusive prefix sums of every row of in (int32; in == out allowed): the entry counts of the window lists. */
 int sgc_scan_rows(const int* in, int* out, int rows, int n, void* stream);
 
@@ -430,6 +436,11 @@ int sgc_conv1_wgrad(const void* dpre, const void* x_bf16, float* slabs, int n_ro
  * 16-byte aligned pointers take the float4 path, anything else a scalar one. */
 int sgc_sgd_momentum_step(float* w, const float* g, float* momentum_buf, long n, float lr, float momentum, float weight_decay,
                           int first_step, void* stream);
+/* The same update for up to 32 SMALL tensors in one launch (w / g / momentum_buf / n: host arrays of n_tensors device pointers / element
+ * counts, read at call time; bit t of first_mask = tensor t has no momentum buffer yet).  18 of the head's 22 parameter tensors are
+ * biases, head rows and 1x1 convolutions: one launch each cost more in launch gaps than in work. */
+int sgc_sgd_momentum_multi(int n_tensors, float* const* w, const float* const* g, float* const* momentum_buf, const long* n, float lr,
+                           float momentum, float weight_decay, unsigned first_mask, void* stream);
 
 /* ----------------------------------------------------------------------------------------------- SGDET / SGCLS object front-end
  * (evaluate.py:309-366 = :543-589, utils.py:58-74,377-425)

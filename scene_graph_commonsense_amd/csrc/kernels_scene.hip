@@ -356,6 +356,22 @@ __global__ __launch_bounds__(1024) void scan_rows_kernel(const int* __restrict__
     }
 }
 
+// Pair lists of the pseudo-pairs (o, background of o's image), (background, o) and - with_bg - the all-background pair of every image,
+// and the window codes of the background maps' 64 windows (the tail of the pair index space: P + 2 n_obj + image): a dozen
+// arange / add / cat launches per step otherwise.
+__global__ void pseudo_pair_tables_kernel(const int* __restrict__ obj_img, int n_obj, int n_img, int n_pairs, int with_bg, int* __restrict__ ps_sub,
+                                          int* __restrict__ ps_obj, int* __restrict__ bg_codes, int* __restrict__ bg_n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_obj) {
+        const int bg = n_obj + obj_img[i];
+        ps_sub[i] = i; ps_obj[i] = bg;
+        ps_sub[n_obj + i] = bg; ps_obj[n_obj + i] = i;
+    }
+    if (with_bg && i < n_img) ps_sub[2 * n_obj + i] = ps_obj[2 * n_obj + i] = n_obj + i;
+    if (bg_codes && i < 64 * n_img) bg_codes[i] = (n_pairs + 2 * n_obj + (i >> 6)) * 64 + (i & 63);
+    if (bg_n && i == 0) *bg_n = 64 * n_img;
+}
+
 extern "C" {
 
 int sgc_fill_zero(void* ptr, long nbytes, void* stream) {
@@ -467,6 +483,16 @@ int sgc_window_rows_conv(const int* codes_conv, int n, const int* incl_conv, con
 int sgc_scan_rows(const int* in, int* out, int rows, int n, void* stream) {
     if (rows <= 0 || n <= 0) return SGC_OK;
     SGC_LAUNCH(scan_rows_kernel, dim3(rows), dim3(1024), 0, (hipStream_t)stream, in, out, n);
+    SGC_CHECK_LAUNCH();
+    return SGC_OK;
+}
+
+int sgc_pseudo_pair_tables(const int* obj_img, int n_obj, int n_img, int n_pairs, int with_bg, int* ps_sub, int* ps_obj, int* bg_codes,
+                           int* bg_n, void* stream) {
+    const int n = n_obj > 64 * n_img ? n_obj : 64 * n_img;
+    if (n <= 0) return SGC_OK;
+    SGC_LAUNCH(pseudo_pair_tables_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, obj_img, n_obj, n_img, n_pairs, with_bg,
+               ps_sub, ps_obj, bg_codes, bg_n);
     SGC_CHECK_LAUNCH();
     return SGC_OK;
 }

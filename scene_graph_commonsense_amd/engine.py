@@ -742,13 +742,21 @@ class RelHeadEngine:
         n_obj, n_img = int(obj_img.shape[0]), plan["n_img"]
         n2 = 2 * n_obj
         objects = bool(plan["objects"]) and wm is not None
-        ar = torch.arange(n_obj, dtype=torch.int32, device=self.device)
-        bg = obj_img.to(torch.int32) + n_obj                                     # every object's background = its image's
-        ps_sub, ps_obj = torch.cat([ar, bg]), torch.cat([bg, ar])
-        if objects:                                                              # + the all-background map of every image
-            bgs = torch.arange(n_obj, n_obj + n_img, dtype=torch.int32, device=self.device)
-            ps_sub, ps_obj = torch.cat([ps_sub, bgs]), torch.cat([ps_obj, bgs])
-        n_tail = int(ps_sub.shape[0])
+        n_tail = n2 + (n_img if objects else 0)                                  # + the all-background map of every image
+        bg_codes = raw_n = None
+        if TUNING.plan_kernels and obj_img.dtype == torch.int32:
+            tabs = sc.get("ps_tables", 2 * n_tail + 64 * n_img + 4, torch.int32)
+            ps_sub, ps_obj = tabs[:n_tail], tabs[n_tail:2 * n_tail]
+            bg_codes, raw_n = tabs[2 * n_tail:2 * n_tail + 64 * n_img], tabs[2 * n_tail + 64 * n_img:2 * n_tail + 64 * n_img + 1]
+            _lib.check(lib.sgc_pseudo_pair_tables(_lib.ptr(obj_img), n_obj, n_img, P, int(objects), _lib.ptr(ps_sub), _lib.ptr(ps_obj),
+                                                  _lib.ptr(bg_codes), _lib.ptr(raw_n), self._st()), "sgc_pseudo_pair_tables")
+        else:
+            ar = torch.arange(n_obj, dtype=torch.int32, device=self.device)
+            bg = obj_img.to(torch.int32) + n_obj                                 # every object's background = its image's
+            ps_sub, ps_obj = torch.cat([ar, bg]), torch.cat([bg, ar])
+            if objects:
+                bgs = torch.arange(n_obj, n_obj + n_img, dtype=torch.int32, device=self.device)
+                ps_sub, ps_obj = torch.cat([ps_sub, bgs]), torch.cat([ps_obj, bgs])
         zt = z[P * 18 * 18 * 512:]
         if keep is None:
             _lib.check(lib.sgc_pair_expand(_lib.ptr(U), _lib.ptr(V), _lib.ptr(ps_sub), _lib.ptr(ps_obj), _lib.ptr(zt), n_tail, ELEM_F16, self._st()),
@@ -793,9 +801,10 @@ class RelHeadEngine:
                     _lib.ptr(z), _lib.ptr(self.w["w3r"]), _lib.ptr(self.w["b3"]), _lib.ptr(gather), _lib.ptr(plan["n_total"]), _lib.ptr(wm["dest_conv"]),
                     plan["bound"], _lib.ptr(y), _lib.ptr(am), _lib.ptr(y_bf), _lib.ptr(raw), plan["entries_real"], self._st()),
                     "sgc_conv3_relu_pool_windows_wm_raw"))
-                bg_codes = ((P + n2 + torch.arange(n_img, device=self.device, dtype=torch.int32))[:, None] * 64
-                            + torch.arange(64, device=self.device, dtype=torch.int32)[None, :]).reshape(-1).contiguous()
-                raw_n = torch.full((1,), 64 * n_img, dtype=torch.int32, device=self.device)
+                if bg_codes is None:
+                    bg_codes = ((P + n2 + torch.arange(n_img, device=self.device, dtype=torch.int32))[:, None] * 64
+                                + torch.arange(64, device=self.device, dtype=torch.int32)[None, :]).reshape(-1).contiguous()
+                    raw_n = torch.full((1,), 64 * n_img, dtype=torch.int32, device=self.device)
                 self._timed("conv3_fwd_raw", lambda: _lib.check(lib.sgc_conv3_windows_raw(
                     _lib.ptr(z), _lib.ptr(self.w["w3r"]), _lib.ptr(bg_codes), _lib.ptr(raw_n), 64 * n_img, _lib.ptr(raw[n_pe * 4096:]), self._st()),
                     "sgc_conv3_windows_raw"))

@@ -1,8 +1,8 @@
 """One-pass SGD with momentum for the relation head (``sgc_sgd_momentum_step``).
 
 Same update as ``torch.optim.SGD(params, lr, momentum, weight_decay)`` with dampening 0 and no Nesterov momentum - the optimizer
-the reference builds in ``train_test.py`` - but one kernel per parameter tensor that reads the gradient, the weight and the momentum
-buffer once and writes the weight and the buffer once (5 x 4 B per parameter; the foreach implementation makes three passes,
+the reference builds in ``train_test.py`` - but one kernel per LARGE parameter tensor (one launch for all the small ones together) that reads the gradient, the weight and the
+momentum buffer once and writes the weight and the buffer once (5 x 4 B per parameter; the foreach implementation makes three passes,
 9 x 4 B).  At 277 M parameters that is 2.4 ms -> 1.1 ms per step.  Subclasses ``torch.optim.Optimizer`` so that ``param_groups``
 (the reference rescales ``lr`` inside its loop), ``state_dict`` and ``zero_grad`` behave as usual.
 """
@@ -29,7 +29,9 @@ class FusedSGD(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         f = ctypes.c_float
+        SMALL = 1 << 20                      # tensors up to this many elements share one launch (sgc_sgd_momentum_multi), 32 at a time
         for group in self.param_groups:
+            small = []
             for p in group["params"]:
                 if p.grad is None:
                     continue
@@ -40,11 +42,23 @@ class FusedSGD(torch.optim.Optimizer):
                 first = "momentum_buffer" not in st
                 if first:
                     st["momentum_buffer"] = torch.empty_like(p, memory_format=torch.contiguous_format)
-                _lib.check(self._lib.sgc_sgd_momentum_step(_lib.ptr(p), _lib.ptr(g), _lib.ptr(st["momentum_buffer"]),
-                                                           ctypes.c_long(p.numel()), f(group["lr"]), f(group["momentum"]),
-                                                           f(group["weight_decay"]), int(first), _lib.stream_ptr()),
-                           "sgc_sgd_momentum_step")
-                # the kernel wrote p behind autograd's back: bump its version counter (the classifier re-derives its 16-bit weight
+                if p.numel() <= SMALL:
+                    small.append((p, g, st["momentum_buffer"], first))
+                else:
+                    _lib.check(self._lib.sgc_sgd_momentum_step(_lib.ptr(p), _lib.ptr(g), _lib.ptr(st["momentum_buffer"]),
+                                                               ctypes.c_long(p.numel()), f(group["lr"]), f(group["momentum"]),
+                                                               f(group["weight_decay"]), int(first), _lib.stream_ptr()),
+                               "sgc_sgd_momentum_step")
+                # the kernel writes p behind autograd's back: bump its version counter (the classifier re-derives its 16-bit weight
                 # copies when a parameter's version changes, and autograd's saved-tensor checks rely on it too)
                 torch.autograd.graph.increment_version(p)
+            for k in range(0, len(small), 32):
+                part = small[k:k + 32]
+                n = len(part)
+                P, L = ctypes.c_void_p * n, ctypes.c_long * n
+                mask = sum(1 << t for t, e in enumerate(part) if e[3])
+                _lib.check(self._lib.sgc_sgd_momentum_multi(n, P(*[e[0].data_ptr() for e in part]), P(*[e[1].data_ptr() for e in part]),
+                                                            P(*[e[2].data_ptr() for e in part]), L(*[e[0].numel() for e in part]),
+                                                            f(group["lr"]), f(group["momentum"]), f(group["weight_decay"]),
+                                                            ctypes.c_uint(mask), _lib.stream_ptr()), "sgc_sgd_momentum_multi")
         return loss
