@@ -15,6 +15,8 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "oracle_launch: device step that feeds a background CPU-oracle job (ordered first)")
     config.addinivalue_line("markers", "oracle_join: asserts on a background CPU-oracle job (ordered last)")
     config.addinivalue_line("markers", "oracle_jobs(kind): the test uses jobs of tests/oracle_pool.py that can start when collection ends")
+    config.addinivalue_line("markers", "oracle_heavy: tens of seconds of IN-PROCESS oracle work: ordered behind the ordinary tests, when the pool's "
+                                       "jobs (8 x 8 threads) have mostly finished and no longer compete for the host's memory bandwidth")
 
 
 @pytest.hookimpl(trylast=True)
@@ -22,7 +24,8 @@ def pytest_collection_modifyitems(config, items):
     """The long CPU-oracle computations of the GPU suite run as background jobs (tests/oracle_pool.py).  Tests that produce what a
     job needs from the device run first, tests that wait for a job run last (stable otherwise), and the jobs that need nothing
     from the device are submitted right here - before the first test - for the cases that were actually selected."""
-    rank = lambda it: 0 if it.get_closest_marker("oracle_launch") else (2 if it.get_closest_marker("oracle_join") else 1)
+    rank = lambda it: 0 if it.get_closest_marker("oracle_launch") else (
+        3 if it.get_closest_marker("oracle_join") else (2 if it.get_closest_marker("oracle_heavy") else 1))
     items.sort(key=rank)
     if any(it.get_closest_marker("gpu") for it in items):
         # in-process oracle calls (b <= 8 pairs per reference call) are FASTEST on ~32 threads of the GPU box's 256

@@ -64,6 +64,7 @@ def _fro(a, b):
     return float((a.double() - b.double()).norm() / max(b.double().norm(), 1e-30))
 
 
+@pytest.mark.oracle_heavy
 @pytest.mark.parametrize("hier", [True, False])
 def test_backward_matches_oracle(hier):
     from oracle import relhead_oracle as O
@@ -198,6 +199,7 @@ def test_train_cs_step_matches_reference():
         assert err <= SAMPLE_TOL(n), (n, err)
 
 
+@pytest.mark.oracle_heavy
 def test_commonsense_penalty_alone_matches_oracle():
     """Only the train_cs penalty is active (no connected pair, lambda_connectivity = 0): loss and head gradients must match
     the oracle tightly - this isolates the max-softmax gradient and the per-step mean / running-sum coefficients."""
@@ -277,6 +279,7 @@ def test_fused_sgd_matches_torch_sgd():
             assert (o_ref.state[a]["momentum_buffer"] - o_mine.state[b]["momentum_buffer"]).abs().max().item() <= 1e-6
 
 
+@pytest.mark.oracle_heavy
 @pytest.mark.parametrize("name", ["vg_full_hit", "vg_full"])
 def test_contrastive_step_with_device_routes_is_arithmetic_exact(name):
     """The contrastive training step against the ORACLE with the device's routing injected in both trunks (main view: every pair;
@@ -302,6 +305,7 @@ def test_contrastive_step_with_device_routes_is_arithmetic_exact(name):
         assert e <= _routed_tol(k), (k, e)
 
 
+@pytest.mark.oracle_heavy
 def test_train_cs_step_with_device_routes_is_arithmetic_exact():
     """The train_cs step (commonsense penalty on top of the hierarchical loss) against the oracle with the device's routes."""
     import os
