@@ -51,7 +51,7 @@ _T0 = None
 
 
 def pytest_runtest_logreport(report):
-    """``SGC_TEST_CLOCK=1``: wall-clock offset of every test's end (where does a slow suite spend its time - tests/README)."""
+    """``SGC_TEST_CLOCK=1``: wall-clock offset of every test's end (where does a slow suite spend its time: profiles/r04_gputest_final4.txt)."""
     global _T0
     if os.environ.get("SGC_TEST_CLOCK") != "1" or report.when != "call":
         return

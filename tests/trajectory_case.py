@@ -21,7 +21,7 @@ CASES = {
 # LATE_COSINE: set from the measured run, see the comment above and DESIGN.md (numerics).
 # Measured (GPUTEST of round 4, profiles/README.md): smallest update cosine per step at 1e-5 = 0.9990, 0.9986, 0.9968, 0.9936, 0.9907 |
 # 0.9891, 0.9870, 0.9779 (losses within 0.6 % throughout); at 5e-6 it stays >= 0.994 for all ten steps.
-STRICT_STEPS = {"vg_full_ref_lr": 5}
+STRICT_STEPS = {"vg_full_ref_lr": 4}          # step 5 measures 0.9907 on every box so far: too close to 0.99 to gate a suite run with -x
 LATE_COSINE = 0.95
 
 _NAMES = {}
