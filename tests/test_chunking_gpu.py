@@ -102,7 +102,7 @@ def test_chunked_step_with_minibatch_coupled_terms_equals_the_one_pass_step(term
              for n in one["grads"]}
     print({k: "%.1e" % v for k, v in worst.items()})
     for n, e in worst.items():
-        assert e <= 2e-4, (n, e)
+        assert e <= 1e-5, (n, e)             # measured <= 1.3e-6 (f32 summation order of the groups' gradient sums)
 
 
 def test_24x64_training_step_runs_in_40gb_groups():
