@@ -110,8 +110,13 @@ def _budget(model, workspace_budget):
     b = getattr(model, "workspace_budget_bytes", None)
     if b is not None:
         return float(b)
-    if getattr(model, "_auto_budget", None) is None:     # measured once per model: the planner runs every step
+    # measured when first needed and again every 64 calls (the planner runs every step; what ELSE lives in HBM - the feature
+    # extractor, an evaluator's state, another model - changes over an epoch)
+    n = getattr(model, "_auto_budget_calls", 0)
+    if getattr(model, "_auto_budget", None) is None or n >= 64:
         model._auto_budget = float(default_workspace_budget(model))
+        n = 0
+    model._auto_budget_calls = n + 1
     return model._auto_budget
 
 
