@@ -29,12 +29,20 @@ def _sampled(spec, out_dir):
     sizes = spec.get("call_sizes")                        # rows per record, record order (needed to slice the route tables)
     start = np.concatenate([[0], np.cumsum(sizes)]) if sizes is not None else None
 
+    seeds = spec.get("dropout_seeds")
+    row0 = spec.get("call_row0")
+
     def hook(t, b):
-        if routes is None:
-            return {}
-        r0 = int(start[t])
-        assert int(start[t + 1]) - r0 == b
-        return {"routes": {k: v[r0:r0 + b] for k, v in routes.items()}}
+        inj = {}
+        if routes is not None:
+            r0 = int(start[t])
+            assert int(start[t + 1]) - r0 == b
+            inj["routes"] = {k: v[r0:r0 + b] for k, v in routes.items()}
+        if seeds is not None:                       # the kernels' keep masks of these pairs (rows of the FULL minibatch's pass), x2
+            from scene_graph_commonsense_amd.synthetic import dropout_keep_mask
+            inj["drop1"] = torch.from_numpy(dropout_keep_mask(seeds[0], b, 4096, row0[t])).float() * 2
+            inj["drop2"] = torch.from_numpy(dropout_keep_mask(seeds[1], b, 512, row0[t])).float() * 2
+        return inj
 
     backward = spec.get("backward", True)
     sdr = {k: v.clone().requires_grad_(backward) for k, v in sd.items()}

@@ -65,11 +65,17 @@ def host_case(name):
     return _CACHE[name]
 
 
-def job_spec(name, backward, routes=None):
+DROPOUT_SEEDS = (0xC0FFEE, 0xBADC0DE)          # the routed comparison runs in TRAINING mode (dropout on): what bench.py times
+
+
+def job_spec(name, backward, routes=None, dropout_seeds=None):
+    """``dropout_seeds``: the oracle gets the kernels' keep masks of the sampled pairs injected (``synthetic.dropout_keep_mask`` over the
+    pair's row in the FULL minibatch: the keep bit is indexed by the position in the pass)."""
     hc = host_case(name)
     return dict(kind="sampled", cfg_kw=hc["cfg_kw"], sd_seed=SD_SEED, head_gain=HEAD_GAIN, nobj=hc["nobj"], batch_seed=BATCH_SEED,
                 connect_frac=CONNECT_FRAC, steps=sorted(hc["steps"]), backward=backward, routes=routes,
-                call_sizes=[len(r) for r in hc["rows"]])
+                call_sizes=[len(r) for r in hc["rows"]], dropout_seeds=dropout_seeds,
+                call_row0=[int(r[0]) for r in hc["rows"]])
 
 
 def job_name(name, routed=False):

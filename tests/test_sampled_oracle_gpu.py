@@ -19,8 +19,9 @@ re-numbered steps: the running-sum weights of the reference's loop restricted to
 exactly the loss the oracle back-propagates (``run_pair_loop(step_filter=...)["losses"].backward()``) - through the patch-form
 data / weight gradients over the listed windows, the linear pairs' backward, the background-map gradients, ``fc1_gsum`` on the
 matrix cores: the kernels the benchmark times, at the size where they dominate.  Bars: as ``tests/test_backward_gpu.py`` -
-un-routed <= 6e-2 relative Frobenius and cosine >= 0.997 below the routing masks, 5e-3 for the head; with the device's own routes
-of the sampled pairs injected into the oracle (``tests/train_case.device_routes(rows=...)``) <= 5e-3, 7e-3 for conv2 / conv1.
+un-routed (dropout off) <= 6e-2 relative Frobenius and cosine >= 0.997 below the routing masks, 5e-3 for the head; in TRAINING mode -
+dropout on, what ``bench.py`` times - with the kernels' keep masks (``synthetic.dropout_keep_mask``) and the device's own routes of
+the sampled pairs injected into the oracle (``tests/train_case.device_routes(rows=...)``) <= 5e-3, 7e-3 for conv2 / conv1.
 
 The oracle runs are jobs of ``tests/oracle_pool.py`` (processes beside the GPU tests): the un-routed ones start when collection
 ends, the routed ones as soon as the device step of the case has produced its routes (``test_device_steps_*``, ordered first by
@@ -33,7 +34,7 @@ import pytest
 import torch
 
 from tests import oracle_pool
-from tests.sampled_case import BACKWARD_CASES, CASES, HEAD_GAIN, SD_SEED, host_case, job_name, job_spec
+from tests.sampled_case import BACKWARD_CASES, CASES, DROPOUT_SEEDS, HEAD_GAIN, SD_SEED, host_case, job_name, job_spec
 
 pytestmark = pytest.mark.gpu
 
@@ -92,15 +93,24 @@ def device_case(name):
     torch.cuda.empty_cache()
     if name in BACKWARD_CASES:
         full, part, rows = _sampled_coefficients(hc)
-        loss, grads, routes, sc = run_train_gpu(cfg, sd, batch, keep_ctx=True, coefs=full, route_rows=rows)
+        for r in hc["rows"]:
+            assert np.array_equal(r, np.arange(r[0], r[0] + len(r)))          # a direction-step's pairs are consecutive rows of the pass
+        # (1) evaluation numerics (dropout off): compared with the oracle as it is
+        loss, grads, _, sc = run_train_gpu(cfg, sd, batch, coefs=full)
         assert sc.linear_windows > 0 and sc.object_windows > 0            # every identity of the default path is exercised
         dev.update(loss=loss, grads=grads, linear_windows=int(sc.linear_windows))
+        del sc
+        torch.cuda.empty_cache()
+        # (2) TRAINING mode, the mode bench.py times (hash dropout in the fc1 / fc2 epilogues, x2 rescale, masks regenerated in the
+        #     backward): the oracle gets the same keep masks AND the device's routes of the sampled pairs
+        loss_d, grads_d, routes, sc = run_train_gpu(cfg, sd, batch, dropout=True, seeds=DROPOUT_SEEDS, keep_ctx=True, coefs=full, route_rows=rows)
+        dev.update(loss_dropout=loss_d, grads_dropout=grads_d)
         if not oracle_pool.submitted(job_name(name)):
             oracle_pool.submit(job_name(name), job_spec(name, backward=True))
         rpath = os.path.join(oracle_pool.job_dir(job_name(name)), "device_routes.pt")
         torch.save(routes, rpath)
-        del routes
-        oracle_pool.submit(job_name(name, routed=True), job_spec(name, backward=True, routes=rpath))
+        del routes, sc
+        oracle_pool.submit(job_name(name, routed=True), job_spec(name, backward=True, routes=rpath, dropout_seeds=DROPOUT_SEEDS))
         torch.cuda.empty_cache()
     elif not oracle_pool.submitted(job_name(name)):
         oracle_pool.submit(job_name(name), job_spec(name, backward=False))
@@ -182,12 +192,13 @@ def test_sampled_steps_of_a_full_size_minibatch_match_the_oracle(name):
 def _compare_gradients(name, routed):
     dev = device_case(name)
     ref = oracle_pool.result(job_name(name, routed=routed))
-    print(name, "routed" if routed else "un-routed", "loss of the sampled steps: device %.4f oracle %.4f" % (dev["loss"], ref["loss"]),
-          "| oracle %.0f s forward, %.0f s in all" % tuple(ref["seconds"]))
-    assert abs(dev["loss"] - ref["loss"]) <= 2e-3 * abs(ref["loss"])
+    mine_loss, mine = (dev["loss_dropout"], dev["grads_dropout"]) if routed else (dev["loss"], dev["grads"])
+    print(name, "training mode (dropout on) + device routes" if routed else "un-routed, dropout off",
+          "loss of the sampled steps: device %.4f oracle %.4f" % (mine_loss, ref["loss"]), "| oracle %.0f s" % ref["seconds"][1])
+    assert abs(mine_loss - ref["loss"]) <= 2e-3 * abs(ref["loss"])
     errs, cosines = {}, {}
     for k, g in ref["grads"].items():
-        a, b = dev["grads"][k].double().flatten(), g.double().flatten()
+        a, b = mine[k].double().flatten(), g.double().flatten()
         errs[k] = float((a - b).norm() / max(float(b.norm()), 1e-30))
         cosines[k] = float(a @ b / float(a.norm() * b.norm())) if float(a.norm()) > 0 or float(b.norm()) > 0 else 1.0
     print({k: "%.1e" % v for k, v in errs.items()})
