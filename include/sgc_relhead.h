@@ -163,6 +163,13 @@ int sgc_windows_wgrad_gather(const void* dy3x, const void* z_pad_bf16, const int
 int sgc_windows_im2patch(const void* z_pad_bf16, const int* gather, const int* gather_n, int entries_pad, void* zpatch, void* stream);
 int sgc_windows_im2patch_f16(const void* z_pad_f16, const int* gather, const int* gather_n, int entries_pad, void* zpatch, void* stream);   /* source: the forward's f16 maps */
 int sgc_windows_wgrad_patch(const void* dy3x, const void* zpatch, float* slabs, int rows, int splits, int* n_slabs, void* stream);
+/* The same product for the first n_entries (a multiple of 16) listed windows on the SPARSE matrix cores (v_smfmac_f32_32x32x32_bf16:
+ * the gradient before ReLU + 2x2 max-pool has one non-zero per window and channel, windows are 4 consecutive K indices - the 2:4
+ * pattern; model.py:145-147 backward).  Valid for the real pairs' windows only (the per-object entries behind them hold sums of
+ * several windows' gradients: sgc_windows_wgrad_patch on that tail).  dywm: POOLED gradient rows, row dest[e]; argmax at gather[e];
+ * pack_ac (n_entries/16 * 64 KiB) / pack_ic (n_entries/16 * 8 KiB): scratch for the packed operand. */
+int sgc_windows_wgrad_patch_sparse(const void* dywm, const unsigned char* argmax, const int* gather, const int* dest, int n_entries,
+                                   const void* zpatch, void* pack_ac, void* pack_ic, float* slabs, int splits, int* n_slabs, void* stream);
 int sgc_windows_dgrad_cols(const void* dy3x, const void* w3col, void* col, int rows, void* stream);
 int sgc_windows_col2im(const void* col, const int* bbox, const int* sub_idx, const int* obj_idx, const int* count_incl, int n_pairs,
                        void* dz, void* stream);

@@ -161,7 +161,11 @@ __global__ __launch_bounds__(512) void unpool_pack_kernel(const u16* __restrict_
 // ---------------------------------------------------------------------------------------------------- sparse TN block
 // Ping-pong schedule and ring exactly as gemm_tn_pp_kernel (two loads per wave per half tile, vmcnt(8)); an A half tile is now
 // 128 rows x 64 B of packed pairs (one load per wave) + 128 x 8 B of index words (one load: wave 0 for A0, wave 1 for A1).
-template <int UNUSED = 0>
+// PATCH = 1: the B operand is the per-window 4 x 4 patch form of a window LIST (BMODE_PATCH of gemm_tn.h: 16 windows per K tile,
+// pixel kr of window kl >> 2 + tap at fixed per-lane offsets) instead of whole padded maps - the conv3 weight gradient over the
+// listed windows (csrc/kernels_shared.hip); the A operand is packed from the listed windows' pooled gradient rows by
+// windows_sparse_pack_kernel.
+template <int PATCH = 0>
 __global__ __launch_bounds__(512, 2) void gemm_tn_sp_kernel(const TnParams p, const u16* __restrict__ Ac, const unsigned* __restrict__ Ic) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int HT = 16384, BM = 256, BN = 256;
@@ -207,7 +211,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_sp_kernel(const TnParams p, co
             const int tap_raw = col / p.Cin;
             const int tap = tap_raw > 8 ? 8 : tap_raw;
             const int ky = tap / 3, kx = tap - 3 * ky;
-            const long b = conv_row_base(kl, p.lgS, p.Cin) + (long)(ky * ((1 << p.lgS) + 2) + kx) * p.Cin + (col - tap_raw * p.Cin);
+            long b;
+            if constexpr (PATCH) b = (long)((kl >> 2) * 16 + ((kr >> 1) + ky) * 4 + (kr & 1) + kx) * p.Cin + (col - tap_raw * p.Cin);
+            else b = conv_row_base(kl, p.lgS, p.Cin) + (long)(ky * ((1 << p.lgS) + 2) + kx) * p.Cin + (col - tap_raw * p.Cin);
             b_voff[h][q] = (int)((b + c8) * 2);
         }
     }
@@ -220,7 +226,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_sp_kernel(const TnParams p, co
             if (wid == h)            // the 1 KiB of index words: wave 0 for A0, wave 1 for A1 (their vmcnt budget is one larger)
                 buf_load_lds16(reinterpret_cast<const char*>(Ic) + (long)kt * (1024 * 8), i_voff[h], 0, base + 8192);
         } else {
-            const u16* g = p.B + conv_row_base(kt * 64, p.lgS, p.Cin);
+            const u16* g = p.B + (PATCH ? (long)kt * 16 * 16 * p.Cin : conv_row_base(kt * 64, p.lgS, p.Cin));
             buf_load_lds16(g, b_voff[kind - 1][0], 0, base + wid * 2048);
             buf_load_lds16(g, b_voff[kind - 1][1], 0, base + wid * 2048 + 1024);
         }
@@ -338,6 +344,50 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_sp_kernel(const TnParams p, co
 }
 
 
+// The packed operand of a window LIST: tile T = listed windows 16T .. 16T+15; window e's pooled gradient row is dywm[dest[e]] (window-
+// major row space of the shared fc1) and its routing bytes are am[gather[e]] (pair-major); entries >= n_entries are padding (no value).
+__global__ __launch_bounds__(256) void windows_sparse_pack_kernel(const u16* __restrict__ dywm, const unsigned char* __restrict__ am,
+                                                                  const int* __restrict__ gather, const int* __restrict__ dest,
+                                                                  int n_entries, u16* __restrict__ Ac, unsigned* __restrict__ Ic, int n_tiles) {
+    __shared__ u16 sv[16][128 + 8];
+    __shared__ unsigned char sp[16][128 + 16];
+    const int T = blockIdx.x, oc0 = blockIdx.y * 128;
+    if (T >= n_tiles) return;
+    {
+        const int w = threadIdx.x >> 4, c8 = (threadIdx.x & 15) * 8;
+        const int e = T * 16 + w;
+        if (e < n_entries) {
+            *reinterpret_cast<uint4*>(&sv[w][c8]) = *reinterpret_cast<const uint4*>(dywm + (long)dest[e] * 1024 + oc0 + c8);
+            *reinterpret_cast<uint2*>(&sp[w][c8]) = *reinterpret_cast<const uint2*>(am + (long)gather[e] * 1024 + oc0 + c8);
+        } else {
+            *reinterpret_cast<uint4*>(&sv[w][c8]) = make_uint4(0, 0, 0, 0);
+            *reinterpret_cast<uint2*>(&sp[w][c8]) = make_uint2(0x04040404u, 0x04040404u);
+        }
+    }
+    __syncthreads();
+    const int oc = threadIdx.x >> 1, ha = threadIdx.x & 1;
+    unsigned pairs[8];
+    unsigned idx = 0;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int ga = 0; ga < 4; ++ga) {
+            const int w = 8 * ha + 4 * s + ga;
+            const unsigned v = sv[w][oc];
+            const int pm = sp[w][oc];
+            unsigned pr, nib;
+            if (pm < 3) { pr = v; nib = (unsigned)pm | (3u << 2); }
+            else if (pm == 3) { pr = v << 16; nib = 2u | (3u << 2); }
+            else { pr = 0; nib = 0u | (1u << 2); }
+            pairs[4 * s + ga] = pr;
+            idx |= nib << (16 * s + 4 * ga);
+        }
+    unsigned* dst = reinterpret_cast<unsigned*>(Ac) + (((long)T * 1024 + oc0 + oc) * 16 + 8 * ha);
+    *reinterpret_cast<uint4*>(dst) = make_uint4(pairs[0], pairs[1], pairs[2], pairs[3]);
+    *reinterpret_cast<uint4*>(dst + 4) = make_uint4(pairs[4], pairs[5], pairs[6], pairs[7]);
+    Ic[((long)T * 1024 + oc0 + oc) * 2 + ha] = idx;
+}
+
 static int launch_sparse_pack(const u16* dy, const unsigned char* am, u16* Ac, unsigned* Ic, int n_pairs, hipStream_t stream) {
     const int n_tiles = n_pairs * 4;                          // 64 windows per pair / 16 windows per K tile
     if (n_tiles <= 0) return SGC_OK;
@@ -357,16 +407,17 @@ static int launch_unpool_pack(const u16* dy, const unsigned char* am, u16* dy3, 
     return SGC_OK;
 }
 
+template <int PATCH = 0>
 static int launch_gemm_tn_sp(TnParams p, const u16* Ac, const unsigned* Ic, int splits, int* slabs_out, hipStream_t stream) {
     constexpr int LDS = 8 * 16384;
-    if (p.M != 1024 || p.N != 9 * 512 || p.Cin != 512 || p.lgS != 4 || (p.K & 63)) return SGC_ERR_ARG;
+    if (p.M != 1024 || p.N != 9 * 512 || p.Cin != 512 || (!PATCH && p.lgS != 4) || (p.K & 63)) return SGC_ERR_ARG;
     p.tiles_m = 4; p.tiles_n = 18;
     const int nk = p.K >> 6;
     if (splits <= 0) splits = tn_auto_splits(72, nk);
     if (splits > nk) splits = nk;
     p.ktiles_per_split = (nk + splits - 1) / splits;
     splits = (nk + p.ktiles_per_split - 1) / p.ktiles_per_split;
-    auto kern = gemm_tn_sp_kernel<0>;
+    auto kern = gemm_tn_sp_kernel<PATCH>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     p.splits = splits;
     SGC_LAUNCH(kern, dim3((unsigned)(72 * splits)), dim3(512), LDS, stream, p, Ac, Ic);

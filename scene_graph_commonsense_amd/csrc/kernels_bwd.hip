@@ -981,6 +981,24 @@ int sgc_conv3_wgrad_sparse(const void* dy, const unsigned char* argmax, const vo
     p.ldc = 9 * 512; p.slab_stride = 1024L * 9 * 512; p.lgS = 4; p.Cin = 512; p.CinA = 1024;
     return launch_gemm_tn_sp(p, (const u16*)pack_ac, (const unsigned*)pack_ic, splits, n_slabs, (hipStream_t)stream);
 }
+// The conv3 weight gradient over a window LIST on the sparse matrix cores (csrc/kernels_shared.hip: the pair-specific windows):
+// the first n_entries (a multiple of 16) listed windows, whose un-pooled gradient has one non-zero per window and channel (the real
+// pairs' windows - the per-object entries behind them collect sums of several windows and stay on the dense block).  dywm: pooled
+// gradient rows (window-major row space, row dest[e]); argmax: routing bytes at gather[e]; zpatch: the windows' 4 x 4 input patches
+// (sgc_windows_im2patch*); pack_ac (n_entries/16 * 64 KiB) / pack_ic (n_entries/16 * 8 KiB): scratch for the packed operand.
+int sgc_windows_wgrad_patch_sparse(const void* dywm, const unsigned char* argmax, const int* gather, const int* dest, int n_entries,
+                                   const void* zpatch, void* pack_ac, void* pack_ic, float* slabs, int splits, int* n_slabs, void* stream) {
+    if (n_entries <= 0) { if (n_slabs) *n_slabs = 0; return SGC_OK; }
+    if (n_entries & 15) return SGC_ERR_ARG;
+    const int n_tiles = n_entries / 16;
+    SGC_LAUNCH(windows_sparse_pack_kernel, dim3((unsigned)n_tiles, 8), dim3(256), 0, (hipStream_t)stream, (const u16*)dywm, argmax, gather, dest,
+               n_entries, (u16*)pack_ac, (unsigned*)pack_ic, n_tiles);
+    SGC_CHECK_LAUNCH();
+    TnParams p{};
+    p.A = nullptr; p.B = (const u16*)zpatch; p.C = slabs; p.M = 1024; p.N = 9 * 512; p.K = n_entries * 4;
+    p.ldc = 9 * 512; p.slab_stride = 1024L * 9 * 512; p.lgS = 4; p.Cin = 512; p.CinA = 1024;
+    return launch_gemm_tn_sp<1>(p, (const u16*)pack_ac, (const unsigned*)pack_ic, splits, n_slabs, (hipStream_t)stream);
+}
 // ---- expansion / contraction
 int sgc_pair_expand_train(const void* U, const void* V, const int* sub_idx, const int* obj_idx, void* z_pad_f16, void* z_pad_bf16,
                           unsigned char* amz, int n_pairs, void* stream) {

@@ -179,6 +179,7 @@ class Tuning:
     plan_kernels: bool = True         # row plan of the shared windows by placement kernels (off: torch.sort / searchsorted / gathers, rounds 2-3)
     weight_kernels: bool = True       # 16-bit weight layouts by one gather + cast launch each (off: torch view / permute / flip / cat chains)
     fc1_own_sums: bool = True         # fc1 assembly reads S'_j[R_j] pre-summed per object (off: four corner vectors per pair; same bits)
+    sparse_wgrad: bool = True         # conv3 weight gradient over the real pairs' listed windows on the sparse matrix cores (off: dense block)
 
     @classmethod
     def from_env(cls):
@@ -1529,11 +1530,34 @@ class RelHeadEngine:
             # (the side stream then waits for it) and runs beside col2im / the pair contraction; the im2col above runs beside the
             # data-gradient GEMM.  Round 2 let the two GEMMs run side by side: 18.8 ms for the pair against 7.7 + 7.6 alone.
             with side():
-                if Epad:
-                    slx = sl[slabs_n.value * 1024 * 4608:]
+                n_slabs = slabs_n.value
+                e_real = sh.get("entries_real")
+                e_sp = (int(e_real) // 16) * 16 if (e_real is not None and TUNING.patch_wgrad and TUNING.sparse_wgrad and dest is not None) else 0
+                if Epad and e_sp >= 4096:
+                    # the real pairs' windows: their un-pooled gradient has ONE non-zero per window and channel (4 consecutive K indices)
+                    # - the 2:4 pattern of the sparse matrix cores; packed straight from the pooled rows.  The per-object entries behind
+                    # them (sums of several windows: dense) and the boundary tile stay on the dense block.
+                    slabs_t = ctypes.c_int(0)
+                    pack_a = ws.get("w3x_pack_a", (e_sp // 16) * 1024 * 64, torch.uint8)
+                    pack_i = ws.get("w3x_pack_i", (e_sp // 16) * 1024 * 8, torch.uint8)
+                    slx = sl[n_slabs * 1024 * 4608:]
+                    self._timed("conv3_wgrad_windows", lambda: _lib.check(lib.sgc_windows_wgrad_patch_sparse(
+                        _lib.ptr(dy), _lib.ptr(ctx.am), _lib.ptr(gather), _lib.ptr(dest), e_sp, _lib.ptr(zcol), _lib.ptr(pack_a), _lib.ptr(pack_i),
+                        _lib.ptr(slx), 0, ctypes.byref(slabs_x), st()), "sgc_windows_wgrad_patch_sparse"))
+                    n_slabs += slabs_x.value
+                    if Epad > e_sp:
+                        slt = sl[n_slabs * 1024 * 4608:]
+                        self._timed("conv3_wgrad_windows_tail", lambda: _lib.check(lib.sgc_windows_wgrad_patch(
+                            _lib.ptr(dy3x[e_sp * 4 * 1024:]), _lib.ptr(zcol[e_sp * 16 * 512:]), _lib.ptr(slt), (Epad - e_sp) * 4, 0,
+                            ctypes.byref(slabs_t), st()), "sgc_windows_wgrad_patch"))
+                        n_slabs += slabs_t.value
+                elif Epad:
+                    slx = sl[n_slabs * 1024 * 4608:]
                     self._timed("conv3_wgrad_windows", lambda: _lib.check((lib.sgc_windows_wgrad_patch if TUNING.patch_wgrad else lib.sgc_windows_wgrad)(
                         _lib.ptr(dy3x), _lib.ptr(zcol), _lib.ptr(slx), Epad * 4, 0, ctypes.byref(slabs_x), st()), "sgc_windows_wgrad"))
-                dW3r = self._slab_sum(sl, 1024 * 4608, slabs_n.value + slabs_x.value)
+                    n_slabs += slabs_x.value
+                assert n_slabs <= 32, "split-K slabs of the conv3 weight gradient exceed the slab buffer"
+                dW3r = self._slab_sum(sl, 1024 * 4608, n_slabs)
                 grads["conv3_1.weight"] = dW3r.view(1024, 3, 3, 512).permute(0, 3, 1, 2).contiguous()
 
         if not TUNING.gemms_apart:

@@ -360,3 +360,37 @@ def test_fc1_assembly_with_presummed_own_rectangles_keeps_its_bits():
             outs.append((o.relation.clone(), o.hidden.clone(), o.connectivity.clone()))
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+def test_window_weight_gradient_on_the_sparse_matrix_cores_equals_the_dense_block():
+    """``TUNING.sparse_wgrad`` (default): the conv3 weight gradient over the real pairs' listed windows runs on
+    ``v_smfmac_f32_32x32x32_bf16`` (one non-zero per window and channel = 4 consecutive K indices = the 2:4 pattern; operand packed
+    from the pooled rows), the per-object entries and the boundary tile on the dense block.  Same products, f32 accumulation in another
+    order: conv3_1.weight's gradient agrees to 1e-5, every other gradient bit for bit."""
+    from scene_graph_commonsense_amd.engine import tuning
+    from scene_graph_commonsense_amd.model import BayesianRelationClassifier
+    from scene_graph_commonsense_amd.pairs import flatten_scene
+    from scene_graph_commonsense_amd.synthetic import HeadConfig, make_scene_batch, make_state_dict
+    cfg = HeadConfig()
+    model = BayesianRelationClassifier(cfg.args()).cuda()
+    model.load_state_dict(make_state_dict(cfg, seed=9, head_gain=4.0))
+    model.eval()
+    batch = make_scene_batch(cfg, (40, 33, 27), seed=91, connect_frac=0.05)
+    sc = flatten_scene(cfg, batch, "cuda:0")
+    assert sc.shared_windows >= 8192 and sc.linear_windows > 0
+    grads = []
+    for on in (True, False):
+        with tuning(sparse_wgrad=on):
+            model.zero_grad(set_to_none=True)
+            loss = model.training_step(sc, batch.relationships, batch.subj_or_obj)
+            torch.cuda.synchronize()
+            grads.append((float(loss), {n: p.grad.detach().clone() for n, p in model.named_parameters()}))
+    (la, a), (lb, b) = grads
+    assert la == lb
+    for n in a:
+        if n == "conv3_1.weight":
+            e = float((a[n].double() - b[n].double()).norm() / b[n].double().norm())
+            print("conv3_1.weight sparse vs dense", e)
+            assert e <= 1e-5, e
+        else:
+            assert torch.equal(a[n], b[n]), n
