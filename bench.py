@@ -194,6 +194,13 @@ def executed_flops(P, n_img, n_obj, n_x, n_list, shared, forward_only=False, lin
         f["conv3"] = (2.0 * n_list * 4 * 1024 * 4608 + 2.0 * n_img * 256 * 1024 * 4608) * passes
         if linear:          # linear pairs: one forward launch for the raw pre-activations of the per-object entries + the background windows
             f["conv3"] += 2.0 * (linear[1] + 64 * n_img) * 4 * 1024 * 4608
+        if linear and not forward_only:
+            from scene_graph_commonsense_amd.engine import TUNING
+            if TUNING.sparse_wgrad and TUNING.patch_wgrad:
+                # the weight gradient of the real pairs' windows runs on the SPARSE matrix cores: half of its multiply-adds (the
+                # structural zeros of the un-pooled gradient) are not executed - they are not counted as work either
+                e_sp = ((n_list - linear[1]) // 16) * 16
+                f["conv3"] -= 0.5 * 2.0 * e_sp * 4 * 1024 * 4608
         f["fc1"] = 2.0 * (n_x + 64 * 2 * n_obj) * 1024 * 4096 * passes
     else:
         f["conv3"] = 2.0 * P * 256 * 1024 * 4608 * passes
