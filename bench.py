@@ -34,8 +34,19 @@ CPU_BASELINE_THREADS = 32      # fastest single-process setting on the GPU box's
 # epilogue (gemm_nt_pp_kernel<ELEM, EPI_POOL, ABL, ACG = 1>: the ping-pong block with gathered conv rows).  With conv3 AND fc1
 # computed over shared windows (csrc/kernels_shared.hip) the three GEMMs over those windows are the longest launches of the step
 # (forward / data gradient / weight gradient, 7.4 / 7.9 / 8.3 ms); the forward one is reported here, the others are in kernels_ms.
-DOMINANT_KERNEL = ("gemm_nt_pp_kernel<0, 3, 0, 1, 0>", "gemm_nt_pp_kernel<0, 3, 0, 1>")      # <ELEM, EPI, ABL, ACG, SEG>; older profiles: four arguments
-PMC_TAGS = ("r04_final5", "r04_final4", "r04_final3", "r04_final2", "r04_final", "r03_final6", "r03_final5", "r03_final4")             # newest committed profile sets first
+# The three GEMMs over the convolved windows are the longest launches of the step.  key of engine.timers -> (rocprofv3 kernel names,
+# newest first, what the launch is).  ``roofline`` reports the LONGEST of them (backward durations from a single-stream pass of the
+# same step: on two streams HIP-event intervals of overlapping launches are not kernel times), ``roofline_kernels`` all three.
+WINDOW_GEMMS = {
+    "conv3_fwd_windows": (("gemm_nt_pp_kernel<0, 3, 0, 1, 0>", "gemm_nt_pp_kernel<0, 3, 0, 1>"),
+                          "gemm_nt_pp_kernel<f16,relu+pool,conv-gather> (sgc_conv3_relu_pool_windows_wm: conv3 forward over the listed windows)"),
+    "conv3_dgrad_windows": (("gemm_nt_sp_kernel", "gemm_nt_pp_kernel<1, 0, 0, 0, 1>"),
+                            "conv3 data gradient over the listed windows in patch form (sgc_windows_dgrad_patches)"),
+    "conv3_wgrad_windows": (("gemm_tn_sp_kernel<1>",),
+                            "gemm_tn_sp_kernel<patch> (sgc_windows_wgrad_patch_sparse: conv3 weight gradient of the real pairs' listed windows, "
+                            "2:4-sparse un-pooled gradient x 4x4 input patches; executed = non-zero multiply-adds only)"),
+}
+PMC_TAGS = ("r05_final", "r05_mid", "r04_final5", "r04_final4", "r04_final3", "r04_final2", "r04_final", "r03_final6")   # newest committed profile sets first
 
 
 def parse_args(argv=None):
@@ -109,9 +120,9 @@ def state_plan_total(eng):
     return None if t is None else int(t[0])
 
 
-def pmc_traffic():
-    """(bytes per launch, rocprof average ms per launch, profile tag) of the dominant kernel from the NEWEST committed profile set
-    under profiles/: HBM-side bytes from the separate rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE runs,
+def pmc_traffic(names):
+    """(bytes per launch, rocprof average ms per launch, profile tag) of the kernel called one of ``names`` from the NEWEST committed
+    profile set under profiles/ that has it: HBM-side bytes from the separate rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE runs,
     profiles/<tag>_pmc_{f,w}.csv; FETCH_SIZE is doubled: gfx950 counts 128-B requests of wide coalesced reads as 64 B,
     MI355X_MICROARCH.md HBM section; both counters are KiB) and the warm-only kernel-trace average of the same set
     (profiles/<tag>_kernel_stats.csv).  These describe the COMMITTED profile run of ``tag``, not this process: the JSON line names the
@@ -123,14 +134,14 @@ def pmc_traffic():
             if not os.path.exists(path):
                 break
             for line in open(path):
-                if any(k in line for k in DOMINANT_KERNEL) and "," + ctr + "," in line:
+                if any(k in line for k in names) and "," + ctr + "," in line:
                     vals[ctr] = float(line.rsplit(",", 1)[1])
         if len(vals) == 2:
             avg = None
             ks = os.path.join(REPO, "profiles", "%s_kernel_stats.csv" % tag)
             if os.path.exists(ks):
                 for line in open(ks):
-                    if any(k in line for k in DOMINANT_KERNEL):
+                    if any(k in line for k in names):
                         avg = float(line.split(",")[2])          # calls,total_ms,avg_ms,...
                         break
             return int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024), avg, tag
@@ -395,6 +406,17 @@ def run_rank(args):
     dt = float(t.item())
     assert int(ranks.item()) == args.gpus, "ranks that took part in the timed region != --gpus"
 
+    # ---- per-kernel durations of the BACKWARD launches: the timed step runs its backward on two streams (weight-gradient chain beside
+    # the data-gradient chain), where HIP-event intervals of overlapping launches are not kernel times.  One more short pass of the
+    # same step on ONE stream (after the timed region; 1 warm-up + 2 steps) gives them; rank 0, N = 1 only.
+    kern_1s = None
+    from scene_graph_commonsense_amd import engine as _engine_mod
+    if world == 1 and not args.forward_only and _engine_mod.TUNING.bwd_streams:
+        with _engine_mod.tuning(bwd_streams=False):
+            kern_1s = measure(batch, 2, 1)["kern"]
+    elif not args.forward_only:
+        kern_1s = kern
+
     # ---- box-size sensitivity (N=1): the same step on scaled boxes - the pair-specific share of conv3 / fc1, hence the step time
     # and the workspace, depend on how much the objects' window rectangles overlap; the reference's cost does not
     sensitivity = None
@@ -420,7 +442,6 @@ def run_rank(args):
         flops = {"conv3_fwd": 2.0 * P * 256 * 1024 * 4608, "conv3_dgrad": 2.0 * P * 256 * 512 * 9216,
                  "conv3_wgrad": 2.0 * P * 256 * 1024 * 4608, "fc1_fwd": 2.0 * P * 65536 * 4096,
                  "fc1_dgrad": 2.0 * P * 65536 * 4096, "fc1_wgrad": 2.0 * P * 65536 * 4096}
-        dom = "conv3_fwd_windows"
         from scene_graph_commonsense_amd.engine import TUNING
         two_streams = TUNING.bwd_streams and not args.forward_only
         fwd_only = ("conv2_fwd", "expand_dense", "expand", "expand_train", "conv3_fwd", "conv3_fwd_objects", "conv3_fwd_windows", "conv3_fwd_raw", "conv3_fwd_linear",
@@ -430,27 +451,52 @@ def run_rank(args):
         if xw is not None:                         # conv3 / fc1 over shared windows: flops of what is actually computed
             n_ps = 2 * args.objects * args.images
             flops["conv3_fwd_windows"] = 2.0 * n_list * 4 * 1024 * 4608
-            flops["conv3_fwd_objects"] = 2.0 * (args.images if n_list > n_x else n_ps) * 256 * 1024 * 4608
+            # whole maps that still go through the ordinary conv3 kernel: the images' background maps (second level of sharing:
+            # TUNING.shared_objects) or every pseudo-pair (first level)
+            flops["conv3_fwd_objects"] = 2.0 * (args.images if (TUNING.shared_objects and TUNING.shared_fc1) else n_ps) * 256 * 1024 * 4608
             flops["conv3_dgrad_windows"] = flops["conv3_wgrad_windows"] = flops["conv3_fwd_windows"]
+            if m["linear"] and TUNING.sparse_wgrad and TUNING.patch_wgrad:
+                # the timer "conv3_wgrad_windows" is the SPARSE launch over the real pairs' windows (the dense tail has its own timer):
+                # executed = the non-zero half of its dense-equivalent multiply-adds
+                e_sp = ((n_list - m["linear"][1]) // 16) * 16
+                flops["conv3_wgrad_windows"] = 0.5 * 2.0 * e_sp * 4 * 1024 * 4608
             flops["fc1_fwd_windows"] = 2.0 * (n_x + 64 * n_ps) * 1024 * 4096          # padding rows not counted
             flops["fc1_dgrad"] = flops["fc1_wgrad"] = flops["fc1_fwd_windows"]
-        roof = None
-        if dom in kern and kern[dom] > 0:
-            ach = flops[dom] / (kern[dom] * 1e-3) / 1e12
-            traffic, rocprof_ms, tag = pmc_traffic() if (P == 32256 and args.box_scale == 1.0 and args.dataset == "vg") else (None, None, None)
-            roof = {"bound": "mfma", "kernel": "gemm_nt_pp_kernel<f16,relu+pool,conv-gather> (sgc_conv3_relu_pool_windows_wm: %d windows x 4 pixels "
-                                               "x 1024 x 4608: the pair-specific windows of the %d per-pair windows + the per-object windows; the "
-                                               "rest is shared)" % (n_list, P * 64),
-                    "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                    "traffic_note": "bytes/launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from profiles/%s_pmc_{f,w}.csv "
-                                    "(separate rocprofv3 --pmc passes at this workload); algorithmic ~2.9e9 (z next to the windows 1.7 + outputs 1.2 + weights 0.01)" % tag,
-                    "ms_per_launch": round(kern[dom], 3),
-                    # the two timings of the dominant kernel, kept apart: ``frac`` = this process's HIP events on this box;
-                    # ``frac_rocprof`` = the warm-only rocprofv3 --kernel-trace average of the committed profile set ``profile_tag``
-                    # (the set ``traffic`` comes from; same workload and window list, possibly another box / an older commit)
+        else:
+            flops["conv3_fwd_windows"] = flops["conv3_fwd"]
+
+        def gemm_record(key, ms, source):
+            names, what = WINDOW_GEMMS[key]
+            ach = flops[key] / (ms * 1e-3) / 1e12
+            traffic, rocprof_ms, tag = pmc_traffic(names) if (P == 32256 and args.box_scale == 1.0 and args.dataset == "vg") else (None, None, None)
+            return {"bound": "mfma", "kernel": "%s: %d listed windows x 4 pixels x 1024 x 4608 (the pair-specific windows of the %d per-pair windows + "
+                                               "the per-object windows; the rest is shared)" % (what, n_list, P * 64),
+                    "timer": key, "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
+                    "traffic": traffic,
+                    "traffic_note": "bytes/launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from profiles/%s_pmc_{f,w}.csv (separate rocprofv3 --pmc passes "
+                                    "at this workload)" % tag,
+                    "ms_per_launch": round(ms, 3), "ms_source": source, "executed_tflop": round(flops[key] / 1e12, 3),
+                    # the two timings, kept apart: ``frac`` = this process's HIP events on this box; ``frac_rocprof`` = the warm-only
+                    # rocprofv3 --kernel-trace average of the committed profile set ``profile_tag`` (the set ``traffic`` comes from; same
+                    # workload and window list, possibly another box / an older commit)
                     "profile_tag": tag, "ms_per_launch_rocprof": rocprof_ms,
-                    "frac_rocprof": None if not rocprof_ms else round(flops[dom] / (rocprof_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4)}
+                    "frac_rocprof": None if not rocprof_ms else round(flops[key] / (rocprof_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4)}
+
+        roof, roof_all = None, []
+        for key in WINDOW_GEMMS:
+            if key == "conv3_fwd_windows":
+                ms_k, src = kern.get(key, 0.0), "HIP events on the launch stream, timed steps"
+            else:
+                ms_k, src = (kern_1s or {}).get(key, 0.0), "HIP events, single-stream pass of the same step after the timed region"
+            if xw is not None and ms_k > 0:
+                roof_all.append(gemm_record(key, ms_k, src))
+        if not roof_all and kern.get("conv3_fwd", 0) > 0:           # per-pair kernels (no shared windows): conv3 forward over whole maps
+            ach = flops["conv3_fwd"] / (kern["conv3_fwd"] * 1e-3) / 1e12
+            roof_all.append({"bound": "mfma", "kernel": "conv16_halo_pp_kernel<f16,relu+pool> (sgc_conv3_relu_pool: every pair a whole map)", "timer": "conv3_fwd",
+                             "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                             "ms_per_launch": round(kern["conv3_fwd"], 3)})
+        if roof_all:
+            roof = dict(max(roof_all, key=lambda r: r["ms_per_launch"]))       # the step's longest launch
         hbm = None
         if m.get("exp_bytes") and kern.get("expand_dense", 0) > 0:
             # north_star names the pair expansion's HBM rate: the longest HBM-bound launch of the forward
@@ -480,6 +526,7 @@ def run_rank(args):
                        "parallelism": "dp%d" % world},
             "loss": None if loss is None else float(loss), "loss_first_step": first_loss,
             "roofline": roof,
+            "roofline_kernels": roof_all,           # the three GEMMs over the listed windows, each against the dense MFMA peak
             "hbm": hbm,
             # SURVEY 8d priced the path at 2.996 (fwd) / 8.99 (fwd+bwd) GFLOP per ordered pair, taking conv3 / fc1 per pair as
             # irreducible; with the shared windows most of that is no longer executed, so this is an equivalence, not a rate
@@ -491,6 +538,8 @@ def run_rank(args):
             "kernels_ms": {k: round(v, 3) for k, v in sorted(kern.items()) if k in fwd_only or not two_streams},
             "kernels_tflops": {k: round(flops[k] / (kern[k] * 1e-3) / 1e12, 1) for k in kern
                                if k in flops and kern[k] > 0 and (k in fwd_only or not two_streams)},
+            # every launch of the step on ONE stream (the pass after the timed region): per-kernel times of the backward
+            "kernels_ms_single_stream": None if (kern_1s is None or kern_1s is kern) else {k: round(v, 3) for k, v in sorted(kern_1s.items())},
             "backward_streams": 2 if two_streams else 1,
             "image_group_lanes": len(getattr(model, "last_image_groups", None) or [1]) if not args.forward_only else 1,
             "peak_memory_gb": round(m["peak_gb"], 1),

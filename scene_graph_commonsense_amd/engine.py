@@ -243,7 +243,38 @@ def make_engine(cfg: HeadConfig, device="cuda:0") -> "RelHeadEngine":
     if cfg.hidden_dim == 128 and cfg.feature_size == 32:
         return RelHeadEngine(cfg, device)
     from .engine_generic import GenericTrunkEngine
+    # per pair: conv2 + conv3 multiply-adds of the reference graph at this size (model.py:141-146)
+    macs = 9.0 * (2 * cfg.hidden_dim) * (4 * cfg.hidden_dim) * cfg.feature_size ** 2 + 9.0 * (4 * cfg.hidden_dim) * (8 * cfg.hidden_dim) * (cfg.feature_size // 2) ** 2
+    if macs > 5e7 and not _GENERIC_WARNED:
+        import warnings
+        _GENERIC_WARNED.append(True)
+        warnings.warn("relation head built with input_dim=%d, feature_size=%d: the tiled gfx950 kernels exist for 128 / 32 only; this size "
+                      "runs on the generic f32 trunk (one thread per output element, %.2g MACs per pair - correct, but orders of magnitude "
+                      "off the MFMA roofline; csrc/kernels_generic.hip)" % (cfg.hidden_dim, cfg.feature_size, macs), RuntimeWarning, stacklevel=2)
     return GenericTrunkEngine(cfg, device)
+
+
+_GENERIC_WARNED = []
+
+
+class _CheckRing:
+    """Pinned int32 words for the deferred consistency checks of all engines of this process (``RelHeadEngine._post_check``)."""
+    SLOTS = 64
+    buf = None
+    free = []
+
+    @classmethod
+    def take(cls, eng):
+        if cls.buf is None:
+            cls.buf = torch.zeros(cls.SLOTS, dtype=torch.int32).pin_memory()
+            cls.free = list(range(cls.SLOTS))
+        if not cls.free:
+            eng.verify_checks()
+        if not cls.free:
+            eng.verify_checks(block=True)
+        if not cls.free:
+            raise RuntimeError("deferred-check ring exhausted: some engine posts checks and never calls verify_checks()")
+        return cls.free.pop()
 
 
 class RelHeadEngine:
@@ -271,26 +302,34 @@ class RelHeadEngine:
     # ------------------------------------------------------------------ deferred consistency checks
     def _post_check(self, bad: torch.Tensor, message: str):
         """``bad`` (device bool/int scalar, non-zero = inconsistent) is copied to pinned memory behind the work enqueued so far and
-        looked at LATER (``verify_checks``: at the next forward, or explicitly) - a host-side ``int(tensor)`` here would stall the
-        launch queue of every training step for a condition that never holds in the drivers' own use."""
-        flag = torch.zeros(1, dtype=torch.int32).pin_memory()
-        flag.copy_(bad.reshape(1).to(torch.int32), non_blocking=True)
+        looked at LATER (``verify_checks``: at the next forward, at the end of an epoch / an evaluation pass, or explicitly) - a
+        host-side ``int(tensor)`` here would stall the launch queue of every training step for a condition that never holds in the
+        drivers' own use.  The pinned words come from one process-wide ring (``_CheckRing``): no allocation per plan."""
+        slot = _CheckRing.take(self)
+        _CheckRing.buf[slot:slot + 1].copy_(bad.reshape(1).to(torch.int32), non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
-        self._checks.append((ev, flag, message))
+        self._checks.append((ev, slot, message))
 
     def verify_checks(self, block: bool = False):
         """Raise if a posted check failed (``block``: wait for the pending ones first)."""
-        keep = []
-        for ev, flag, message in self._checks:
+        keep, failed = [], None
+        for ev, slot, message in self._checks:
             if block:
                 ev.synchronize()
             if not ev.query():
-                keep.append((ev, flag, message))
-            elif int(flag[0]) != 0:
-                del self._checks[:]
-                raise RuntimeError(message)
+                keep.append((ev, slot, message))
+                continue
+            if int(_CheckRing.buf[slot]) != 0 and failed is None:
+                failed = message
+            _CheckRing.free.append(slot)
+        if failed is not None:
+            for _, slot, _ in keep:
+                _CheckRing.free.append(slot)
+            keep = []
         self._checks[:] = keep
+        if failed is not None:
+            raise RuntimeError(failed)
 
     def child(self) -> "RelHeadEngine":
         """An engine that shares this one's weights and transient scratch but owns the buffers of its training context: the
@@ -632,7 +671,9 @@ class RelHeadEngine:
             _lib.check(lib.sgc_shared_objects_fill(_lib.ptr(bbox), n_obj, P, _lib.ptr(inc), _lib.ptr(ga), self._st()), "sgc_shared_objects_fill")
         # the linear windows ordered by (image, window) for the background side of the backward (stable: sums in list order):
         # one placement kernel instead of sort + searchsorted + gathers (sgc_bucket_place, bit-identical: tests/test_scene_gpu.py)
-        if TUNING.plan_kernels:
+        # (one workgroup per (image, window) key scans the whole list twice: O(keys x entries).  0.09 ms at 8 images; a 32-image
+        # minibatch would be 16 x that, so beyond 1e8 key-entry visits the sort path below takes over - ADVICE r4)
+        if TUNING.plan_kernels and 64.0 * n_img * e_lin <= 1e8:
             order = own.get("xw_lin_order", e_lin + 64, torch.int32)
             seg = own.get("xw_lin_seg", 64 * n_img + 1, torch.int32)
             _lib.check(lib.sgc_bucket_place(_lib.ptr(gather_l), e_lin, _lib.ptr(sub_idx), _lib.ptr(obj_img), 1, 64 * n_img, None, _lib.ptr(order),
@@ -1525,6 +1566,20 @@ class RelHeadEngine:
                     self._timed("im2col_windows", lambda: _lib.check(lib.sgc_windows_im2col(_lib.ptr(z_bf), _lib.ptr(gather), _lib.ptr(gn), Epad,
                                                                                            _lib.ptr(zcol), st()), "sgc_windows_im2col"))
 
+        def auto_splits(k_rows, tiles=72):
+            # host mirror of csrc/gemm_tn.h:tn_auto_splits (72 tiles of the [1024][4608] gradient): what a launch with splits = 0 writes
+            nk, best = max(int(k_rows) >> 6, 1), 1
+            for s_ in range(1, 65):
+                if s_ > 1 and nk // s_ < 8:
+                    break
+                blocks = tiles * s_
+                best = s_
+                if blocks >= 256 and blocks * 100 >= ((blocks + 255) // 256) * 256 * 95:
+                    break
+            best = min(best, nk)
+            per = (nk + best - 1) // best
+            return (nk + per - 1) // per
+
         def wgrad_windows():
             # the second big GEMM of the window backward.  With ``TUNING.gemms_apart`` it is enqueued after the data-gradient GEMM
             # (the side stream then waits for it) and runs beside col2im / the pair contraction; the im2col above runs beside the
@@ -1533,6 +1588,11 @@ class RelHeadEngine:
                 n_slabs = slabs_n.value
                 e_real = sh.get("entries_real")
                 e_sp = (int(e_real) // 16) * 16 if (e_real is not None and TUNING.patch_wgrad and TUNING.sparse_wgrad and dest is not None) else 0
+                # slab capacity is checked BEFORE anything is launched into the 32-slab buffer (the launches' own counts are the mirror's)
+                need = n_slabs + ((auto_splits(e_sp * 4) + (auto_splits((Epad - e_sp) * 4) if Epad > e_sp else 0)) if (Epad and e_sp >= 4096)
+                                  else (auto_splits(Epad * 4) if Epad else 0))
+                if need > 32:
+                    raise RuntimeError("split-K slabs of the conv3 weight gradient (%d) exceed the 32-slab buffer" % need)
                 if Epad and e_sp >= 4096:
                     # the real pairs' windows: their un-pooled gradient has ONE non-zero per window and channel (4 consecutive K indices)
                     # - the 2:4 pattern of the sparse matrix cores; packed straight from the pooled rows.  The per-object entries behind
@@ -1556,7 +1616,7 @@ class RelHeadEngine:
                     self._timed("conv3_wgrad_windows", lambda: _lib.check((lib.sgc_windows_wgrad_patch if TUNING.patch_wgrad else lib.sgc_windows_wgrad)(
                         _lib.ptr(dy3x), _lib.ptr(zcol), _lib.ptr(slx), Epad * 4, 0, ctypes.byref(slabs_x), st()), "sgc_windows_wgrad"))
                     n_slabs += slabs_x.value
-                assert n_slabs <= 32, "split-K slabs of the conv3 weight gradient exceed the slab buffer"
+                assert n_slabs <= need, "split-K counts of the launches differ from their host mirror"
                 dW3r = self._slab_sum(sl, 1024 * 4608, n_slabs)
                 grads["conv3_1.weight"] = dW3r.view(1024, 3, 3, 512).permute(0, 3, 1, 2).contiguous()
 

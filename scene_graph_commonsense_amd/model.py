@@ -163,7 +163,9 @@ class _RelationBase(nn.Module):
         eng = self.refresh_weights(backward=True)
         if k == 0:
             return eng
-        eng.w["w1p"], eng.w["w1pT"]                    # deferred copies: made on the caller's stream, before the lanes' streams read them
+        for key in ("w1p", "w1pT"):                    # deferred copies: made on the caller's stream, before the lanes' streams read them
+            if key in eng.w or key in eng.w.deferred:  # (the generic trunk keeps fc1's copies under other names, made eagerly)
+                eng.w[key]
         lanes = self.__dict__.setdefault("_lane_engines", {})
         if k not in lanes or lanes[k].device != eng.device:
             lanes[k] = make_engine(self.head_config(), eng.device)

@@ -287,6 +287,10 @@ def training(gpu, args, train_subset, test_subset):
                 # (zero gradients), applies the same update as its peers and joins the print_freq barrier.
                 if world_size > 1:
                     optimizer.zero_grad(set_to_none=True)
+                    # lr of this update: the reference never takes this path (it hangs), so there is no golden value; the sqrt(n_max
+                    # fraction) rescale of the line below needs a minibatch this rank does not have, and the lr the PREVIOUS minibatch
+                    # left behind is arbitrary - take the un-rescaled epoch rate (with ShardedSGD this rank's shard uses it)
+                    optimizer.param_groups[0]["lr"] = original_lr * lr_decay
                     relation_classifier.zero_gradient_step(reducer)
                     optimizer.step()
                     if batch_count % T["print_freq"] == 0 or batch_count + 1 == len(train_loader):
@@ -341,6 +345,7 @@ def training(gpu, args, train_subset, test_subset):
             stats[0] = 0; stats[1] = 0; stats[3] = 0
         if hasattr(optimizer, "wait_gathers"):
             optimizer.wait_gathers()                         # deferred all-gather of fc1.weight: land it before the parameters are read
+        relation_classifier.engine().verify_checks(block=True)   # deferred device-side plan checks of the epoch's last steps: before the checkpoint
         if rank == 0:
             path = checkpoint_name(args, epoch, cs_mode)[0]
             print("Saving model to %s..." % path)
@@ -404,5 +409,6 @@ def testing(args, detr, relation_classifier, test_loader, test_record, epoch, ra
                             torch.tensor(float(s[4])), s[1], s[0], torch.tensor(float(s[3])), s[2], wmap_rel, wmap_phrase)
                 if dist.is_initialized():
                     dist.barrier()
+    relation_classifier.engine().verify_checks(block=True)       # plan checks posted by the last evaluation passes
     print("FINISHED EVALUATING\n")
     return recall, mean_recall, stats

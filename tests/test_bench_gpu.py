@@ -46,6 +46,16 @@ def test_bench_single_rank_line(capsys, monkeypatch):
     roof = out["roofline"]
     assert roof["bound"] == "mfma" and 0 < roof["frac"] < 1 and roof["ms_per_launch"] < out["ms_per_step"]
     assert out["loss"] == out["loss"]          # finite, not NaN
+    # no printed rate may exceed the chip's dense peak (a mis-labelled flop count once printed 14x the peak), the
+    # roofline record is the step's LONGEST launch among the three window GEMMs, backward durations from the single-stream pass
+    import bench
+    rk = out["roofline_kernels"]
+    assert {r["timer"] for r in rk} == {"conv3_fwd_windows", "conv3_dgrad_windows", "conv3_wgrad_windows"}
+    assert all(0 < r["frac"] < 1 and 0 < r["achieved"] < bench.MFMA_PEAK_TFLOPS for r in rk)
+    assert roof["ms_per_launch"] == max(r["ms_per_launch"] for r in rk)
+    assert all(0 < v < bench.MFMA_PEAK_TFLOPS for v in out["kernels_tflops"].values()), out["kernels_tflops"]
+    assert out["hbm"] is None or 0 < out["hbm"]["frac"] < 1
+    assert out["kernels_ms_single_stream"] and "conv3_dgrad_windows" in out["kernels_ms_single_stream"]
     # whole-step efficiency on executed flops, and the box-size sensitivity sweep of the default invocation
     assert 0 < roof["step_frac"] < roof["frac"] + 0.2 and roof["step_frac"] < 1
     assert out["ranks_seen"] == 1 and len(out["rank_ms_per_step"]) == 1 and out["peak_memory_gb"] > 1
