@@ -95,3 +95,22 @@ def test_bench_two_ranks_end_to_end_on_one_gpu_over_gloo():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "dp2" and out["value"] > 0
     assert out["loss"] == out["loss"] and out["scaling"] == "weak"
+
+
+def test_bench_eight_ranks_end_to_end_on_one_gpu_over_gloo():
+    """The node size the path is built for (8 ranks, ``/root/reference/train_test.py:72-80``) through ONE real step without eight
+    GPUs: all ranks share the test box's device over gloo (SGC_BENCH_SHARE_GPU), smallest scene.  Exercises what world = 2 never
+    does: ShardedSGD's 8 row blocks x 8 shards of the real fc1.weight (2^28 elements), the padded flat bucket at W = 8, the early
+    reduce-scatters from the side stream, deferred gathers, eight per-rank synthetic shards, MAX-reduced time."""
+    env = dict(os.environ, SGC_BENCH_SHARE_GPU="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "1", "--objects", "6",
+                        "--images", "2", "--backend", "gloo", "--no-cpu-baseline"], capture_output=True, text=True, timeout=1500, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["ranks_seen"] == 8 and out["config"]["parallelism"] == "dp8" and out["value"] > 0
+    assert out["dp_mode"] == "sharded" and len(out["rank_ms_per_step"]) == 8 and all(t > 0 for t in out["rank_ms_per_step"])
+    assert out["loss"] == out["loss"] and out["scaling"] == "weak"
