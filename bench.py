@@ -70,6 +70,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-sensitivity", action="store_true", help="skip the three short box-size sensitivity runs (N=1 only)")
     ap.add_argument("--box-scale", type=float, default=1.0,
                     help="scale every box about its centre (clipped to the image); >= 100 = every box is the full image")
+    ap.add_argument("--box-dist", default="survey", choices=["survey", "vg03", "vg06", "vg12"],
+                    help="survey: SURVEY 8d's boxes (the benchmark); vgNN: raw boxes with ASSUMED VG-like marginals (median area NN %% of the "
+                         "image) through the reference's own box pipeline (synthetic.vg_like_boxes, tools/vg_box_statistic.py)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / rendezvous / reduction plumbing only, no GPU work (the CPU test of the N-rank launch uses it with gloo)")
     return ap.parse_args(argv)
@@ -323,6 +326,9 @@ def run_rank(args):
     batch = make_scene_batch(cfg, [args.objects] * args.images, seed=1000 + rank, connect_frac=0.02)
     if args.box_scale != 1.0:
         scale_boxes(batch, args.box_scale)
+    if args.box_dist != "survey":
+        from scene_graph_commonsense_amd.synthetic import with_vg_like_boxes
+        with_vg_like_boxes(batch, 1000 + rank, median_area=int(args.box_dist[2:]) / 100.0)
     # inputs resident in HBM when the timed region starts (the DETR features are produced on the GPU upstream); the ragged
     # annotation lists stay host-side Python objects exactly as the reference's dataloader hands them over
     batch.image_feature = batch.image_feature.to(dev)
@@ -420,13 +426,16 @@ def run_rank(args):
     # ---- box-size sensitivity (N=1): the same step on scaled boxes - the pair-specific share of conv3 / fc1, hence the step time
     # and the workspace, depend on how much the objects' window rectangles overlap; the reference's cost does not
     sensitivity = None
-    if world == 1 and not args.no_sensitivity and not args.forward_only and args.box_scale == 1.0:
+    if world == 1 and not args.no_sensitivity and not args.forward_only and args.box_scale == 1.0 and args.box_dist == "survey":
         sensitivity = []
-        for label, factor in (("boxes x1.5", 1.5), ("boxes x2.5", 2.5), ("every box = full image", 100.0)):
+        from scene_graph_commonsense_amd.synthetic import with_vg_like_boxes
+        vg = "raw boxes with assumed VG-like marginals (median area %d %% of the image) through the reference's box pipeline"
+        for label, factor in ((vg % 3, -0.03), (vg % 6, -0.06), (vg % 12, -0.12), ("boxes x1.5", 1.5), ("boxes x2.5", 2.5), ("every box = full image", 100.0)):
             eng.ws.bufs.clear()                       # the workspace only grows: start every point from an empty one
             model._weights_version = None
             torch.cuda.empty_cache()
-            b2 = scale_boxes(make_scene_batch(cfg, [args.objects] * args.images, seed=1000 + rank, connect_frac=0.02), factor)
+            b2 = make_scene_batch(cfg, [args.objects] * args.images, seed=1000 + rank, connect_frac=0.02)
+            b2 = with_vg_like_boxes(b2, 1000 + rank, median_area=-factor) if factor < 0 else scale_boxes(b2, factor)
             b2.image_feature, b2.image_depth = batch.image_feature, batch.image_depth
             r = measure(b2, 2, 1)
             fl = executed_flops(r["P"], args.images, r["n_obj"], r["n_x"], r["n_list"], r["shared"], linear=r["linear"])

@@ -295,3 +295,43 @@ def make_scene_batch(cfg: HeadConfig, num_objects: Sequence[int], seed: int = 0,
         dirs.append(dir_i)
     return SceneBatch(feat, depth, bboxes, cats, spcats if cfg.dataset == "vg" else None, rels, dirs,
                       list(num_objects))
+
+
+# ---------------------------------------------------------------------------------------------------------------- VG-like boxes
+VG_IMAGE_SIZES = ((375, 500), (333, 500), (500, 375), (600, 800), (768, 1024))      # (height, width) of typical Visual Genome images
+
+
+def vg_like_boxes(n: int, seed: int, median_area: float = 0.06, sigma_area: float = 1.2, sigma_aspect: float = 0.5,
+                  feature_size: int = 32) -> np.ndarray:
+    """[n,4] int boxes (x0,x1,y0,y1) on the feature grid, produced by the REFERENCE'S OWN box pipeline from raw pixel boxes whose
+    marginals are ASSUMED (no Visual Genome annotation is available offline): area fraction log-normal around ``median_area`` with
+    a heavy tail (a few near-full-image boxes: sky / building / wall), aspect ratio log-normal, position uniform, on an image of a
+    typical VG size.  Pipeline, line by line: pixel box (xmin, ymin, xmax, ymax) -> ``utils.resize_boxes`` (``utils.py:38-55``:
+    ``int(coordinate * new / original)`` - truncation, so small boxes can become EMPTY on the grid) -> stored as (x0, x1, y0, y1)
+    (``dataset_utils.py:124-126``), objects sorted by raw area, descending (``:113-116``) -> the loader's ``bbox.int()``
+    (``dataloader.py:129``).  The loader's drop rules (image dropped when a box is empty at image resolution, ``:123-128``; <= 1 or
+    > 20 objects, ``:119``) are the caller's (``annotations.prepare_annotation``); empty grid boxes stay in the list exactly as the
+    reference keeps them."""
+    rng = np.random.default_rng(seed)
+    h_img, w_img = VG_IMAGE_SIZES[int(rng.integers(len(VG_IMAGE_SIZES)))]
+    area = np.clip(np.exp(rng.normal(np.log(median_area), sigma_area, n)), 0.0005, 0.98)
+    asp = np.exp(rng.normal(0.0, sigma_aspect, n))
+    w = np.clip(np.sqrt(area * asp), 0.01, 1.0) * w_img
+    h = np.clip(np.sqrt(area / asp), 0.01, 1.0) * h_img
+    xmin = rng.uniform(0, w_img - w)
+    ymin = rng.uniform(0, h_img - h)
+    raw = np.stack([xmin, ymin, xmin + w, ymin + h], axis=1)
+    order = np.argsort(-(w * h), kind="stable")
+    rh, rw = feature_size / h_img, feature_size / w_img
+    out = []
+    for k in order:
+        b = raw[k]
+        r = [int(b[0] * rw), int(b[1] * rh), int(b[2] * rw), int(b[3] * rh)]         # resize_boxes: xmin, ymin, xmax, ymax
+        out.append([r[0], r[2], r[1], r[3]])                                          # x_min, x_max, y_min, y_max
+    return np.asarray(out, dtype=np.int32).reshape(-1, 4)
+
+
+def with_vg_like_boxes(batch: "SceneBatch", seed: int, **kw) -> "SceneBatch":
+    """``batch`` with every image's boxes replaced by ``vg_like_boxes`` (same object counts; features, labels, relations untouched)."""
+    batch.bbox = [torch.from_numpy(vg_like_boxes(int(b.shape[0]), seed * 7919 + i, **kw)).to(b.dtype) for i, b in enumerate(batch.bbox)]
+    return batch
