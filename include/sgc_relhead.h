@@ -443,6 +443,14 @@ int sgc_conv1_wgrad(const void* dpre, const void* x_bf16, float* slabs, int n_ro
  * 16-byte aligned pointers take the float4 path, anything else a scalar one. */
 int sgc_sgd_momentum_step(float* w, const float* g, float* momentum_buf, long n, float lr, float momentum, float weight_decay,
                           int first_step, void* stream);
+/* The same update for fc1.weight ([rows][1024 channels * 64 windows] f32, reference order channel*64 + window: model.py:118) with the
+ * gradient given in GEMM order ([rows][window*1024 + channel], what sgc_fc1_windows_wgrad / sgc_fc1_wgrad write) - the transposition
+ * of the gradient back to the reference order, the update (train_test.py:100,277) and the f16 compute copy of the forward
+ * (w1p_f16 [rows][window*1024 + channel], may be NULL) in ONE pass over gradient, weight and momentum buffer.  rows may be a row range
+ * (pointers at its first row).  Weights and momentum bit-identical to sgc_transpose_cast(kind 2) + sgc_sgd_momentum_step, the copy to
+ * sgc_transpose_cast(kind 0) of the result. */
+int sgc_sgd_fc1_fused(float* w, const float* g_gemm_order, float* momentum_buf, int rows, float lr, float momentum, float weight_decay,
+                      int first_step, void* w1p_f16, void* stream);
 /* The same update for up to 32 SMALL tensors in one launch (w / g / momentum_buf / n: host arrays of n_tensors device pointers / element
  * counts, read at call time; bit t of first_mask = tensor t has no momentum buffer yet).  18 of the head's 22 parameter tensors are
  * biases, head rows and 1x1 convolutions: one launch each cost more in launch gaps than in work. */

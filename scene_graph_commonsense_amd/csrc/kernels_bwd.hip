@@ -701,6 +701,51 @@ __global__ void segment_cast_kernel(const SegmentCastParams p) {
     }
 }
 
+// SGD step of fc1.weight fused with the two within-row layout passes around it (the step's largest HBM-bound chain: 277 M
+// parameters, 97 % of them here).  The fc1 weight-gradient GEMM leaves dW in GEMM order [n][window*1024 + channel]; the reference's
+// parameter (and its momentum buffer) is [n][channel*64 + window] (model.py:118, the flatten of [1024, 8, 8]); the forward's f16 compute
+// copy is again [n][window*1024 + channel].  Unfused: transpose_cast<2> (gradient -> reference order) + sgd_momentum_kernel +
+// transpose_cast<0> (f16 copy) = 10.7 GB of traffic; here one pass reads gradient, weight and momentum once and writes weight,
+// momentum and the f16 copy once (6.4 GB).  One workgroup = one row n x one block of 64 channels x 64 windows: the gradient tile
+// goes through LDS transposed, the update runs in the parameter's own (contiguous) order with the SAME expressions as
+// sgd_momentum_kernel (bit-identical weights: tests/test_gemm_gpu.py), the new weights go back through the same LDS tile for the
+// f16 rows.  w1p == nullptr: no compute copy (sharded data parallelism: the copy is made after the all-gather).
+__global__ __launch_bounds__(256) void sgd_fc1_fused_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ buf,
+                                                            float lr, float momentum, float wd, int first, u16* __restrict__ w1p) {
+    __shared__ float tile[64][65];
+    const long row = (long)blockIdx.x * 65536;
+    const int cb = blockIdx.y;
+    const int lane = threadIdx.x & 63, wq = threadIdx.x >> 6;
+    const float* gs = g + row + cb * 64;                  // [window][64 channels of the block], window stride 1024
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int win = r * 4 + wq;
+        tile[win][lane] = gs[(long)win * 1024 + lane];
+    }
+    __syncthreads();
+    float* wp = w + row + cb * 4096;                      // [64 channels][64 windows] contiguous
+    float* bp = buf + row + cb * 4096;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int c = r * 4 + wq, i = c * 64 + lane;      // lane = window
+        const float wi = wp[i];
+        const float gg = tile[lane][c] + wd * wi;
+        const float b = first ? gg : momentum * bp[i] + gg;
+        const float wn = wi - lr * b;
+        bp[i] = b;
+        wp[i] = wn;
+        tile[lane][c] = wn;                               // the element this thread read: no hazard
+    }
+    if (w1p == nullptr) return;
+    __syncthreads();
+    u16* os = w1p + row + cb * 64;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int win = r * 4 + wq;
+        os[(long)win * 1024 + lane] = f32_to_f16_bits(tile[win][lane]);
+    }
+}
+
 // Up to 32 SMALL tensors in one launch (blockIdx.y = tensor): the relation head has 22 parameter tensors, 18 of them below a million
 // elements (biases, head rows, conv1) - one launch each cost more in launch gaps than in work.  Same update, scalar accesses.
 struct SgdMultiParams {
@@ -797,6 +842,16 @@ int sgc_sgd_momentum_multi(int n_tensors, float* const* w, const float* const* g
     p.lr = lr; p.momentum = momentum; p.weight_decay = weight_decay; p.first_mask = first_mask;
     const unsigned bx = (unsigned)((nmax + 255) / 256 < 1024 ? ((nmax + 255) / 256 > 0 ? (nmax + 255) / 256 : 1) : 1024);
     SGC_LAUNCH(sgd_momentum_multi_kernel, dim3(bx, n_tensors), dim3(256), 0, (hipStream_t)stream, p);
+    SGC_CHECK_LAUNCH();
+    return SGC_OK;
+}
+
+int sgc_sgd_fc1_fused(float* w, const float* g_gemm_order, float* momentum_buf, int rows, float lr, float momentum, float weight_decay,
+                      int first_step, void* w1p_f16, void* stream) {
+    if (rows <= 0) return SGC_OK;
+    if ((((uintptr_t)w | (uintptr_t)g_gemm_order | (uintptr_t)momentum_buf) & 3) != 0) return SGC_ERR_ARG;
+    SGC_LAUNCH(sgd_fc1_fused_kernel, dim3((unsigned)rows, 16), dim3(256), 0, (hipStream_t)stream, w, g_gemm_order, momentum_buf, lr, momentum,
+               weight_decay, first_step, (u16*)w1p_f16);
     SGC_CHECK_LAUNCH();
     return SGC_OK;
 }

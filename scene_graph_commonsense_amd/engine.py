@@ -180,6 +180,8 @@ class Tuning:
     weight_kernels: bool = True       # 16-bit weight layouts by one gather + cast launch each (off: torch view / permute / flip / cat chains)
     fc1_own_sums: bool = True         # fc1 assembly reads S'_j[R_j] pre-summed per object (off: four corner vectors per pair; same bits)
     sparse_wgrad: bool = True         # conv3 weight gradient over the real pairs' listed windows on the sparse matrix cores (off: dense block)
+    fused_sgd: bool = True            # train_minibatch + optim.FusedSGD: fc1.weight's gradient stays in GEMM order, one pass un-permutes, updates and
+                                      # writes the f16 copy (off: transposition + update + transposition; same bits)
 
     @classmethod
     def from_env(cls):
@@ -298,6 +300,11 @@ class RelHeadEngine:
         self.T = (1.0, 1.0, 1.0)
         self.timers = None          # optional {name: [(start_event, end_event), ...]} filled by bench.py
         self._checks = []           # deferred device-side consistency checks: (event, pinned flag, message), see ``_post_check``
+        # fc1.weight's gradient leaves the backward in GEMM order [4096][window*1024 + channel] instead of the reference's
+        # [4096][channel*64 + window] (``optim.FusedSGD`` consumes that order in its fused update; set per call by
+        # ``pair_loop.train_minibatch``, never while a caller may look at ``fc1.weight.grad``)
+        self.fc1_grad_gemm_order = False
+        self._w1p_fresh = None      # (data_ptr, version) of the fc1.weight whose f16 copy the fused optimizer step has already written
 
     # ------------------------------------------------------------------ deferred consistency checks
     def _post_check(self, bad: torch.Tensor, message: str):
@@ -339,6 +346,7 @@ class RelHeadEngine:
         c.cfg, c.device, c.lib, c.w, c.T, c.timers = self.cfg, self.device, self.lib, self.w, self.T, None
         c._checks = self._checks
         c.head_rows = getattr(self, "head_rows", None)
+        c.fc1_grad_gemm_order, c._w1p_fresh = False, None
         c.ws, c.scratch = Workspace(self.device), self.scratch
         c._side_stream = getattr(self, "_side_stream", None)
         return c
@@ -394,9 +402,14 @@ class RelHeadEngine:
         else:
             self._load_trunk_weights_torch(g)
 
+        fc1_param = sd["fc1.weight"]
+
         def make_w1p():
             if fc1_sync is not None:
                 fc1_sync()
+            fresh = getattr(self, "_w1p_fresh", None)
+            if fresh is not None and fresh == (fc1_param.data_ptr(), fc1_param._version) and "w1p" in self.ws.bufs:
+                return self.ws.bufs["w1p"][:fc1_param.numel()]       # written by the fused optimizer step (sgc_sgd_fc1_fused) for this version
             with torch.no_grad():
                 return self._transpose_cast(g("fc1.weight").contiguous(), "w1p", torch.float16, 0, 4096, 16, 65536, 4096, 64, 65536, 64, 1024)
         w.defer("w1p", make_w1p)
@@ -1367,6 +1380,14 @@ class RelHeadEngine:
     def _fc1_finish_wgrad(self, dW1p, dh1, Ppad, grads, grad_hook):
         """dW1p [4096][(window, channel)] -> the reference's column order (channel*64 + window), bias gradient, early all-reduce hook."""
         lib, dev, st = self.lib, self.device, self._st
+        if self.fc1_grad_gemm_order:
+            # handed over as the GEMM wrote it (a view of the engine's scratch: valid until the next backward); the optimizer's fused
+            # update un-permutes it on the fly
+            grads["fc1.weight"] = dW1p[:4096 * 65536].view(4096, 65536)
+            if grad_hook is not None:
+                grad_hook("fc1.weight", grads["fc1.weight"])
+            grads["fc1.bias"] = self._colsum(dh1, Ppad, 4096)
+            return
         gfc1 = torch.empty(4096, 65536, dtype=torch.float32, device=dev)
         _lib.check(lib.sgc_transpose_cast(_lib.ptr(dW1p), _lib.ptr(gfc1), 2, 4096, 16, _c_long(65536), _c_long(64), _c_long(1024),
                                           _c_long(65536), _c_long(4096), _c_long(64), st()), "sgc_transpose_cast")

@@ -360,8 +360,15 @@ class _RelationBase(nn.Module):
                 if reducer is not None:
                     reducer.finish_grads(grads)
                 if not getattr(reducer, "owns_grads", False):      # a sharded reducer keeps the mean gradient shards itself
+                    gemm_order = bool(getattr(eng, "fc1_grad_gemm_order", False))
                     for name, p in self.named_parameters():
                         g = grads[name].view_as(p)
+                        if name == "fc1.weight":
+                            # column order of this gradient: the reference's, or the GEMM's (only inside pair_loop.train_minibatch with
+                            # an optimizer that consumes it, optim.FusedSGD); never mixed within one accumulation
+                            if p.grad is not None and bool(getattr(p, "_sgc_grad_gemm_order", False)) != gemm_order:
+                                raise RuntimeError("fc1.weight.grad is being accumulated in two different column orders")
+                            p._sgc_grad_gemm_order = gemm_order
                         if p.grad is None:
                             p.grad = g if g.is_contiguous() else g.contiguous()
                         else:

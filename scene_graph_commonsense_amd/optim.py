@@ -21,6 +21,23 @@ class FusedSGD(torch.optim.Optimizer):
             raise ValueError("lr, momentum and weight_decay must be non-negative")
         super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay))
         self._lib = _lib.load()
+        self._fc1_engine = None
+
+    def fuse_fc1(self, model):
+        """Called by ``pair_loop.train_minibatch`` before the step: if this optimizer updates ``model.fc1.weight`` (the reference's
+        [4096, 1024 * 64] layer on the tiled engine), return the engine whose backward may hand the gradient over in GEMM order - the
+        update then runs as ``sgc_sgd_fc1_fused`` (gradient un-permuted on the fly, f16 compute copy of the forward written by the same
+        pass: 6.4 instead of 10.7 GB of traffic per step) - else None."""
+        fc1 = getattr(model, "fc1", None)
+        if fc1 is None or tuple(fc1.weight.shape) != (4096, 65536) or not fc1.weight.is_cuda:
+            return None
+        if not any(p is fc1.weight for group in self.param_groups for p in group["params"]):
+            return None
+        eng = model.engine()
+        if not hasattr(eng, "fc1_grad_gemm_order") or type(eng).__name__ != "RelHeadEngine":
+            return None
+        self._fc1_engine = eng
+        return eng
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -42,6 +59,20 @@ class FusedSGD(torch.optim.Optimizer):
                 first = "momentum_buffer" not in st
                 if first:
                     st["momentum_buffer"] = torch.empty_like(p, memory_format=torch.contiguous_format)
+                if getattr(p, "_sgc_grad_gemm_order", False):
+                    # fc1.weight with its gradient in GEMM order (engine.fc1_grad_gemm_order): fused un-permute + update + f16 copy
+                    eng = self._fc1_engine
+                    if eng is None or tuple(p.shape) != (4096, 65536):
+                        raise RuntimeError("fc1.weight.grad is in GEMM order but this optimizer was not prepared by fuse_fc1()")
+                    w1p = eng.ws.get("w1p", p.numel(), torch.float16)
+                    _lib.check(self._lib.sgc_sgd_fc1_fused(_lib.ptr(p), _lib.ptr(g), _lib.ptr(st["momentum_buffer"]), 4096, f(group["lr"]),
+                                                           f(group["momentum"]), f(group["weight_decay"]), int(first), _lib.ptr(w1p),
+                                                           _lib.stream_ptr()), "sgc_sgd_fc1_fused")
+                    torch.autograd.graph.increment_version(p)
+                    eng._w1p_fresh = (p.data_ptr(), p._version)
+                    p.grad = None                       # it was a view of the engine's scratch, in an order nobody else should read
+                    p._sgc_grad_gemm_order = False
+                    continue
                 if p.numel() <= SMALL:
                     small.append((p, g, st["momentum_buffer"], first))
                 else:

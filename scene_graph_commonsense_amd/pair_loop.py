@@ -332,10 +332,25 @@ def train_minibatch(model, batch, optimizer=None, reducer=None, scene: Optional[
     model.last_image_groups = groups
     if scene is None:
         scene = flatten_scene(cfg, batch, dev)
-    if len(groups) == 1:
-        loss = model.training_step(scene, batch.relationships, batch.subj_or_obj, reducer=reducer, **loss_kw)
-    else:
-        loss = _train_image_groups(model, cfg, batch, scene, groups, reducer, loss_kw, lanes=lanes)
+    # fc1.weight's gradient in GEMM order for an optimizer that consumes it (optim.FusedSGD.fuse_fc1): one pass, one step, one rank -
+    # the plain case bench.py and the drivers run; every other case keeps the reference's column order
+    fuse_eng = None
+    if (optimizer is not None and len(groups) == 1 and loss_kw.get("image_feature_aug") is None and scene.n_pairs > 0
+            and (reducer is None or (getattr(reducer, "world", 1) == 1 and not getattr(reducer, "owns_grads", False)
+                                     and not getattr(reducer, "active", False)))):
+        from .engine import TUNING
+        fuse = getattr(optimizer, "fuse_fc1", None) if TUNING.fused_sgd else None
+        fuse_eng = fuse(model) if fuse is not None else None
+    try:
+        if fuse_eng is not None:
+            fuse_eng.fc1_grad_gemm_order = True
+        if len(groups) == 1:
+            loss = model.training_step(scene, batch.relationships, batch.subj_or_obj, reducer=reducer, **loss_kw)
+        else:
+            loss = _train_image_groups(model, cfg, batch, scene, groups, reducer, loss_kw, lanes=lanes)
+    finally:
+        if fuse_eng is not None:
+            fuse_eng.fc1_grad_gemm_order = False
     model.last_scene = scene
     if optimizer is not None:
         optimizer.step()
