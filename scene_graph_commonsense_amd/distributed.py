@@ -122,6 +122,18 @@ def _hip_sgd_update(p, g, m, lr, momentum, weight_decay, first):
                                                  f(weight_decay), int(first), _lib.stream_ptr()), "sgc_sgd_momentum_step")
 
 
+def _hip_sgd_fc1_update(p, g, m, lr, momentum, weight_decay, first):
+    """The same update for whole rows of fc1.weight with the gradient in GEMM order (``sgc_sgd_fc1_fused`` without the f16 copy: the
+    compute copies are made from the gathered masters)."""
+    import ctypes
+    from . import _lib
+    if not p.is_cuda or p.numel() % 65536:
+        raise RuntimeError("fused fc1 update: whole rows of a GPU tensor")
+    f = ctypes.c_float
+    _lib.check(_lib.load().sgc_sgd_fc1_fused(_lib.ptr(p), _lib.ptr(g), _lib.ptr(m), p.numel() // 65536, f(lr), f(momentum), f(weight_decay),
+                                             int(first), None, _lib.stream_ptr()), "sgc_sgd_fc1_fused")
+
+
 class _Piece:
     """One shard this rank owns: ``length`` elements at ``offset`` of a flat f32 buffer (a big parameter's storage or the small
     parameters' bucket), with its momentum buffer and the step's (accumulated) mean gradient."""
@@ -194,6 +206,32 @@ class ShardedSGD:
         self._keep: List = []
         self.exposed_events: List = []     # (start, end) event pairs around every wait on the compute stream
         self._native_rs = None
+        # True (set by ``fuse_fc1``, sticky): EVERY fc1.weight gradient handed to this object is in GEMM order [4096][window*1024 +
+        # channel] - the backward skips its transposition to the reference order (0.4 ms in front of the first reduce-scatter), the
+        # collectives move the rows as they are (the permutation is inside a row, the shards are whole rows) and the shard update
+        # un-permutes on the fly (``sgc_sgd_fc1_fused``)
+        self.fc1_gemm_order = False
+        self.update_fc1 = _hip_sgd_fc1_update
+
+    def fuse_fc1(self, model):
+        """Called by ``attach`` (and asked again by ``pair_loop.train_minibatch``); returns the engine whose backward keeps fc1.weight's
+        gradient in GEMM order, or None (shapes other than the reference's, shards that are not whole rows, an injected CPU update rule,
+        a module this object was not attached to).  Once on, ``model.training_step(reducer=self)`` sets the engine's switch itself."""
+
+        fc1 = getattr(model, "fc1", None)
+        if fc1 is None or "fc1.weight" not in self.big or tuple(fc1.weight.shape) != (4096, 65536) or not fc1.weight.is_cuda:
+            return None
+        if self.update is not _hip_sgd_update or dict(self.named).get("fc1.weight") is not fc1.weight:
+            return None
+        if any(pc.length % 65536 or pc.offset % 65536 for pc in self.pieces["fc1.weight"]):
+            return None
+        eng = model.engine()
+        if type(eng).__name__ != "RelHeadEngine":
+            return None
+        if not self.fc1_gemm_order and any(pc.acc is not None for pc in self.pieces["fc1.weight"]):
+            return None                    # a reference-order gradient is being accumulated: not in the middle of it
+        self.fc1_gemm_order = True
+        return eng
 
     # ------------------------------------------------------------------ collectives
     def _reduce_scatter(self, out, inp, async_op):
@@ -312,6 +350,9 @@ class ShardedSGD:
         (checkpoints, EMA snapshots, ``load_state_dict`` round trips), which gets a pre-hook that waits too.  Code that reads
         ``model.parameters()`` directly between ``step()`` and the next forward must call ``wait_gathers()`` itself."""
         model.__dict__["weight_sync"] = self.wait_gathers
+        from .engine import TUNING
+        if TUNING.fused_sgd:
+            self.fuse_fc1(model)          # fc1.weight's gradient in GEMM order from now on, on every path of this model that feeds this object
         if hasattr(model, "register_state_dict_pre_hook") and not getattr(model, "_sgc_gather_hook", False):
             opt = self
             model.register_state_dict_pre_hook(lambda module, prefix, keep_vars: opt.wait_gathers())
@@ -353,7 +394,7 @@ class ShardedSGD:
                 mine = flat[pc.offset:pc.offset + pc.length]
                 if pc.mom is None:
                     pc.mom = torch.empty_like(mine)
-                self.update(mine, pc.acc, pc.mom, lr, mom, wd, pc.first)
+                (self.update_fc1 if (self.fc1_gemm_order and n == "fc1.weight") else self.update)(mine, pc.acc, pc.mom, lr, mom, wd, pc.first)
                 pc.first = False
                 if self.collective:
                     src = mine.clone()        # a copy of the shard (1/W of the block): no aliasing of a collective's input and output

@@ -59,6 +59,11 @@ class Weights(dict):
     def __init__(self):
         super().__init__()
         self.deferred = {}
+        # fc1.weight's gradient leaves the backward in GEMM order [4096][window*1024 + channel] instead of the reference's
+        # [4096][channel*64 + window]: set for the duration of one ``pair_loop.train_minibatch`` call whose optimizer consumes that order
+        # (``optim.FusedSGD`` / ``distributed.ShardedSGD``); kept HERE because every engine of a module (image-group lanes, the
+        # augmented view's) shares this object - never set while a caller may look at ``fc1.weight.grad``
+        self.fc1_grad_gemm_order = False
 
     def defer(self, key, make):
         self.deferred[key] = make
@@ -300,10 +305,6 @@ class RelHeadEngine:
         self.T = (1.0, 1.0, 1.0)
         self.timers = None          # optional {name: [(start_event, end_event), ...]} filled by bench.py
         self._checks = []           # deferred device-side consistency checks: (event, pinned flag, message), see ``_post_check``
-        # fc1.weight's gradient leaves the backward in GEMM order [4096][window*1024 + channel] instead of the reference's
-        # [4096][channel*64 + window] (``optim.FusedSGD`` consumes that order in its fused update; set per call by
-        # ``pair_loop.train_minibatch``, never while a caller may look at ``fc1.weight.grad``)
-        self.fc1_grad_gemm_order = False
         self._w1p_fresh = None      # (data_ptr, version) of the fc1.weight whose f16 copy the fused optimizer step has already written
 
     # ------------------------------------------------------------------ deferred consistency checks
@@ -338,6 +339,14 @@ class RelHeadEngine:
         if failed is not None:
             raise RuntimeError(failed)
 
+    @property
+    def fc1_grad_gemm_order(self) -> bool:
+        return bool(getattr(self.w, "fc1_grad_gemm_order", False))
+
+    @fc1_grad_gemm_order.setter
+    def fc1_grad_gemm_order(self, v: bool):
+        self.w.fc1_grad_gemm_order = bool(v)
+
     def child(self) -> "RelHeadEngine":
         """An engine that shares this one's weights and transient scratch but owns the buffers of its training context: the
         per-step ``forward()`` of the drop-in modules keeps many contexts alive until ``losses.backward()``
@@ -346,7 +355,7 @@ class RelHeadEngine:
         c.cfg, c.device, c.lib, c.w, c.T, c.timers = self.cfg, self.device, self.lib, self.w, self.T, None
         c._checks = self._checks
         c.head_rows = getattr(self, "head_rows", None)
-        c.fc1_grad_gemm_order, c._w1p_fresh = False, None
+        c._w1p_fresh = None
         c.ws, c.scratch = Workspace(self.device), self.scratch
         c._side_stream = getattr(self, "_side_stream", None)
         return c

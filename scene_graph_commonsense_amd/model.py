@@ -266,10 +266,20 @@ class _RelationBase(nn.Module):
         pass reproduces it bit for bit -, cs_coef [P, n_cand] or None - this group's rows of the minibatch's commonsense
         coefficients -, contrast=(dF_main [M, 512], dF_aug [M, 512]) or None - this group's rows of the SupCon feature gradient,
         M = its connected pairs in pair order).  The loss returned then lacks the contrastive term (the caller adds it once)."""
+        # a reducer that is also the optimizer (distributed.ShardedSGD after ``attach``) may want fc1.weight's gradient in GEMM order on
+        # EVERY path that feeds it - also these direct calls (gradient accumulation: zero_grad, several training_step, step)
+        eng = engine if engine is not None else self.refresh_weights(backward=True)
+        if bool(getattr(reducer, "fc1_gemm_order", False)) and not eng.fc1_grad_gemm_order:
+            eng.fc1_grad_gemm_order = True
+            try:
+                return self.training_step(scene, relationships, subj_or_obj, directed, lambda_connectivity, lambda_not_connected, class_weight,
+                                          grad_hook, reducer, image_feature_aug, lambda_contrast, commonsense, lambda_commonsense,
+                                          lambda_cs_weak, lambda_cs_strong, loss_coefs, grads_out, engine, coupled)
+            finally:
+                eng.fc1_grad_gemm_order = False
         if reducer is not None:
             grad_hook = reducer.hook
         cfg = self.head_config()
-        eng = engine if engine is not None else self.refresh_weights(backward=True)
         dev = eng.device
         P = scene.n_pairs
         if P == 0 and grads_out is not None:       # an image group without pairs adds nothing to the minibatch's gradient sum
@@ -360,25 +370,28 @@ class _RelationBase(nn.Module):
                 if reducer is not None:
                     reducer.finish_grads(grads)
                 if not getattr(reducer, "owns_grads", False):      # a sharded reducer keeps the mean gradient shards itself
-                    gemm_order = bool(getattr(eng, "fc1_grad_gemm_order", False))
-                    for name, p in self.named_parameters():
-                        g = grads[name].view_as(p)
-                        if name == "fc1.weight":
-                            # column order of this gradient: the reference's, or the GEMM's (only inside pair_loop.train_minibatch with
-                            # an optimizer that consumes it, optim.FusedSGD); never mixed within one accumulation
-                            if p.grad is not None and bool(getattr(p, "_sgc_grad_gemm_order", False)) != gemm_order:
-                                raise RuntimeError("fc1.weight.grad is being accumulated in two different column orders")
-                            p._sgc_grad_gemm_order = gemm_order
-                        if p.grad is None:
-                            p.grad = g if g.is_contiguous() else g.contiguous()
-                        else:
-                            p.grad.add_(g)
+                    self.accumulate_grads(grads, eng)
             # connectivity statistics of train_one_direction (train_utils.py:66-87) summed over the minibatch: a [5] device
             # tensor (not connected, connected, predicted connected, precision numerator, recall numerator), no host sync
             raw_d = scene.raw_target if (directed is None and scene.raw_target is not None) else directed_d
             self.last_connectivity_stats = eng.connectivity_stats(ctx.out.connectivity, directed_d, raw_d)
         self.last_outputs = ctx.out
         return loss
+
+    def accumulate_grads(self, grads, eng):
+        """``param.grad`` += the step's gradients (like autograd).  fc1.weight's carries its column order: the reference's, or the GEMM's
+        (only inside ``pair_loop.train_minibatch`` with an optimizer that consumes it); never mixed within one accumulation."""
+        gemm_order = bool(getattr(eng, "fc1_grad_gemm_order", False))
+        for name, p in self.named_parameters():
+            g = grads[name].view_as(p)
+            if name == "fc1.weight":
+                if p.grad is not None and bool(getattr(p, "_sgc_grad_gemm_order", False)) != gemm_order:
+                    raise RuntimeError("fc1.weight.grad is being accumulated in two different column orders")
+                p._sgc_grad_gemm_order = gemm_order
+            if p.grad is None:
+                p.grad = g if g.is_contiguous() else g.contiguous()
+            else:
+                p.grad.add_(g)
 
     def _commonsense_bitmaps(self, commonsense, dev):
         from .commonsense import TripletBitmaps

@@ -332,14 +332,18 @@ def train_minibatch(model, batch, optimizer=None, reducer=None, scene: Optional[
     model.last_image_groups = groups
     if scene is None:
         scene = flatten_scene(cfg, batch, dev)
-    # fc1.weight's gradient in GEMM order for an optimizer that consumes it (optim.FusedSGD.fuse_fc1): one pass, one step, one rank -
-    # the plain case bench.py and the drivers run; every other case keeps the reference's column order
+    # fc1.weight's gradient in GEMM order for an optimizer that consumes it (optim.FusedSGD / distributed.ShardedSGD: ``fuse_fc1``):
+    # the backward skips the transposition to the reference's column order, the optimizer's fused update un-permutes on the fly.  Not
+    # with an all-reduce reducer over several ranks (a rank without pairs would apply its peers' mean gradient untagged); a ShardedSGD
+    # that has taken one such gradient takes every later one that way (its accumulators and its peers' must agree).
     fuse_eng = None
-    if (optimizer is not None and len(groups) == 1 and loss_kw.get("image_feature_aug") is None and scene.n_pairs > 0
-            and (reducer is None or (getattr(reducer, "world", 1) == 1 and not getattr(reducer, "owns_grads", False)
-                                     and not getattr(reducer, "active", False)))):
-        from .engine import TUNING
-        fuse = getattr(optimizer, "fuse_fc1", None) if TUNING.fused_sgd else None
+    from .engine import TUNING
+    sharded = reducer is not None and reducer is optimizer and getattr(reducer, "owns_grads", False)
+    allreduce = reducer is not None and not sharded and getattr(reducer, "active", False)
+    # decided by configuration only, never by this rank's data: every rank of a step must hand over the same column order (a rank
+    # without pairs contributes zeros - order-free - but its optimizer must read its peers' mean gradient the way they wrote it)
+    if optimizer is not None and not allreduce and (TUNING.fused_sgd or getattr(optimizer, "fc1_gemm_order", False)):
+        fuse = getattr(optimizer, "fuse_fc1", None)
         fuse_eng = fuse(model) if fuse is not None else None
     try:
         if fuse_eng is not None:
@@ -504,11 +508,6 @@ def _train_image_groups(model, cfg, batch, scene: DeviceScene, groups, reducer, 
             reducer.hook("fc1.weight", acc["fc1.weight"])
         reducer.finish_grads(acc)
     if not getattr(reducer, "owns_grads", False):
-        for name, p in model.named_parameters():
-            g = acc[name].view_as(p)
-            if p.grad is None:
-                p.grad = g if g.is_contiguous() else g.contiguous()
-            else:
-                p.grad.add_(g)
+        model.accumulate_grads(acc, lane[0]["engine"])
     model.last_outputs, model.last_connectivity_stats = full, stats
     return loss

@@ -115,3 +115,50 @@ def test_direct_training_step_keeps_the_reference_column_order():
     assert torch.equal(g2.view(4096, 64, 1024).transpose(1, 2).reshape(4096, 65536), g1)
     with pytest.raises(RuntimeError, match="two different column orders"):
         model.training_step(sc, batch.relationships, batch.subj_or_obj)       # accumulating the reference order onto the GEMM order
+
+
+@pytest.mark.parametrize("kind", ["fused_groups", "sharded_world1", "fused_contrast"])
+def test_gemm_order_gradient_through_image_groups_sharded_sgd_and_the_contrastive_branch(kind):
+    """The GEMM-order gradient on the other paths of ``train_minibatch``: a minibatch cut into image groups (gradient sums of several
+    engine passes), ``distributed.ShardedSGD`` as reducer + optimizer (world 1: its pieces, accumulators and the row-shard update
+    ``sgc_sgd_fc1_fused`` without the f16 copy), the augmented view's second engine.  Two steps; every parameter bit-identical to
+    the same run with the fusion off."""
+    from scene_graph_commonsense_amd import distributed as D
+    from scene_graph_commonsense_amd import engine as E
+    from scene_graph_commonsense_amd.model import BayesianRelationClassifier
+    from scene_graph_commonsense_amd.optim import FusedSGD
+    from scene_graph_commonsense_amd.pair_loop import train_minibatch
+    from scene_graph_commonsense_amd.synthetic import HeadConfig, make_scene_batch, make_state_dict
+    cfg = HeadConfig()
+    sd = make_state_dict(cfg, seed=13, head_gain=4.0)
+    batches = [make_scene_batch(cfg, (6, 5, 7, 4), seed=70 + k, connect_frac=0.5) for k in range(2)]
+    aug = [torch.randn(4, 256, 32, 32, generator=torch.Generator().manual_seed(k)).cuda() for k in range(2)] if kind == "fused_contrast" else [None, None]
+    runs = []
+    for fused in (True, False):
+        with E.tuning(fused_sgd=fused):
+            model = BayesianRelationClassifier(cfg.args(run_mode="train")).cuda()
+            model.load_state_dict(sd)
+            model.train()
+            kw = {}
+            if kind == "sharded_world1":
+                opt = D.ShardedSGD(model.named_parameters(), 1, 0, lr=2e-5, momentum=0.9, weight_decay=1e-4).attach(model)
+                kw["reducer"] = opt
+            else:
+                opt = FusedSGD(model.parameters(), lr=2e-5, momentum=0.9, weight_decay=1e-4)
+            if kind == "fused_groups":
+                kw["workspace_budget"] = 2.5e8                       # one or two images per group
+            for b, a in zip(batches, aug):
+                if a is not None:
+                    kw["image_feature_aug"] = a
+                train_minibatch(model, b, opt, **kw)
+                if kind == "fused_groups":
+                    assert len(model.last_image_groups) > 1
+            if kind == "sharded_world1":
+                assert opt.fc1_gemm_order == fused
+            torch.cuda.synchronize()
+            runs.append({n: p.detach().clone() for n, p in model.named_parameters()})
+            del model, opt
+            torch.cuda.empty_cache()
+    for n in runs[0]:
+        assert torch.equal(runs[0][n], runs[1][n]), n
+    assert not torch.equal(runs[0]["fc1.weight"], sd["fc1.weight"].cuda())
