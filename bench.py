@@ -41,7 +41,8 @@ WINDOW_GEMMS = {
     "conv3_fwd_windows": (("gemm_nt_pp_kernel<0, 3, 0, 1, 0>", "gemm_nt_pp_kernel<0, 3, 0, 1>"),
                           "gemm_nt_pp_kernel<f16,relu+pool,conv-gather> (sgc_conv3_relu_pool_windows_wm: conv3 forward over the listed windows)"),
     "conv3_dgrad_windows": (("gemm_nt_sp_kernel", "gemm_nt_pp_kernel<1, 0, 0, 0, 1>"),
-                            "conv3 data gradient over the listed windows in patch form (sgc_windows_dgrad_patches)"),
+                            "gemm_nt_sp_kernel (sgc_windows_dgrad_patches_sparse: conv3 data gradient of the real pairs' listed windows in patch "
+                            "form on the sparse matrix cores; executed = issued multiply-adds, 20 of the dense form's 36 per window)"),
     "conv3_wgrad_windows": (("gemm_tn_sp_kernel<1>",),
                             "gemm_tn_sp_kernel<patch> (sgc_windows_wgrad_patch_sparse: conv3 weight gradient of the real pairs' listed windows, "
                             "2:4-sparse un-pooled gradient x 4x4 input patches; executed = non-zero multiply-adds only)"),
@@ -215,6 +216,10 @@ def executed_flops(P, n_img, n_obj, n_x, n_list, shared, forward_only=False, lin
                 # structural zeros of the un-pooled gradient) are not executed - they are not counted as work either
                 e_sp = ((n_list - linear[1]) // 16) * 16
                 f["conv3"] -= 0.5 * 2.0 * e_sp * 4 * 1024 * 4608
+            if TUNING.sparse_dgrad and TUNING.patch_dgrad and TUNING.weight_kernels and (n_list - linear[1]) >= 4096:
+                # the data gradient of the real pairs' windows likewise: 20 sparse instructions' worth of issued multiply-adds per
+                # (window, 1024 x 512 block) instead of 36 dense ones
+                f["conv3"] -= 2.0 * (((n_list - linear[1]) // 256) * 256) * 16 * 1024 * 512
         f["fc1"] = 2.0 * (n_x + 64 * 2 * n_obj) * 1024 * 4096 * passes
     else:
         f["conv3"] = 2.0 * P * 256 * 1024 * 4608 * passes
@@ -469,6 +474,10 @@ def run_rank(args):
                 # executed = the non-zero half of its dense-equivalent multiply-adds
                 e_sp = ((n_list - m["linear"][1]) // 16) * 16
                 flops["conv3_wgrad_windows"] = 0.5 * 2.0 * e_sp * 4 * 1024 * 4608
+            if m["linear"] and TUNING.sparse_dgrad and TUNING.patch_dgrad and TUNING.weight_kernels and (n_list - m["linear"][1]) >= 4096:
+                # likewise the timer "conv3_dgrad_windows" = the SPARSE launch (csrc/kernels_dgrad_sp.hip): 20 slots x 1024 compressed k x 512
+                # issued multiply-adds per window (the dense form: 36 x 1024 x 512)
+                flops["conv3_dgrad_windows"] = 2.0 * (((n_list - m["linear"][1]) // 256) * 256) * 20 * 1024 * 512
             flops["fc1_fwd_windows"] = 2.0 * (n_x + 64 * n_ps) * 1024 * 4096          # padding rows not counted
             flops["fc1_dgrad"] = flops["fc1_wgrad"] = flops["fc1_fwd_windows"]
         else:

@@ -179,6 +179,20 @@ int sgc_windows_col2im(const void* col, const int* bbox, const int* sub_idx, con
  * combinations each, so that K <= 2048); w3patch as engine.prep_bwd_weights lays it out.  sgc_windows_patch_sum[_objects]: dz of a
  * pixel = sum of the rows of the <= 2 x 2 windows of the pair's rectangle that cover it (same output as sgc_windows_col2im[_objects];
  * reference: the autograd of model.py:144-146's conv3). */
+/* Data gradient of conv3 over the listed windows 0 .. n_sparse-1 (a multiple of 256; the real pairs' windows: one non-zero per window and
+ * channel in the un-pooled gradient) on the SPARSE matrix cores - the patch form of sgc_windows_dgrad_patches (same 20 slots, same
+ * patch [entries][20][512] bf16 output, same products, the structural zeros not issued); reference arithmetic: the backward of
+ * model.py:145-147.  dywm: pooled gradient rows (row dest[e], or gather[e] when dest is NULL); argmax: routing bytes at gather[e];
+ * w3sp [20][512][2048] bf16 from sgc_windows_dgrad_sparse_weights(conv3_1.weight f32 [1024][512][3][3]); sgc_windows_dgrad_sparse_pack
+ * fills pack_a (4 * n_sparse * 2 KiB: the pooled rows masked to the four own-pixel sets) and pack_i (4 * n_sparse * 256 B: index words) and,
+ * when bias_part is given, the conv3 bias partial sums of these windows ([*n_parts][1024], reduce with sgc_slab_sum).  The entries behind n_sparse (per-object entries: dense sums) take sgc_windows_unpool_from +
+ * sgc_windows_dgrad_patches into the rows behind. */
+int sgc_windows_dgrad_sparse_weights(const float* conv3_weight, void* w3sp, void* stream);
+int sgc_windows_dgrad_sparse_pack(const void* dywm, const unsigned char* argmax, const int* gather, const int* dest, int n_sparse,
+                                  void* pack_a, void* pack_i, float* bias_part, int* n_parts, void* stream);
+int sgc_windows_dgrad_patches_sparse(const void* pack_a, const void* pack_i, int n_sparse, const void* w3sp, void* patch, void* stream);
+int sgc_windows_unpool_from(const void* dy, const unsigned char* argmax, const int* gather, const int* gather_n, const int* dest, int entry0,
+                            int entries_pad, void* dy3x, float* bias_part, int* n_parts, void* stream);
 int sgc_windows_patch_slots(void);
 int sgc_windows_dgrad_patches(const void* dy3x, const void* w3patch, void* patch, int entries, void* stream);
 int sgc_windows_patch_sum(const void* patch, const int* bbox, const int* sub_idx, const int* obj_idx, const int* count_incl, int n_pairs,

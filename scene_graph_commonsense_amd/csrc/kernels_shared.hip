@@ -257,10 +257,10 @@ __global__ __launch_bounds__(256) void shared_assemble_bwd_kernel(const int* __r
 __global__ __launch_bounds__(256) void windows_unpool_kernel(const u16* __restrict__ dy, const unsigned char* __restrict__ am,
                                                              const int* __restrict__ gather, const int* __restrict__ gather_n,
                                                              const int* __restrict__ dest, int entries_pad, u16* __restrict__ dy3x,
-                                                             float* __restrict__ bias_part) {
+                                                             float* __restrict__ bias_part, int entry0) {
     __shared__ float red[4][1024];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int E = *gather_n;
+    const int E = *gather_n - entry0;             // gather / dest / dy3x point at entry ``entry0`` of the list
     float bs[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) bs[k] = 0.f;
@@ -1184,7 +1184,21 @@ int sgc_windows_unpool(const void* dy, const unsigned char* argmax, const int* g
     const int blocks = grid_cap(entries_pad, 4 * 8, 1024);
     if (n_parts) *n_parts = blocks;
     SGC_LAUNCH(windows_unpool_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const u16*)dy, argmax, gather, gather_n, dest,
-               entries_pad, (u16*)dy3x, bias_part);
+               entries_pad, (u16*)dy3x, bias_part, 0);
+    SGC_CHECK_LAUNCH();
+    return SGC_OK;
+}
+
+// the same for the entries entry0 .. entry0 + entries_pad - 1 only (dy3x row 0 = entry entry0): the entries in front of them go
+// through the sparse forms of both backward GEMMs, which pack their operand from the pooled rows and need no un-pooled ones
+int sgc_windows_unpool_from(const void* dy, const unsigned char* argmax, const int* gather, const int* gather_n, const int* dest, int entry0,
+                            int entries_pad, void* dy3x, float* bias_part, int* n_parts, void* stream) {
+    if (entries_pad <= 0) { if (n_parts) *n_parts = 0; return SGC_OK; }
+    if (entry0 < 0) return SGC_ERR_ARG;
+    const int blocks = grid_cap(entries_pad, 4 * 8, 1024);
+    if (n_parts) *n_parts = blocks;
+    SGC_LAUNCH(windows_unpool_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const u16*)dy, argmax, gather + entry0, gather_n,
+               dest ? dest + entry0 : nullptr, entries_pad, (u16*)dy3x, bias_part, entry0);
     SGC_CHECK_LAUNCH();
     return SGC_OK;
 }

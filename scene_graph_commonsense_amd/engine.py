@@ -185,6 +185,7 @@ class Tuning:
     weight_kernels: bool = True       # 16-bit weight layouts by one gather + cast launch each (off: torch view / permute / flip / cat chains)
     fc1_own_sums: bool = True         # fc1 assembly reads S'_j[R_j] pre-summed per object (off: four corner vectors per pair; same bits)
     sparse_wgrad: bool = True         # conv3 weight gradient over the real pairs' listed windows on the sparse matrix cores (off: dense block)
+    sparse_dgrad: bool = True         # conv3 data gradient over the real pairs' listed windows on the sparse matrix cores (off: dense patch form)
     fused_sgd: bool = True            # train_minibatch + optim.FusedSGD: fc1.weight's gradient stays in GEMM order, one pass un-permutes, updates and
                                       # writes the f16 copy (off: transposition + update + transposition; same bits)
 
@@ -1087,6 +1088,10 @@ class RelHeadEngine:
         _lib.check(self.lib.sgc_segment_cast(_lib.ptr(c3), _lib.ptr(w3patch), 1, 512, 1024, _c_long(9), _c_long(4608), n, L(*d_off), L(*d_ld), L(*s_off),
                                              self._st()), "sgc_segment_cast")
         w["w3patch"] = w3patch
+        # sparse form of the same data gradient (csrc/kernels_dgrad_sp.hip): per slot [512 c_in][(c_out, own pixel of the slot's set)]
+        w3sp = self.ws.get("w3sp", 20 * 512 * 2048, torch.bfloat16)
+        _lib.check(self.lib.sgc_windows_dgrad_sparse_weights(_lib.ptr(c3), _lib.ptr(w3sp), self._st()), "sgc_windows_dgrad_sparse_weights")
+        w["w3sp"] = w3sp
         wd2 = self.ws.get("wd2", 2 * 128 * 4608, torch.bfloat16)
         for r in (0, 1):
             self._permute_cast(c2, wd2, 1, [128, 8, 9, 64], [9, 64 * 2304, -1, 2304], src_off=r * 128 * 9 + 8, dst_off=r * 128 * 4608)
@@ -1544,11 +1549,29 @@ class RelHeadEngine:
             dy3_bg = ws.get("dy3_bg_pad", n_maps * 18 * 18 * 1024, torch.bfloat16)        # created zeroed: the halo stays zero
             self._timed("unpool_objects", lambda: _lib.check(lib.sgc_unpool_relu_bwd(
                 _lib.ptr(dy_maps), _lib.ptr(am_maps), _lib.ptr(dy3_bg), _lib.ptr(bpart), ctypes.byref(nparts), n_maps, st()), "sgc_unpool_relu_bwd"))
-        # ---- listed windows: compact un-pool
+        # ---- listed windows: compact un-pool.  The real pairs' windows in front of the list (one non-zero per window and channel in
+        # their un-pooled gradient) go through the SPARSE forms of both backward GEMMs, which pack their operand from the pooled rows:
+        # only the entries behind them (per-object entries: sums of several windows, + the boundary tile) are un-pooled
+        e_real = sh.get("entries_real")
+        sp_ok = e_real is not None and dest is not None and Epad and int(e_real) >= 4096
+        e_spw = (int(e_real) // 16) * 16 if (sp_ok and TUNING.patch_wgrad and TUNING.sparse_wgrad) else 0
+        e_spd = (int(e_real) // 256) * 256 if (sp_ok and TUNING.patch_dgrad and TUNING.sparse_dgrad and "w3sp" in w) else 0
+        e_un0 = min(e_spw, e_spd)
         dy3x = ws.get("dy3x", max(Epad, 16) * 4 * 1024, torch.bfloat16)
-        self._timed("unpool_windows", lambda: _lib.check(lib.sgc_windows_unpool(
-            _lib.ptr(dy), _lib.ptr(ctx.am), _lib.ptr(gather), _lib.ptr(gn), _lib.ptr(dest), Epad, _lib.ptr(dy3x), _lib.ptr(bpart_x),
-            ctypes.byref(nparts_x), st()), "sgc_windows_unpool"))
+        self._timed("unpool_windows", lambda: _lib.check(lib.sgc_windows_unpool_from(
+            _lib.ptr(dy), _lib.ptr(ctx.am), _lib.ptr(gather), _lib.ptr(gn), _lib.ptr(dest), e_un0, Epad - e_un0, _lib.ptr(dy3x[e_un0 * 4096:]),
+            _lib.ptr(bpart_x), ctypes.byref(nparts_x), st()), "sgc_windows_unpool_from"))
+        nparts_s, bpart_s = ctypes.c_int(0), None
+        if e_spd:
+            spa = ws.get("w3d_pack_a", 4 * e_spd * 1024, torch.bfloat16)
+            spi = ws.get("w3d_pack_i", 4 * e_spd * 64, torch.int32)
+            if e_un0 == e_spd and e_un0 > 0:          # the un-pool pass skipped these windows: their bias partial sums come from the packer
+                bpart_s = ws.get("b3_part_s", 1024 * 1024, torch.float32)
+            self._timed("dgrad_pack_windows", lambda: _lib.check(lib.sgc_windows_dgrad_sparse_pack(
+                _lib.ptr(dy), _lib.ptr(ctx.am), _lib.ptr(gather), _lib.ptr(dest), e_spd, _lib.ptr(spa), _lib.ptr(spi), _lib.ptr(bpart_s),
+                ctypes.byref(nparts_s), st()), "sgc_windows_dgrad_sparse_pack"))
+        elif e_un0 > 0:
+            raise RuntimeError("internal: windows skipped by the un-pool pass without a sparse data gradient to count their bias")
         if lin is not None:
             # transpose of sgc_windows_linear_forward: + into the un-pooled rows of the two per-object entries, - into the background map
             e_real = sh["entries_real"]
@@ -1565,6 +1588,8 @@ class RelHeadEngine:
             gb = self._slab_sum(bpart, 1024, nparts.value)
             if nparts_x.value:
                 gb = gb + self._slab_sum(bpart_x, 1024, nparts_x.value)
+            if bpart_s is not None and nparts_s.value:
+                gb = gb + self._slab_sum(bpart_s, 1024, nparts_s.value)
             if bpart_l is not None:
                 gb = gb + self._slab_sum(bpart_l, 1024, 64 * n_img)
             grads["conv3_1.bias"] = gb
@@ -1616,8 +1641,7 @@ class RelHeadEngine:
             # data-gradient GEMM.  Round 2 let the two GEMMs run side by side: 18.8 ms for the pair against 7.7 + 7.6 alone.
             with side():
                 n_slabs = slabs_n.value
-                e_real = sh.get("entries_real")
-                e_sp = (int(e_real) // 16) * 16 if (e_real is not None and TUNING.patch_wgrad and TUNING.sparse_wgrad and dest is not None) else 0
+                e_sp = e_spw
                 # slab capacity is checked BEFORE anything is launched into the 32-slab buffer (the launches' own counts are the mirror's)
                 need = n_slabs + ((auto_splits(e_sp * 4) + (auto_splits((Epad - e_sp) * 4) if Epad > e_sp else 0)) if (Epad and e_sp >= 4096)
                                   else (auto_splits(Epad * 4) if Epad else 0))
@@ -1663,9 +1687,18 @@ class RelHeadEngine:
             # PATCH form: the 16 pixels of every listed window's input patch leave the GEMM already summed over the taps (K = 1024 x
             # 1 / 2 per output element instead of 1024: 4.7 instead of 8.4 GB of stores per launch at the benchmark's size, and the
             # sum over a pair's windows reads 20 instead of 36 rows per window)
-            patch = ws.get("xpatch", Epad * int(lib.sgc_windows_patch_slots()) * 512, torch.bfloat16)
-            self._timed("conv3_dgrad_windows", lambda: _lib.check(lib.sgc_windows_dgrad_patches(_lib.ptr(dy3x), _lib.ptr(w["w3patch"]), _lib.ptr(patch), Epad, st()),
-                                                                  "sgc_windows_dgrad_patches"))
+            slots = int(lib.sgc_windows_patch_slots())
+            patch = ws.get("xpatch", Epad * slots * 512, torch.bfloat16)
+            if e_spd:
+                self._timed("conv3_dgrad_windows", lambda: _lib.check(lib.sgc_windows_dgrad_patches_sparse(
+                    _lib.ptr(spa), _lib.ptr(spi), e_spd, _lib.ptr(w["w3sp"]), _lib.ptr(patch), st()), "sgc_windows_dgrad_patches_sparse"))
+                if Epad > e_spd:
+                    self._timed("conv3_dgrad_windows_tail", lambda: _lib.check(lib.sgc_windows_dgrad_patches(
+                        _lib.ptr(dy3x[e_spd * 4096:]), _lib.ptr(w["w3patch"]), _lib.ptr(patch[e_spd * slots * 512:]), Epad - e_spd, st()),
+                        "sgc_windows_dgrad_patches"))
+            else:
+                self._timed("conv3_dgrad_windows", lambda: _lib.check(lib.sgc_windows_dgrad_patches(_lib.ptr(dy3x), _lib.ptr(w["w3patch"]), _lib.ptr(patch), Epad, st()),
+                                                                      "sgc_windows_dgrad_patches"))
             if TUNING.gemms_apart:
                 wgrad_windows()                      # side stream: after the data-gradient GEMM, beside the patch sums / the contraction
             self._timed("col2im_windows", lambda: (

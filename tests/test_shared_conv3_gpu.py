@@ -380,7 +380,7 @@ def test_window_weight_gradient_on_the_sparse_matrix_cores_equals_the_dense_bloc
     assert sc.shared_windows >= 8192 and sc.linear_windows > 0
     grads = []
     for on in (True, False):
-        with tuning(sparse_wgrad=on):
+        with tuning(sparse_wgrad=on, sparse_dgrad=False):          # (the sparse data gradient moves the conv3 bias sums to its packer: own test below)
             model.zero_grad(set_to_none=True)
             loss = model.training_step(sc, batch.relationships, batch.subj_or_obj)
             torch.cuda.synchronize()
@@ -394,3 +394,42 @@ def test_window_weight_gradient_on_the_sparse_matrix_cores_equals_the_dense_bloc
             assert e <= 1e-5, e
         else:
             assert torch.equal(a[n], b[n]), n
+
+
+def test_window_data_gradient_on_the_sparse_matrix_cores_equals_the_dense_patch_form():
+    """``TUNING.sparse_dgrad`` (default): the conv3 data gradient over the real pairs' listed windows runs on
+    ``v_smfmac_f32_32x32x32_bf16`` (csrc/kernels_dgrad_sp.hip: the pooled rows masked to the own-pixel sets are the compressed operand),
+    the per-object entries and the boundary tile on the dense patch block.  Same products per output element, f32 accumulation in
+    another order before the bf16 rounding of the patch rows: everything above conv3's input (conv3 weight, fc1, fc2, head) is bit
+    for bit the same, the conv3 bias sum is taken in another order (1e-6), conv2 / conv1 gradients agree to the bf16 noise of one
+    re-rounded tensor (measured 1e-3; the oracle-routed bars of tests/test_sampled_oracle_gpu.py hold with it on)."""
+    from scene_graph_commonsense_amd.engine import tuning
+    from scene_graph_commonsense_amd.model import BayesianRelationClassifier
+    from scene_graph_commonsense_amd.pairs import flatten_scene
+    from scene_graph_commonsense_amd.synthetic import HeadConfig, make_scene_batch, make_state_dict
+    cfg = HeadConfig()
+    model = BayesianRelationClassifier(cfg.args()).cuda()
+    model.load_state_dict(make_state_dict(cfg, seed=9, head_gain=4.0))
+    model.eval()
+    batch = make_scene_batch(cfg, (40, 33, 27), seed=91, connect_frac=0.05)
+    sc = flatten_scene(cfg, batch, "cuda:0")
+    assert sc.shared_windows >= 8192 and sc.linear_windows > 0
+    grads = []
+    for on in (True, False):
+        with tuning(sparse_dgrad=on):
+            model.zero_grad(set_to_none=True)
+            loss = model.training_step(sc, batch.relationships, batch.subj_or_obj)
+            torch.cuda.synchronize()
+            grads.append((float(loss), {n: p.grad.detach().clone() for n, p in model.named_parameters()}))
+    (la, a), (lb, b) = grads
+    assert la == lb
+    worst = {}
+    for n in a:
+        if n.startswith(("conv1", "conv2")):
+            worst[n] = float((a[n].double() - b[n].double()).norm() / b[n].double().norm())
+            assert worst[n] <= 3e-3, (n, worst[n])
+        elif n == "conv3_1.bias":
+            assert float((a[n].double() - b[n].double()).abs().max() / b[n].double().abs().max()) <= 1e-5
+        else:
+            assert torch.equal(a[n], b[n]), n
+    print("sparse vs dense window data gradient:", {k: "%.1e" % v for k, v in worst.items()})
