@@ -69,15 +69,33 @@ __host__ __device__ __forceinline__ int nt_sp_slot_set(int slot, int* pp_out = n
     return py == 0 ? 0 : 1;                            // corner: own pixel (qy, qx) = (py == 3, px == 3) inside the row set of qy
 }
 
+// (Measured and dropped: issuing the global -> LDS pieces INSIDE the matrix slots, between the sparse instructions, instead of in the
+// load sections - 5.10 against 5.10 ms: the load sections are not issue-bound.  What the block waits for is the ARRIVAL of its
+// operands: matrix pipes 37 % busy, LDS 26 % busy (profiles/r05_mid_pmc_*.csv); see the tile walk below.)
 __global__ __launch_bounds__(512, 2) void gemm_nt_sp_kernel(const NtSpParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int HT = 16384;                        // ring slot = parity*4 + kind, kind 0 A0, 1 B0, 2 B1, 3 A1
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wid >> 2, wc = wid & 3;
-    int tm, tn;
-    xcd_patch_map(blockIdx.x, p.tiles_m, 40, tm, tn, 16, 2);      // an XCD's 32 resident blocks: 16 M tiles x the two channel halves of a slot
-    const int slot = tn >> 1, nhalf = tn & 1;
+    // Tile walk.  Patch = 16 M tiles x the two channel halves of ONE slot (32 blocks = what an XCD holds: the slot's weights stay in
+    // its L2); patches are numbered M-group major and dealt round-robin to the 8 XCDs (block id % 8 = XCD), so at any time the whole
+    // chip works on the 20 slots of a FEW M groups: their masked rows (16 tiles x 4 sets x 0.6 MB) are fetched from HBM once and
+    // re-read - by the other slots of the set, on other XCDs - from the Infinity Cache.  Measured against the walk of gemm_nt_pp_kernel
+    // <SEG> (every XCD its own contiguous range of M groups: eight groups' rows + the weights exceed the 256 MB of that cache):
+    // 5.07 against 5.67 ms per launch, alternated (profiles/r05_sparse_dgrad_walk_ab.txt).
+    int tm, slot, nhalf;
+    {
+        const int x = blockIdx.x & 7, jj = blockIdx.x >> 3;
+        const int patch = (jj >> 5) * 8 + x, w = jj & 31;
+        const int npatch = ((p.tiles_m + 15) >> 4) * 20;
+        if (patch >= npatch) return;
+        const int G = patch / 20;
+        slot = patch - G * 20;
+        tm = G * 16 + (w >> 1);
+        nhalf = w & 1;
+        if (tm >= p.tiles_m) return;
+    }
     const int set = nt_sp_slot_set(slot);
     const int m0 = tm * 256;
 
@@ -150,6 +168,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_sp_kernel(const NtSpParams p) 
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    auto mm = [&](int a, int s, int i, int j) __attribute__((always_inline)) {
+        const bf16x8_sp av = __builtin_bit_cast(bf16x8_sp, af[i][s]);
+        const s16x16_sp_t bw = __builtin_shufflevector(bfr[j][s][0], bfr[j][s][1], 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+        const bf16x16_sp bv = __builtin_bit_cast(bf16x16_sp, bw);
+        if (s == 0) acc[2 * a + i][j] = __builtin_amdgcn_smfmac_f32_32x32x32_bf16(av, bv, acc[2 * a + i][j], (int)ai[i], 0, 0);
+        else acc[2 * a + i][j] = __builtin_amdgcn_smfmac_f32_32x32x32_bf16(av, bv, acc[2 * a + i][j], (int)ai[i], 0, 1);
+    };
     auto half = [&](int a) __attribute__((always_inline)) {
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -157,13 +182,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_sp_kernel(const NtSpParams p) 
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const bf16x8_sp av = __builtin_bit_cast(bf16x8_sp, af[i][s]);
-                    const s16x16_sp_t bw = __builtin_shufflevector(bfr[j][s][0], bfr[j][s][1], 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
-                    const bf16x16_sp bv = __builtin_bit_cast(bf16x16_sp, bw);
-                    if (s == 0) acc[2 * a + i][j] = __builtin_amdgcn_smfmac_f32_32x32x32_bf16(av, bv, acc[2 * a + i][j], (int)ai[i], 0, 0);
-                    else acc[2 * a + i][j] = __builtin_amdgcn_smfmac_f32_32x32x32_bf16(av, bv, acc[2 * a + i][j], (int)ai[i], 0, 1);
-                }
+                for (int j = 0; j < 2; ++j) mm(a, s, i, j);
         SGC_PP_BARRIER();
     };
 
@@ -231,66 +250,94 @@ __global__ __launch_bounds__(256) void nt_sp_weights_kernel(const float* __restr
 }
 
 // Masked pooled rows + index words of the four sets for the listed windows 0 .. n_sparse-1 (a multiple of 256), and the conv3 bias
-// partial sums of those windows (what windows_unpool_kernel provides for the entries it un-pools).  One wavefront per window, lane =
-// 16 channels = one instruction half-pair (K tile lane/2, s = lane & 1).
+// partial sums of those windows (what windows_unpool_kernel provides for the entries it un-pools).  A workgroup walks GROUPS of 64
+// consecutive windows (one (M tile, wave row, half) of the GEMM block: the 64 rows r0 .. r0+63 of its index lines); one wavefront per
+// window, lane = 16 channels = one instruction (K tile lane/2, s = lane & 1); the masked rows leave as 2 KiB per wavefront, the index
+// words are collected in LDS ([set][K tile][lane half][64 rows]) and leave as 256-byte runs.
 __global__ __launch_bounds__(256) void nt_sp_pack_kernel(const u16* __restrict__ dywm, const unsigned char* __restrict__ am,
                                                          const int* __restrict__ gather, const int* __restrict__ dest, int n_sparse,
                                                          u16* __restrict__ Ac, unsigned* __restrict__ Ic, float* __restrict__ bias_part) {
-    __shared__ float red[4][1024];
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned* sidx = reinterpret_cast<unsigned*>(smem);            // [4 sets][32 K tiles][2 lane halves][64 rows]
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int tiles_m = n_sparse >> 8;
+    const int tiles_m = n_sparse >> 8, n_groups = n_sparse >> 6;
     float bs[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) bs[k] = 0.f;
-    for (int e = blockIdx.x * 4 + wv; e < n_sparse; e += gridDim.x * 4) {
-        const long row = gather[e], drow = dest ? (long)dest[e] : row;
-        uint4 v[2];
-        v[0] = *reinterpret_cast<const uint4*>(dywm + drow * 1024 + lane * 16);
-        v[1] = *reinterpret_cast<const uint4*>(dywm + drow * 1024 + lane * 16 + 8);
-        const uint4 cd = *reinterpret_cast<const uint4*>(am + row * 1024 + lane * 16);
-        const u16* vh = reinterpret_cast<const u16*>(v);
-        const unsigned char* ch = reinterpret_cast<const unsigned char*>(&cd);
+    for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+        for (int wi = wv; wi < 64; wi += 4) {
+            const int e = grp * 64 + wi;
+            const long row = gather[e], drow = dest ? (long)dest[e] : row;
+            uint4 v[2];
+            v[0] = *reinterpret_cast<const uint4*>(dywm + drow * 1024 + lane * 16);
+            v[1] = *reinterpret_cast<const uint4*>(dywm + drow * 1024 + lane * 16 + 8);
+            const uint4 cd = *reinterpret_cast<const uint4*>(am + row * 1024 + lane * 16);
+            const u16* vh = reinterpret_cast<const u16*>(v);
+            const unsigned cw[4] = {cd.x, cd.y, cd.z, cd.w};           // 16 routing bytes (0..3 own pixel, 4 = killed by the ReLU)
+            const unsigned vw[8] = {v[0].x, v[0].y, v[0].z, v[0].w, v[1].x, v[1].y, v[1].z, v[1].w};
+            // SWAR over the routing bytes (all < 0x80): eq[q][d] has bit 0 of byte b set where channel 4d + b routes to own pixel q
+            unsigned eq[4][4];
 #pragma unroll
-        for (int k = 0; k < 16; ++k)
-            if (ch[k] < 4u) bs[k] += bf16_bits_to_f32(vh[k]);
-        const int tm = e >> 8, el = e & 255;
-        const int h = (el >> 6) & 1, r = (el >> 7) * 64 + (el & 63);
+            for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int set = 0; set < 4; ++set) {
-            const unsigned q0 = set == 0 ? 0u : (set == 1 ? 2u : (set == 2 ? 0u : 1u)), q1 = set == 0 ? 1u : (set == 1 ? 3u : (set == 2 ? 2u : 3u));
-            uint4 o[2];
-            u16* oh = reinterpret_cast<u16*>(o);
-            unsigned bits[2] = {0u, 0u};               // 16 index bits of lane half ha = 0 / 1 of this lane's instruction
+                for (int d = 0; d < 4; ++d) {
+                    const unsigned x = cw[d] ^ (0x01010101u * (unsigned)q);
+                    eq[q][d] = (~(x + 0x7f7f7f7fu) >> 7) & 0x01010101u;
+                }
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const unsigned code = ch[k];
-                const bool in = code == q0 || code == q1;
-                oh[k] = in ? vh[k] : (u16)0;
-                const unsigned j = code == q1 ? 1u : 0u;
-                // channel k of the lane: lane half ha = k >> 3, group g' = (k & 7) >> 1, first (k even: position j) or second (2 + j)
-                const unsigned pos = (k & 1) ? (2u + j) : j;
-                bits[k >> 3] |= pos << (4 * ((k & 7) >> 1) + 2 * (k & 1));
+            for (int d = 0; d < 4; ++d) {
+                const unsigned live = eq[0][d] | eq[1][d] | eq[2][d] | eq[3][d];
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    if ((live >> (8 * b)) & 1u) bs[4 * d + b] += bf16_bits_to_f32(vh[4 * d + b]);
             }
-            u16* dst = Ac + ((long)set * n_sparse + e) * 1024 + lane * 16;
-            *reinterpret_cast<uint4*>(dst) = o[0];
-            *reinterpret_cast<uint4*>(dst + 8) = o[1];
-            // the 32-bit word of (K tile, lane half): s = 0 from the even lane (low 16 bits), s = 1 from the odd lane (high)
-            const unsigned mine = bits[0] | (bits[1] << 16);
-            const unsigned other = __shfl_xor(mine, 1);
-            if (!(lane & 1)) {
-                const int t = lane >> 1;
-                unsigned* ib = Ic + ((((long)(set * tiles_m + tm) * 2 + h) * 32 + t) * 2) * 128 + r;
-                ib[0] = (mine & 0xffffu) | (other << 16);                 // lane half 0
-                ib[128] = (mine >> 16) | (other & 0xffff0000u);           // lane half 1
+#pragma unroll
+            for (int set = 0; set < 4; ++set) {
+                const int q0 = set == 0 ? 0 : (set == 1 ? 2 : (set == 2 ? 0 : 1)), q1 = set == 0 ? 1 : (set == 1 ? 3 : (set == 2 ? 2 : 3));
+                unsigned ow[8];
+                unsigned jb[4];                            // per code dword: the four j bits of its channels at bit positions 0, 2, 4, 6
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const unsigned in = (eq[q0][d] | eq[q1][d]) * 0xffu;                // 0xff where the channel belongs to the set
+                    ow[2 * d] = vw[2 * d] & __builtin_amdgcn_perm(0u, in, 0x01010000u);          // channels 4d, 4d+1: bytes 0, 1 of ``in`` doubled
+                    ow[2 * d + 1] = vw[2 * d + 1] & __builtin_amdgcn_perm(0u, in, 0x03030202u);  // channels 4d+2, 4d+3
+                    jb[d] = (eq[q1][d] * 0x01041040u) >> 24;
+                }
+                // index nibble of the channel pair (2g', 2g'+1): first kept position j(even) in {0,1}, second 2 + j(odd): 8 | j_even | j_odd << 2
+                const unsigned bits0 = 0x8888u | jb[0] | (jb[1] << 8), bits1 = 0x8888u | jb[2] | (jb[3] << 8);     // lane half 0 / 1
+                u16* dst = Ac + ((long)set * n_sparse + e) * 1024 + lane * 16;
+                *reinterpret_cast<uint4*>(dst) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+                *reinterpret_cast<uint4*>(dst + 8) = make_uint4(ow[4], ow[5], ow[6], ow[7]);
+                // the 32-bit word of (K tile, lane half): s = 0 from the even lane (low 16 bits), s = 1 from the odd lane (high)
+                const unsigned mine = bits0 | (bits1 << 16);
+                const unsigned other = __shfl_xor(mine, 1);
+                if (!(lane & 1)) {
+                    const int t = lane >> 1;
+                    unsigned* ib = sidx + ((set * 32 + t) * 2) * 64 + wi;
+                    ib[0] = (mine & 0xffffu) | (other << 16);                 // lane half 0
+                    ib[64] = (mine >> 16) | (other & 0xffff0000u);            // lane half 1
+                }
             }
         }
+        __syncthreads();
+        {   // group grp = windows e0 .. e0+63: M tile tm, rows r0 .. r0+63 of half h
+            const int e0 = grp * 64, tm = e0 >> 8, el = e0 & 255;
+            const int h = (el >> 6) & 1, r0 = (el >> 7) * 64;
+            for (int i = threadIdx.x; i < 4 * 32 * 2 * 64; i += 256) {
+                const int rr = i & 63, line = i >> 6;                      // line = (set * 32 + t) * 2 + ha
+                const int set = line >> 6, t = (line >> 1) & 31, ha = line & 1;
+                Ic[(((((long)(set * tiles_m + tm) * 2 + h) * 32 + t) * 2 + ha) * 128) + r0 + rr] = sidx[i];
+            }
+        }
+        __syncthreads();
     }
     if (bias_part) {
+        float* red = reinterpret_cast<float*>(smem);       // [4][1024]
 #pragma unroll
-        for (int k = 0; k < 16; ++k) red[wv][lane * 16 + k] = bs[k];
+        for (int k = 0; k < 16; ++k) red[wv * 1024 + lane * 16 + k] = bs[k];
         __syncthreads();
         for (int c = threadIdx.x; c < 1024; c += 256)
-            bias_part[(long)blockIdx.x * 1024 + c] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+            bias_part[(long)blockIdx.x * 1024 + c] = (red[c] + red[1024 + c]) + (red[2048 + c] + red[3072 + c]);
     }
 }
 
@@ -301,7 +348,9 @@ static int launch_gemm_nt_sp(NtSpParams p, hipStream_t stream) {
     p.tiles_m = p.entries >> 8;
     auto kern = gemm_nt_sp_kernel;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    SGC_LAUNCH(kern, dim3((unsigned)(p.tiles_m * 40)), dim3(512), LDS, stream, p);
+    const int npatch = ((p.tiles_m + 15) >> 4) * 20;
+    const unsigned grid = (unsigned)(((npatch + 7) / 8) * 8 * 32);          // whole patches, 8 at a time (one per XCD)
+    SGC_LAUNCH(kern, dim3(grid), dim3(512), LDS, stream, p);
     SGC_CHECK_LAUNCH();
     return SGC_OK;
 }
@@ -319,9 +368,10 @@ int sgc_windows_dgrad_sparse_pack(const void* dywm, const unsigned char* argmax,
     if (n_parts) *n_parts = 0;
     if (n_sparse <= 0) return SGC_OK;
     if (n_sparse & 255) return SGC_ERR_ARG;
-    const int blocks = grid_cap_sp(n_sparse, 4 * 8, 1024);
+    const int blocks = grid_cap_sp(n_sparse >> 6, 1, 768);           // groups of 64 windows; 64 KiB of LDS: two workgroups per CU
     if (n_parts && bias_part) *n_parts = blocks;
-    SGC_LAUNCH(nt_sp_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const u16*)dywm, argmax, gather, dest, n_sparse, (u16*)pack_a,
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nt_sp_pack_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    SGC_LAUNCH(nt_sp_pack_kernel, dim3(blocks), dim3(256), 65536, (hipStream_t)stream, (const u16*)dywm, argmax, gather, dest, n_sparse, (u16*)pack_a,
                (unsigned*)pack_i, bias_part);
     SGC_CHECK_LAUNCH();
     return SGC_OK;
