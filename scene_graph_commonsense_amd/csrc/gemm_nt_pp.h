@@ -89,6 +89,9 @@ __device__ __forceinline__ bool xcd_patch_map_aligned(int id, int tiles_m, int t
 // W_t, i.e. a product with K = 1024 x combinations whose A row is made of SEGMENTS (rows 4m + q_c of dy) and whose B is the matching
 // stack of tap matrices (prepared per pp, contiguous).  Against the column form (rows 4m + q, N = 9 x 512, K = 1024) the same
 // multiply-adds leave 16 instead of 36 rows of 512 values per window, and the 9-tap sum of col2im happens in the accumulators.
+template <int ELEM, bool GATHER>
+__device__ __forceinline__ void nt_epilogue_pool16(const NtParams& p, f32x16 (&acc)[4][2], int m0, int n0, int wr, int wc, int lane,
+                                                   int wid, char* smem, int m_limit);
 template <int ELEM, int EPI, int ABL = 0, int ACG = 0, int SEG = 0>
 __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(const NtParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -296,6 +299,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(const NtParams p) {
         }
 #endif
     }
+    else if constexpr (ACG && EPI == EPI_POOL) {
+        if (p.epi_lds) nt_epilogue_pool16<ELEM, true>(p, acc, m0, n0, wr, wc, lane, wid, smem, Mlim);
+        else nt_epilogue<ELEM, EPI, 4, 2, true>(p, acc, m0, n0, wr, wc, lane, Mlim);
+    }
     else if constexpr (ACG) nt_epilogue<ELEM, EPI, 4, 2, true>(p, acc, m0, n0, wr, wc, lane, Mlim);
     else nt_epilogue<ELEM, EPI, 4, 2>(p, acc, m0, n0, wr, wc, lane);
 }
@@ -309,6 +316,7 @@ static int launch_gemm_nt_pp_conv_gather(NtParams p, hipStream_t stream) {
     p.tiles_n = p.N / 256;
     const int al = sgc_tuning().acg_aligned;      // 1: grid padded to whole per-XCD patches
     p.patch_aligned = al;
+    if (EPI == EPI_POOL) p.epi_lds = sgc_tuning().epi_lds;      // pooled rows through LDS to 16-byte row stores (nt_epilogue_pool16<.., GATHER>)
     auto kern = gemm_nt_pp_kernel<ELEM, EPI, 0, 1>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     SGC_LAUNCH(kern, dim3((unsigned)(al ? xcd_patch_grid(p.tiles_m, p.tiles_n) : p.tiles_m * p.tiles_n)), dim3(512), LDS, stream, p);
@@ -358,9 +366,13 @@ static int launch_gemm_nt_pp(NtParams p, hipStream_t stream) {
 // accumulator registers of a window), writes its 32 windows x 64 channels into a private LDS tile (pitch 144 B / 80 B) and
 // streams complete 128-byte / 64-byte rows out with 16-byte stores.
 constexpr int POOL_EPI_WAVE_BYTES = 32 * 144 * 2 + 32 * 80;      // f16 tile + bf16 tile + argmax tile
-template <int ELEM>
+// GATHER (conv3 over a window LIST, gemm_nt_pp_kernel<.., ACG = 1>): pooled row prow of the tile is list entry prow - y / its bf16 copy go
+// to row dest[prow] (window-major row space) or gather[prow], the routing bytes to gather[prow]; entries >= *gather_n are not written;
+// the raw accumulators of the entries >= raw_first (linear pairs: per-object pre-activations) leave directly from the registers.
+// Rounds 2-4 sent this launch - the step's longest - through the generic epilogue: 96 two- and one-byte stores per lane.
+template <int ELEM, bool GATHER>
 __device__ __forceinline__ void nt_epilogue_pool16(const NtParams& p, f32x16 (&acc)[4][2], int m0, int n0, int wr, int wc, int lane,
-                                                   int wid, char* smem) {
+                                                   int wid, char* smem, int m_limit) {
     __syncthreads();                                   // every wave is done reading operand tiles
     char* ty = smem + wid * POOL_EPI_WAVE_BYTES;
     char* tb = ty + 32 * 144;
@@ -384,6 +396,13 @@ __device__ __forceinline__ void nt_epilogue_pool16(const NtParams& p, f32x16 (&a
                 v += bias;
                 if (!(v > 0.f)) { v = 0.f; am = 4; }        // ReLU killed: no gradient path
                 const int row = i * 8 + 2 * w + h;          // window inside the wave's 32
+                if constexpr (GATHER) {
+                    const int prow = (m0 >> 2) + wr * 32 + row;
+                    if (p.raw && prow >= p.raw_first && prow * 4 < m_limit) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) p.raw[((long)(prow - p.raw_first) * 4 + q) * p.ldc + n0 + wc * 64 + colw] = acc[i][j][4 * w + q];
+                    }
+                }
                 *reinterpret_cast<u16*>(ty + row * 144 + colw * 2) = to_elem<ELEM>(v);
                 if (p.C2) *reinterpret_cast<u16*>(tb + row * 144 + colw * 2) = f32_to_bf16_bits(v);
                 if (p.argmax) *reinterpret_cast<unsigned char*>(ta + row * 80 + colw) = (unsigned char)am;
@@ -397,7 +416,10 @@ __device__ __forceinline__ void nt_epilogue_pool16(const NtParams& p, f32x16 (&a
     for (int it = 0; it < 4; ++it) {
         const int row = it * 8 + r8;
         long orow = prow0 + row;
-        if (p.wm_goff) orow = p.wm_goff[orow & 63] + (orow >> 6);      // window-major row space (shared fc1); argmax stays pair-major
+        if constexpr (GATHER) {
+            if (orow * 4 >= m_limit) continue;
+            orow = p.dest ? p.dest[orow] : p.gather[orow];
+        } else if (p.wm_goff) orow = p.wm_goff[orow & 63] + (orow >> 6);      // window-major row space (shared fc1); argmax stays pair-major
         const long o = orow * p.ldc + n0 + wc * 64 + c8 * 8;
         *reinterpret_cast<uint4*>(out + o) = *reinterpret_cast<const uint4*>(ty + row * 144 + c8 * 16);
         if (p.C2) *reinterpret_cast<uint4*>(p.C2 + o) = *reinterpret_cast<const uint4*>(tb + row * 144 + c8 * 16);
@@ -407,7 +429,12 @@ __device__ __forceinline__ void nt_epilogue_pool16(const NtParams& p, f32x16 (&a
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
             const int row = it * 16 + r16;
-            *reinterpret_cast<uint4*>(p.argmax + (prow0 + row) * p.ldc + n0 + wc * 64 + c4 * 16) =
+            long arow = prow0 + row;
+            if constexpr (GATHER) {
+                if (arow * 4 >= m_limit) continue;
+                arow = p.gather[arow];
+            }
+            *reinterpret_cast<uint4*>(p.argmax + arow * p.ldc + n0 + wc * 64 + c4 * 16) =
                 *reinterpret_cast<const uint4*>(ta + row * 80 + c4 * 16);
         }
     }
@@ -663,7 +690,7 @@ __global__ __launch_bounds__(512, 2) void conv16_halo_pp_kernel(const NtParams p
         if (p.epi_lds) { nt_epilogue_store16<ELEM>(p, acc, m0, n0, wr, wc, lane, wid, smem); return; }
     }
     if constexpr (EPI == EPI_POOL) {
-        if (p.epi_lds) { nt_epilogue_pool16<ELEM>(p, acc, m0, n0, wr, wc, lane, wid, smem); return; }
+        if (p.epi_lds) { nt_epilogue_pool16<ELEM, false>(p, acc, m0, n0, wr, wc, lane, wid, smem, 0); return; }
     }
     nt_epilogue<ELEM, EPI, 4, 2>(p, acc, m0, n0, wr, wc, lane);
 }
