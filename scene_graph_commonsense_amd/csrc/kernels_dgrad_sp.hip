@@ -72,9 +72,22 @@ __host__ __device__ __forceinline__ int nt_sp_slot_set(int slot, int* pp_out = n
 // (Measured and dropped: issuing the global -> LDS pieces INSIDE the matrix slots, between the sparse instructions, instead of in the
 // load sections - 5.10 against 5.10 ms: the load sections are not issue-bound.  What the block waits for is the ARRIVAL of its
 // operands: matrix pipes 37 % busy, LDS 26 % busy (profiles/r05_mid_pmc_*.csv); see the tile walk below.)
+// STAGES: K tiles of the operand ring.  2 (shipped): the ring of gemm_nt_pp.h (a half tile's successor is issued two K tiles ahead); 3:
+// three K tiles ahead - a stage is 50 KiB here ([A0 9][A1 9][B0 16][B1 16] KiB: the masked rows are half the size of a dense operand),
+// so three fit the 160 KiB and the epilogue reuses them.  Measured, alternated in one box (profiles/r05_sparse_dgrad_walk_ab.txt): three
+// stages 5.17 / 5.19 / 5.15 ms against 5.05 / 5.05 / 5.00 for two - a deeper ring does not help (as gemm_tn_sp.h found for the weight
+// gradient), although the operands' arrival is what the block waits for: with the masked rows of ONE M tile fed to every block
+// (all operands L2-resident; an experiment, results wrong) the launch takes 4.43 instead of 5.08 ms, i.e. 46 instead of 36 GB/s of
+// global -> LDS traffic per CU - the dense block's rate (43 GB/s at 1 450 TFLOP/s).  The sparse blocks run at the rate the CUs' load
+// path delivers 50 KiB per K tile, not at the matrix pipes' (37 % busy): what would help is fewer operand bytes per instruction.
+template <int STAGES>
 __global__ __launch_bounds__(512, 2) void gemm_nt_sp_kernel(const NtSpParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int HT = 16384;                        // ring slot = parity*4 + kind, kind 0 A0, 1 B0, 2 B1, 3 A1
+    constexpr int ST = 51200;                        // stage stride; in a stage: kind 0 A0 at 0, 3 A1 at 9216, 1 B0 at 18432, 2 B1 at 34816
+    auto slot_base = [&](int t, int kind) __attribute__((always_inline)) {
+        const int koff = kind == 0 ? 0 : (kind == 3 ? 9216 : (kind == 1 ? 18432 : 34816));
+        return smem + (STAGES == 2 ? (t & 1) : (t % 3)) * ST + koff;
+    };
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wid >> 2, wc = wid & 3;
@@ -121,7 +134,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_sp_kernel(const NtSpParams p) 
         for (int h = 0; h < 2; ++h) b_voff[h][q] = (((r >> 5) * 64 + h * 32 + (r & 31)) * 2048 + chunk) * 2;
     }
     auto stage = [&](int kind, int t) __attribute__((always_inline)) {
-        char* base = smem + (((t & 1) << 2) + kind) * HT;
+        char* base = slot_base(t, kind);
         if (kind == 0 || kind == 3) {
             const int h = kind ? 1 : 0;
             buf_load_lds16(a_set, a_voff[h], t << 6, base + wid * 1024);                   // 32 channels = 64 B per K tile
@@ -138,7 +151,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_sp_kernel(const NtSpParams p) 
     unsigned ai[2];                 // index word of tile i (low 16 bits: s = 0, high: s = 1)
     s16x8 bfr[2][2][2];             // [b half j][s][first / second 8 elements]
     auto read_a = [&](int h, int par) __attribute__((always_inline)) {
-        const char* base = smem + ((par << 2) + (h ? 3 : 0)) * HT;
+        const char* base = slot_base(par, h ? 3 : 0);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int r = wr * 64 + i * 32 + l31;
@@ -152,7 +165,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_sp_kernel(const NtSpParams p) 
     auto read_b = [&](int par) __attribute__((always_inline)) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const char* base = smem + ((par << 2) + 1 + h) * HT + b_rd;
+            const char* base = slot_base(par, 1 + h) + b_rd;
 #pragma unroll
             for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -187,36 +200,46 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_sp_kernel(const NtSpParams p) 
     };
 
     constexpr int nk = 32;
-    stage(0, 0); stage(1, 0); stage(2, 0); stage(3, 0);
-    stage(0, 1); stage(1, 1); stage(2, 1);
-    if (wid == 0) SGC_WAIT_VM(6); else SGC_WAIT_VM(5);       // tile 0 landed; [A0 B0 B1](1) may stay in flight
+    // pieces per wave and K tile: A0 1 (+1 index load on wave 0), B0 2, B1 2, A1 1 (+1 on wave 1)
+    if constexpr (STAGES == 2) {
+        stage(0, 0); stage(1, 0); stage(2, 0); stage(3, 0);
+        stage(0, 1); stage(1, 1); stage(2, 1);
+        if (wid == 0) SGC_WAIT_VM(6); else SGC_WAIT_VM(5);       // tile 0 landed; [A0 B0 B1](1) may stay in flight
+    } else {
+        stage(0, 0); stage(1, 0); stage(2, 0); stage(3, 0);
+        stage(0, 1); stage(1, 1); stage(2, 1); stage(3, 1);
+        stage(0, 2); stage(1, 2); stage(2, 2);
+        if (wid == 0) SGC_WAIT_VM(13); else if (wid == 1) SGC_WAIT_VM(12); else SGC_WAIT_VM(11);      // tile 0 landed; tile 1 (6 / 7 pieces) and [A0 B0 B1](2) (5 / 6) may fly
+    }
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();
-    // loads per wave and K tile: A0 1 (+1 index load on wave 0), B0 2, B1 2, A1 1 (+1 on wave 1): the counted wait that leaves the
-    // last four half tiles in flight is vmcnt(7) on waves 0 and 1 and vmcnt(6) on the others (as gemm_tn_sp_kernel)
+    // counted waits.  Two stages: phase X(t) issues A1(t+1), phase Y(t) [A0 B0 B1](t+2); the wait that leaves the last four half tiles
+    // in flight is vmcnt(7) on waves 0 and 1 and vmcnt(6) on the others (as gemm_tn_sp_kernel).  Three stages: X(t) issues A1(t+2),
+    // Y(t) [A0 B0 B1](t+3); close X needs A1(t) [issued X(t-2)], close Y needs [A0 B0 B1](t+1) [issued Y(t-2)]: in both cases the four
+    // groups issued since may fly: 2 x (5 + 1) = 12 pieces, + the index loads of waves 0 and 1 (two each).
     auto close = [&](bool steady) __attribute__((always_inline)) {
         if (!steady) SGC_WAIT_VM(0);
-        else if (wid < 2) SGC_WAIT_VM(7);
-        else SGC_WAIT_VM(6);
+        else if (STAGES == 2) { if (wid < 2) SGC_WAIT_VM(7); else SGC_WAIT_VM(6); }
+        else { if (wid < 2) SGC_WAIT_VM(14); else SGC_WAIT_VM(12); }
         SGC_WAIT_LGKM0();
         SGC_PP_BARRIER();
     };
     auto tile = [&](int it, int par, auto steady_c) __attribute__((always_inline)) {
-        constexpr bool STEADY = decltype(steady_c)::value;
+        constexpr bool STEADY = decltype(steady_c)::value;       // tile it + STAGES exists
         read_a(0, par); read_b(par);
-        if (it + 1 < nk) stage(3, it + 1);
+        if (it + STAGES - 1 < nk) stage(3, it + STAGES - 1);
         close(STEADY);
         half(0);
         read_a(1, par);
-        if (STEADY) { stage(0, it + 2); stage(1, it + 2); stage(2, it + 2); }
+        if (STEADY) { stage(0, it + STAGES); stage(1, it + STAGES); stage(2, it + STAGES); }
         close(STEADY);
         half(1);
     };
     int it = 0;
 #pragma unroll 1
-    for (; it + 2 < nk; ++it) tile(it, it & 1, std::true_type{});
+    for (; it + STAGES < nk; ++it) tile(it, it, std::true_type{});
 #pragma unroll 1
-    for (; it < nk; ++it) tile(it, it & 1, std::false_type{});
+    for (; it < nk; ++it) tile(it, it, std::false_type{});
     if (wr == 0) __builtin_amdgcn_s_barrier();
 
     NtParams q{};
@@ -342,11 +365,11 @@ __global__ __launch_bounds__(256) void nt_sp_pack_kernel(const u16* __restrict__
 }
 
 static int launch_gemm_nt_sp(NtSpParams p, hipStream_t stream) {
-    constexpr int LDS = EPI_LDS_BYTES > 8 * 16384 ? EPI_LDS_BYTES : 8 * 16384;
+    constexpr int LDS = 3 * 51200;                                  // three stages (the epilogue's 128 KiB fit inside)
     if (p.entries <= 0) return SGC_OK;
     if (p.entries & 255) return SGC_ERR_ARG;
     p.tiles_m = p.entries >> 8;
-    auto kern = gemm_nt_sp_kernel;
+    auto kern = gemm_nt_sp_kernel<2>;          // <3>: measured, no gain (see the kernel's header)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     const int npatch = ((p.tiles_m + 15) >> 4) * 20;
     const unsigned grid = (unsigned)(((npatch + 7) / 8) * 8 * 32);          // whole patches, 8 at a time (one per XCD)
