@@ -132,23 +132,25 @@ def pmc_traffic(names):
     (profiles/<tag>_kernel_stats.csv).  These describe the COMMITTED profile run of ``tag``, not this process: the JSON line names the
     tag next to them and keeps its own live HIP-event duration apart (``ms_per_launch`` / ``frac`` vs ``frac_rocprof``)."""
     for tag in PMC_TAGS:
-        vals = {}
-        for suffix, ctr in (("f", "FETCH_SIZE"), ("w", "WRITE_SIZE")):
-            path = os.path.join(REPO, "profiles", "%s_pmc_%s.csv" % (tag, suffix))
-            if not os.path.exists(path):
-                break
-            for line in open(path):
-                if any(k in line for k in names) and "," + ctr + "," in line:
-                    vals[ctr] = float(line.rsplit(",", 1)[1])
-        if len(vals) == 2:
-            avg = None
-            ks = os.path.join(REPO, "profiles", "%s_kernel_stats.csv" % tag)
-            if os.path.exists(ks):
-                for line in open(ks):
-                    if any(k in line for k in names):
-                        avg = float(line.split(",")[2])          # calls,total_ms,avg_ms,...
+        for name in names:                   # names in priority order: the first one the set knows is the launch (older sets: older kernels)
+            vals = {}
+            for suffix, ctr in (("f", "FETCH_SIZE"), ("w", "WRITE_SIZE")):
+                path = os.path.join(REPO, "profiles", "%s_pmc_%s.csv" % (tag, suffix))
+                if not os.path.exists(path):
+                    break
+                for line in open(path):
+                    if name in line and "," + ctr + "," in line:
+                        vals[ctr] = float(line.rsplit(",", 1)[1])
                         break
-            return int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024), avg, tag
+            if len(vals) == 2:
+                avg = None
+                ks = os.path.join(REPO, "profiles", "%s_kernel_stats.csv" % tag)
+                if os.path.exists(ks):
+                    for line in open(ks):
+                        if name in line:
+                            avg = float(line.split(",")[2])          # calls,total_ms,avg_ms,...
+                            break
+                return int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024), avg, tag
     return None, None, None
 
 
