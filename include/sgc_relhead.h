@@ -180,14 +180,20 @@ int sgc_windows_col2im(const void* col, const int* bbox, const int* sub_idx, con
  * pixel = sum of the rows of the <= 2 x 2 windows of the pair's rectangle that cover it (same output as sgc_windows_col2im[_objects];
  * reference: the autograd of model.py:144-146's conv3). */
 /* Data gradient of conv3 over the listed windows 0 .. n_sparse-1 (a multiple of 256; the real pairs' windows: one non-zero per window and
- * channel in the un-pooled gradient) on the SPARSE matrix cores - the patch form of sgc_windows_dgrad_patches (same 20 slots, same
- * patch [entries][20][512] bf16 output, same products, the structural zeros not issued); reference arithmetic: the backward of
+ * channel in the un-pooled gradient) on the SPARSE matrix cores - the patch form of sgc_windows_dgrad_patches (same products, the structural
+ * zeros not issued; output patch [n_sparse][16][512] bf16: one row per patch pixel, see sgc_windows_patch_sum2); reference arithmetic: the backward of
  * model.py:145-147.  dywm: pooled gradient rows (row dest[e], or gather[e] when dest is NULL); argmax: routing bytes at gather[e];
  * w3sp [20][512][2048] bf16 from sgc_windows_dgrad_sparse_weights(conv3_1.weight f32 [1024][512][3][3]); sgc_windows_dgrad_sparse_pack
  * fills pack_a (4 * n_sparse * 2 KiB: the pooled rows masked to the four own-pixel sets) and pack_i (4 * n_sparse * 256 B: index words) and,
  * when bias_part is given, the conv3 bias partial sums of these windows ([*n_parts][1024], reduce with sgc_slab_sum).  The entries behind n_sparse (per-object entries: dense sums) take sgc_windows_unpool_from +
  * sgc_windows_dgrad_patches into the rows behind. */
 int sgc_windows_dgrad_sparse_weights(const float* conv3_weight, void* w3sp, void* stream);
+/* sgc_windows_patch_sum / _objects for a patch buffer whose first n16 entries are in the sparse form's layout - 16 rows of 512 per entry, one
+ * per patch pixel (the centre pixels' two halves are summed in its accumulators) - followed by the dense form's 20 rows per entry for the
+ * entries behind them (at patch + n16 * 16 * 512). */
+int sgc_windows_patch_sum2(const void* patch, int n16, const int* bbox, const int* sub_idx, const int* obj_idx, const int* count_incl, int n_pairs,
+                           void* dz, void* stream);
+int sgc_windows_patch_sum_objects2(const void* patch, int n16, const int* bbox, int n_obj, int n_real, const int* count_incl, void* dz, void* stream);
 int sgc_windows_dgrad_sparse_pack(const void* dywm, const unsigned char* argmax, const int* gather, const int* dest, int n_sparse,
                                   void* pack_a, void* pack_i, float* bias_part, int* n_parts, void* stream);
 int sgc_windows_dgrad_patches_sparse(const void* pack_a, const void* pack_i, int n_sparse, const void* w3sp, void* patch, void* stream);
@@ -444,6 +450,14 @@ int sgc_unpool_relu_bwd_pack(const void* dy, const unsigned char* argmax, void* 
  * amz: the nibble-packed routing codes written by the expansion. */
 int sgc_pair_contract(const void* dz, const unsigned char* amz, const int* ptr, const int* list, void* dU_pad, int n_obj, void* stream);
 int sgc_conv2_dgrad(const void* dU_pad, const void* wd2, void* da, int n_obj, void* stream);
+/* The same on the objects' GRADIENT regions (the backward of model.py:141-143 restricted to where the gradient can be non-zero): the pair
+ * contraction writes dU_o only inside the pixel rectangle of o's pseudo-pair, so the 2x2-pixel cells outside it hold exact zeros.
+ * sgc_conv2_bwd_regions lists (object * 256 + cell) for the n_real boxed objects (their rectangle widened by ``dilate`` cells: 1 for the
+ * data gradient, 0 for the weight gradient) and all cells of the n_objx - n_real background objects behind them; sgc_conv2_dgrad_regions
+ * writes the rows of the listed cells of da (the caller zero-fills the rest: bit-identical to sgc_conv2_dgrad). */
+int sgc_conv2_bwd_regions(const int* bbox, int n_real, int n_objx, int dilate, int* gather, int* n_out, void* stream);
+int sgc_conv2_dgrad_regions(const void* dU_pad, const void* wd2, const int* gather, const int* gather_n, int max_entries, void* da,
+                            void* stream);
 int sgc_conv2_wgrad(const void* dU_pad, const void* a_pad_bf16, float* slabs, int n_obj, int splits, int* n_slabs, void* stream);
 /* dA [n_img*F*F][D] f32 = gradient of the per-image map (inside the boxes); dcst_part [*n_parts][D] f32 = partial sums of the gradient
  * of the tanh(b1) constant (outside the boxes), *n_parts = n_img * F*F*D/2048 rows, reduced by sgc_slab_sum (fixed order, no atomics). */

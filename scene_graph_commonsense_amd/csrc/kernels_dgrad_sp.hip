@@ -46,7 +46,7 @@ struct NtSpParams {
     const u16* Ac;            // [4 sets][entries][1024] bf16: pooled rows masked to the set
     const unsigned* Ic;       // [4 sets][entries / 256][2 halves][32 K tiles][2 lane halves][128 rows] u32 index words
     const u16* B;             // [20 slots][512][2048] bf16
-    u16* C;                   // patch [entries][20][512] bf16
+    u16* C;                   // patch [entries][16][512] bf16 (one row per patch pixel)
     int entries;              // multiple of 256
     int tiles_m;
 };
@@ -91,25 +91,35 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_sp_kernel(const NtSpParams p) 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wid >> 2, wc = wid & 3;
-    // Tile walk.  Patch = 16 M tiles x the two channel halves of ONE slot (32 blocks = what an XCD holds: the slot's weights stay in
-    // its L2); patches are numbered M-group major and dealt round-robin to the 8 XCDs (block id % 8 = XCD), so at any time the whole
-    // chip works on the 20 slots of a FEW M groups: their masked rows (16 tiles x 4 sets x 0.6 MB) are fetched from HBM once and
-    // re-read - by the other slots of the set, on other XCDs - from the Infinity Cache.  Measured against the walk of gemm_nt_pp_kernel
-    // <SEG> (every XCD its own contiguous range of M groups: eight groups' rows + the weights exceed the 256 MB of that cache):
-    // 5.07 against 5.67 ms per launch, alternated (profiles/r05_sparse_dgrad_walk_ab.txt).
-    int tm, slot, nhalf;
+    // Tile walk.  A patch = 16 M tiles x the two channel halves of ONE patch pixel (32 blocks = what an XCD holds: the pixel's weights
+    // stay in its L2); patches are dealt to the 8 XCDs (block id % 8 = XCD) M-group major, so at any time the whole chip works on the 16
+    // pixels of a FEW M groups: their masked rows (16 tiles x 4 sets x 0.6 MB) are fetched from HBM once and re-read - by the other
+    // pixels of the set, on other XCDs - from the Infinity Cache.  Measured against the walk of gemm_nt_pp_kernel<SEG> (every XCD its own
+    // contiguous range of M groups: eight groups' rows + the weights exceed the 256 MB of that cache): 5.07 against 5.67 ms per launch,
+    // alternated (profiles/r05_sparse_dgrad_walk_ab.txt).  The four centre pixels run both of their sets (64 K tiles instead of 32), so
+    // the deal is by work: per period of two M groups (G0, G1) every XCD gets one centre pixel and three others -
+    //   XCD x < 4 :  centre x of G0,  other 8+x of G0,  other x of G1,    other 4+x of G1
+    //   XCD 4 + y :  other y of G0,   other 4+y of G0,  centre y of G1,   other 8+y of G1          (5 units of 32 K tiles each).
+    int tm, pp, nhalf;
     {
         const int x = blockIdx.x & 7, jj = blockIdx.x >> 3;
-        const int patch = (jj >> 5) * 8 + x, w = jj & 31;
-        const int npatch = ((p.tiles_m + 15) >> 4) * 20;
-        if (patch >= npatch) return;
-        const int G = patch / 20;
-        slot = patch - G * 20;
+        const int seq = jj >> 5, w = jj & 31;
+        const int period = seq >> 2, n = seq & 3, y = x & 3;
+        int gsel, centre, idx;
+        if (x < 4) { gsel = n >> 1; centre = n == 0; idx = n == 0 ? y : (n == 1 ? 8 + y : (n == 2 ? y : 4 + y)); }
+        else { gsel = n >> 1; centre = n == 2; idx = n == 0 ? y : (n == 1 ? 4 + y : (n == 2 ? y : 8 + y)); }
+        const int G = 2 * period + gsel;
+        if (G * 16 >= p.tiles_m) return;
+        // centre pixels 5, 6, 9, 10; the twelve others in natural order: 0 1 2 3 4 7 8 11 12 13 14 15
+        pp = centre ? (5 + (idx & 1) + 4 * (idx >> 1)) : (idx < 5 ? idx : (idx == 5 ? 7 : (idx == 6 ? 8 : idx + 4)));
         tm = G * 16 + (w >> 1);
         nhalf = w & 1;
         if (tm >= p.tiles_m) return;
     }
-    const int set = nt_sp_slot_set(slot);
+    const bool is_centre = ((pp >> 2) == 1 || (pp >> 2) == 2) && ((pp & 3) == 1 || (pp & 3) == 2);
+    // weight matrices in the order of the dense form's 20 slots (centre pixels: two consecutive matrices, one per set)
+    const int slot = pp + (pp > 5) + (pp > 6) + (pp > 9) + (pp > 10);
+    const int set = nt_sp_slot_set(slot);          // first (or only) set of the pixel; a centre pixel's second pass: set + 1, matrix slot + 1
     const int m0 = tm * 256;
 
     // ---- staging sources
@@ -133,15 +143,18 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_sp_kernel(const NtSpParams p) 
 #pragma unroll
         for (int h = 0; h < 2; ++h) b_voff[h][q] = (((r >> 5) * 64 + h * 32 + (r & 31)) * 2048 + chunk) * 2;
     }
+    // second pass of a centre pixel (K tiles 32 .. 63): the next set's rows / index words, the next weight matrix (wave-uniform bases)
+    const long a_pass = (long)p.entries * 1024, i_pass = (long)p.tiles_m * 2 * 32 * 256, b_pass = 512L * 2048;
     auto stage = [&](int kind, int t) __attribute__((always_inline)) {
         char* base = slot_base(t, kind);
+        const int pass = t >> 5, tt = t & 31;
         if (kind == 0 || kind == 3) {
             const int h = kind ? 1 : 0;
-            buf_load_lds16(a_set, a_voff[h], t << 6, base + wid * 1024);                   // 32 channels = 64 B per K tile
-            if (wid == h) buf_load_lds16(i_blk, lane << 4, (h * 32 + t) << 10, base + 8192);
+            buf_load_lds16(a_set + pass * a_pass, a_voff[h], tt << 6, base + wid * 1024);                   // 32 channels = 64 B per K tile
+            if (wid == h) buf_load_lds16(i_blk + pass * i_pass, lane << 4, (h * 32 + tt) << 10, base + 8192);
         } else {
-            buf_load_lds16(b_blk, b_voff[kind - 1][0], t << 7, base + wid * 2048);          // 64 k = 128 B per K tile
-            buf_load_lds16(b_blk, b_voff[kind - 1][1], t << 7, base + wid * 2048 + 1024);
+            buf_load_lds16(b_blk + pass * b_pass, b_voff[kind - 1][0], tt << 7, base + wid * 2048);          // 64 k = 128 B per K tile
+            buf_load_lds16(b_blk + pass * b_pass, b_voff[kind - 1][1], tt << 7, base + wid * 2048 + 1024);
         }
     };
 
@@ -199,7 +212,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_sp_kernel(const NtSpParams p) 
         SGC_PP_BARRIER();
     };
 
-    constexpr int nk = 32;
+    const int nk = is_centre ? 64 : 32;
     // pieces per wave and K tile: A0 1 (+1 index load on wave 0), B0 2, B1 2, A1 1 (+1 on wave 1)
     if constexpr (STAGES == 2) {
         stage(0, 0); stage(1, 0); stage(2, 0); stage(3, 0);
@@ -243,8 +256,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_sp_kernel(const NtSpParams p) 
     if (wr == 0) __builtin_amdgcn_s_barrier();
 
     NtParams q{};
-    q.C = p.C; q.M = p.entries; q.ldc = 20 * 512; q.bias = nullptr;
-    nt_epilogue_store16<ELEM_BF16>(q, acc, m0, slot * 512 + nhalf * 256, wr, wc, lane, wid, smem);
+    q.C = p.C; q.M = p.entries; q.ldc = 16 * 512; q.bias = nullptr;
+    nt_epilogue_store16<ELEM_BF16>(q, acc, m0, pp * 512 + nhalf * 256, wr, wc, lane, wid, smem);
 }
 
 // ---------------------------------------------------------------------------------------------------- operands
@@ -371,8 +384,8 @@ static int launch_gemm_nt_sp(NtSpParams p, hipStream_t stream) {
     p.tiles_m = p.entries >> 8;
     auto kern = gemm_nt_sp_kernel<2>;          // <3>: measured, no gain (see the kernel's header)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    const int npatch = ((p.tiles_m + 15) >> 4) * 20;
-    const unsigned grid = (unsigned)(((npatch + 7) / 8) * 8 * 32);          // whole patches, 8 at a time (one per XCD)
+    const int groups = (p.tiles_m + 15) >> 4, periods = (groups + 1) >> 1;
+    const unsigned grid = (unsigned)(periods * 4 * 8 * 32);                 // per period (two M groups): four patches of 32 blocks on each of the 8 XCDs
     SGC_LAUNCH(kern, dim3(grid), dim3(512), LDS, stream, p);
     SGC_CHECK_LAUNCH();
     return SGC_OK;

@@ -409,7 +409,11 @@ __global__ __launch_bounds__(256) void windows_col2im_kernel(const u16* __restri
 // two consecutive rows (two of their four (own pixel, tap) combinations each: the product keeps K <= 2048, see gemm_nt_pp_kernel<SEG>);
 // dz of a pixel adds the rows of the (at most 2 x 2) windows of the pair's rectangle whose patch covers it.
 constexpr int PATCH_SLOTS = 20;
-__device__ __forceinline__ void patch_sum_rect(const u16* __restrict__ patch, const WRect& x, int off, long p, u16* __restrict__ dz) {
+// Two row layouts in one buffer: the entries e < n16 (the real pairs' windows whose data gradient ran on the sparse matrix cores,
+// csrc/kernels_dgrad_sp.hip) have 16 rows - one per patch pixel, the centre pixels' two halves already summed in the accumulators -
+// at patch + e * 16 * 512; the entries behind them have the dense form's PATCH_SLOTS rows at patch + n16 * 16 * 512 + (e - n16) *
+// PATCH_SLOTS * 512.  n16 = 0: every entry in the dense form.
+__device__ __forceinline__ void patch_sum_rect(const u16* __restrict__ patch, const WRect& x, int off, long p, u16* __restrict__ dz, int n16) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (x.x1 <= x.x0) return;
     const int wdt = x.x1 - x.x0;
@@ -429,8 +433,11 @@ __device__ __forceinline__ void patch_sum_rect(const u16* __restrict__ patch, co
                 const int wx = ((xx + 1) >> 1) - b;
                 if (wx < x.x0 || wx >= x.x1) continue;
                 const int py = y - 2 * wy + 1, px = xx - 2 * wx + 1, pp = py * 4 + px;
-                const bool centre = (py == 1 || py == 2) && (px == 1 || px == 2);          // two slots (two of the four combinations each)
-                const long row = (long)PATCH_SLOTS * (off + (wy - x.y0) * wdt + (wx - x.x0)) + pp + (pp > 5) + (pp > 6) + (pp > 9) + (pp > 10);
+                bool centre = (py == 1 || py == 2) && (px == 1 || px == 2);          // dense form: two slots (two of the four combinations each)
+                const int ew = off + (wy - x.y0) * wdt + (wx - x.x0);
+                long row;
+                if (ew < n16) { row = 16L * ew + pp; centre = false; }
+                else row = 16L * n16 + (long)PATCH_SLOTS * (ew - n16) + pp + (pp > 5) + (pp > 6) + (pp > 9) + (pp > 10);
                 const uint4 v = *reinterpret_cast<const uint4*>(patch + row * 512 + lane * 8);
                 const u16* vh = reinterpret_cast<const u16*>(&v);
 #pragma unroll
@@ -454,19 +461,19 @@ __device__ __forceinline__ void patch_sum_rect(const u16* __restrict__ patch, co
 
 __global__ __launch_bounds__(256) void windows_patch_sum_kernel(const u16* __restrict__ patch, const int* __restrict__ bbox,
                                                                 const int* __restrict__ sub, const int* __restrict__ obj,
-                                                                const int* __restrict__ incl, u16* __restrict__ dz) {
+                                                                const int* __restrict__ incl, u16* __restrict__ dz, int n16) {
     const int p = blockIdx.x;
     const int e0 = p ? incl[p - 1] : 0;
     if (incl[p] == e0) return;                 // no entries of its own in this list (no X window, or a linear pair: no dz either)
     const WRect x = pair_windows(object_windows(bbox + 4 * sub[p]), object_windows(bbox + 4 * obj[p]));
-    patch_sum_rect(patch, x, e0, p, dz);
+    patch_sum_rect(patch, x, e0, p, dz, n16);
 }
 
 __global__ __launch_bounds__(256) void windows_patch_sum_objects_kernel(const u16* __restrict__ patch, const int* __restrict__ bbox, int n_obj,
-                                                                        int n_real, const int* __restrict__ incl, u16* __restrict__ dz) {
+                                                                        int n_real, const int* __restrict__ incl, u16* __restrict__ dz, int n16) {
     const int ps = blockIdx.x, pair = n_real + ps;
     const WRect x = object_windows(bbox + 4 * (ps >= n_obj ? ps - n_obj : ps));
-    patch_sum_rect(patch, x, pair ? incl[pair - 1] : 0, pair, dz);
+    patch_sum_rect(patch, x, pair ? incl[pair - 1] : 0, pair, dz, n16);
 }
 
 // the same for the window-list entries of the pseudo-pairs (pair index n_real + ps, windows R_o)
@@ -1118,6 +1125,50 @@ __global__ __launch_bounds__(256) void conv2_regions_fill_kernel(const int* __re
     for (int wy = y0; wy < y1; ++wy)
         for (int wx = x0; wx < x1; ++wx) gather[e++] = o * 256 + wy * 16 + wx;
 }
+// Backward of conv2 on the objects' GRADIENT regions (round 5).  The gradient of object o's conv2 half arrives through the pair
+// contraction, which writes a pixel only inside the packed pixel rectangle of o's pseudo-pair - the pixels of the 16-grid within one
+// pixel of the windows R_o (pack_pixel_rect(object_windows(box))): every pair of o lives inside it - so dU_o is zero outside that
+// rectangle's 2x2-pixel cells of the 32-grid (40 % of the map on the benchmark's boxes).  List of (object, cell) for the conv2
+// backward GEMMs: the cells of the rectangle widened by ``dilate`` cells on every side (data gradient: 1 - a 3x3 transposed
+// convolution reaches one pixel further; weight gradient: 0); the images' background objects (o >= n_real) collect gradient everywhere:
+// all 256 cells.  ONE workgroup: per-object counts, an exclusive scan in chunks of 1024 objects, fill; *n_out = list length.
+__global__ __launch_bounds__(1024) void conv2_bwd_regions_kernel(const int* __restrict__ bbox, int n_real, int n_objx, int dilate,
+                                                                 int* __restrict__ gather, int* __restrict__ n_out) {
+    __shared__ int wave_tot[16];
+    __shared__ int s_base;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    for (int o0 = 0; o0 < n_objx; o0 += 1024) {
+        const int o = o0 + tid;
+        int X0 = 0, X1 = 0, Y0 = 0, Y1 = 0;
+        if (o < n_real) {
+            const WRect r = object_windows(bbox + 4 * o);
+            if (r.x1 > r.x0) {
+                Y0 = max(2 * r.y0 - 1 - dilate, 0); Y1 = min(2 * r.y1 + 1 + dilate, 16);
+                X0 = max(2 * r.x0 - 1 - dilate, 0); X1 = min(2 * r.x1 + 1 + dilate, 16);
+            }
+        } else if (o < n_objx) { X1 = 16; Y1 = 16; }
+        const int cnt = (X1 - X0) * (Y1 - Y0);
+        int incl = cnt;                                  // inclusive scan inside the wavefront
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int v = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += v;
+        }
+        if (lane == 63) wave_tot[wid] = incl;
+        __syncthreads();
+        int before = s_base;
+        for (int w = 0; w < wid; ++w) before += wave_tot[w];
+        int e = before + incl - cnt;
+        for (int y = Y0; y < Y1; ++y)
+            for (int x = X0; x < X1; ++x) gather[e++] = o * 256 + y * 16 + x;
+        __syncthreads();
+        if (tid == 1023) s_base = before + incl;
+        __syncthreads();
+    }
+    if (tid == 0) *n_out = s_base;
+}
 // rows of object o outside its region <- the rows of the background object n_obj + obj_img[o]; one wavefront per (object, window): 4 KiB
 __global__ __launch_bounds__(256) void conv2_fill_background_kernel(const int* __restrict__ bbox, const int* __restrict__ obj_img, int n_obj,
                                                                     uint4* __restrict__ uv, long n_items) {
@@ -1280,6 +1331,9 @@ int sgc_windows_dgrad_cols(const void* dy3x, const void* w3col, void* col, int r
     return launch_gemm_nt<ELEM_BF16, AMODE_PLAIN, EPI_STORE>(p, (hipStream_t)stream);
 }
 
+int sgc_windows_patch_sum2(const void* patch, int n16, const int* bbox, const int* sub_idx, const int* obj_idx, const int* count_incl, int n_pairs,
+                           void* dz, void* stream);
+int sgc_windows_patch_sum_objects2(const void* patch, int n16, const int* bbox, int n_obj, int n_real, const int* count_incl, void* dz, void* stream);
 int sgc_windows_patch_slots(void) { return PATCH_SLOTS; }
 // patch [entries][PATCH_SLOTS][512] bf16: gradient of the 4 x 4 input patch of every listed window (entries = list length, padded freely);
 // w3patch: for pp = 4 py + px in order, [512 c_in][combinations x 1024 c_out] bf16 with the combinations (own pixel q, tap t), q + t = pp,
@@ -1294,16 +1348,24 @@ int sgc_windows_dgrad_patches(const void* dy3x, const void* w3patch, void* patch
 }
 int sgc_windows_patch_sum(const void* patch, const int* bbox, const int* sub_idx, const int* obj_idx, const int* count_incl, int n_pairs,
                           void* dz, void* stream) {
+    return sgc_windows_patch_sum2(patch, 0, bbox, sub_idx, obj_idx, count_incl, n_pairs, dz, stream);
+}
+int sgc_windows_patch_sum_objects(const void* patch, const int* bbox, int n_obj, int n_real, const int* count_incl, void* dz, void* stream) {
+    return sgc_windows_patch_sum_objects2(patch, 0, bbox, n_obj, n_real, count_incl, dz, stream);
+}
+// the same with the first n16 entries in the 16-row layout of the sparse data gradient (see patch_sum_rect)
+int sgc_windows_patch_sum2(const void* patch, int n16, const int* bbox, const int* sub_idx, const int* obj_idx, const int* count_incl, int n_pairs,
+                           void* dz, void* stream) {
     if (n_pairs <= 0) return SGC_OK;
     SGC_LAUNCH(windows_patch_sum_kernel, dim3(n_pairs), dim3(256), 0, (hipStream_t)stream, (const u16*)patch, bbox, sub_idx, obj_idx,
-               count_incl, (u16*)dz);
+               count_incl, (u16*)dz, n16);
     SGC_CHECK_LAUNCH();
     return SGC_OK;
 }
-int sgc_windows_patch_sum_objects(const void* patch, const int* bbox, int n_obj, int n_real, const int* count_incl, void* dz, void* stream) {
+int sgc_windows_patch_sum_objects2(const void* patch, int n16, const int* bbox, int n_obj, int n_real, const int* count_incl, void* dz, void* stream) {
     if (n_obj <= 0) return SGC_OK;
     SGC_LAUNCH(windows_patch_sum_objects_kernel, dim3(2 * n_obj), dim3(256), 0, (hipStream_t)stream, (const u16*)patch, bbox, n_obj, n_real,
-               count_incl, (u16*)dz);
+               count_incl, (u16*)dz, n16);
     SGC_CHECK_LAUNCH();
     return SGC_OK;
 }
@@ -1415,6 +1477,23 @@ int sgc_conv2_object_regions(const void* a_pad, const void* w2r, const float* bi
     p.A = (const u16*)a_pad; p.B = (const u16*)w2r; p.C = uv; p.M = max_entries * 4; p.N = 512; p.K = 9 * 128;
     p.ldb = 9 * 128; p.ldc = 512; p.lgS = 5; p.Cin = 128; p.bias = bias; p.gather = gather; p.gather_n = gather_n;
     return launch_gemm_nt_pp_conv_gather<ELEM_F16, EPI_STORE>(p, (hipStream_t)stream);
+}
+// list [<= n_objx * 256] of (object * 256 + cell) for the conv2 backward over the objects' gradient regions, *n_out its length
+int sgc_conv2_bwd_regions(const int* bbox, int n_real, int n_objx, int dilate, int* gather, int* n_out, void* stream) {
+    if (n_objx <= 0 || n_real < 0 || n_real > n_objx || dilate < 0) return SGC_ERR_ARG;
+    SGC_LAUNCH(conv2_bwd_regions_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, bbox, n_real, n_objx, dilate, gather, n_out);
+    SGC_CHECK_LAUNCH();
+    return SGC_OK;
+}
+// da rows 4*gather[e] + q (window-major rows of [n][1024][128] bf16) = the conv2 data gradient (sgc_conv2_dgrad) on the listed cells
+// only; rows of unlisted cells are NOT written (the caller zero-fills da: the gradient there is exactly zero)
+int sgc_conv2_dgrad_regions(const void* dU_pad, const void* wd2, const int* gather, const int* gather_n, int max_entries, void* da,
+                            void* stream) {
+    if (max_entries <= 0) return SGC_OK;
+    NtParams p{};
+    p.A = (const u16*)dU_pad; p.B = (const u16*)wd2; p.C = da; p.M = max_entries * 4; p.N = 128; p.K = 9 * 512;
+    p.ldb = 9 * 512; p.ldc = 128; p.lgS = 5; p.Cin = 512; p.gather = gather; p.gather_n = gather_n;
+    return launch_gemm_nt_cfg<ELEM_BF16, AMODE_CONV_GATHER, EPI_STORE, 2, 2, 2, 2>(p, (hipStream_t)stream);
 }
 int sgc_conv2_fill_background(const int* bbox, const int* obj_img, int n_obj, void* uv, void* stream) {
     if (n_obj <= 0) return SGC_OK;

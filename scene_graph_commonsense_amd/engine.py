@@ -185,6 +185,8 @@ class Tuning:
     weight_kernels: bool = True       # 16-bit weight layouts by one gather + cast launch each (off: torch view / permute / flip / cat chains)
     fc1_own_sums: bool = True         # fc1 assembly reads S'_j[R_j] pre-summed per object (off: four corner vectors per pair; same bits)
     sparse_wgrad: bool = True         # conv3 weight gradient over the real pairs' listed windows on the sparse matrix cores (off: dense block)
+    conv2_bwd_regions: bool = True    # conv2 data gradient only on the cells where an object's gradient can be non-zero (its pseudo-pair's pixel
+                                      # rectangle + 1 cell; off: whole 32x32 maps; same bits)
     sparse_dgrad: bool = True         # conv3 data gradient over the real pairs' listed windows on the sparse matrix cores (off: dense patch form)
     fused_sgd: bool = True            # train_minibatch + optim.FusedSGD: fc1.weight's gradient stays in GEMM order, one pass un-permutes, updates and
                                       # writes the f16 copy (off: transposition + update + transposition; same bits)
@@ -266,22 +268,17 @@ _GENERIC_WARNED = []
 
 
 class _CheckRing:
-    """Pinned int32 words for the deferred consistency checks of all engines of this process (``RelHeadEngine._post_check``)."""
-    SLOTS = 64
-    buf = None
+    """Pinned int32 words for the deferred consistency checks of all engines of this process (``RelHeadEngine._post_check``): a pool of
+    one-word views of pinned blocks; a word goes back to the pool when ``verify_checks`` has looked at it, the pool grows by a block
+    when it is empty (engines that are dropped with checks pending simply never return theirs)."""
+    BLOCK = 64
     free = []
 
     @classmethod
-    def take(cls, eng):
-        if cls.buf is None:
-            cls.buf = torch.zeros(cls.SLOTS, dtype=torch.int32).pin_memory()
-            cls.free = list(range(cls.SLOTS))
+    def take(cls):
         if not cls.free:
-            eng.verify_checks()
-        if not cls.free:
-            eng.verify_checks(block=True)
-        if not cls.free:
-            raise RuntimeError("deferred-check ring exhausted: some engine posts checks and never calls verify_checks()")
+            block = torch.zeros(cls.BLOCK, dtype=torch.int32).pin_memory()
+            cls.free = [block[i:i + 1] for i in range(cls.BLOCK)]
         return cls.free.pop()
 
 
@@ -314,28 +311,26 @@ class RelHeadEngine:
         looked at LATER (``verify_checks``: at the next forward, at the end of an epoch / an evaluation pass, or explicitly) - a
         host-side ``int(tensor)`` here would stall the launch queue of every training step for a condition that never holds in the
         drivers' own use.  The pinned words come from one process-wide ring (``_CheckRing``): no allocation per plan."""
-        slot = _CheckRing.take(self)
-        _CheckRing.buf[slot:slot + 1].copy_(bad.reshape(1).to(torch.int32), non_blocking=True)
+        word = _CheckRing.take()
+        word.copy_(bad.reshape(1).to(torch.int32), non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
-        self._checks.append((ev, slot, message))
+        self._checks.append((ev, word, message))
 
     def verify_checks(self, block: bool = False):
         """Raise if a posted check failed (``block``: wait for the pending ones first)."""
         keep, failed = [], None
-        for ev, slot, message in self._checks:
+        for ev, word, message in self._checks:
             if block:
                 ev.synchronize()
             if not ev.query():
-                keep.append((ev, slot, message))
+                keep.append((ev, word, message))
                 continue
-            if int(_CheckRing.buf[slot]) != 0 and failed is None:
+            if int(word[0]) != 0 and failed is None:
                 failed = message
-            _CheckRing.free.append(slot)
+            _CheckRing.free.append(word)
         if failed is not None:
-            for _, slot, _ in keep:
-                _CheckRing.free.append(slot)
-            keep = []
+            keep = []                 # (their words are not reused: copies into them may still be in flight)
         self._checks[:] = keep
         if failed is not None:
             raise RuntimeError(failed)
@@ -1341,6 +1336,13 @@ class RelHeadEngine:
 
         # ---- pair contraction + conv2 + masks + conv1 (per-role buffers: the side stream may still read role 0's while role 1 runs)
         gc2 = torch.empty(512, 256, 3, 3, dtype=torch.float32, device=dev)
+        # second level of sharing on: an object's dU is zero outside the pixel rectangle of its pseudo-pair (every pair of the object
+        # lives inside it), so the conv2 data gradient runs on those cells + one more ring (csrc/kernels_shared.hip: conv2_bwd_regions)
+        c2_list = c2_n = None
+        if (shared is not None and TUNING.conv2_bwd_regions and bool(shared.get("objects")) and shared.get("wm") is not None and n_obj > 0):
+            c2_list = ws.get("c2b_list", n_objx * 256 + 64, torch.int32)
+            c2_n = ws.get("c2b_n", 4, torch.int32)
+            _lib.check(lib.sgc_conv2_bwd_regions(_lib.ptr(ctx.bbox), n_obj, n_objx, 1, _lib.ptr(c2_list), _lib.ptr(c2_n), st()), "sgc_conv2_bwd_regions")
         for r, csr in ((0, sub_csr), (1, obj_csr)):
             dU = ws.get("dU_pad_%d" % r, n_objx * 34 * 34 * 512, torch.bfloat16)
             if shared is not None:
@@ -1361,7 +1363,12 @@ class RelHeadEngine:
                 if r == 1:
                     grads["conv2_1.bias"] = self._colsum(dU, n_objx * 34 * 34, 512)
             da = ws.get("da", n_objx * 1024 * 128, torch.bfloat16)
-            self._timed("conv2_dgrad", lambda: _lib.check(lib.sgc_conv2_dgrad(_lib.ptr(dU), _lib.ptr(w["wd2"][r]), _lib.ptr(da), n_objx, st()), "sgc_conv2_dgrad"))
+            if c2_list is not None:
+                Workspace._zero(da)                  # unlisted cells: the gradient there is exactly zero
+                self._timed("conv2_dgrad", lambda: _lib.check(lib.sgc_conv2_dgrad_regions(
+                    _lib.ptr(dU), _lib.ptr(w["wd2"][r]), _lib.ptr(c2_list), _lib.ptr(c2_n), n_objx * 256, _lib.ptr(da), st()), "sgc_conv2_dgrad_regions"))
+            else:
+                self._timed("conv2_dgrad", lambda: _lib.check(lib.sgc_conv2_dgrad(_lib.ptr(dU), _lib.ptr(w["wd2"][r]), _lib.ptr(da), n_objx, st()), "sgc_conv2_dgrad"))
             dcst_bg = None
             if shared is not None:                   # the background objects are constant everywhere: all of their gradient goes to tanh(b1)
                 dcst_bg = self.ws.get("dcst_bg_%d" % r, 128, torch.float32)      # on THIS stream: ``da`` is rewritten by the next role
@@ -1692,9 +1699,9 @@ class RelHeadEngine:
             if e_spd:
                 self._timed("conv3_dgrad_windows", lambda: _lib.check(lib.sgc_windows_dgrad_patches_sparse(
                     _lib.ptr(spa), _lib.ptr(spi), e_spd, _lib.ptr(w["w3sp"]), _lib.ptr(patch), st()), "sgc_windows_dgrad_patches_sparse"))
-                if Epad > e_spd:
+                if Epad > e_spd:          # the dense form's 20 rows per entry behind the sparse form's 16 rows per entry
                     self._timed("conv3_dgrad_windows_tail", lambda: _lib.check(lib.sgc_windows_dgrad_patches(
-                        _lib.ptr(dy3x[e_spd * 4096:]), _lib.ptr(w["w3patch"]), _lib.ptr(patch[e_spd * slots * 512:]), Epad - e_spd, st()),
+                        _lib.ptr(dy3x[e_spd * 4096:]), _lib.ptr(w["w3patch"]), _lib.ptr(patch[e_spd * 16 * 512:]), Epad - e_spd, st()),
                         "sgc_windows_dgrad_patches"))
             else:
                 self._timed("conv3_dgrad_windows", lambda: _lib.check(lib.sgc_windows_dgrad_patches(_lib.ptr(dy3x), _lib.ptr(w["w3patch"]), _lib.ptr(patch), Epad, st()),
@@ -1702,10 +1709,10 @@ class RelHeadEngine:
             if TUNING.gemms_apart:
                 wgrad_windows()                      # side stream: after the data-gradient GEMM, beside the patch sums / the contraction
             self._timed("col2im_windows", lambda: (
-                _lib.check(lib.sgc_windows_patch_sum(_lib.ptr(patch), _lib.ptr(ctx.bbox), _lib.ptr(ctx.sub_idx), _lib.ptr(ctx.obj_idx), _lib.ptr(sh["incl"]),
-                                                     P, _lib.ptr(dz), st()), "sgc_windows_patch_sum"),
-                _lib.check(lib.sgc_windows_patch_sum_objects(_lib.ptr(patch), _lib.ptr(ctx.bbox), n_obj, P, _lib.ptr(sh["incl"]), _lib.ptr(dz), st()),
-                           "sgc_windows_patch_sum_objects") if objects else None))
+                _lib.check(lib.sgc_windows_patch_sum2(_lib.ptr(patch), e_spd, _lib.ptr(ctx.bbox), _lib.ptr(ctx.sub_idx), _lib.ptr(ctx.obj_idx),
+                                                      _lib.ptr(sh["incl"]), P, _lib.ptr(dz), st()), "sgc_windows_patch_sum2"),
+                _lib.check(lib.sgc_windows_patch_sum_objects2(_lib.ptr(patch), e_spd, _lib.ptr(ctx.bbox), n_obj, P, _lib.ptr(sh["incl"]), _lib.ptr(dz), st()),
+                           "sgc_windows_patch_sum_objects2") if objects else None))
         elif Epad:
             col = ws.get("xcol", Epad * 4 * 9 * 512, torch.bfloat16)
             self._timed("conv3_dgrad_windows", lambda: _lib.check(lib.sgc_windows_dgrad_cols(_lib.ptr(dy3x), _lib.ptr(w["w3col"]), _lib.ptr(col), Epad * 4, st()),

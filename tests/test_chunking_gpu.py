@@ -102,7 +102,11 @@ def test_chunked_step_with_minibatch_coupled_terms_equals_the_one_pass_step(term
              for n in one["grads"]}
     print({k: "%.1e" % v for k, v in worst.items()})
     for n, e in worst.items():
-        assert e <= 1e-5, (n, e)             # measured <= 1.3e-6 (f32 summation order of the groups' gradient sums)
+        # measured <= 1.3e-6 above conv3's input (f32 summation order of the groups' gradient sums).  Below it the groups' window lists
+        # differ from the one-pass list in WHICH windows take the sparse form of the conv3 data gradient (whole 256-window tiles of the
+        # real pairs' windows, lists of >= 4096 only; the rest the dense patch form): same products, but the bf16 patch rows round f32
+        # sums taken in another order - 3.6e-5 on conv1, far below the 4e-3 bf16 noise of those gradients
+        assert e <= (1e-4 if n.startswith(("conv1", "conv2")) else 1e-5), (n, e)
 
 
 def test_24x64_training_step_runs_in_40gb_groups():

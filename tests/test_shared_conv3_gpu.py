@@ -433,3 +433,31 @@ def test_window_data_gradient_on_the_sparse_matrix_cores_equals_the_dense_patch_
         else:
             assert torch.equal(a[n], b[n]), n
     print("sparse vs dense window data gradient:", {k: "%.1e" % v for k, v in worst.items()})
+
+
+def test_conv2_backward_on_the_objects_gradient_regions_is_bit_identical():
+    """``TUNING.conv2_bwd_regions`` (default): the conv2 data gradient runs only on the 2x2-pixel cells where an object's gradient can be
+    non-zero - the pixel rectangle of its pseudo-pair (every pair of the object writes its dz inside it) + one ring for the 3x3 transposed
+    convolution - and the rest of ``da`` is zero-filled.  The skipped cells hold exact zeros either way: every gradient is bit for bit
+    the whole-map result, on boxes that include full-image, 1x1, zero-area and corner boxes."""
+    from scene_graph_commonsense_amd.engine import tuning
+    from scene_graph_commonsense_amd.model import BayesianRelationClassifier
+    from scene_graph_commonsense_amd.pairs import flatten_scene
+    from scene_graph_commonsense_amd.synthetic import HeadConfig, make_scene_batch, make_state_dict
+    cfg = HeadConfig()
+    model = BayesianRelationClassifier(cfg.args()).cuda()
+    model.load_state_dict(make_state_dict(cfg, seed=9, head_gain=4.0))
+    model.eval()
+    batch = make_scene_batch(cfg, (40, 33, 27), seed=92, connect_frac=0.05, edge_boxes=True)
+    sc = flatten_scene(cfg, batch, "cuda:0")
+    grads = []
+    for on in (True, False):
+        with tuning(conv2_bwd_regions=on):
+            model.zero_grad(set_to_none=True)
+            loss = model.training_step(sc, batch.relationships, batch.subj_or_obj)
+            torch.cuda.synchronize()
+            grads.append((float(loss), {n: p.grad.detach().clone() for n, p in model.named_parameters()}))
+    (la, a), (lb, b) = grads
+    assert la == lb
+    for n in a:
+        assert torch.equal(a[n], b[n]), n
