@@ -453,7 +453,7 @@ int sgc_conv2_dgrad(const void* dU_pad, const void* wd2, void* da, int n_obj, vo
 /* The same on the objects' GRADIENT regions (the backward of model.py:141-143 restricted to where the gradient can be non-zero): the pair
  * contraction writes dU_o only inside the pixel rectangle of o's pseudo-pair, so the 2x2-pixel cells outside it hold exact zeros.
  * sgc_conv2_bwd_regions lists (object * 256 + cell) for the n_real boxed objects (their rectangle widened by ``dilate`` cells: 1 for the
- * data gradient, 0 for the weight gradient) and all cells of the n_objx - n_real background objects behind them; sgc_conv2_dgrad_regions
+ * data gradient) and all cells of the n_objx - n_real background objects behind them; sgc_conv2_dgrad_regions
  * writes the rows of the listed cells of da (the caller zero-fills the rest: bit-identical to sgc_conv2_dgrad). */
 int sgc_conv2_bwd_regions(const int* bbox, int n_real, int n_objx, int dilate, int* gather, int* n_out, void* stream);
 int sgc_conv2_dgrad_regions(const void* dU_pad, const void* wd2, const int* gather, const int* gather_n, int max_entries, void* da,

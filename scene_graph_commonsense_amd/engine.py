@@ -1343,8 +1343,9 @@ class RelHeadEngine:
             c2_list = ws.get("c2b_list", n_objx * 256 + 64, torch.int32)
             c2_n = ws.get("c2b_n", 4, torch.int32)
             _lib.check(lib.sgc_conv2_bwd_regions(_lib.ptr(ctx.bbox), n_obj, n_objx, 1, _lib.ptr(c2_list), _lib.ptr(c2_n), st()), "sgc_conv2_bwd_regions")
+        mapU, mapA = 34 * 34 * 512, 34 * 34 * 128
         for r, csr in ((0, sub_csr), (1, obj_csr)):
-            dU = ws.get("dU_pad_%d" % r, n_objx * 34 * 34 * 512, torch.bfloat16)
+            dU = ws.get("dU_pad_%d" % r, n_objx * mapU, torch.bfloat16)
             if shared is not None:
                 self._timed("contract", lambda: _lib.check(lib.sgc_pair_contract_windows(
                     _lib.ptr(dz), _lib.ptr(ctx.amz), _lib.ptr(csr[0]), _lib.ptr(csr[1]), _lib.ptr(shared["pixrect"]), _lib.ptr(img_ptr),
@@ -1354,8 +1355,8 @@ class RelHeadEngine:
                 self._timed("contract", lambda: _lib.check(lib.sgc_pair_contract(_lib.ptr(dz), _lib.ptr(ctx.amz), _lib.ptr(csr[0]), _lib.ptr(csr[1]), _lib.ptr(dU), n_obj, st()),
                            "sgc_pair_contract"))
             with side():
-                a_pad = self.ws.get("a_pad_%d" % r, n_objx * 34 * 34 * 128, torch.float16)      # kept by the forward
-                a_bf = self._to_bf16("a_pad_bf", a_pad, n_objx * 34 * 34 * 128)
+                a_pad = self.ws.get("a_pad_%d" % r, n_objx * mapA, torch.float16)      # kept by the forward
+                a_bf = self._to_bf16("a_pad_bf", a_pad, n_objx * mapA)
                 self._timed("conv2_wgrad", lambda: _lib.check(lib.sgc_conv2_wgrad(_lib.ptr(dU), _lib.ptr(a_bf), _lib.ptr(sl), n_objx, 0, ctypes.byref(slabs_n), st()),
                            "sgc_conv2_wgrad"))
                 dW2r = self._slab_sum(sl, 512 * 1152, slabs_n.value)
