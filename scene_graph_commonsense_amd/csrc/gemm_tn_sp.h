@@ -28,7 +28,7 @@
 //
 // Packed operands (sgc_sparse_pack): per K tile T (16 windows)
 //   Ac [T][1024 oc][16 windows][2] bf16   the two kept values of every window (value + one zero)      64 B per (tile, oc)
-//   Ic [T][1024 oc][2] u32                per lane half: index bits of s = 0 (low 16) and s = 1 (high 16)
+//   Ic [T][2 lane halves][1024 oc] u32    per lane half: index bits of s = 0 (low 16) and s = 1 (high 16)
 #pragma once
 #include "gemm_tn.h"
 
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void sparse_pack_kernel(const u16* __restrict_
     unsigned* dst = reinterpret_cast<unsigned*>(Ac) + (((long)T * 1024 + oc0 + oc) * 16 + 8 * ha);
     *reinterpret_cast<uint4*>(dst) = make_uint4(pairs[0], pairs[1], pairs[2], pairs[3]);
     *reinterpret_cast<uint4*>(dst + 4) = make_uint4(pairs[4], pairs[5], pairs[6], pairs[7]);
-    Ic[((long)T * 1024 + oc0 + oc) * 2 + ha] = idx;
+    Ic[((long)T * 2 + ha) * 1024 + oc0 + oc] = idx;
 }
 
 // Fused pass over the pooled gradient: un-pooling for the input gradient (dy3_pad, what unpool_kernel writes), the conv3 bias
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(512) void unpool_pack_kernel(const u16* __restrict_
             unsigned* dst = reinterpret_cast<unsigned*>(Ac) + (((long)T * 1024 + oc) * 16 + 8 * ha);
             *reinterpret_cast<uint4*>(dst) = make_uint4(pairs[0], pairs[1], pairs[2], pairs[3]);
             *reinterpret_cast<uint4*>(dst + 4) = make_uint4(pairs[4], pairs[5], pairs[6], pairs[7]);
-            Ic[((long)T * 1024 + oc) * 2 + ha] = idx;
+            Ic[((long)T * 2 + ha) * 1024 + oc] = idx;
         }
         __syncthreads();
     }
@@ -195,9 +195,11 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_sp_kernel(const TnParams p, co
     for (int h = 0; h < 2; ++h) {
         const int oc = m0 + (arow >> 6) * 128 + h * 64 + (arow & 63);
         a_voff[h] = oc * 64 + achunk * 16;
-        // index words of the half: 128 rows x 8 B = 1 KiB = one instruction; lane l covers rows 2l, 2l+1
-        const int ir = 2 * lane;
-        i_voff[h] = (m0 + (ir >> 6) * 128 + h * 64 + (ir & 63)) * 8;
+        // index words of the half: [lane half][128 rows] u32 = 1 KiB = one instruction; lane l covers rows 4(l&31) .. +3 of lane half l>>5
+        // (rounds 2-4 kept the two words of a row together - [row][lane half] - and read them with a stride of 8 bytes: two-way bank
+        // conflicts on every ds_read_b32, 10 % of the block's LDS-active cycles)
+        const int ir = 4 * (lane & 31);
+        i_voff[h] = ((lane >> 5) * 1024 + m0 + (ir >> 6) * 128 + h * 64 + (ir & 63)) * 4;
     }
     // B half tiles: as gemm_tn_pp_kernel (BMODE_CONV, per-lane taps)
     const int kr = (lane >> 1) & 3, sb = lane >> 3, c8 = (lane & 1) * 8;
@@ -247,7 +249,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_sp_kernel(const TnParams p, co
 #pragma unroll
             for (int s = 0; s < 2; ++s)
                 af[i][s] = *reinterpret_cast<const s16x8*>(base + r * 64 + (((2 * kh + s) ^ ((r >> 2) & 3)) << 4));
-            ai[i] = *reinterpret_cast<const unsigned*>(base + 8192 + r * 8 + kh * 4);
+            ai[i] = *reinterpret_cast<const unsigned*>(base + 8192 + kh * 512 + r * 4);
         }
     };
     auto tr4 = [&](const char* ptr) __attribute__((always_inline)) {
@@ -385,7 +387,7 @@ __global__ __launch_bounds__(256) void windows_sparse_pack_kernel(const u16* __r
     unsigned* dst = reinterpret_cast<unsigned*>(Ac) + (((long)T * 1024 + oc0 + oc) * 16 + 8 * ha);
     *reinterpret_cast<uint4*>(dst) = make_uint4(pairs[0], pairs[1], pairs[2], pairs[3]);
     *reinterpret_cast<uint4*>(dst + 4) = make_uint4(pairs[4], pairs[5], pairs[6], pairs[7]);
-    Ic[((long)T * 1024 + oc0 + oc) * 2 + ha] = idx;
+    Ic[((long)T * 2 + ha) * 1024 + oc0 + oc] = idx;
 }
 
 static int launch_sparse_pack(const u16* dy, const unsigned char* am, u16* Ac, unsigned* Ic, int n_pairs, hipStream_t stream) {
