@@ -245,6 +245,11 @@ int sgc_fc1_own_rect_sums(const float* S, const int* bbox, int n_obj, float* own
 int sgc_fc1_assemble(const float* S, const float* owm, const int* bbox, const int* sub_idx, const int* obj_idx, const int* count_incl,
                      const int* dest, int n_obj, const float* bias, int drop_enable, unsigned drop_seed, void* h1, int n_pairs,
                      const float* own_rect_sums /* may be NULL: the four corner reads per pair */, void* stream);
+/* The same rows, workgroup b assembling pair pair_order[b] (a permutation of the pairs, e.g. the contraction's list sorted by subject: the
+ * subject's prefix table then stays L2-resident over its ~N-1 consecutive pairs; NULL = pair order).  Same bits. */
+int sgc_fc1_assemble_ordered(const float* S, const float* owm, const int* bbox, const int* sub_idx, const int* obj_idx, const int* count_incl,
+                             const int* dest, int n_obj, const float* bias, int drop_enable, unsigned drop_seed, void* h1, int n_pairs,
+                             const float* own_rect_sums, const int* pair_order, void* stream);
 
 /* Backward of the shared fc1 (window-major rows; all bf16, f32 sums):
  *   sgc_fc1_gsum           pseudo rows of gwm [rows][4096]: row goff[w] + role*n_obj + o = sum of dh1 over the pairs of object o in that

@@ -656,8 +656,11 @@ __global__ __launch_bounds__(256) void fc1_assemble_kernel(const float* __restri
                                                            const int* __restrict__ obj, const int* __restrict__ incl,
                                                            const int* __restrict__ dest, int n_obj, const float* __restrict__ bias,
                                                            int drop_enable, unsigned seed, float scale, u16* __restrict__ h1,
-                                                           const float* __restrict__ own) {
-    const int p = blockIdx.x, c0 = threadIdx.x * 16;
+                                                           const float* __restrict__ own, const int* __restrict__ order) {
+    // ``order`` (optional): workgroup b assembles pair order[b].  With the pairs sorted by SUBJECT (the contraction's CSR list) the ~63
+    // consecutive workgroups of a subject read their five subject-side vectors from the same 1.3 MB prefix table S_i, which then stays
+    // in the L2s; in the reference's pair order (graph_iter, direction, image) neighbours share nothing
+    const int p = order ? order[blockIdx.x] : blockIdx.x, c0 = threadIdx.x * 16;
     const int i = sub[p], j = obj[p];
     const WRect ri = object_windows(bbox + 4 * i), rj = object_windows(bbox + 4 * j);
     const WRect x = pair_windows(ri, rj);
@@ -1339,6 +1342,9 @@ int sgc_windows_dgrad_cols(const void* dy3x, const void* w3col, void* col, int r
 int sgc_windows_patch_sum2(const void* patch, int n16, const int* bbox, const int* sub_idx, const int* obj_idx, const int* count_incl, int n_pairs,
                            void* dz, void* stream);
 int sgc_windows_patch_sum_objects2(const void* patch, int n16, const int* bbox, int n_obj, int n_real, const int* count_incl, void* dz, void* stream);
+int sgc_fc1_assemble_ordered(const float* S, const float* owm, const int* bbox, const int* sub_idx, const int* obj_idx, const int* count_incl,
+                             const int* dest, int n_obj, const float* bias, int drop_enable, unsigned drop_seed, void* h1, int n_pairs,
+                             const float* own_rect_sums, const int* pair_order, void* stream);
 int sgc_windows_patch_slots(void) { return PATCH_SLOTS; }
 // patch [entries][PATCH_SLOTS][512] bf16: gradient of the 4 x 4 input patch of every listed window (entries = list length, padded freely);
 // w3patch: for pp = 4 py + px in order, [512 c_in][combinations x 1024 c_out] bf16 with the combinations (own pixel q, tap t), q + t = pp,
@@ -1453,9 +1459,16 @@ int sgc_fc1_own_rect_sums(const float* S, const int* bbox, int n_obj, float* own
 int sgc_fc1_assemble(const float* S, const float* owm, const int* bbox, const int* sub_idx, const int* obj_idx, const int* count_incl,
                      const int* dest, int n_obj, const float* bias, int drop_enable, unsigned drop_seed, void* h1, int n_pairs,
                      const float* own_rect_sums, void* stream) {
+    return sgc_fc1_assemble_ordered(S, owm, bbox, sub_idx, obj_idx, count_incl, dest, n_obj, bias, drop_enable, drop_seed, h1, n_pairs,
+                                    own_rect_sums, nullptr, stream);
+}
+// the same rows, assembled in the order of ``pair_order`` (a permutation of the pairs: e.g. sorted by subject; NULL = pair order)
+int sgc_fc1_assemble_ordered(const float* S, const float* owm, const int* bbox, const int* sub_idx, const int* obj_idx, const int* count_incl,
+                             const int* dest, int n_obj, const float* bias, int drop_enable, unsigned drop_seed, void* h1, int n_pairs,
+                             const float* own_rect_sums, const int* pair_order, void* stream) {
     if (n_pairs <= 0) return SGC_OK;
     SGC_LAUNCH(fc1_assemble_kernel, dim3(n_pairs), dim3(256), 0, (hipStream_t)stream, S, owm, owm_pitch(), bbox, sub_idx, obj_idx, count_incl, dest,
-               n_obj, bias, drop_enable, drop_seed, 2.f, (u16*)h1, own_rect_sums);
+               n_obj, bias, drop_enable, drop_seed, 2.f, (u16*)h1, own_rect_sums, pair_order);
     SGC_CHECK_LAUNCH();
     return SGC_OK;
 }

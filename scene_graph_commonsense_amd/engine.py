@@ -185,6 +185,7 @@ class Tuning:
     weight_kernels: bool = True       # 16-bit weight layouts by one gather + cast launch each (off: torch view / permute / flip / cat chains)
     fc1_own_sums: bool = True         # fc1 assembly reads S'_j[R_j] pre-summed per object (off: four corner vectors per pair; same bits)
     sparse_wgrad: bool = True         # conv3 weight gradient over the real pairs' listed windows on the sparse matrix cores (off: dense block)
+    assemble_by_subject: bool = True  # fc1 assembly walks the pairs sorted by subject (the subject's prefix table stays in the L2s; same bits)
     conv2_bwd_regions: bool = True    # conv2 data gradient only on the cells where an object's gradient can be non-zero (its pseudo-pair's pixel
                                       # rectangle + 1 cell; off: whole 32x32 maps; same bits)
     sparse_dgrad: bool = True         # conv3 data gradient over the real pairs' listed windows on the sparse matrix cores (off: dense patch form)
@@ -771,7 +772,7 @@ class RelHeadEngine:
         return dict(goff=goff_d, goff_host=goff, gend=gend, tile_group=tile_group_d, dest=dest, dest_conv=dest_conv,
                     rows=int(goff[64]), E=E, E_total=Et, n2=n2)
 
-    def fc1_shared(self, wm, ywm, bbox, sub_idx, obj_idx, incl, P, n_obj, h1, dropout, seed):
+    def fc1_shared(self, wm, ywm, bbox, sub_idx, obj_idx, incl, P, n_obj, h1, dropout, seed, order=None):
         """fc1 + ReLU (+ dropout) from the window-major rows: grouped GEMM, per-object 2-D prefix sums, per-pair assembly."""
         lib, sc = self.lib, self.scratch
         w1p = self.w["w1p"]                          # deferred copy: made here (after the wait for fc1.weight's all-gather, if one is in flight)
@@ -785,9 +786,12 @@ class RelHeadEngine:
         if TUNING.fc1_own_sums:            # S'_j[R_j] per object: read once per pair instead of four corners
             own = sc.get("fc1_own", max(n_obj, 1) * 4096, torch.float32)
             _lib.check(lib.sgc_fc1_own_rect_sums(_lib.ptr(S), _lib.ptr(bbox), n_obj, _lib.ptr(own), self._st()), "sgc_fc1_own_rect_sums")
-        self._timed("fc1_fwd_assemble", lambda: _lib.check(lib.sgc_fc1_assemble(
+        if order is not None and (not TUNING.assemble_by_subject or int(order.shape[0]) != P):
+            order = None
+        self._timed("fc1_fwd_assemble", lambda: _lib.check(lib.sgc_fc1_assemble_ordered(
             _lib.ptr(S), _lib.ptr(owm), _lib.ptr(bbox), _lib.ptr(sub_idx), _lib.ptr(obj_idx), _lib.ptr(incl), _lib.ptr(wm["dest"]), n_obj,
-            _lib.ptr(self.w["bf1"]), int(dropout), ctypes.c_uint(seed), _lib.ptr(h1), P, _lib.ptr(own), self._st()), "sgc_fc1_assemble"))
+            _lib.ptr(self.w["bf1"]), int(dropout), ctypes.c_uint(seed), _lib.ptr(h1), P, _lib.ptr(own), _lib.ptr(order), self._st()),
+            "sgc_fc1_assemble_ordered"))
 
     def conv3_shared(self, plan, z, U, V, bbox, obj_img, sub_idx, obj_idx, P, y, am, y_bf, keep=None, wm=None):
         """conv3 + ReLU + pool with the per-object part computed once per object (``csrc/kernels_shared.hip``): U / V hold
@@ -890,7 +894,7 @@ class RelHeadEngine:
         return out
 
     def pair_trunk(self, U, V, sub_idx, obj_idx, lsub, lobj, train=False, seeds=(0, 0), keep_argmax=False,
-                   iou_mask=None, dense=None, shared=None) -> PairOutputs:
+                   iou_mask=None, dense=None, shared=None, pair_order=None) -> PairOutputs:
         lib, ws, cfg = self.lib, self.ws, self.cfg
         P = int(sub_idx.shape[0])
         Ppad = (P + 63) // 64 * 64
@@ -913,7 +917,7 @@ class RelHeadEngine:
             # conv3 and fc1 over shared windows: the rows fc1 multiplies are written window-major, y [P, 65536] never exists
             ywm = ws.get("ywm", wm["rows"] * 1024, torch.float16)
             self.conv3_shared(plan, z, U, V, shared[0], shared[1], sub_idx, obj_idx, P, ywm, am, None, wm=wm)
-            self.fc1_shared(wm, ywm, shared[0], sub_idx, obj_idx, plan.get("incl_all", plan["incl"]), P, n_obj, h1, train, seeds[0])
+            self.fc1_shared(wm, ywm, shared[0], sub_idx, obj_idx, plan.get("incl_all", plan["incl"]), P, n_obj, h1, train, seeds[0], order=pair_order)
         else:
             y = ws.get("y", Ppad * 65536, torch.float16)
             if shared is not None:
@@ -952,7 +956,7 @@ class RelHeadEngine:
 
     # ------------------------------------------------------------------ fused entry
     def forward_pairs(self, image_feature, image_depth, obj_img, bbox, cats, super_mh, sub_idx, obj_idx, train=False,
-                      seeds=(0, 0), keep_argmax=False, iou_mask=None, dense=None, select=None, shared_windows=None) -> PairOutputs:
+                      seeds=(0, 0), keep_argmax=False, iou_mask=None, dense=None, select=None, shared_windows=None, pair_order=None) -> PairOutputs:
         """One call per minibatch: image maps -> per-object halves -> all pairs.
         ``select`` ([P] bool / uint8 device tensor): run the per-pair trunk (expansion, conv3, fc1, fc2, head) ONLY for the selected
         pairs and scatter the results into full-size outputs; the other pairs get confidence -inf (exactly what the overlap filter
@@ -966,13 +970,13 @@ class RelHeadEngine:
         lsub, lobj = self.label_vectors(cats, super_mh)
         self._lsub, self._lobj = lsub, lobj
         if select is None:
-            return self.pair_trunk(uv[0], uv[1], sub_idx, obj_idx, lsub, lobj, train, seeds, keep_argmax, iou_mask, dense, shared)
+            return self.pair_trunk(uv[0], uv[1], sub_idx, obj_idx, lsub, lobj, train, seeds, keep_argmax, iou_mask, dense, shared, pair_order)
         sel = select.bool()
         if share and shared_windows is not None:
             # With conv3 / fc1 over shared windows a pair whose boxes do not overlap has (almost) no pair-specific window: skipping it
             # saves nothing, while a pair SUBSET loses the host's window counts (read-backs) and the dense expansion.  Compute every
             # pair and blank the unselected ones - the same outputs (measured 21.4 vs 34.2 ms per 8x64 minibatch).
-            out = self.pair_trunk(uv[0], uv[1], sub_idx, obj_idx, lsub, lobj, train, seeds, keep_argmax, iou_mask, dense, shared)
+            out = self.pair_trunk(uv[0], uv[1], sub_idx, obj_idx, lsub, lobj, train, seeds, keep_argmax, iou_mask, dense, shared, pair_order)
             drop = ~sel
             out.relation[drop] = 0
             if out.super_relation is not None:
@@ -1131,7 +1135,7 @@ class RelHeadEngine:
 
 
     def train_forward(self, image_feature, image_depth, obj_img, bbox, cats, super_mh, sub_idx, obj_idx, seeds=(0, 0),
-                      dropout=True, dense=None, role_inputs=None, cats_obj=None, super_mh_obj=None, shared_windows=None) -> "TrainContext":
+                      dropout=True, dense=None, role_inputs=None, cats_obj=None, super_mh_obj=None, shared_windows=None, pair_order=None) -> "TrainContext":
         """Forward that keeps what the backward needs (pool argmaxes, expansion routing mask).
         ``role_inputs=(h_sub, h_obj)``: the reference's per-step call on PRE-MASKED ``[b,257,32,32]`` inputs (``model.py:170``):
         row k of each is the subject / object crop of pair k, with labels ``cats`` / ``cats_obj``; every crop is its own
@@ -1187,7 +1191,7 @@ class RelHeadEngine:
             ywm_bf = ws.get("ywm_bf", wm["rows"] * 1024, torch.bfloat16)
             ctx.shared = self.conv3_shared(plan, z, ctx.uv[0], ctx.uv[1], bbox, obj_img, sub_idx, obj_idx, P, ywm, am, ywm_bf, keep=(z_bf, amz, ctx.z_bf_base), wm=wm)
             ctx.shared["ywm_bf"] = ywm_bf
-            self.fc1_shared(wm, ywm, bbox, sub_idx, obj_idx, plan.get("incl_all", plan["incl"]), P, ctx.n_obj, h1, dropout, seeds[0])
+            self.fc1_shared(wm, ywm, bbox, sub_idx, obj_idx, plan.get("incl_all", plan["incl"]), P, ctx.n_obj, h1, dropout, seeds[0], order=pair_order)
         else:
             y = sc.get("y", Ppad * 65536, torch.float16)
             y_bf = ws.get("y_bf", Ppad * 65536, torch.bfloat16)     # bf16 copy for the fc1 weight gradient, written by the same epilogue

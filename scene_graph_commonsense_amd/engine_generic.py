@@ -100,7 +100,7 @@ class GenericTrunkEngine(RelHeadEngine):
 
     # ------------------------------------------------------------------ the engine interface
     def forward_pairs(self, image_feature, image_depth, obj_img, bbox, cats, super_mh, sub_idx, obj_idx, train=False, seeds=(0, 0),
-                      keep_argmax=False, iou_mask=None, dense=None, select=None, shared_windows=None) -> PairOutputs:
+                      keep_argmax=False, iou_mask=None, dense=None, select=None, shared_windows=None, pair_order=None) -> PairOutputs:
         P = int(sub_idx.shape[0])
         Ppad = (P + 63) // 64 * 64
         src, img, box = self._sides(image_feature, image_depth, obj_img, bbox, sub_idx, obj_idx, None)
@@ -131,7 +131,7 @@ class GenericTrunkEngine(RelHeadEngine):
         return self._fc2_head(h1, lsub, lobj, ids, ids, b, Ppad, train, seeds[1])[1]
 
     def train_forward(self, image_feature, image_depth, obj_img, bbox, cats, super_mh, sub_idx, obj_idx, seeds=(0, 0), dropout=True, dense=None,
-                      role_inputs=None, cats_obj=None, super_mh_obj=None, shared_windows=None) -> TrainContext:
+                      role_inputs=None, cats_obj=None, super_mh_obj=None, shared_windows=None, pair_order=None) -> TrainContext:
         ctx = TrainContext()
         ctx.n_obj = int(obj_img.shape[0])
         ctx.P = P = int(sub_idx.shape[0])

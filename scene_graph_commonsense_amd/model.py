@@ -189,7 +189,7 @@ class _RelationBase(nn.Module):
             return eng.forward_pairs(scene.image_feature, scene.image_depth, scene.obj_img, scene.bbox, scene.cats,
                                      scene.super_mh, scene.sub_idx, scene.obj_idx, train=self.training, seeds=seeds,
                                      iou_mask=iou_mask, dense=_dense(scene), select=select,
-                                     shared_windows=_shared_hint(scene))
+                                     shared_windows=_shared_hint(scene), pair_order=getattr(scene, "sub_list", None))
 
     def _next_seeds(self):
         self._step += 1
@@ -316,7 +316,7 @@ class _RelationBase(nn.Module):
             ctx = eng.train_forward(scene.image_feature, scene.image_depth, scene.obj_img, scene.bbox, scene.cats,
                                     scene.super_mh, scene.sub_idx, scene.obj_idx,
                                     seeds=seeds_main, dropout=self.training,
-                                    dense=_dense(scene), shared_windows=_shared_hint(scene))
+                                    dense=_dense(scene), shared_windows=_shared_hint(scene), pair_order=getattr(scene, "sub_list", None))
             cs_coef = None
             if coupled is not None:
                 cs_coef = None if coupled.get("cs_coef") is None else coupled["cs_coef"].contiguous()
@@ -435,7 +435,7 @@ class _RelationBase(nn.Module):
         with torch.no_grad():
             ctx = eng.train_forward(scene.image_feature, scene.image_depth, scene.obj_img, scene.bbox, scene.cats, scene.super_mh,
                                     scene.sub_idx, scene.obj_idx, seeds=seeds[0], dropout=self.training, dense=_dense(scene),
-                                    shared_windows=_shared_hint(scene))
+                                    shared_windows=_shared_hint(scene), pair_order=getattr(scene, "sub_list", None))
             if want_candidates:
                 out["cand_pred"] = ctx.out.cand_pred.clone()
             if image_feature_aug is not None:
