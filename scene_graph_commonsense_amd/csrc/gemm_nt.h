@@ -223,7 +223,7 @@ __device__ __forceinline__ void supertile_map_g(int id, int tiles_m, int tiles_n
 // pieces and issues 16 full-line 16-byte stores per lane instead of 128 2-byte ones.  Needs 8 x 16 KiB of LDS.
 // Row pitch 128 B (no padding): the read-back is a ds_read_b128 whose 16-lane groups cover rows (r, r+1, r+2, r+3) x half a row -
 // with 32 dwords per row the four pieces land on disjoint quarters of the 64 banks; the dword writes of an (even, odd) lane pair
-// fall on one bank two-way, which costs a ds_write_b32 nothing (MI355X_MICROARCH.md, LDS).  Rounds 2-4 padded the rows to 144 B:
+// would fall on one bank two-way (free for a ds_write_b32, but counted): odd rows swap their halves.  Rounds 2-4 padded the rows to 144 B:
 // conflict-light writes, but two-way conflicts on every read (SQ_LDS_BANK_CONFLICT 5.6 % of the LDS-active cycles of the window
 // data gradient, 2.8 % of fc1's).
 constexpr int EPI_LDS_PITCH = 128;
@@ -251,7 +251,9 @@ __device__ __forceinline__ void nt_epilogue_store16(const NtParams& p, f32x16 (&
                 if constexpr (ELEM == ELEM_BF16) packed = f32x2_to_bf16x2_bits(flo, fhi);      // one v_cvt_pk_bf16_f32
                 else packed = (unsigned)to_elem<ELEM>(flo) | ((unsigned)to_elem<ELEM>(fhi) << 16);
                 const int row = i * 32 + r0 + (odd ? 1 : 0);
-                *reinterpret_cast<unsigned*>(reg + row * EPI_LDS_PITCH + (j * 32 + (cl & ~1)) * 2) = packed;
+                // odd rows keep their two 64-byte halves swapped: the dwords of an (even, odd) lane pair - rows R and R + 1, same column -
+                // then fall on different banks (conflict-free writes), and the read-back below stays conflict-free
+                *reinterpret_cast<unsigned*>(reg + row * EPI_LDS_PITCH + (((j * 32 + (cl & ~1)) * 2) ^ ((row & 1) << 6))) = packed;
             }
         }
     }
@@ -261,7 +263,7 @@ __device__ __forceinline__ void nt_epilogue_store16(const NtParams& p, f32x16 (&
 #pragma unroll
     for (int it = 0; it < 16; ++it) {
         const int rowl = it * 8 + rsub;
-        const uint4 v = *reinterpret_cast<const uint4*>(reg + rowl * EPI_LDS_PITCH + c8 * 16);
+        const uint4 v = *reinterpret_cast<const uint4*>(reg + rowl * EPI_LDS_PITCH + ((c8 * 16) ^ ((rowl & 1) << 6)));
         const int row = m0 + wr * 128 + rowl;
         if (row < p.M) {
             uint4* dst = reinterpret_cast<uint4*>(out + (long)row * p.ldc + n0 + wc * 64 + c8 * 8);

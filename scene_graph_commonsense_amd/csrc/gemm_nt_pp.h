@@ -363,9 +363,13 @@ static int launch_gemm_nt_pp(NtParams p, hipStream_t stream) {
 // LDS-staged bias + ReLU + 2x2 max-pool epilogue of the 8-wave block (conv3 forward: 4.2 GB of f16 + 2.1 GB of routing bytes
 // per launch, + 4.2 GB when the bf16 copy is requested).  In the MFMA C layout a lane owns ONE column, so the direct form
 // issues 2-byte and 1-byte stores (measured 2.0 ms of the 59 ms launch).  Here every wave pools in registers (the four
-// accumulator registers of a window), writes its 32 windows x 64 channels into a private LDS tile (pitch 144 B / 80 B) and
+// accumulator registers of a window), writes its 32 windows x 64 channels into a private LDS tile (pitch 128 B / 64 B) and
 // streams complete 128-byte / 64-byte rows out with 16-byte stores.
-constexpr int POOL_EPI_WAVE_BYTES = 32 * 144 * 2 + 32 * 80;      // f16 tile + bf16 tile + argmax tile
+// Row pitches 128 B (16-bit tiles) and 64 B (arg-max tile), no padding: the 16-byte read-back covers four rows per 16-lane group and
+// 32 / 16 dwords per row put them on disjoint bank quarters (see EPI_LDS_PITCH in gemm_nt.h; rounds 2-4: 144 / 80 B, two-way conflicts
+// on every read); the narrow writes of a row fall several lanes to a dword either way.
+constexpr int POOL_EPI_PY = 128, POOL_EPI_PA = 64;
+constexpr int POOL_EPI_WAVE_BYTES = 32 * POOL_EPI_PY * 2 + 32 * POOL_EPI_PA;      // f16 tile + bf16 tile + argmax tile
 // GATHER (conv3 over a window LIST, gemm_nt_pp_kernel<.., ACG = 1>): pooled row prow of the tile is list entry prow - y / its bf16 copy go
 // to row dest[prow] (window-major row space) or gather[prow], the routing bytes to gather[prow]; entries >= *gather_n are not written;
 // the raw accumulators of the entries >= raw_first (linear pairs: per-object pre-activations) leave directly from the registers.
@@ -375,8 +379,8 @@ __device__ __forceinline__ void nt_epilogue_pool16(const NtParams& p, f32x16 (&a
                                                    int wid, char* smem, int m_limit) {
     __syncthreads();                                   // every wave is done reading operand tiles
     char* ty = smem + wid * POOL_EPI_WAVE_BYTES;
-    char* tb = ty + 32 * 144;
-    char* ta = tb + 32 * 144;
+    char* tb = ty + 32 * POOL_EPI_PY;
+    char* ta = tb + 32 * POOL_EPI_PY;
     const int h = lane >> 5, cl = lane & 31;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -403,9 +407,9 @@ __device__ __forceinline__ void nt_epilogue_pool16(const NtParams& p, f32x16 (&a
                         for (int q = 0; q < 4; ++q) p.raw[((long)(prow - p.raw_first) * 4 + q) * p.ldc + n0 + wc * 64 + colw] = acc[i][j][4 * w + q];
                     }
                 }
-                *reinterpret_cast<u16*>(ty + row * 144 + colw * 2) = to_elem<ELEM>(v);
-                if (p.C2) *reinterpret_cast<u16*>(tb + row * 144 + colw * 2) = f32_to_bf16_bits(v);
-                if (p.argmax) *reinterpret_cast<unsigned char*>(ta + row * 80 + colw) = (unsigned char)am;
+                *reinterpret_cast<u16*>(ty + row * POOL_EPI_PY + colw * 2) = to_elem<ELEM>(v);
+                if (p.C2) *reinterpret_cast<u16*>(tb + row * POOL_EPI_PY + colw * 2) = f32_to_bf16_bits(v);
+                if (p.argmax) *reinterpret_cast<unsigned char*>(ta + row * POOL_EPI_PA + colw) = (unsigned char)am;
             }
         }
     __builtin_amdgcn_wave_barrier();
@@ -421,8 +425,8 @@ __device__ __forceinline__ void nt_epilogue_pool16(const NtParams& p, f32x16 (&a
             orow = p.dest ? p.dest[orow] : p.gather[orow];
         } else if (p.wm_goff) orow = p.wm_goff[orow & 63] + (orow >> 6);      // window-major row space (shared fc1); argmax stays pair-major
         const long o = orow * p.ldc + n0 + wc * 64 + c8 * 8;
-        *reinterpret_cast<uint4*>(out + o) = *reinterpret_cast<const uint4*>(ty + row * 144 + c8 * 16);
-        if (p.C2) *reinterpret_cast<uint4*>(p.C2 + o) = *reinterpret_cast<const uint4*>(tb + row * 144 + c8 * 16);
+        *reinterpret_cast<uint4*>(out + o) = *reinterpret_cast<const uint4*>(ty + row * POOL_EPI_PY + c8 * 16);
+        if (p.C2) *reinterpret_cast<uint4*>(p.C2 + o) = *reinterpret_cast<const uint4*>(tb + row * POOL_EPI_PY + c8 * 16);
     }
     if (p.argmax) {
         const int c4 = lane & 3, r16 = lane >> 2;
@@ -435,7 +439,7 @@ __device__ __forceinline__ void nt_epilogue_pool16(const NtParams& p, f32x16 (&a
                 arow = p.gather[arow];
             }
             *reinterpret_cast<uint4*>(p.argmax + arow * p.ldc + n0 + wc * 64 + c4 * 16) =
-                *reinterpret_cast<const uint4*>(ta + row * 80 + c4 * 16);
+                *reinterpret_cast<const uint4*>(ta + row * POOL_EPI_PA + c4 * 16);
         }
     }
 }
