@@ -250,6 +250,14 @@ int sgc_fc1_assemble(const float* S, const float* owm, const int* bbox, const in
 int sgc_fc1_assemble_ordered(const float* S, const float* owm, const int* bbox, const int* sub_idx, const int* obj_idx, const int* count_incl,
                              const int* dest, int n_obj, const float* bias, int drop_enable, unsigned drop_seed, void* h1, int n_pairs,
                              const float* own_rect_sums, const int* pair_order, void* stream);
+/* fc1 over the window-major rows with the pair-specific (X) rows as f16: sgc_fc1_windows_gemm_x16 writes the rows whose index inside their
+ * window group is >= n_pseudo (goff: the groups' first rows) to oxh [rows][4096] f16 and only the per-object rows in front of them to
+ * owm (f32: their 2-D prefix sums follow); sgc_fc1_assemble_x16 reads the pairs' X products from oxh.  Reference: model.py:148-149. */
+int sgc_fc1_windows_gemm_x16(const void* ywm, const void* w1p, const int* tile_group, const int* goff, int n_pseudo, float* owm, void* oxh,
+                             int rows, void* stream);
+int sgc_fc1_assemble_x16(const float* S, const void* oxh, const int* bbox, const int* sub_idx, const int* obj_idx, const int* count_incl,
+                         const int* dest, int n_obj, const float* bias, int drop_enable, unsigned drop_seed, void* h1, int n_pairs,
+                         const float* own_rect_sums, const int* pair_order, void* stream);
 
 /* Backward of the shared fc1 (window-major rows; all bf16, f32 sums):
  *   sgc_fc1_gsum           pseudo rows of gwm [rows][4096]: row goff[w] + role*n_obj + o = sum of dh1 over the pairs of object o in that

@@ -48,6 +48,9 @@ struct NtParams {
     float* raw; int raw_first;                      // AMODE_CONV_GATHER + EPI_POOL: the accumulators (no bias / ReLU / pooling) of the entries
                                                     // e >= raw_first also go to raw[(e - raw_first) * 4 + pixel][ldc] (linear pairs, kernels_shared.hip)
     const int* tile_group; long group_stride;       // gemm_nt_pp_kernel: M tile t multiplies with B + tile_group[t] * group_stride
+    u16* Cx; int x_first;                           // nt_epilogue_f32t (fc1 over the window-major rows): rows whose index inside their group (row -
+                                                    // wm_goff[tile_group[tile]]) is >= x_first - the pair-specific X rows - leave as f16 to Cx [M][N]
+                                                    // instead of f32 to C; the per-object rows in front of them (2-D prefix sums follow) stay f32
     int nt_store;                                   // nt_epilogue_f32t / nt_epilogue_store16: non-temporal stores (tools/fc1_windows_microbench.py)
     unsigned long long* clk;                        // gemm_nt_pp_kernel (tools/fc1_windows_microbench.py): per-block wall clocks summed: [0] main loop, [1] epilogue, [2] blocks
     long seg_stride; int seg_bpad, seg_split, patch_gn;                  // gemm_nt_pp_kernel<SEG>: elements between the segments (own pixels q) of a row of A; padding of B_pp's rows
@@ -157,10 +160,12 @@ __device__ __forceinline__ void nt_epilogue_f32t(const NtParams& p, f32x16 (&acc
     const int h = lane >> 5, cl = lane & 31;
     float* out = reinterpret_cast<float*>(p.C);
     if (!out) return;                                  // tools/fc1_windows_microbench.py: the launch without its stores
+    const int g_first = p.Cx ? p.wm_goff[p.tile_group[m0 >> 8]] + p.x_first : 0;      // first X row of this tile's group
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int row = m0 + wr * 128 + i * 32 + cl;
         if (row >= p.M) continue;
+        const bool xrow = p.Cx && row >= g_first;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
 #pragma unroll
@@ -170,6 +175,13 @@ __device__ __forceinline__ void nt_epilogue_f32t(const NtParams& p, f32x16 (&acc
                 if (p.bias) {
                     const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + col);
                     v += b;
+                }
+                if (xrow) {                                // a pair-specific row: one of ~7 products added per pair, f16 carries it
+                    uint2 hv;
+                    hv.x = (unsigned)f32_to_f16_bits(v[0]) | ((unsigned)f32_to_f16_bits(v[1]) << 16);
+                    hv.y = (unsigned)f32_to_f16_bits(v[2]) | ((unsigned)f32_to_f16_bits(v[3]) << 16);
+                    *reinterpret_cast<uint2*>(p.Cx + (long)row * p.N + col) = hv;
+                    continue;
                 }
                 f32x4* dst = reinterpret_cast<f32x4*>(out + (long)row * p.ldc + col);
 #ifdef SGC_EXPERIMENTS      // tools/fc1_windows_microbench.py: tile-contiguous output, cache-policy bits of the store (1 nt, 2 sc1, 3 sc0 sc1, 4 sc0 sc1 nt)

@@ -656,7 +656,8 @@ __global__ __launch_bounds__(256) void fc1_assemble_kernel(const float* __restri
                                                            const int* __restrict__ obj, const int* __restrict__ incl,
                                                            const int* __restrict__ dest, int n_obj, const float* __restrict__ bias,
                                                            int drop_enable, unsigned seed, float scale, u16* __restrict__ h1,
-                                                           const float* __restrict__ own, const int* __restrict__ order) {
+                                                           const float* __restrict__ own, const int* __restrict__ order,
+                                                           const u16* __restrict__ oxh) {
     // ``order`` (optional): workgroup b assembles pair order[b].  With the pairs sorted by SUBJECT (the contraction's CSR list) the ~63
     // consecutive workgroups of a subject read their five subject-side vectors from the same 1.3 MB prefix table S_i, which then stays
     // in the L2s; in the reference's pair order (graph_iter, direction, image) neighbours share nothing
@@ -687,12 +688,23 @@ __global__ __launch_bounds__(256) void fc1_assemble_kernel(const float* __restri
         if (x.x1 > x.x0) rect_acc(acc, Sj, x, -1.f, c0);
     }
     const int e0 = p ? incl[p - 1] : 0, e1 = incl[p];
-    for (int e = e0; e < e1; ++e) {
-        const float* o = owm + (long)dest[e] * pitch + c0;
+    if (oxh) {                                       // the pair's X products as f16 rows [rows][4096] (sgc_fc1_windows_gemm_x16)
+        for (int e = e0; e < e1; ++e) {
+            const uint4* o = reinterpret_cast<const uint4*>(oxh + (long)dest[e] * 4096 + c0);
+            const uint4 t0 = o[0], t1 = o[1];
+            const u16* h0 = reinterpret_cast<const u16*>(&t0);
+            const u16* h1v = reinterpret_cast<const u16*>(&t1);
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const float4 t = reinterpret_cast<const float4*>(o)[v];
-            acc[4 * v + 0] += t.x; acc[4 * v + 1] += t.y; acc[4 * v + 2] += t.z; acc[4 * v + 3] += t.w;
+            for (int k = 0; k < 8; ++k) { acc[k] += f16_bits_to_f32(h0[k]); acc[8 + k] += f16_bits_to_f32(h1v[k]); }
+        }
+    } else {
+        for (int e = e0; e < e1; ++e) {
+            const float* o = owm + (long)dest[e] * pitch + c0;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const float4 t = reinterpret_cast<const float4*>(o)[v];
+                acc[4 * v + 0] += t.x; acc[4 * v + 1] += t.y; acc[4 * v + 2] += t.z; acc[4 * v + 3] += t.w;
+            }
         }
     }
     uint4 out[2];
@@ -1443,6 +1455,19 @@ int sgc_fc1_windows_gemm(const void* ywm, const void* w1p, const int* tile_group
     if (sgc_tuning().f32_swap) return launch_gemm_nt_pp<ELEM_F16, EPI_STORE_F32T>(p, (hipStream_t)stream);
     return launch_gemm_nt_pp<ELEM_F16, EPI_STORE_F32>(p, (hipStream_t)stream);
 }
+// the same with the pair-specific rows (index inside their group >= n_pseudo) written as f16 to oxh [rows][4096] instead of f32 to owm: each
+// is one of the ~7 products a pair adds to 13 f32 prefix-sum vectors before its sum is rounded to f16 anyway (model.py:148: h1), and the
+// f32 store of those rows was a third of the launch; the per-object rows (2-D prefix sums, differences of large sums) stay f32
+int sgc_fc1_windows_gemm_x16(const void* ywm, const void* w1p, const int* tile_group, const int* goff, int n_pseudo, float* owm, void* oxh,
+                             int rows, void* stream) {
+    if (rows <= 0) return SGC_OK;
+    if (rows & 255) return SGC_ERR_ARG;
+    NtParams p{};
+    p.A = (const u16*)ywm; p.B = (const u16*)w1p; p.C = owm; p.M = rows; p.N = 4096; p.K = 1024;
+    p.lda = 1024; p.ldb = 65536; p.ldc = owm_pitch(); p.tile_group = tile_group; p.group_stride = 1024;
+    p.Cx = (u16*)oxh; p.x_first = n_pseudo; p.wm_goff = goff;
+    return launch_gemm_nt_pp<ELEM_F16, EPI_STORE_F32T>(p, (hipStream_t)stream);
+}
 int sgc_fc1_integral(const float* owm, const int* goff, int n_pseudo, float* S, void* stream) {
     if (n_pseudo <= 0) return SGC_OK;
     SGC_LAUNCH(fc1_integral_kernel, dim3((unsigned)(((long)n_pseudo * 4096 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, owm, owm_pitch(), goff,
@@ -1468,7 +1493,18 @@ int sgc_fc1_assemble_ordered(const float* S, const float* owm, const int* bbox, 
                              const float* own_rect_sums, const int* pair_order, void* stream) {
     if (n_pairs <= 0) return SGC_OK;
     SGC_LAUNCH(fc1_assemble_kernel, dim3(n_pairs), dim3(256), 0, (hipStream_t)stream, S, owm, owm_pitch(), bbox, sub_idx, obj_idx, count_incl, dest,
-               n_obj, bias, drop_enable, drop_seed, 2.f, (u16*)h1, own_rect_sums, pair_order);
+               n_obj, bias, drop_enable, drop_seed, 2.f, (u16*)h1, own_rect_sums, pair_order, (const u16*)nullptr);
+    SGC_CHECK_LAUNCH();
+    return SGC_OK;
+}
+// the same with the pairs' X products read from the f16 rows of sgc_fc1_windows_gemm_x16
+int sgc_fc1_assemble_x16(const float* S, const void* oxh, const int* bbox, const int* sub_idx, const int* obj_idx, const int* count_incl,
+                         const int* dest, int n_obj, const float* bias, int drop_enable, unsigned drop_seed, void* h1, int n_pairs,
+                         const float* own_rect_sums, const int* pair_order, void* stream) {
+    if (n_pairs <= 0) return SGC_OK;
+    if (!oxh) return SGC_ERR_ARG;
+    SGC_LAUNCH(fc1_assemble_kernel, dim3(n_pairs), dim3(256), 0, (hipStream_t)stream, S, (const float*)nullptr, owm_pitch(), bbox, sub_idx, obj_idx,
+               count_incl, dest, n_obj, bias, drop_enable, drop_seed, 2.f, (u16*)h1, own_rect_sums, pair_order, (const u16*)oxh);
     SGC_CHECK_LAUNCH();
     return SGC_OK;
 }

@@ -185,6 +185,7 @@ class Tuning:
     weight_kernels: bool = True       # 16-bit weight layouts by one gather + cast launch each (off: torch view / permute / flip / cat chains)
     fc1_own_sums: bool = True         # fc1 assembly reads S'_j[R_j] pre-summed per object (off: four corner vectors per pair; same bits)
     sparse_wgrad: bool = True         # conv3 weight gradient over the real pairs' listed windows on the sparse matrix cores (off: dense block)
+    fc1_x16: bool = True              # fc1's pair-specific products leave the grouped GEMM as f16 rows (the per-object rows stay f32); off: all f32
     assemble_by_subject: bool = True  # fc1 assembly walks the pairs sorted by subject (the subject's prefix table stays in the L2s; same bits)
     conv2_bwd_regions: bool = True    # conv2 data gradient only on the cells where an object's gradient can be non-zero (its pseudo-pair's pixel
                                       # rectangle + 1 cell; off: whole 32x32 maps; same bits)
@@ -777,8 +778,15 @@ class RelHeadEngine:
         lib, sc = self.lib, self.scratch
         w1p = self.w["w1p"]                          # deferred copy: made here (after the wait for fc1.weight's all-gather, if one is in flight)
         owm = sc.get("owm", wm["rows"] * int(lib.sgc_fc1_products_pitch()), torch.float32)
-        self._timed("fc1_fwd_windows", lambda: _lib.check(lib.sgc_fc1_windows_gemm(
-            _lib.ptr(ywm), _lib.ptr(w1p), _lib.ptr(wm["tile_group"]), _lib.ptr(owm), wm["rows"], self._st()), "sgc_fc1_windows_gemm"))
+        oxh = None
+        if TUNING.fc1_x16:
+            oxh = sc.get("oxh", wm["rows"] * 4096, torch.float16)
+            self._timed("fc1_fwd_windows", lambda: _lib.check(lib.sgc_fc1_windows_gemm_x16(
+                _lib.ptr(ywm), _lib.ptr(w1p), _lib.ptr(wm["tile_group"]), _lib.ptr(wm["goff"]), wm["n2"], _lib.ptr(owm), _lib.ptr(oxh), wm["rows"],
+                self._st()), "sgc_fc1_windows_gemm_x16"))
+        else:
+            self._timed("fc1_fwd_windows", lambda: _lib.check(lib.sgc_fc1_windows_gemm(
+                _lib.ptr(ywm), _lib.ptr(w1p), _lib.ptr(wm["tile_group"]), _lib.ptr(owm), wm["rows"], self._st()), "sgc_fc1_windows_gemm"))
         S = sc.get("fc1_S", wm["n2"] * 81 * 4096, torch.float32)
         self._timed("fc1_fwd_integral", lambda: _lib.check(lib.sgc_fc1_integral(_lib.ptr(owm), _lib.ptr(wm["goff"]), wm["n2"], _lib.ptr(S), self._st()),
                                                            "sgc_fc1_integral"))
@@ -788,10 +796,16 @@ class RelHeadEngine:
             _lib.check(lib.sgc_fc1_own_rect_sums(_lib.ptr(S), _lib.ptr(bbox), n_obj, _lib.ptr(own), self._st()), "sgc_fc1_own_rect_sums")
         if order is not None and (not TUNING.assemble_by_subject or int(order.shape[0]) != P):
             order = None
-        self._timed("fc1_fwd_assemble", lambda: _lib.check(lib.sgc_fc1_assemble_ordered(
-            _lib.ptr(S), _lib.ptr(owm), _lib.ptr(bbox), _lib.ptr(sub_idx), _lib.ptr(obj_idx), _lib.ptr(incl), _lib.ptr(wm["dest"]), n_obj,
-            _lib.ptr(self.w["bf1"]), int(dropout), ctypes.c_uint(seed), _lib.ptr(h1), P, _lib.ptr(own), _lib.ptr(order), self._st()),
-            "sgc_fc1_assemble_ordered"))
+        if oxh is not None:
+            self._timed("fc1_fwd_assemble", lambda: _lib.check(lib.sgc_fc1_assemble_x16(
+                _lib.ptr(S), _lib.ptr(oxh), _lib.ptr(bbox), _lib.ptr(sub_idx), _lib.ptr(obj_idx), _lib.ptr(incl), _lib.ptr(wm["dest"]), n_obj,
+                _lib.ptr(self.w["bf1"]), int(dropout), ctypes.c_uint(seed), _lib.ptr(h1), P, _lib.ptr(own), _lib.ptr(order), self._st()),
+                "sgc_fc1_assemble_x16"))
+        else:
+            self._timed("fc1_fwd_assemble", lambda: _lib.check(lib.sgc_fc1_assemble_ordered(
+                _lib.ptr(S), _lib.ptr(owm), _lib.ptr(bbox), _lib.ptr(sub_idx), _lib.ptr(obj_idx), _lib.ptr(incl), _lib.ptr(wm["dest"]), n_obj,
+                _lib.ptr(self.w["bf1"]), int(dropout), ctypes.c_uint(seed), _lib.ptr(h1), P, _lib.ptr(own), _lib.ptr(order), self._st()),
+                "sgc_fc1_assemble_ordered"))
 
     def conv3_shared(self, plan, z, U, V, bbox, obj_img, sub_idx, obj_idx, P, y, am, y_bf, keep=None, wm=None):
         """conv3 + ReLU + pool with the per-object part computed once per object (``csrc/kernels_shared.hip``): U / V hold
