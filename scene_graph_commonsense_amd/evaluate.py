@@ -18,7 +18,7 @@ import torch.distributed as dist
 
 from .evaluator import Evaluator, Evaluator_Top3
 from .object_frontend import DetrFrontEnd
-from .pair_loop import evaluate_minibatch, evaluate_sgdet_minibatch
+from .pair_loop import evaluate_minibatch, evaluate_sgdet_minibatch, freeze_setup_objects
 from .train_test import (_collate, _host, _record_test, _to_batch, build_classifier, build_feature_encoder, load_checkpoint, setup)
 from .train_utils import process_image_features
 
@@ -69,6 +69,7 @@ def eval_pc(gpu, args, test_subset, curr_dataset=None, prepare_cs_step=-1):
     recall = recall_top3 = mean_recall_top3 = mean_recall = recall_zs = mean_recall_zs = wmap_rel = wmap_phrase = None
     skip = bool(T.get("skip_filtered_pairs", False))
     print("Start Testing PC...")
+    freeze_setup_objects()
     with torch.no_grad():
         for batch_count, data in enumerate(loader):
             try:
@@ -134,6 +135,7 @@ def _sg_common(gpu, args, test_subset, sgcls: bool):
     recall = mean_recall = recall_zs = mean_recall_zs = None
     name = "SGC" if sgcls else "SGD"
     print("Start Testing %s..." % name)
+    freeze_setup_objects()
     with torch.no_grad():
         for batch_count, data in enumerate(loader):
             try:

@@ -33,6 +33,18 @@ _COST = {
 }
 
 
+def freeze_setup_objects() -> int:
+    """Call once after the model, datasets and evaluators are built, before the minibatch loop: collects garbage and moves everything
+    alive (``torch``'s and ``numpy``'s module objects, the annotations: 2-3 x 10^5 tracked containers) to the permanent generation.
+    Without it CPython's full (generation-2) collection walks all of them every few dozen minibatches - 77 ms measured on the MI355X
+    box, a step and a half of the benchmark's 43-46 ms, landing in the middle of an asynchronous launch sequence
+    (profiles/r05_host_gc.txt).  The per-minibatch garbage (pair tables, ragged lists) stays collectable.  Returns the number frozen."""
+    import gc
+    gc.collect()
+    gc.freeze()
+    return gc.get_freeze_count()
+
+
 def slice_batch(batch, a: int, b: int):
     """Images [a, b) of a ``SceneBatch`` (views; the per-image lists are shared)."""
     from .synthetic import SceneBatch

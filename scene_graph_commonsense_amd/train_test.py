@@ -30,7 +30,7 @@ from .distributed import GradReducer, ShardedSGD
 from .evaluator import Evaluator, Evaluator_Top3
 from .model import BayesianRelationClassifier, FlatRelationClassifier, strip_ddp_prefix
 from .optim import FusedSGD
-from .pair_loop import evaluate_minibatch, feed_evaluators, train_minibatch
+from .pair_loop import evaluate_minibatch, feed_evaluators, freeze_setup_objects, train_minibatch
 from .synthetic import SceneBatch
 from .train_utils import process_image_features
 
@@ -274,6 +274,7 @@ def training(gpu, args, train_subset, test_subset):
     stats = torch.zeros(5, dtype=torch.int64, device=rank)     # not connected, connected, predicted connected, precision, recall numerators
 
     lr_decay = 1
+    freeze_setup_objects()              # host GC: nothing built so far is garbage; keep the full collections out of the step loop
     for epoch in range(T["start_epoch"], T["num_epoch"]):
         print("Start Training... EPOCH %d / %d\n" % (epoch, T["num_epoch"]))
         if epoch == T["scheduler_param1"] or epoch == T["scheduler_param2"]:
