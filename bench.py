@@ -406,8 +406,9 @@ def run_rank(args):
         xw = getattr(eng, "_xw", None)
         n_x = int(xw[1][-1]) if xw is not None else 0
         exp_bytes = None
-        if xw is not None and "expand_dense" in kern and "xw_pixrect" in eng.ws.bufs and not args.forward_only:
-            Pn = scene0.n_pairs
+        Pn = scene0.n_pairs
+        one_group = eng.ws.bufs["xw_pixrect"].numel() >= Pn if "xw_pixrect" in eng.ws.bufs else False    # image groups / lanes: per-group tables
+        if xw is not None and "expand_dense" in kern and one_group and not args.forward_only and (args.streams or 1) == 1:
             exp_bytes = expansion_bytes(eng.ws.bufs["xw_pixrect"][:Pn].cpu().numpy(), scene0.sub_idx.cpu().numpy(), scene0.obj_idx.cpu().numpy(),
                                         int(scene0.obj_img.shape[0]), bf16_copy="z_pad_bf" in eng.ws.bufs and
                                         eng.ws.bufs["z_pad_bf"].numel() >= (Pn + 1) * 18 * 18 * 512)
