@@ -31,5 +31,5 @@ python3 "$R/tools/pmc_summary.py" "$(find /tmp/prof_m -name '*counter_collection
 # the bench line comes LAST and reads the counter passes just taken (roofline.traffic is derived from them): shipped defaults again
 unset SGC_BWD_STREAMS
 mkdir -p "$R/profiles" && cp "$OUT"/${TAG}_pmc_*.csv "$OUT"/${TAG}_kernel_stats.csv "$R/profiles/" 2>/dev/null
-cd "$R" && python3 bench.py --steps 5 --warmup 2 2>/dev/null | tail -1 > "$OUT/${TAG}_bench.json"
+cd "$R" && python3 bench.py --steps 20 --warmup 5 2>/dev/null | tail -1 > "$OUT/${TAG}_bench.json"
 ls -la "$OUT"/${TAG}_*
