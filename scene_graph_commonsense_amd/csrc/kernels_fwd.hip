@@ -226,66 +226,84 @@ __device__ __forceinline__ int wave_min_int(int v) {
     return v;
 }
 
-__global__ __launch_bounds__(256) void bayes_head_kernel(const HeadParams hp) {
+// Four pairs per wavefront pass: a lane keeps p[pair][lane + 64 i] of its four pairs in registers and the 512 products walk k in
+// ascending order - p[k] arrives by v_readlane (an SGPR operand of the FMA), W[k][lane] by ONE LDS read shared by the four pairs.
+// Round 5: the one-pair loop read p[k] and W[k][lane] from LDS for every FMA (1 024 LDS instructions per pair, one wavefront per SIMD
+// waiting on each): 0.29 ms; the sums are the same fmaf chain, bit for bit.
+constexpr int HEAD_PAIRS = 4;
+__global__ __launch_bounds__(512) void bayes_head_kernel(const HeadParams hp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* Wl = reinterpret_cast<float*>(smem);             // [512][64]
-    float* pl = Wl + 512 * 64;                              // [4 waves][512]
-    for (int i = threadIdx.x; i < 512 * 64; i += 256) Wl[i] = hp.Wt[i];
+    for (int i = threadIdx.x; i < 512 * 64; i += blockDim.x) Wl[i] = hp.Wt[i];
     __syncthreads();
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
     const int R = hp.ng + hp.np + hp.ns;
-    float* pw = pl + w * 512;
     const float bias = hp.bias[lane];
-    for (int pr = blockIdx.x * 4 + w; pr < hp.n_pairs; pr += gridDim.x * 4) {
-        const float* prow = hp.p + (long)pr * 512;
+    for (int pr0 = (blockIdx.x * nw + w) * HEAD_PAIRS; pr0 < hp.n_pairs; pr0 += gridDim.x * nw * HEAD_PAIRS) {
+        int preg[HEAD_PAIRS][8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) pw[lane + 64 * k] = prow[lane + 64 * k];
-        __builtin_amdgcn_wave_barrier();
-        float acc = 0.f;
+        for (int j = 0; j < HEAD_PAIRS; ++j) {
+            const float* prow = hp.p + (long)min(pr0 + j, hp.n_pairs - 1) * 512;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) preg[j][i] = __float_as_int(prow[lane + 64 * i]);
+        }
+        float accs[HEAD_PAIRS];
+#pragma unroll
+        for (int j = 0; j < HEAD_PAIRS; ++j) accs[j] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
 #pragma unroll 8
-        for (int k = 0; k < 512; ++k) acc = fmaf(pw[k], Wl[k * 64 + lane], acc);
-        acc += bias;
-        __builtin_amdgcn_wave_barrier();
-        const bool is_conn = lane == (hp.hier ? R + 3 : R);
-        if (is_conn) hp.conn[pr] = acc;
-        const bool masked = hp.iou_mask && !hp.iou_mask[pr];
-        if (hp.hier) {
-            const bool in_sup = lane >= R && lane < R + 3;
-            const float smax = wave_max_pred(acc, in_sup);
-            const float ssum = wave_sum_pred(expf(acc - smax), in_sup);
-            const float slog = acc - smax - logf(ssum);             // valid on the three super lanes
-            if (in_sup) hp.sup[(long)pr * 3 + (lane - R)] = slog;
-            const int seg = lane < hp.ng ? 0 : (lane < hp.ng + hp.np ? 1 : 2);
-            const int lo = seg == 0 ? 0 : (seg == 1 ? hp.ng : hp.ng + hp.np);
-            const float invT = seg == 0 ? hp.invT1 : (seg == 1 ? hp.invT2 : hp.invT3);
-            const float x = acc * invT;
-            float out = 0.f;
+            for (int l = 0; l < 64; ++l) {
+                const float wv = Wl[(i * 64 + l) * 64 + lane];
 #pragma unroll
-            for (int s = 0; s < 3; ++s) {
-                const bool in = lane < R && seg == s;
-                const float m = wave_max_pred(x, in);
-                const float sm = wave_sum_pred(expf(x - m), in);
-                const float sl = __shfl(slog, R + s);
-                const float lp = x - m - logf(sm) + sl;
-                if (in) out = lp;
-                // candidate: max log-prob of the segment and its first argmax (evaluator.py:160-174)
-                const float cm = wave_max_pred(lp, in);
-                const int am = wave_min_int((in && lp == cm) ? lane : 1 << 20);
-                if (lane == 0) {
-                    hp.cand_conf[(long)pr * 3 + s] = masked ? -INFINITY : cm;
-                    hp.cand_pred[(long)pr * 3 + s] = am;
-                }
-                (void)lo;
+                for (int j = 0; j < HEAD_PAIRS; ++j) accs[j] = fmaf(__int_as_float(__builtin_amdgcn_readlane(preg[j][i], l)), wv, accs[j]);
             }
-            if (lane < R) hp.rel[(long)pr * R + lane] = out;
-        } else {
-            const bool in = lane < R;
-            if (in) hp.rel[(long)pr * R + lane] = acc;
-            const float cm = wave_max_pred(acc, in);
-            const int am = wave_min_int((in && acc == cm) ? lane : 1 << 20);
-            if (lane == 0) {
-                hp.cand_conf[pr] = masked ? -INFINITY : cm;
-                hp.cand_pred[pr] = am;
+        }
+#pragma unroll
+        for (int j = 0; j < HEAD_PAIRS; ++j) {
+            const int pr = pr0 + j;
+            if (pr >= hp.n_pairs) break;                    // wave-uniform
+            const float acc = accs[j] + bias;
+            const bool is_conn = lane == (hp.hier ? R + 3 : R);
+            if (is_conn) hp.conn[pr] = acc;
+            const bool masked = hp.iou_mask && !hp.iou_mask[pr];
+            if (hp.hier) {
+                const bool in_sup = lane >= R && lane < R + 3;
+                const float smax = wave_max_pred(acc, in_sup);
+                const float ssum = wave_sum_pred(expf(acc - smax), in_sup);
+                const float slog = acc - smax - logf(ssum);             // valid on the three super lanes
+                if (in_sup) hp.sup[(long)pr * 3 + (lane - R)] = slog;
+                const int seg = lane < hp.ng ? 0 : (lane < hp.ng + hp.np ? 1 : 2);
+                const float invT = seg == 0 ? hp.invT1 : (seg == 1 ? hp.invT2 : hp.invT3);
+                const float x = acc * invT;
+                float out = 0.f;
+#pragma unroll
+                for (int sg = 0; sg < 3; ++sg) {
+                    const bool in = lane < R && seg == sg;
+                    const float m = wave_max_pred(x, in);
+                    const float sm = wave_sum_pred(expf(x - m), in);
+                    const float sl = __shfl(slog, R + sg);
+                    const float lp = x - m - logf(sm) + sl;
+                    if (in) out = lp;
+                    // candidate: max log-prob of the segment and its first argmax (evaluator.py:160-174)
+                    const float cm = wave_max_pred(lp, in);
+                    const int am = wave_min_int((in && lp == cm) ? lane : 1 << 20);
+                    if (lane == 0) {
+                        hp.cand_conf[(long)pr * 3 + sg] = masked ? -INFINITY : cm;
+                        hp.cand_pred[(long)pr * 3 + sg] = am;
+                    }
+                }
+                if (lane < R) hp.rel[(long)pr * R + lane] = out;
+            } else {
+                const bool in = lane < R;
+                if (in) hp.rel[(long)pr * R + lane] = acc;
+                const float cm = wave_max_pred(acc, in);
+                const int am = wave_min_int((in && acc == cm) ? lane : 1 << 20);
+                if (lane == 0) {
+                    hp.cand_conf[pr] = masked ? -INFINITY : cm;
+                    hp.cand_pred[pr] = am;
+                }
             }
         }
     }
@@ -400,11 +418,13 @@ int sgc_bayes_head(const float* p, const float* Wt, const float* bias, int n_pai
     if (n_pairs <= 0) return SGC_OK;
     HeadParams hp{p, Wt, bias, n_pairs, ng, np, ns, hier, 1.f / T1, 1.f / T2, 1.f / T3, rel, sup, conn, cand_conf,
                   cand_pred, iou_mask};
-    const int lds = (512 * 64 + 4 * 512) * 4;
+    const int lds = 512 * 64 * 4;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bayes_head_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    int blocks = (n_pairs + 3) / 4;
+    // eight wavefronts per workgroup (one weight image in LDS per CU) when there are pairs for them, four pairs per wavefront pass
+    const int waves = n_pairs >= 256 * 8 * HEAD_PAIRS ? 8 : 4;
+    int blocks = (n_pairs + waves * HEAD_PAIRS - 1) / (waves * HEAD_PAIRS);
     if (blocks > 256) blocks = 256;
-    SGC_LAUNCH(bayes_head_kernel, dim3(blocks), dim3(256), lds, (hipStream_t)stream, hp);
+    SGC_LAUNCH(bayes_head_kernel, dim3(blocks), dim3(64 * waves), lds, (hipStream_t)stream, hp);
     SGC_CHECK_LAUNCH();
     return SGC_OK;
 }
