@@ -23,7 +23,7 @@ opt = FusedSGD(model.parameters(), lr=1e-5, momentum=0.9, weight_decay=1e-4)
 reducer = sgd_dist.GradReducer(1)
 sc = flatten_scene(cfg, batch, dev)
 opt.param_groups[0]["lr"] = lr_scale * 1e-5 * min(1.0, (380.0 / max(sc.n_steps, 1)) ** 2)
-ts, losses = [], []
+ts, losses, host = [], [], []
 import gc
 gcl = []
 def _cb(phase, info, _t=[0.0]):
@@ -36,8 +36,10 @@ if len(sys.argv) > 3 and sys.argv[3] == "freeze":
 for i in range(n):
     torch.cuda.synchronize(); t0 = time.time()
     l = train_minibatch(model, batch, opt, reducer=reducer)
+    host.append((time.time() - t0) * 1e3)                   # the call returns when everything is enqueued
     torch.cuda.synchronize(); ts.append((time.time() - t0) * 1e3); losses.append(float(l))
 print("lr_scale", lr_scale, "ms:", " ".join("%.1f" % t for t in ts))
+print("   host ms until train_minibatch returns (enqueue only): median %.1f, max after the first %.1f" % (float(np.median(host[1:])), max(host[1:])))
 print("   loss:", " ".join("%.4g" % l for l in losses[::5]))
 print("   gc events (step, gen, ms, collected) with ms > 2:", [(a, b, round(c, 1), d) for a, b, c, d in gcl if c > 2], "count", len(gcl), "tracked objects", len(gc.get_objects()))
 eng = model.engine()
