@@ -18,7 +18,8 @@ import torch.distributed as dist
 
 from .evaluator import Evaluator, Evaluator_Top3
 from .object_frontend import DetrFrontEnd
-from .pair_loop import evaluate_minibatch, evaluate_sgdet_minibatch, freeze_setup_objects
+from .pair_loop import MinibatchLookahead, evaluate_minibatch, evaluate_sgdet_minibatch, freeze_setup_objects
+from .pairs import flatten_scene
 from .train_test import (_collate, _host, _record_test, _to_batch, build_classifier, build_feature_encoder, load_checkpoint, setup)
 from .train_utils import process_image_features
 
@@ -70,16 +71,23 @@ def eval_pc(gpu, args, test_subset, curr_dataset=None, prepare_cs_step=-1):
     skip = bool(T.get("skip_filtered_pairs", False))
     print("Start Testing PC...")
     freeze_setup_objects()
+    cfg, dev = model.head_config(), next(model.parameters()).device
+
+    def prepare(batch_count, data):
+        """minibatch k+1 is loaded, encoded and flattened while the device scores minibatch k (pair_loop.MinibatchLookahead)"""
+        try:
+            batch, _, annot_path = _to_batch(args, data, detr, rank, with_aug=False)
+        except (ValueError, IndexError):
+            return None
+        return batch, annot_path, flatten_scene(cfg, batch, dev)
     with torch.no_grad():
-        for batch_count, data in enumerate(loader):
-            try:
-                batch, _, annot_path = _to_batch(args, data, detr, rank, with_aug=False)
-            except (ValueError, IndexError):
-                continue
+        ahead = MinibatchLookahead(loader, prepare)
+        for batch_count, (batch, annot_path, scene) in ahead:
             Recall.load_annotation_paths(annot_path)
             last = batch_count + 1 == len(loader)
             feed = batch_count % T["eval_freq_test"] == 0 or last
-            evaluate_minibatch(model, batch, Recall if feed else None, Recall_top3 if (feed and hier) else None, skip_filtered=skip)
+            evaluate_minibatch(model, batch, Recall if feed else None, Recall_top3 if (feed and hier) else None, skip_filtered=skip,
+                               scene=scene, while_running=ahead.fetch_next)
             if model.last_connectivity_stats is not None:
                 stats += model.last_connectivity_stats
             if feed:

@@ -235,8 +235,46 @@ def feed_evaluators(model, scene: DeviceScene, out, evaluator=None, evaluator_to
     return included
 
 
+class MinibatchLookahead:
+    """Iterate the minibatches of a loader ONE AHEAD: ``prepare(data)`` (the drivers' ``_to_batch`` + ``flatten_scene``: loader,
+    feature extractor launches, ragged lists -> pinned staging -> device) of minibatch k+1 runs when the consumer calls
+    ``fetch_next()`` - which ``evaluate_minibatch(while_running=...)`` does right after it has enqueued the forward of minibatch k,
+    i.e. while the device is busy, instead of after the feed's host synchronisation with the device idle (4-5 ms of a 20 ms evaluated
+    minibatch at 8 x 64).  ``prepare(index, data)`` returns None for a minibatch to skip and ``MinibatchLookahead.STOP`` to end the
+    iteration.  Yields (index, prepared)."""
+    STOP = object()
+
+    def __init__(self, loader, prepare):
+        self._it, self._prepare, self._next, self._fetched = enumerate(loader), prepare, None, False
+        self.fetch_next()
+
+    def fetch_next(self):
+        if self._fetched:
+            return
+        self._fetched, self._next = True, None
+        for i, data in self._it:
+            item = self._prepare(i, data)
+            if item is MinibatchLookahead.STOP:
+                self._it = iter(())
+                return
+            if item is not None:
+                self._next = (i, item)
+                return
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        self.fetch_next()                        # the consumer did not look ahead (an exception path, a caller without the hook)
+        if self._next is None:
+            raise StopIteration
+        cur, self._fetched = self._next, False
+        return cur
+
+
 def evaluate_minibatch(model, batch, evaluator=None, evaluator_top3=None, overlap_filtering: bool = True,
-                       scene: Optional[DeviceScene] = None, skip_filtered: bool = False, workspace_budget: Optional[float] = None):
+                       scene: Optional[DeviceScene] = None, skip_filtered: bool = False, workspace_budget: Optional[float] = None,
+                       while_running=None):
     """Returns (scene, outputs, included[P] bool numpy, directed targets numpy).
     ``skip_filtered=True`` runs the per-pair trunk only for the pairs that pass the overlap filter (about 40 % of the ordered pairs
     on the synthetic boxes) in every image that has at least top-K such pairs: Recall@K is unchanged (a filtered pair's
@@ -245,7 +283,9 @@ def evaluate_minibatch(model, batch, evaluator=None, evaluator_top3=None, overla
     ``model.last_connectivity_stats`` holds the counters of ``evaluate_one_direction`` (``train_utils.py:176-184``) summed over the
     kept steps ([5] int64 device tensor; None with ``skip_filtered``).
     ``workspace_budget`` (bytes; default ``model.workspace_budget_bytes`` or 70 % of the free HBM): a minibatch whose fused pass
-    would need more is scored in consecutive image groups (``plan_image_groups``) - same outputs, same evaluator feed."""
+    would need more is scored in consecutive image groups (``plan_image_groups``) - same outputs, same evaluator feed.
+    ``while_running``: called once, with no arguments, after the forward has been enqueued and before the evaluator feed's first
+    host synchronisation - the place for host work that does not depend on this minibatch (``MinibatchLookahead.fetch_next``)."""
     cfg = model.head_config()
     dev = next(model.parameters()).device
     if scene is None:
@@ -260,6 +300,8 @@ def evaluate_minibatch(model, batch, evaluator=None, evaluator_top3=None, overla
     else:
         out = model.forward_pairs(scene, iou_mask=iou, select=select)
     model.last_image_groups = groups
+    if while_running is not None:
+        while_running()
     directed_d = scene.directed
     if directed_d is None:
         directed_d = torch.from_numpy(pair_targets_fast(batch.relationships, batch.subj_or_obj, scene.pidx).astype(np.int32)).to(dev)

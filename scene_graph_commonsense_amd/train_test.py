@@ -30,7 +30,8 @@ from .distributed import GradReducer, ShardedSGD
 from .evaluator import Evaluator, Evaluator_Top3
 from .model import BayesianRelationClassifier, FlatRelationClassifier, strip_ddp_prefix
 from .optim import FusedSGD
-from .pair_loop import evaluate_minibatch, feed_evaluators, freeze_setup_objects, train_minibatch
+from .pairs import flatten_scene
+from .pair_loop import MinibatchLookahead, evaluate_minibatch, feed_evaluators, freeze_setup_objects, train_minibatch
 from .synthetic import SceneBatch
 from .train_utils import process_image_features
 
@@ -376,18 +377,25 @@ def testing(args, detr, relation_classifier, test_loader, test_record, epoch, ra
     record_test = _host("record_test_results", _record_test)
     skip = bool(T.get("skip_filtered_pairs", False))          # 2x faster, identical Recall@K; connectivity counters are then not collected
     print("Start Testing PC...")
+    cfg, dev = relation_classifier.head_config(), next(relation_classifier.parameters()).device
+
+    def prepare(batch_count, data):
+        """minibatch k+1 is loaded, encoded and flattened while the device scores minibatch k (pair_loop.MinibatchLookahead)"""
+        if epoch < 2 and batch_count > 100:
+            return MinibatchLookahead.STOP
+        try:
+            batch, _, _ = _to_batch(args, data, detr, rank, with_aug=False)
+        except EmptyMinibatch:
+            return None
+        return batch, flatten_scene(cfg, batch, dev)
     with torch.no_grad():
-        for batch_count, data in enumerate(test_loader):
-            if epoch < 2 and batch_count > 100:
-                break
-            try:
-                batch, _, _ = _to_batch(args, data, detr, rank, with_aug=False)
-            except EmptyMinibatch:
-                continue
+        ahead = MinibatchLookahead(test_loader, prepare)
+        for batch_count, (batch, scene) in ahead:
             last = batch_count + 1 == len(test_loader)
             feed = batch_count % T["eval_freq_test"] == 0 or last
             evaluate_minibatch(relation_classifier, batch, Recall if feed else None,
-                               Recall_top3 if (feed and args["models"]["hierarchical_pred"]) else None, skip_filtered=skip)
+                               Recall_top3 if (feed and args["models"]["hierarchical_pred"]) else None, skip_filtered=skip,
+                               scene=scene, while_running=ahead.fetch_next)
             if relation_classifier.last_connectivity_stats is not None:
                 stats += relation_classifier.last_connectivity_stats
             if feed:

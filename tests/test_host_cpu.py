@@ -634,3 +634,25 @@ def test_deferred_weight_entries_are_made_at_first_use():
     assert w["b"] == 2 and w["b"] == 2 and calls == ["made"]
     w.defer("b", lambda: calls.append("again") or 3)          # the next weight version replaces the entry
     assert w["b"] == 3 and calls == ["made", "again"]
+
+
+def test_minibatch_lookahead_order_skip_stop():
+    """pair_loop.MinibatchLookahead (the evaluation drivers prepare minibatch k+1 while the device scores minibatch k): every prepared
+    item is used exactly once and in order, skipped items never surface, STOP ends the iteration without touching the rest of the
+    loader, and a consumer that never looks ahead still sees everything."""
+    from scene_graph_commonsense_amd.pair_loop import MinibatchLookahead as L
+    log = []
+
+    def prep(i, d):
+        log.append(("prep", i))
+        return None if d == "skip" else (L.STOP if d == "stop" else d.upper())
+    a = L(["a", "skip", "b", "c", "stop", "d"], prep)
+    assert log == [("prep", 0)]                                  # one ahead from the start
+    for i, x in a:
+        log.append(("use", i, x))
+        if x != "B":                                             # the consumer of B forgets to look ahead
+            a.fetch_next()
+            a.fetch_next()                                       # idempotent until the item is taken
+    assert log == [("prep", 0), ("use", 0, "A"), ("prep", 1), ("prep", 2), ("use", 2, "B"), ("prep", 3), ("use", 3, "C"), ("prep", 4)]
+    assert list(L([], prep)) == [] and list(L(["skip"], prep)) == []
+    assert [x for _, x in L(["x", "y"], prep)] == ["X", "Y"]
