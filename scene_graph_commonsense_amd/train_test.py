@@ -275,6 +275,7 @@ def training(gpu, args, train_subset, test_subset):
     stats = torch.zeros(5, dtype=torch.int64, device=rank)     # not connected, connected, predicted connected, precision, recall numerators
 
     lr_decay = 1
+    pending_scalar = None
     freeze_setup_objects()              # host GC: nothing built so far is garbage; keep the full collections out of the step loop
     for epoch in range(T["start_epoch"], T["num_epoch"]):
         print("Start Training... EPOCH %d / %d\n" % (epoch, T["num_epoch"]))
@@ -330,7 +331,12 @@ def training(gpu, args, train_subset, test_subset):
                     wmap_rel, wmap_phrase = Recall.compute_precision()
                 Recall.clear_data()
             if rank == 0 and writer is not None:
-                writer.add_scalar("train/running_losses", float(running_losses), batch_count + len(train_loader) * epoch)
+                # the reference logs float(loss) every step (train_test.py:266): reading THIS step's value would stop the host until the
+                # step has run (the device then idles ~3 ms per step while the next one is prepared); the value is written one
+                # iteration later instead, under its own step index
+                if pending_scalar is not None:
+                    writer.add_scalar("train/running_losses", float(pending_scalar[0]), pending_scalar[1])
+                pending_scalar = (running_losses.clone(), batch_count + len(train_loader) * epoch)
             if (batch_count % T["print_freq"] == 0 or last) and recall is not None:
                 s = stats.tolist()
                 record_train(args, record, rank, epoch, batch_count, optimizer.param_groups[0]["lr"], recall_top3, recall, mean_recall_top3,
@@ -345,6 +351,9 @@ def training(gpu, args, train_subset, test_subset):
             # connectivity and commonsense as 0.)
             running_losses.zero_(); running_contrast.zero_()
             stats[0] = 0; stats[1] = 0; stats[3] = 0
+        if pending_scalar is not None:
+            writer.add_scalar("train/running_losses", float(pending_scalar[0]), pending_scalar[1])
+            pending_scalar = None
         if hasattr(optimizer, "wait_gathers"):
             optimizer.wait_gathers()                         # deferred all-gather of fc1.weight: land it before the parameters are read
         relation_classifier.engine().verify_checks(block=True)   # deferred device-side plan checks of the epoch's last steps: before the checkpoint
