@@ -488,12 +488,18 @@ __global__ __launch_bounds__(256) void windows_col2im_objects_kernel(const u16* 
 // (Y, X) only if the pixel lies within one pixel of its X windows (elsewhere dz does not exist); every object also has its
 // pseudo-pair (o, bg) / (bg, o) at pair index n_real + o / n_real + n_obj + o, and the background object of image b (index
 // n_obj + b) collects the other side of the pseudo-pairs of that image's objects.
+// PIPE (round 5): the candidates that pass the pixel-rectangle test are compacted into a per-wavefront list first, and the rows of the
+// NEXT group of four are requested before the current group is routed into the accumulators (the plain form asks for four rows, waits,
+// routes them, and only then learns the next four pair indices from the ballot); same candidates in the same order: same sums.
+template <bool PIPE>
 __global__ __launch_bounds__(256) void pair_contract_windows_kernel(const u16* __restrict__ dz, const unsigned char* __restrict__ amz,
                                                                     const int* __restrict__ ptr, const int* __restrict__ list,
                                                                     const int* __restrict__ pixrect, const int* __restrict__ img_ptr,
                                                                     int role, int n_real, int n_obj, int bg_maps, u16* __restrict__ dU,
                                                                     long n_items) {
+    __shared__ int cand_s[4][64];
     const int lane = threadIdx.x & 63;
+    int* const cand = cand_s[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];
     for (long it = (long)blockIdx.x * 4 + (threadIdx.x >> 6); it < n_items; it += (long)gridDim.x * 4) {
         const int o = (int)(it >> 8), W = (int)(it & 255);
         const int Y = W >> 4, X = W & 15;
@@ -525,6 +531,29 @@ __global__ __launch_bounds__(256) void pair_contract_windows_kernel(const u16* _
                     }
                 }
         };
+        auto request = [&](int u0, int cnt, uint4 (&g)[4], unsigned (&a)[4]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (u0 + u < cnt) {
+                    const long v = (long)__builtin_amdgcn_readfirstlane(cand[u0 + u]);
+                    g[u] = *reinterpret_cast<const uint4*>(dz + (v * 256 + m3) * 512 + lane * 8);
+                    a[u] = *reinterpret_cast<const unsigned*>(amz + (v * 256 + W) * 256 + lane * 4);
+                }
+        };
+        auto route = [&](int u0, int cnt, const uint4 (&g)[4], const unsigned (&a)[4]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (u0 + u < cnt) {
+                    const u16* gh = reinterpret_cast<const u16*>(&g[u]);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const float v = bf16_bits_to_f32(gh[k]);
+                        const unsigned code = (a[u] >> (4 * k)) & 15u;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) acc[q][k] += (code == (unsigned)q) ? v : 0.f;
+                    }
+                }
+        };
         // candidates of this (object, pixel), 64 at a time: lane k looks at the k-th one, a ballot keeps those whose rows exist
         auto scan = [&](int i0, int i1, bool real) __attribute__((always_inline)) {
             for (int base = i0; base < i1; base += 64) {
@@ -536,6 +565,27 @@ __global__ __launch_bounds__(256) void pair_contract_windows_kernel(const u16* _
                     ok = in_pixel_rect(pixrect[pk], Y, X);                  // pixrect covers real pairs, pseudo-pairs and background maps
                 }
                 unsigned long long m = __ballot(ok);
+                if constexpr (PIPE) {
+                    const int cnt = __popcll(m);
+                    if (cnt == 0) continue;
+                    __builtin_amdgcn_wave_barrier();                        // the previous chunk's list has been read
+                    if (ok) cand[__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = pk;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    uint4 g0[4], g1[4];
+                    unsigned a0[4], a1[4];
+                    request(0, cnt, g0, a0);
+                    for (int u0 = 0; u0 < cnt; u0 += 8) {
+                        if (u0 + 4 < cnt) request(u0 + 4, cnt, g1, a1);
+                        route(u0, cnt, g0, a0);
+                        if (u0 + 4 < cnt) {
+                            if (u0 + 8 < cnt) request(u0 + 8, cnt, g0, a0);
+                            route(u0 + 4, cnt, g1, a1);
+                        }
+                    }
+                    continue;
+                }
                 while (m) {
                     long vp[4];
                     int nv = 0;
@@ -1407,7 +1457,16 @@ int sgc_pair_contract_windows(const void* dz, const unsigned char* amz, const in
                               void* stream) {
     if (n_obj <= 0) return SGC_OK;
     const long items = (long)(n_obj + n_img) * 256;
-    SGC_LAUNCH(pair_contract_windows_kernel, dim3(grid_cap(items, 4, 262144)), dim3(256), 0, (hipStream_t)stream, (const u16*)dz, amz,
+#ifdef SGC_EXPERIMENTS
+    static const int pipe = [] { const char* e = getenv("SGC_CONTRACT_PIPE"); return e ? atoi(e) : 1; }();      // A/B: profiles/r05_contract_pipe_ab.txt
+#else
+    constexpr int pipe = 1;
+#endif
+    if (pipe)
+        SGC_LAUNCH(pair_contract_windows_kernel<true>, dim3(grid_cap(items, 4, 262144)), dim3(256), 0, (hipStream_t)stream, (const u16*)dz, amz,
+               ptr, list, pixel_rect, img_ptr, role, n_real_pairs, n_obj, bg_maps, (u16*)dU_pad, items);
+    else
+        SGC_LAUNCH(pair_contract_windows_kernel<false>, dim3(grid_cap(items, 4, 262144)), dim3(256), 0, (hipStream_t)stream, (const u16*)dz, amz,
                ptr, list, pixel_rect, img_ptr, role, n_real_pairs, n_obj, bg_maps, (u16*)dU_pad, items);
     SGC_CHECK_LAUNCH();
     return SGC_OK;
