@@ -477,7 +477,7 @@ __global__ __launch_bounds__(256) void pair_expand_train_kernel(const u16* __res
         const u16* up = U + ((long)sub[p] * 1024 + 4 * W) * 512 + lane * 8;
         const u16* vp = V + ((long)obj[p] * 1024 + 4 * W) * 512 + lane * 8;
         float best[8];
-        unsigned char arg[8];
+        unsigned arg[8];                                // 32-bit: as bytes the compiler spends ~145 sub-dword instructions per item on them
 #pragma unroll
         for (int k = 0; k < 8; ++k) { best[k] = 0.f; arg[k] = 4; }
 #pragma unroll
@@ -489,7 +489,7 @@ __global__ __launch_bounds__(256) void pair_expand_train_kernel(const u16* __res
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const float s = f16_bits_to_f32(ah[k]) + f16_bits_to_f32(bh[k]);
-                if (s > best[k]) { best[k] = s; arg[k] = (unsigned char)q; }
+                if (s > best[k]) { best[k] = s; arg[k] = (unsigned)q; }
             }
         }
         const int Y = W >> 4, X = W & 15;
@@ -511,7 +511,7 @@ __global__ __launch_bounds__(256) void pair_expand_train_kernel(const u16* __res
         if (amz) {                                             // two 4-bit routing codes per byte: channel 2k low, 2k+1 high
             unsigned ao = 0;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) ao |= (unsigned)arg[k] << (4 * k);
+            for (int k = 0; k < 8; ++k) ao |= arg[k] << (4 * k);
             *reinterpret_cast<unsigned*>(amz + it * 256 + lane * 4) = ao;
         }
     }

@@ -160,7 +160,7 @@ __global__ __launch_bounds__(512) void pair_expand_dense_kernel(const u16* __res
             todo &= todo - 1;
             const int p = __builtin_amdgcn_readlane(pl, jj);
             float best[8];
-            unsigned char arg[8];
+            unsigned arg[8];                                // 32-bit: as bytes the compiler spends ~145 sub-dword instructions per item on them
 #pragma unroll
             for (int k = 0; k < 8; ++k) { best[k] = 0.f; arg[k] = 4; }
 #pragma unroll
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(512) void pair_expand_dense_kernel(const u16* __res
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     const float sm = uf[q][k] + f16_bits_to_f32(bh[k]);
-                    if (sm > best[k]) { best[k] = sm; arg[k] = (unsigned char)q; }
+                    if (sm > best[k]) { best[k] = sm; arg[k] = (unsigned)q; }
                 }
             }
             if (z) {
@@ -190,8 +190,149 @@ __global__ __launch_bounds__(512) void pair_expand_dense_kernel(const u16* __res
             if (amz) {                                  // two 4-bit routing codes per byte: channel 2k low, 2k+1 high
                 unsigned ao = 0;
 #pragma unroll
-                for (int k = 0; k < 8; ++k) ao |= (unsigned)arg[k] << (4 * k);
+                for (int k = 0; k < 8; ++k) ao |= arg[k] << (4 * k);
                 *reinterpret_cast<unsigned*>(amz + (long)p * (256 * 256) + aoff) = ao;
+            }
+        }
+    }
+}
+
+// The same launch with the live (subject, object) combinations of a workgroup LISTED first (round 5).  On the shared-window path only
+// ~15 % of the (pair, pixel) items are live (the pixel rectangles), and the loop above spent most of its time finding them: every
+// wavefront walked all subjects of the image, loaded each one's four U rows whether or not a partner was live, and reached each
+// partner's rectangle through two dependent global loads (pair index, then its rectangle) inside the loop; the matrix of live items
+// is also very uneven across the eight wavefronts.  Here, per chunk of 64 subjects: (1) all 512 threads test their two (subject,
+// object) combinations and the survivors are compacted - in (subject, object) order - into LDS with the per-subject run ends; (2) the
+// list is cut into eight equal pieces, one per wavefront; a wavefront loads U rows only for subjects that have a live item and asks
+// for the next subject's rows when it starts on the current one.  Same arithmetic per item: same bits.
+__global__ __launch_bounds__(512) void pair_expand_dense_list_kernel(const u16* __restrict__ U, const u16* __restrict__ V,
+                                                                     const int* __restrict__ img_ptr, const int* __restrict__ pid,
+                                                                     int pid_ld, u16* __restrict__ z, u16* __restrict__ zb,
+                                                                     unsigned char* __restrict__ amz, const int* __restrict__ pixrect) {
+    __shared__ __attribute__((aligned(16))) char sv[EXPAND_JT * 4096];
+    __shared__ unsigned short live[1024];                 // (subject within the chunk) << 4 | object within the tile
+    __shared__ int lpair[1024];
+    __shared__ int subj_cnt[64], subj_end[64];
+    const int W = blockIdx.x, jt = blockIdx.y, img = blockIdx.z;
+    const int o0 = img_ptr[img], n = img_ptr[img + 1] - o0;
+    const int j0 = jt * EXPAND_JT;
+    if (j0 >= n) return;
+    const int nj = min(EXPAND_JT, n - j0);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Y = W >> 4, X = W & 15;
+    const long zoff = ((long)(Y + 1) * 18 + X + 1) * 512 + lane * 8;
+    const long aoff = (long)W * 256 + lane * 4;
+    bool staged = false;
+    for (int ibase = 0; ibase < n; ibase += 64) {
+        // ---- (1) the chunk's live combinations, c = subject * 16 + object, two per thread (c = tid, tid + 512)
+        int pl[2];
+        unsigned long long bal[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int c = h * 512 + tid, il = c >> 4, jj = c & 15, i = ibase + il;
+            pl[h] = -1;
+            if (i < n && jj < nj) {
+                pl[h] = pid[(long)(o0 + i) * pid_ld + j0 + jj];
+                if (pl[h] >= 0 && pixrect && !in_pixel_rect(pixrect[pl[h]], Y, X)) pl[h] = -1;
+            }
+            bal[h] = __ballot(pl[h] >= 0);
+            if ((lane & 15) == 0) subj_cnt[h * 32 + wid * 4 + (lane >> 4)] = __popcll((bal[h] >> lane) & 0xFFFFull);
+        }
+        __syncthreads();
+        if (wid == 0) {                                   // inclusive scan of the 64 per-subject counts
+            int v = subj_cnt[lane];
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int t = __shfl_up(v, d);
+                if (lane >= d) v += t;
+            }
+            subj_end[lane] = v;
+        }
+        __syncthreads();
+        const int total = subj_end[63];
+        if (total == 0) continue;                         // uniform: nothing of this chunk touches the pixel
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (pl[h] >= 0) {
+                const int c = h * 512 + tid, s4 = (h * 8 + wid) * 4;          // first subject of this wavefront's 64 combinations
+                const int pos = (s4 ? subj_end[s4 - 1] : 0) +
+                                (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal[h] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal[h], 0u));
+                live[pos] = (unsigned short)c;
+                lpair[pos] = pl[h];
+            }
+        }
+        if (!staged) {                                    // V of the tile's objects: 4 pixels x 1 KiB each, once per workgroup
+            for (int it = tid; it < nj * 256; it += 512) {
+                const int jj = it >> 8, part = it & 255;
+                const u16* src = V + ((long)(o0 + j0 + jj) * 1024 + 4 * W) * 512 + part * 8;
+                *reinterpret_cast<uint4*>(sv + jj * 4096 + part * 16) = *reinterpret_cast<const uint4*>(src);
+            }
+            staged = true;
+        }
+        __syncthreads();
+        // ---- (2) an eighth of the list per wavefront
+        const int per = (total + 7) >> 3;
+        int k = wid * per;
+        const int kend = min(total, k + per);
+        if (k >= kend) continue;
+        int il = __builtin_amdgcn_readfirstlane((int)live[k]) >> 4;
+        uint4 unext[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            unext[q] = *reinterpret_cast<const uint4*>(U + ((long)(o0 + ibase + il) * 1024 + 4 * W + q) * 512 + lane * 8);
+        while (k < kend) {
+            float uf[4][8];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const u16* ah = reinterpret_cast<const u16*>(&unext[q]);
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) uf[q][kk] = f16_bits_to_f32(ah[kk]);
+            }
+            const int run_end = min(kend, __builtin_amdgcn_readfirstlane(subj_end[il]));
+            if (run_end < kend) {                         // the next subject with a live item: its rows are on their way during this run
+                il = __builtin_amdgcn_readfirstlane((int)live[run_end]) >> 4;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    unext[q] = *reinterpret_cast<const uint4*>(U + ((long)(o0 + ibase + il) * 1024 + 4 * W + q) * 512 + lane * 8);
+            }
+            for (; k < run_end; ++k) {
+                const int jj = __builtin_amdgcn_readfirstlane((int)live[k]) & 15;
+                const int p = __builtin_amdgcn_readfirstlane(lpair[k]);
+                float best[8];
+                unsigned arg[8];                                // 32-bit: as bytes the compiler spends ~145 sub-dword instructions per item on them
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) { best[kk] = 0.f; arg[kk] = 4; }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint4 b = *reinterpret_cast<const uint4*>(sv + jj * 4096 + q * 1024 + lane * 16);
+                    const u16* bh = reinterpret_cast<const u16*>(&b);
+#pragma unroll
+                    for (int kk = 0; kk < 8; ++kk) {
+                        const float sm = uf[q][kk] + f16_bits_to_f32(bh[kk]);
+                        if (sm > best[kk]) { best[kk] = sm; arg[kk] = (unsigned)q; }
+                    }
+                }
+                if (z) {
+                    uint4 o;
+                    u16* oh = reinterpret_cast<u16*>(&o);
+#pragma unroll
+                    for (int kk = 0; kk < 8; ++kk) oh[kk] = f32_to_f16_bits(best[kk]);
+                    *reinterpret_cast<uint4*>(z + (long)p * (18 * 18 * 512) + zoff) = o;
+                }
+                if (zb) {
+                    uint4 o;
+                    u16* oh = reinterpret_cast<u16*>(&o);
+#pragma unroll
+                    for (int kk = 0; kk < 8; ++kk) oh[kk] = f32_to_bf16_bits(best[kk]);
+                    *reinterpret_cast<uint4*>(zb + (long)p * (18 * 18 * 512) + zoff) = o;
+                }
+                if (amz) {
+                    unsigned ao = 0;
+#pragma unroll
+                    for (int kk = 0; kk < 8; ++kk) ao |= arg[kk] << (4 * kk);
+                    *reinterpret_cast<unsigned*>(amz + (long)p * (256 * 256) + aoff) = ao;
+                }
             }
         }
     }
@@ -372,8 +513,17 @@ int sgc_pair_expand_dense_windows(const void* U, const void* V, const int* img_p
                                   void* z_pad_f16, void* z_pad_bf16, unsigned char* amz, const int* pixel_rect, void* stream) {
     if (max_n > 150 || max_n < 1) return SGC_ERR_ARG;
     if (n_img <= 0) return SGC_OK;
-    SGC_LAUNCH(pair_expand_dense_kernel, dim3(256, (max_n + EXPAND_JT - 1) / EXPAND_JT, n_img), dim3(512), 0, (hipStream_t)stream,
-               (const u16*)U, (const u16*)V, img_ptr, pid, pid_ld, (u16*)z_pad_f16, (u16*)z_pad_bf16, amz, pixel_rect);
+#ifdef SGC_EXPERIMENTS
+    static const int listed = [] { const char* e = getenv("SGC_EXPAND_LIST"); return e ? atoi(e) : 1; }();     // A/B: profiles/r05_expand_ab.txt
+#else
+    constexpr int listed = 1;
+#endif
+    if (listed && pixel_rect)
+        SGC_LAUNCH(pair_expand_dense_list_kernel, dim3(256, (max_n + EXPAND_JT - 1) / EXPAND_JT, n_img), dim3(512), 0, (hipStream_t)stream,
+                   (const u16*)U, (const u16*)V, img_ptr, pid, pid_ld, (u16*)z_pad_f16, (u16*)z_pad_bf16, amz, pixel_rect);
+    else
+        SGC_LAUNCH(pair_expand_dense_kernel, dim3(256, (max_n + EXPAND_JT - 1) / EXPAND_JT, n_img), dim3(512), 0, (hipStream_t)stream,
+                   (const u16*)U, (const u16*)V, img_ptr, pid, pid_ld, (u16*)z_pad_f16, (u16*)z_pad_bf16, amz, pixel_rect);
     SGC_CHECK_LAUNCH();
     return SGC_OK;
 }
