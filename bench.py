@@ -535,13 +535,14 @@ def run_rank(args):
             # north_star names the pair expansion's HBM rate: the longest HBM-bound launch of the forward
             eb, live = m["exp_bytes"]
             gbs = eb / (kern["expand_dense"] * 1e-3) / 1e9
-            hbm = {"bound": "hbm", "kernel": "pair_expand_dense_kernel (sgc_pair_expand_dense_windows: z_ij = maxpool2(relu(U_i + V_j)) on the "
+            hbm = {"bound": "hbm", "kernel": "pair_expand_dense_list_kernel (sgc_pair_expand_dense_windows: z_ij = maxpool2(relu(U_i + V_j)) on the "
                                              "%d live (pair, pixel) items next to the pair-specific windows, of %d)" % (live, P * 256),
                    "bytes": int(eb), "ms_per_launch": round(kern["expand_dense"], 3), "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
                    "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                    "note": "algorithmic bytes: 1 KiB z row + 256 B routing codes per live item, 4 KiB per distinct (object, role, pixel) read "
-                           "once; the launch is bound by its vector arithmetic (~220 f32 operations per lane and item), not by these "
-                           "bytes (DESIGN: measured by dropping 40 % of its stores for -6 % time)"}
+                           "once; the launch is bound by its vector instructions (~195 per lane and item: SQ_INSTS_VALU, vector pipes "
+                           "~55 % busy), not by these bytes (profiles/r05_expand_ab.txt: 308 -> 195 instructions per item took it from "
+                           "1.33 to 0.83 ms)"}
         ex = executed_flops(P, args.images, m["n_obj"], n_x, n_list, m["shared"], args.forward_only, linear=m["linear"])
         if roof is not None:
             # whole-step efficiency on EXECUTED matrix flops (the per-pair form SURVEY 8d prices is mostly not executed any more)
