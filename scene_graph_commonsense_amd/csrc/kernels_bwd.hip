@@ -38,16 +38,19 @@ __device__ __forceinline__ float wave_sum_f(float x) {
 }
 __device__ __forceinline__ float softplusf(float x) { return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x))); }
 
-__global__ __launch_bounds__(256) void head_loss_bwd_kernel(const HeadBwdParams hp) {
+__global__ __launch_bounds__(512) void head_loss_bwd_kernel(const HeadBwdParams hp) {
+    // 4 or 8 wavefronts per workgroup (one weight image in LDS per CU); a pair's work is a chain of small dependent loads and 54 LDS rows,
+    // so the wavefronts in flight are what hides it (round 5: 8 when there are pairs for them, 0.18 -> see profiles/r05_small_kernels.txt)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* Wl = reinterpret_cast<float*>(smem);          // [64][512]
-    float* dls = Wl + 64 * 512;                          // [4][64]
-    for (int i = threadIdx.x; i < 64 * 512; i += 256) Wl[i] = hp.W[i];
+    float* dls = Wl + 64 * 512;                          // [waves][64]
+    const int nw = blockDim.x >> 6;
+    for (int i = threadIdx.x; i < 64 * 512; i += blockDim.x) Wl[i] = hp.W[i];
     __syncthreads();
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int R = hp.ng + hp.np + hp.ns;
     float* dlw = dls + w * 64;
-    for (int pr = blockIdx.x * 4 + w; pr < hp.n_pairs; pr += gridDim.x * 4) {
+    for (int pr = blockIdx.x * nw + w; pr < hp.n_pairs; pr += gridDim.x * nw) {
         const bool up = hp.g_rel != nullptr;
         const int t = up ? -1 : hp.tgt[pr];
         const float a = up ? 0.f : hp.coef_a[pr], b = up ? 0.f : hp.coef_b[pr], cc = up ? 0.f : hp.coef_c[pr], y = up ? 0.f : hp.conn_y[pr];
@@ -643,9 +646,10 @@ static inline int grid_for(long items, long per_block, int cap) {
 }
 
 static int launch_head_bwd(const HeadBwdParams& hp, hipStream_t stream) {
-    const int lds = (64 * 512 + 4 * 64) * 4;
+    const int lds = (64 * 512 + 8 * 64) * 4;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(head_loss_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    SGC_LAUNCH(head_loss_bwd_kernel, dim3(grid_for(hp.n_pairs, 4, 256)), dim3(256), lds, stream, hp);
+    const int waves = hp.n_pairs >= 256 * 8 * 2 ? 8 : 4;
+    SGC_LAUNCH(head_loss_bwd_kernel, dim3(grid_for(hp.n_pairs, waves, 256)), dim3(64 * waves), lds, stream, hp);
     SGC_CHECK_LAUNCH();
     return SGC_OK;
 }

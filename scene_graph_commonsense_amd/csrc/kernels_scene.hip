@@ -183,24 +183,49 @@ __global__ __launch_bounds__(512) void label_grads_kernel(const float* __restric
                                                           const long* __restrict__ cats_s, const long* __restrict__ cats_o,
                                                           const float* __restrict__ mh_s, const float* __restrict__ mh_o, int n_obj,
                                                           int C, int S, float* __restrict__ gW, int ld, int col0) {
-    const int c = blockIdx.x, r = threadIdx.x;
+    // Round 5: the objects that carry the column's label are FOUND by all 512 threads at once (thread = object, compacted in ascending
+    // order into LDS) and only those rows are added - the first form walked all objects one scalar load and branch after the other in
+    // every workgroup (0.13 ms for ~4 rows per column).  Same rows in the same order: same sums.
+    __shared__ int s_obj[512];
+    __shared__ float s_m[512];
+    __shared__ int s_cnt[8];
+    const int c = blockIdx.x, r = threadIdx.x, lane = r & 63, wv = r >> 6;
+    const bool by_class = c < 2 * C;
+    const bool sub = by_class ? c < C : c < 2 * C + S;
+    const float* src = sub ? dls : dlo;
+    const long* cats = sub ? cats_s : cats_o;
+    const float* mh = sub ? mh_s : mh_o;
+    const int key = by_class ? (sub ? c : c - C) : (sub ? c - 2 * C : c - 2 * C - S);
     float acc = 0.f;
-    if (c < 2 * C) {
-        const bool sub = c < C;
-        const float* src = sub ? dls : dlo;
-        const long* cats = sub ? cats_s : cats_o;
-        const int cls = sub ? c : c - C;
-        for (int o = 0; o < n_obj; ++o)
-            if ((int)cats[o] == cls) acc += src[(long)o * 512 + r];
-    } else {
-        const bool sub = c < 2 * C + S;
-        const float* src = sub ? dls : dlo;
-        const float* mh = sub ? mh_s : mh_o;
-        const int k = sub ? c - 2 * C : c - 2 * C - S;
-        for (int o = 0; o < n_obj; ++o) {
-            const float m = mh[(long)o * S + k];
-            if (m != 0.f) acc += m * src[(long)o * 512 + r];
+    for (int base = 0; base < n_obj; base += 512) {
+        const int o = base + r;
+        float m = 0.f;
+        bool ok = false;
+        if (o < n_obj) {
+            if (by_class) ok = (int)cats[o] == key;
+            else { m = mh[(long)o * S + key]; ok = m != 0.f; }
         }
+        const unsigned long long bal = __ballot(ok);
+        if (lane == 0) s_cnt[wv] = __popcll(bal);
+        __syncthreads();
+        int off = 0, total = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { off += k < wv ? s_cnt[k] : 0; total += s_cnt[k]; }
+        if (ok) {
+            const int pos = off + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+            s_obj[pos] = o;
+            s_m[pos] = m;
+        }
+        __syncthreads();
+        if (by_class) {
+            for (int t = 0; t < total; ++t) acc += src[(long)s_obj[t] * 512 + r];
+        } else {
+            for (int t = 0; t < total; ++t) {
+                const float mm = s_m[t];
+                acc += mm * src[(long)s_obj[t] * 512 + r];
+            }
+        }
+        __syncthreads();
     }
     gW[(long)r * ld + col0 + c] = acc;
 }

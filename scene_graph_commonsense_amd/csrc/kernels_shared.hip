@@ -115,30 +115,49 @@ __global__ __launch_bounds__(256) void shared_fill_object_rows_kernel(const int*
 __global__ __launch_bounds__(256) void shared_bg_grad_kernel(const int* __restrict__ bbox, const int* __restrict__ img_ptr, int n_obj,
                                                              const int* __restrict__ goff, const u16* __restrict__ dywm,
                                                              u16* __restrict__ dy_bg, long n_items) {
+    // one wavefront per (image, window, half of the 1024 channels).  Round 5: the rows that contribute are found by a ballot (lane = object)
+    // and requested eight at a time before they are added - in object order, role 0 then role 1, as before: same sums.  The first form
+    // walked the 2 x n objects one dependent 2 KiB load after the other on 512 wavefronts: 0.23 ms of latency for 130 MB.
     const int lane = threadIdx.x & 63;
     for (long it = (long)blockIdx.x * 4 + (threadIdx.x >> 6); it < n_items; it += (long)gridDim.x * 4) {
-        const int b = (int)(it >> 6), w = (int)(it & 63);
-        float acc[16];
+        const int half = (int)(it & 1);
+        const long bw = it >> 1;
+        const int b = (int)(bw >> 6), w = (int)(bw & 63);
+        const int o0 = img_ptr[b], o1 = img_ptr[b + 1];
+        const u16* rows = dywm + (long)goff[w] * 1024 + half * 512 + lane * 8;
+        float acc[8];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+        for (int k = 0; k < 8; ++k) acc[k] = 0.f;
         for (int role = 0; role < 2; ++role)
-            for (int o = img_ptr[b]; o < img_ptr[b + 1]; ++o) {
-                if (in_rect(object_windows(bbox + 4 * o), w & 7, w >> 3)) continue;
-                const u16* r = dywm + ((long)goff[w] + role * n_obj + o) * 1024 + lane * 8;
-                const uint4 a = *reinterpret_cast<const uint4*>(r), c = *reinterpret_cast<const uint4*>(r + 512);
-                const u16* ah = reinterpret_cast<const u16*>(&a);
-                const u16* ch = reinterpret_cast<const u16*>(&c);
+            for (int base = o0; base < o1; base += 64) {
+                const int o = base + lane;
+                const bool ok = o < o1 && !in_rect(object_windows(bbox + 4 * o), w & 7, w >> 3);
+                unsigned long long m = __ballot(ok);
+                while (m) {
+                    uint4 g[8];
+                    int nv = 0;
 #pragma unroll
-                for (int k = 0; k < 8; ++k) { acc[k] += bf16_bits_to_f32(ah[k]); acc[8 + k] += bf16_bits_to_f32(ch[k]); }
+                    for (int u = 0; u < 8; ++u)
+                        if (m) {
+                            const int bit = __ffsll((long long)m) - 1;
+                            m &= m - 1;
+                            g[u] = *reinterpret_cast<const uint4*>(rows + (long)(role * n_obj + base + bit) * 1024);
+                            nv = u + 1;
+                        }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (u < nv) {
+                            const u16* gh = reinterpret_cast<const u16*>(&g[u]);
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) acc[k] += bf16_bits_to_f32(gh[k]);
+                        }
+                }
             }
-        uint4 oa, ob;
+        uint4 oa;
         u16* oah = reinterpret_cast<u16*>(&oa);
-        u16* obh = reinterpret_cast<u16*>(&ob);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { oah[k] = f32_to_bf16_bits(acc[k]); obh[k] = f32_to_bf16_bits(acc[8 + k]); }
-        u16* dst = dy_bg + it * 1024 + lane * 8;
-        *reinterpret_cast<uint4*>(dst) = oa;
-        *reinterpret_cast<uint4*>(dst + 512) = ob;
+        for (int k = 0; k < 8; ++k) oah[k] = f32_to_bf16_bits(acc[k]);
+        *reinterpret_cast<uint4*>(dy_bg + bw * 1024 + half * 512 + lane * 8) = oa;
     }
 }
 
@@ -1740,7 +1759,7 @@ int sgc_shared_objects_fill_rows(const int* bbox, const int* obj_img, int n_obj,
 int sgc_shared_objects_bg_grad(const int* bbox, const int* img_ptr, int n_obj, int n_img, const int* goff, const void* dywm, void* dy_bg,
                                void* stream) {
     if (n_img <= 0) return SGC_OK;
-    const long items = (long)n_img * 64;
+    const long items = (long)n_img * 64 * 2;
     SGC_LAUNCH(shared_bg_grad_kernel, dim3(grid_cap(items, 4, 65536)), dim3(256), 0, (hipStream_t)stream, bbox, img_ptr, n_obj, goff,
                (const u16*)dywm, (u16*)dy_bg, items);
     SGC_CHECK_LAUNCH();
