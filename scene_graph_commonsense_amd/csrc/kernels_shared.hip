@@ -440,9 +440,10 @@ __device__ __forceinline__ void patch_sum_rect(const u16* __restrict__ patch, co
     const int nx = X1 - X0, n = (Y1 - Y0) * nx;
     for (int t = wv; t < n; t += 4) {
         const int y = Y0 + t / nx, xx = X0 + t % nx;
-        float acc[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+        // the rows that cover this pixel, in the order they are added (window row-major; a dense-form centre pixel has two) - all of them
+        // requested before the first is added (round 5: they used to be loaded and added one after the other behind uniform branches)
+        long rows[8];
+        int nr = 0;
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
             const int wy = ((y + 1) >> 1) - a;                 // windows whose patch rows 2 wy - 1 .. 2 wy + 2 contain y
@@ -457,18 +458,24 @@ __device__ __forceinline__ void patch_sum_rect(const u16* __restrict__ patch, co
                 long row;
                 if (ew < n16) { row = 16L * ew + pp; centre = false; }
                 else row = 16L * n16 + (long)PATCH_SLOTS * (ew - n16) + pp + (pp > 5) + (pp > 6) + (pp > 9) + (pp > 10);
-                const uint4 v = *reinterpret_cast<const uint4*>(patch + row * 512 + lane * 8);
-                const u16* vh = reinterpret_cast<const u16*>(&v);
-#pragma unroll
-                for (int k = 0; k < 8; ++k) acc[k] += bf16_bits_to_f32(vh[k]);
-                if (centre) {
-                    const uint4 v2 = *reinterpret_cast<const uint4*>(patch + (row + 1) * 512 + lane * 8);
-                    const u16* vh2 = reinterpret_cast<const u16*>(&v2);
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) acc[k] += bf16_bits_to_f32(vh2[k]);
-                }
+                rows[nr++] = row;
+                if (centre) rows[nr++] = row + 1;
             }
         }
+        uint4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (u < nr) v[u] = *reinterpret_cast<const uint4*>(patch + rows[u] * 512 + lane * 8);
+        float acc[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (u < nr) {
+                const u16* vh = reinterpret_cast<const u16*>(&v[u]);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc[k] += bf16_bits_to_f32(vh[k]);
+            }
         uint4 ov;
         u16* oh = reinterpret_cast<u16*>(&ov);
 #pragma unroll
