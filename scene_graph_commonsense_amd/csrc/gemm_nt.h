@@ -240,7 +240,10 @@ __device__ __forceinline__ void supertile_map_g(int id, int tiles_m, int tiles_n
 // data gradient, 2.8 % of fc1's).
 constexpr int EPI_LDS_PITCH = 128;
 constexpr int EPI_LDS_BYTES = 8 * 128 * EPI_LDS_PITCH;
-template <int ELEM>
+// MASK (EPI_RELUMASK through this epilogue, round 5): the value is multiplied by p.scale before it is rounded, and the read-back zeroes the
+// elements whose forward activation p.mask_src (f16, the output's shape) is not > 0 - 16-byte mask loads beside the 16-byte stores; the
+// generic epilogue did this with a 2-byte load and a 2-byte store per element (fc2's data gradient: 0.50 ms for 0.5 GB).  Same values.
+template <int ELEM, bool MASK = false>
 __device__ __forceinline__ void nt_epilogue_store16(const NtParams& p, f32x16 (&acc)[4][2], int m0, int n0, int wr, int wc, int lane,
                                                     int wid, char* smem) {
     __syncthreads();                                   // every wave is done reading operand tiles
@@ -255,7 +258,8 @@ __device__ __forceinline__ void nt_epilogue_store16(const NtParams& p, f32x16 (&
             const float bias = p.bias ? p.bias[col] : 0.f;
 #pragma unroll
             for (int rp = 0; rp < 8; ++rp) {
-                const float v0 = acc[i][j][2 * rp] + bias, v1 = acc[i][j][2 * rp + 1] + bias;
+                float v0 = acc[i][j][2 * rp] + bias, v1 = acc[i][j][2 * rp + 1] + bias;
+                if constexpr (MASK) { v0 *= p.scale; v1 *= p.scale; }
                 const float recv = __shfl_xor(odd ? v0 : v1, 1);
                 const int r0 = ((2 * rp) & 3) + 8 * ((2 * rp) >> 2) + 4 * h;       // row of register 2rp; register 2rp+1 is r0+1
                 const float flo = odd ? recv : v0, fhi = odd ? v1 : recv;
@@ -275,11 +279,19 @@ __device__ __forceinline__ void nt_epilogue_store16(const NtParams& p, f32x16 (&
 #pragma unroll
     for (int it = 0; it < 16; ++it) {
         const int rowl = it * 8 + rsub;
-        const uint4 v = *reinterpret_cast<const uint4*>(reg + rowl * EPI_LDS_PITCH + ((c8 * 16) ^ ((rowl & 1) << 6)));
+        uint4 v = *reinterpret_cast<const uint4*>(reg + rowl * EPI_LDS_PITCH + ((c8 * 16) ^ ((rowl & 1) << 6)));
         const int row = m0 + wr * 128 + rowl;
         if (row < p.M) {
-            uint4* dst = reinterpret_cast<uint4*>(out + (long)row * p.ldc + n0 + wc * 64 + c8 * 8);
-            *dst = v;
+            const long o = (long)row * p.ldc + n0 + wc * 64 + c8 * 8;
+            if constexpr (MASK) {
+                const uint4 f = *reinterpret_cast<const uint4*>(p.mask_src + o);
+                const u16* fh = reinterpret_cast<const u16*>(&f);
+                u16* vh = reinterpret_cast<u16*>(&v);
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (!(from_elem<ELEM_F16>(fh[k]) > 0.f)) vh[k] = 0;
+            }
+            *reinterpret_cast<uint4*>(out + o) = v;
         }
     }
 }

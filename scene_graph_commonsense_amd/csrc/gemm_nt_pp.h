@@ -285,6 +285,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(const NtParams p) {
     if constexpr (EPI == EPI_STORE && !ACG) {         // (gathered rows are scattered: the generic epilogue)
         if (p.epi_lds) { nt_epilogue_store16<ELEM>(p, acc, m0, n0, wr, wc, lane, wid, smem); stored = true; }
     }
+    if constexpr (EPI == EPI_RELUMASK && !ACG) {
+        if (p.epi_lds && !p.bias && (p.ldc & 7) == 0) { nt_epilogue_store16<ELEM, true>(p, acc, m0, n0, wr, wc, lane, wid, smem); stored = true; }
+    }
     if (stored) {
     } else if constexpr (EPI == EPI_STORE_F32T) {
         static_assert(!ACG, "transposed f32 tile: plain rows only");
