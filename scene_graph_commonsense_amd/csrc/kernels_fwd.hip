@@ -558,6 +558,15 @@ int sgc_fc2_labels_relu(const void* h1, const void* w2m, const float* b, const f
     p.A = (const u16*)h1; p.B = (const u16*)w2m; p.C = p_out; p.M = n_pairs; p.N = 512; p.K = 4096;
     p.lda = 4096; p.ldb = 4096; p.ldc = 512; p.bias = b; p.lsub = lsub; p.lobj = lobj; p.sub_idx = sub_idx;
     p.obj_idx = obj_idx; p.drop_enable = drop_enable; p.drop_seed = drop_seed; p.scale = 2.f;
+#ifdef SGC_EXPERIMENTS
+    static const int big = [] { const char* e = getenv("SGC_FC2_BIG"); return e ? atoi(e) : 1; }();       // A/B: profiles/r05_small_kernels.txt
+#else
+    constexpr int big = 1;
+#endif
+    if (big && n_pairs >= 16384) {          // N = 512: two column tiles; from 64 row tiles on the 256 x 256 ping-pong block (the size rule of launch_gemm_nt starts at 256^3 outputs)
+        p.epi_lds = 0;
+        return launch_gemm_nt_pp<ELEM_F16, EPI_FC2>(p, (hipStream_t)stream);
+    }
     return launch_gemm_nt<ELEM_F16, AMODE_PLAIN, EPI_FC2>(p, (hipStream_t)stream);
 }
 
