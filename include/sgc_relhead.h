@@ -555,6 +555,8 @@ int sgc_generic_conv1_bwd(const float* feat, const float* depth, long stride_fea
 /* ----------------------------------------------------------------------------------------------- test hooks (raw GEMM engines) */
 int sgc_dbg_gemm_nt(int elem, const void* A, const void* B, void* C, int M, int N, int K, long lda, long ldb, long ldc, const float* bias, void* stream);
 int sgc_dbg_gemm_nt_abl(int abl, const void* A, const void* B, void* C, int M, int N, int K, void* stream);
+/* tools/stride_microbench.py: the ping-pong NT block with the operands' row pitches as parameters (power-of-two pitches cost nothing: profiles/r05_stride_microbench.txt) */
+int sgc_dbg_gemm_nt_ld(const void* A, const void* B, void* C, int M, int N, int K, long lda, long ldb, void* stream);
 int sgc_dbg_fc1_windows_gemm(const void* ywm, const void* w, const int* tile_group, void* owm, int rows, long ldb, long group_stride, long ldc, int mode, int stagger, int phases, unsigned long long* clk, void* stream);
 int sgc_dbg_dgrad_patches(const void* dy3x, const void* w3patch, void* patch, int entries, long lda, long seg_stride, int bpad, int split, void* stream);
 int sgc_dbg_conv_nt(int elem, const void* A, const void* B, void* C, int n_img, int lgS, int Cin, int N, const float* bias, void* stream);

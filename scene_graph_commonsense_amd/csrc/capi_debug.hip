@@ -37,6 +37,15 @@ int sgc_dbg_gemm_nt_abl(int abl, const void* A, const void* B, void* C, int M, i
     return SGC_ERR_ARG;
 }
 
+// tools/stride_microbench.py: the ping-pong NT block with operand row pitches as parameters (do power-of-two pitches cost cache channels?)
+int sgc_dbg_gemm_nt_ld(const void* A, const void* B, void* C, int M, int N, int K, long lda, long ldb, void* stream) {
+    NtParams p{};
+    p.A = (const u16*)A; p.B = (const u16*)B; p.C = C; p.M = M; p.N = N; p.K = K;
+    p.lda = lda; p.ldb = ldb; p.ldc = N; p.epi_lds = 1;
+    if ((N % 256) || (K % 64) || (lda % 8) || (ldb % 8)) return SGC_ERR_ARG;
+    return launch_gemm_nt_pp<ELEM_BF16, EPI_STORE, 0>(p, (hipStream_t)stream);
+}
+
 // tools/fc1_windows_microbench.py: the grouped fc1 product over window-major rows (sgc_fc1_windows_gemm) with the weight layout and the
 // epilogue as parameters.  mode 0: f32 tile in the MFMA's C layout (4-byte stores), 1: transposed tile (16-byte stores), 2: the same
 // without its stores (C ignored), 3: f16 output through the LDS-staged epilogue.
