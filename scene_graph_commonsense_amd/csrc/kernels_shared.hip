@@ -991,7 +991,7 @@ __global__ __launch_bounds__(256) void windows_linear_fwd_kernel(const int* __re
         const long eb = n_pe + (long)obj_img[i] * 64 + w;
         const int c0 = lane * 16;
         float best[16];
-        unsigned char arg[16];
+        unsigned arg[16];                             // 32-bit in registers (as bytes: sub-dword instruction bloat, profiles/r05_expand_ab.txt)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float* a = raw + ((ei * 4 + q) << 10) + c0;
@@ -1005,23 +1005,24 @@ __global__ __launch_bounds__(256) void windows_linear_fwd_kernel(const int* __re
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     if (q == 0) { best[4 * v + k] = s[k]; arg[4 * v + k] = 0; }
-                    else if (s[k] > best[4 * v + k]) { best[4 * v + k] = s[k]; arg[4 * v + k] = (unsigned char)q; }
+                    else if (s[k] > best[4 * v + k]) { best[4 * v + k] = s[k]; arg[4 * v + k] = (unsigned)q; }
                 }
             }
         }
         uint4 o16[2], ob[2], oa;
         u16* oh = reinterpret_cast<u16*>(o16);
         u16* bh = reinterpret_cast<u16*>(ob);
-        unsigned char* ah = reinterpret_cast<unsigned char*>(&oa);
+        unsigned aw[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             float v = best[k] + bias[c0 + k];
-            unsigned char a = arg[k];
+            unsigned a = arg[k];
             if (!(v > 0.f)) { v = 0.f; a = 4; }                 // ReLU killed: no gradient path (same rule as the GEMM's pooled epilogue)
             oh[k] = f32_to_f16_bits(v);
             bh[k] = f32_to_bf16_bits(v);
-            ah[k] = a;
+            aw[k >> 2] |= a << (8 * (k & 3));
         }
+        oa = make_uint4(aw[0], aw[1], aw[2], aw[3]);
         uint4* yo = reinterpret_cast<uint4*>(y + drow * 1024 + c0);
         yo[0] = o16[0]; yo[1] = o16[1];
         if (y_bf) { uint4* yb = reinterpret_cast<uint4*>(y_bf + drow * 1024 + c0); yb[0] = ob[0]; yb[1] = ob[1]; }
