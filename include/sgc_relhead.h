@@ -340,6 +340,11 @@ int sgc_scene_tables(const int* n_per_img, const int* img_ptr, const int* goff, 
  * key, bit for bit, without one. */
 int sgc_bucket_place(const int* codes, int n, const int* sub_idx, const int* obj_img, int img_key, int n_keys, const int* base, int* out,
                      int* seg, int mode, void* stream);
+/* the same placement through two-level kernels (a workgroup per (key, segment of 8192 entries): count, key offsets, place) - same ranks,
+ * 0.09 -> 0.02 ms per call at the benchmark's sizes; scratch: int[sgc_bucket_place_scratch_ints(n, n_keys)] */
+long sgc_bucket_place_scratch_ints(int n, int n_keys);
+int sgc_bucket_place_seg(const int* codes, int n, const int* sub_idx, const int* obj_img, int img_key, int n_keys, const int* base, int* out,
+                         int* seg, int mode, int* scratch, long scratch_ints, void* stream);
 
 /* Pair lists of the pseudo-pairs of conv3 over shared windows (csrc/kernels_shared.hip): ps_sub / ps_obj [2 n_obj (+ n_img)] = (o, bg(o)),
  * (bg(o), o) (, (bg, bg) per image) with bg(o) = n_obj + obj_img[o]; bg_codes [64 n_img] (may be NULL) = window codes of the background

@@ -257,6 +257,100 @@ __global__ __launch_bounds__(256) void fill_zero_kernel(uint4* __restrict__ p, l
     if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = 0;
 }
 
+// Two-level form of bucket_place (round 5): the list is cut into segments of BP_SEG entries and a workgroup owns one (key, segment):
+// pass 1 counts the key's entries per segment, pass 2 (mode 1 only) turns the per-key totals into the keys' start offsets, pass 3 places
+// with rank = entries of the key in earlier segments + rank inside the segment - the same ranks as the one-level kernel, which let ONE
+// workgroup per key walk the whole list (64 workgroups x 56 iterations for the 228 k window entries of the benchmark: 0.09 ms of mostly
+// idle chip, twice per step).  No assumption about the order of the list.
+constexpr int BP_SEG = 8192;
+__device__ __forceinline__ int bp_key(const int* __restrict__ codes, const int* __restrict__ sub_idx, const int* __restrict__ obj_img,
+                                      int img_key, int e) {
+    const int c = codes[e];
+    return img_key ? obj_img[sub_idx[c >> 6]] * 64 + (c & 63) : (c & 63);
+}
+__global__ __launch_bounds__(1024) void bucket_count_kernel(const int* __restrict__ codes, int n, const int* __restrict__ sub_idx,
+                                                            const int* __restrict__ obj_img, int img_key, int S, int* __restrict__ cnt) {
+    __shared__ int s_c;
+    const int k = blockIdx.x, sg = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    const int e0 = sg * BP_SEG, e1 = min(n, e0 + BP_SEG);
+    int c = 0;
+    for (int e = e0 + tid; e < e1; e += 1024) c += bp_key(codes, sub_idx, obj_img, img_key, e) == k ? 1 : 0;
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+    if (tid == 0) s_c = 0;
+    __syncthreads();
+    if (lane == 0 && c) atomicAdd(&s_c, c);                       // integer LDS atomics: order-independent
+    __syncthreads();
+    if (tid == 0) cnt[k * S + sg] = s_c;
+}
+// seg[k] = number of entries with a smaller key, seg[n_keys] = n (one workgroup; keys in chunks of 1024)
+__global__ __launch_bounds__(1024) void bucket_starts_kernel(const int* __restrict__ cnt, int n_keys, int S, int n, int* __restrict__ seg) {
+    __shared__ int wave_tot[16];
+    __shared__ int s_base;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    for (int k0 = 0; k0 < n_keys; k0 += 1024) {
+        const int k = k0 + tid;
+        int t = 0;
+        if (k < n_keys)
+            for (int sg = 0; sg < S; ++sg) t += cnt[k * S + sg];
+        int v = t;                                                // inclusive scan inside the wavefront
+        for (int d = 1; d < 64; d <<= 1) {
+            const int u = __shfl_up(v, d);
+            if (lane >= d) v += u;
+        }
+        if (lane == 63) wave_tot[wid] = v;
+        __syncthreads();
+        int off = s_base;
+        for (int w = 0; w < wid; ++w) off += wave_tot[w];
+        if (k < n_keys) seg[k] = off + v - t;
+        __syncthreads();
+        if (tid == 1023) s_base = off + v;
+        __syncthreads();
+    }
+    if (tid == 0) seg[n_keys] = n;
+}
+__global__ __launch_bounds__(1024) void bucket_place2_kernel(const int* __restrict__ codes, int n, const int* __restrict__ sub_idx,
+                                                             const int* __restrict__ obj_img, int img_key, int S,
+                                                             const int* __restrict__ cnt, const int* __restrict__ start, int* __restrict__ out,
+                                                             int mode) {
+    __shared__ int wave_tot[4][16];
+    const int k = blockIdx.x, sg = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (cnt[k * S + sg] == 0) return;                             // uniform
+    int before = start[k];
+    for (int s2 = 0; s2 < sg; ++s2) before += cnt[k * S + s2];
+    const int e0 = sg * BP_SEG, e1 = min(n, e0 + BP_SEG);
+    for (int it = e0; it < e1; it += 4096) {
+        unsigned long long bal[4];
+        bool m[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int e = it + j * 1024 + tid;
+            m[j] = e < e1 && bp_key(codes, sub_idx, obj_img, img_key, e) == k;
+            bal[j] = __ballot(m[j]);
+            if (lane == 0) wave_tot[j][wid] = __popcll(bal[j]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int off = 0, tot = 0;
+#pragma unroll
+            for (int w = 0; w < 16; ++w) {
+                const int t = wave_tot[j][w];
+                off += w < wid ? t : 0;
+                tot += t;
+            }
+            if (m[j]) {
+                const int rank = before + off + __popcll(bal[j] & ((1ull << lane) - 1ull));
+                const int e = it + j * 1024 + tid;
+                if (mode == 0) out[e] = rank; else out[rank] = e;
+            }
+            before += tot;
+        }
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ C ABI
 // ---- stable bucket placement of a window list (the row plan of conv3 / fc1 over shared windows, csrc/kernels_shared.hip) ----------
 // codes[e] = pair*64 + window (list order = pair order).  key(e) = window (img_key = 0) or image(pair)*64 + window (img_key = 1:
@@ -485,6 +579,27 @@ int sgc_bucket_place(const int* codes, int n, const int* sub_idx, const int* obj
     if (img_key && (sub_idx == nullptr || obj_img == nullptr)) return SGC_ERR_ARG;
     SGC_LAUNCH(bucket_place_kernel, dim3(n_keys), dim3(1024), 0, (hipStream_t)stream, codes, n < 0 ? 0 : n, sub_idx, obj_img, img_key, n_keys, base,
                out, seg, mode);
+    SGC_CHECK_LAUNCH();
+    return SGC_OK;
+}
+
+// the same result through the two-level kernels; scratch: int[n_keys * S] with S = ceil(n / 8192) segments (sgc_bucket_place_scratch_ints)
+long sgc_bucket_place_scratch_ints(int n, int n_keys) { return (long)n_keys * (((n > 0 ? n : 1) + BP_SEG - 1) / BP_SEG); }
+int sgc_bucket_place_seg(const int* codes, int n, const int* sub_idx, const int* obj_img, int img_key, int n_keys, const int* base, int* out,
+                         int* seg, int mode, int* scratch, long scratch_ints, void* stream) {
+    if (n_keys <= 0 || (mode != 0 && mode != 1) || (mode == 0 && base == nullptr) || (mode == 1 && seg == nullptr)) return SGC_ERR_ARG;
+    if (img_key && (sub_idx == nullptr || obj_img == nullptr)) return SGC_ERR_ARG;
+    if (n <= 0) {
+        if (mode == 1) SGC_LAUNCH(bucket_starts_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, scratch, n_keys, 0, 0, seg);
+        SGC_CHECK_LAUNCH();
+        return SGC_OK;
+    }
+    const int S = (n + BP_SEG - 1) / BP_SEG;
+    if (scratch == nullptr || scratch_ints < (long)n_keys * S) return SGC_ERR_ARG;
+    SGC_LAUNCH(bucket_count_kernel, dim3(n_keys, S), dim3(1024), 0, (hipStream_t)stream, codes, n, sub_idx, obj_img, img_key, S, scratch);
+    if (mode == 1) SGC_LAUNCH(bucket_starts_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, scratch, n_keys, S, n, seg);
+    SGC_LAUNCH(bucket_place2_kernel, dim3(n_keys, S), dim3(1024), 0, (hipStream_t)stream, codes, n, sub_idx, obj_img, img_key, S, scratch,
+               mode == 1 ? seg : base, out, mode);
     SGC_CHECK_LAUNCH();
     return SGC_OK;
 }

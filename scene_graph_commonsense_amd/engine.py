@@ -700,8 +700,7 @@ class RelHeadEngine:
         if TUNING.plan_kernels and 64.0 * n_img * e_lin <= 1e8:
             order = own.get("xw_lin_order", e_lin + 64, torch.int32)
             seg = own.get("xw_lin_seg", 64 * n_img + 1, torch.int32)
-            _lib.check(lib.sgc_bucket_place(_lib.ptr(gather_l), e_lin, _lib.ptr(sub_idx), _lib.ptr(obj_img), 1, 64 * n_img, None, _lib.ptr(order),
-                                            _lib.ptr(seg), 1, self._st()), "sgc_bucket_place")
+            self._bucket_place(gather_l, e_lin, sub_idx, obj_img, 1, 64 * n_img, None, order, seg, 1)
         else:
             code_l = gather_l[:e_lin].long()
             keys = obj_img.long()[sub_idx.long()[code_l >> 6]] * 64 + (code_l & 63)
@@ -748,8 +747,7 @@ class RelHeadEngine:
         # by window gives; sgc_bucket_place computes the ranks directly)
         kern = TUNING.plan_kernels
         if E > 0 and kern:
-            _lib.check(self.lib.sgc_bucket_place(_lib.ptr(gather), E, None, None, 0, 64, _lib.ptr(xbase), _lib.ptr(dest), None, 0, self._st()),
-                       "sgc_bucket_place")
+            self._bucket_place(gather, E, None, None, 0, 64, xbase, dest, None, 0)
         elif E > 0:
             cex = np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(np.int64)
             skeys, order = torch.sort((gather[:E] & 63).long(), stable=True)
@@ -776,6 +774,16 @@ class RelHeadEngine:
                 dest_conv = dest[torch.arange(Ec, device=dev) - first(plan["incl"])[pair_k] + first(plan["incl_all"])[pair_k]].contiguous()
         return dict(goff=goff_d, goff_host=goff, gend=gend, tile_group=tile_group_d, dest=dest, dest_conv=dest_conv,
                     rows=int(goff[64]), E=E, E_total=Et, n2=n2)
+
+    def _bucket_place(self, codes, n, sub_idx, obj_img, img_key, n_keys, base, out, seg, mode):
+        """Stable placement of a window list by key (``sgc_bucket_place_seg``: two-level kernels, scratch from the workspace)."""
+        lib = self.lib
+        lib.sgc_bucket_place_scratch_ints.restype = ctypes.c_long
+        need = int(lib.sgc_bucket_place_scratch_ints(int(n), int(n_keys)))
+        scratch = self.scratch.get("bucket_cnt", max(need, 1), torch.int32)
+        _lib.check(lib.sgc_bucket_place_seg(_lib.ptr(codes), int(n), _lib.ptr(sub_idx), _lib.ptr(obj_img), int(img_key), int(n_keys), _lib.ptr(base),
+                                            _lib.ptr(out), _lib.ptr(seg), int(mode), _lib.ptr(scratch), _c_long(need), self._st()),
+                   "sgc_bucket_place_seg")
 
     def fc1_shared(self, wm, ywm, bbox, sub_idx, obj_idx, incl, P, n_obj, h1, dropout, seed, order=None):
         """fc1 + ReLU (+ dropout) from the window-major rows: grouped GEMM, per-object 2-D prefix sums, per-pair assembly."""

@@ -208,6 +208,24 @@ def test_bucket_placement_equals_a_stable_sort(n, n_img):
     sk, ord_ref = torch.sort(keys1, stable=True)
     seg_ref = torch.searchsorted(sk, torch.arange(nk + 1, device="cuda"))
     assert torch.equal(order1.long(), ord_ref) and torch.equal(seg.long(), seg_ref)
+    # the two-level kernels the engine uses (a workgroup per (key, segment of 8192 entries)): the same tables
+    lib.sgc_bucket_place_scratch_ints.restype = ctypes.c_long
+    need = int(lib.sgc_bucket_place_scratch_ints(n, nk))
+    scratch = torch.full((max(need, 1),), -7, dtype=torch.int32, device="cuda")
+    out2 = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    _lib.check(lib.sgc_bucket_place_seg(_lib.ptr(codes), n, None, None, 0, 64, _lib.ptr(base), _lib.ptr(out2), None, 0, _lib.ptr(scratch),
+                                        ctypes.c_long(need), _lib.stream_ptr()), "sgc_bucket_place_seg")
+    assert torch.equal(out2, out)
+    order2 = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    seg2 = torch.full((nk + 1,), -1, dtype=torch.int32, device="cuda")
+    _lib.check(lib.sgc_bucket_place_seg(_lib.ptr(codes), n, _lib.ptr(sub_idx), _lib.ptr(obj_img), 1, nk, None, _lib.ptr(order2), _lib.ptr(seg2), 1,
+                                        _lib.ptr(scratch), ctypes.c_long(need), _lib.stream_ptr()), "sgc_bucket_place_seg")
+    assert torch.equal(order2, order1) and torch.equal(seg2, seg)
+    # an empty list: every segment start 0
+    seg3 = torch.full((nk + 1,), -1, dtype=torch.int32, device="cuda")
+    _lib.check(lib.sgc_bucket_place_seg(_lib.ptr(codes), 0, _lib.ptr(sub_idx), _lib.ptr(obj_img), 1, nk, None, _lib.ptr(order2), _lib.ptr(seg3), 1,
+                                        _lib.ptr(scratch), ctypes.c_long(need), _lib.stream_ptr()), "sgc_bucket_place_seg")
+    assert int(seg3.abs().sum()) == 0
 
 
 def test_row_plan_by_kernels_equals_the_torch_form_at_benchmark_size():
