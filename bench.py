@@ -47,7 +47,7 @@ WINDOW_GEMMS = {
                             "gemm_tn_sp_kernel<patch> (sgc_windows_wgrad_patch_sparse: conv3 weight gradient of the real pairs' listed windows, "
                             "2:4-sparse un-pooled gradient x 4x4 input patches; executed = non-zero multiply-adds only)"),
 }
-PMC_TAGS = ("r05_final6", "r05_final5", "r05_final3", "r05_final2", "r05_final", "r05_mid", "r04_final5", "r04_final4", "r04_final3", "r04_final2", "r04_final", "r03_final6")   # newest committed profile sets first
+PMC_TAGS = ("r05_final7", "r05_final6", "r05_final5", "r05_final3", "r05_final2", "r05_final", "r05_mid", "r04_final5", "r04_final4", "r04_final3", "r04_final2", "r04_final", "r03_final6")   # newest committed profile sets first
 
 
 BENCH_LR_SCALE = 1e-3
