@@ -126,10 +126,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_sp_kernel(const NtSpParams p) 
     // A half h: LDS row r (0..127) <-> window m0 + (r>>6)*128 + h*64 + (r&63); wave w stages rows 16w .. 16w+15 (64 B each)
     const int arow = wid * 16 + (lane >> 2);
     const int achunk = (lane & 3) ^ ((arow >> 2) & 3);
-    const u16* const a_set = p.Ac + (long)set * p.entries * 1024;
+    // wave-uniform base = this M tile's first row (64-bit), per-lane offsets relative to it (< 512 KiB): the list may hold any number of
+    // windows - offsets from the set's first row would leave the buffer descriptor's 2 GiB range at 2^20 windows and read zeros
+    const u16* const a_set = p.Ac + ((long)set * p.entries + m0) * 1024;
     int a_voff[2];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) a_voff[h] = ((m0 + (arow >> 6) * 128 + h * 64 + (arow & 63)) * 1024 + achunk * 8) * 2;
+    for (int h = 0; h < 2; ++h) a_voff[h] = (((arow >> 6) * 128 + h * 64 + (arow & 63)) * 1024 + achunk * 8) * 2;
     // index words of half h, K tile t: 1 KiB contiguous at ((((set * tiles_m + tm) * 2 + h) * 32 + t) * 256) words
     const unsigned* const i_blk = p.Ic + ((long)(set * p.tiles_m + tm) * 2) * 32 * 256;
     // B half h: LDS row r <-> c_in nhalf*256 + (r>>5)*64 + h*32 + (r&31); wave w stages rows 16w .. 16w+15 (two loads of 8 rows x 128 B)

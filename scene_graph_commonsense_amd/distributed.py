@@ -218,6 +218,13 @@ class ShardedSGD:
         gradient in GEMM order, or None (shapes other than the reference's, shards that are not whole rows, an injected CPU update rule,
         a module this object was not attached to).  Once on, ``model.training_step(reducer=self)`` sets the engine's switch itself."""
 
+        eng = self._fc1_fusable(model)
+        if eng is not None:
+            self.fc1_gemm_order = True
+        return eng
+
+    def _fc1_fusable(self, model):
+        """The engine ``fuse_fc1`` would switch, or None; changes nothing (``attach`` asks every rank before any of them switches)."""
         fc1 = getattr(model, "fc1", None)
         if fc1 is None or "fc1.weight" not in self.big or tuple(fc1.weight.shape) != (4096, 65536) or not fc1.weight.is_cuda:
             return None
@@ -230,7 +237,6 @@ class ShardedSGD:
             return None
         if not self.fc1_gemm_order and any(pc.acc is not None for pc in self.pieces["fc1.weight"]):
             return None                    # a reference-order gradient is being accumulated: not in the middle of it
-        self.fc1_gemm_order = True
         return eng
 
     # ------------------------------------------------------------------ collectives
@@ -351,8 +357,23 @@ class ShardedSGD:
         ``model.parameters()`` directly between ``step()`` and the next forward must call ``wait_gathers()`` itself."""
         model.__dict__["weight_sync"] = self.wait_gathers
         from .engine import TUNING
-        if TUNING.fused_sgd:
-            self.fuse_fc1(model)          # fc1.weight's gradient in GEMM order from now on, on every path of this model that feeds this object
+        # fc1.weight's gradient in GEMM order from now on, on every path of this model that feeds this object - but only if EVERY rank
+        # can (the flag changes how the bytes of the shared reduce-scatter are read: a rank with another SGC_* environment, an injected
+        # update rule or row blocks that are not whole rows must not mix its order into the collective)
+        want = bool(TUNING.fused_sgd) and self._fc1_fusable(model) is not None
+        agreed = want
+        if self.collective and dist.is_available() and dist.is_initialized():
+            fc1 = getattr(model, "fc1", None)
+            on_dev = dist.get_backend(self.group) == "nccl" and fc1 is not None and fc1.weight.is_cuda
+            flag = torch.tensor([int(want), -int(want)], dtype=torch.int32, device=fc1.weight.device if on_dev else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)          # (min, -max)
+            agreed = bool(int(flag[0]))
+            if int(flag[0]) != -int(flag[1]):
+                import warnings
+                warnings.warn("ShardedSGD.attach: the ranks disagree on the fused fc1 update (this rank: %s) - every rank keeps the "
+                              "reference column order" % want)
+        if agreed:
+            self.fuse_fc1(model)
         if hasattr(model, "register_state_dict_pre_hook") and not getattr(model, "_sgc_gather_hook", False):
             opt = self
             model.register_state_dict_pre_hook(lambda module, prefix, keep_vars: opt.wait_gathers())

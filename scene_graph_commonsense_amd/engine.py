@@ -695,9 +695,9 @@ class RelHeadEngine:
             _lib.check(lib.sgc_shared_objects_fill(_lib.ptr(bbox), n_obj, P, _lib.ptr(inc), _lib.ptr(ga), self._st()), "sgc_shared_objects_fill")
         # the linear windows ordered by (image, window) for the background side of the backward (stable: sums in list order):
         # one placement kernel instead of sort + searchsorted + gathers (sgc_bucket_place, bit-identical: tests/test_scene_gpu.py)
-        # (one workgroup per (image, window) key scans the whole list twice: O(keys x entries).  0.09 ms at 8 images; a 32-image
-        # minibatch would be 16 x that, so beyond 1e8 key-entry visits the sort path below takes over - ADVICE r4)
-        if TUNING.plan_kernels and 64.0 * n_img * e_lin <= 1e8:
+        # (two-level placement, sgc_bucket_place_seg: cost linear in the list at any minibatch size; the torch sort below is only the
+        # reference the kernel is tested against, ``TUNING.plan_kernels`` off)
+        if TUNING.plan_kernels:
             order = own.get("xw_lin_order", e_lin + 64, torch.int32)
             seg = own.get("xw_lin_seg", 64 * n_img + 1, torch.int32)
             self._bucket_place(gather_l, e_lin, sub_idx, obj_img, 1, 64 * n_img, None, order, seg, 1)

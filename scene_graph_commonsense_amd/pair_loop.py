@@ -370,7 +370,11 @@ def train_minibatch(model, batch, optimizer=None, reducer=None, scene: Optional[
     ``streams`` (default ``model.pipeline_streams`` or 1): image groups run on that many concurrent HIP streams, each with its own
     engine workspace - the HBM-bound kernels of one group (expansion, contraction, im2col / col2im, fc1 assembly, ...) then share
     the chip with the MFMA-bound GEMMs of the other instead of leaving the matrix cores idle; a minibatch that fits in one pass
-    is cut into ``streams`` balanced groups for that purpose.  Same arithmetic as the sequential groups."""
+    is cut into ``streams`` balanced groups for that purpose.  Same arithmetic as the sequential groups.
+    After a step taken HERE (``optimizer`` given) with ``TUNING.fused_sgd`` (default) ``model.fc1.weight.grad`` is None - its gradient
+    lived in the engine's scratch in GEMM order and the fused update consumed it - while every other parameter keeps its ``.grad``
+    like the reference's optimizer leaves it; callers that want to look at fc1.weight's gradient (norm logging, clipping) pass
+    ``optimizer=None`` and step themselves, or run under ``engine.tuning(fused_sgd=False)``."""
     cfg = model.head_config()
     dev = next(model.parameters()).device
     if optimizer is not None:
@@ -392,13 +396,21 @@ def train_minibatch(model, batch, optimizer=None, reducer=None, scene: Optional[
     # that has taken one such gradient takes every later one that way (its accumulators and its peers' must agree).
     fuse_eng = None
     from .engine import TUNING
-    sharded = reducer is not None and reducer is optimizer and getattr(reducer, "owns_grads", False)
+    # the object that ends up holding the step's gradients: a reducer that owns them (ShardedSGD - also when the caller steps it later,
+    # ``optimizer=None``: gradient accumulation), else the optimizer
+    owner = reducer if (reducer is not None and getattr(reducer, "owns_grads", False)) else optimizer
+    sharded = owner is reducer and reducer is not None
+    if sharded and optimizer is not None and optimizer is not reducer:
+        raise ValueError("a reducer that owns the gradients (ShardedSGD) is its own optimizer: pass it as both, or optimizer=None")
     allreduce = reducer is not None and not sharded and getattr(reducer, "active", False)
     # decided by configuration only, never by this rank's data: every rank of a step must hand over the same column order (a rank
     # without pairs contributes zeros - order-free - but its optimizer must read its peers' mean gradient the way they wrote it)
-    if optimizer is not None and not allreduce and (TUNING.fused_sgd or getattr(optimizer, "fc1_gemm_order", False)):
-        fuse = getattr(optimizer, "fuse_fc1", None)
+    # (a ShardedSGD switches in ``attach`` only, where the ranks agree on it; a local FusedSGD whenever the tuning flag is on)
+    if owner is not None and not allreduce and (getattr(owner, "fc1_gemm_order", False) or (not sharded and TUNING.fused_sgd)):
+        fuse = getattr(owner, "fuse_fc1", None)
         fuse_eng = fuse(model) if fuse is not None else None
+        if fuse_eng is None and getattr(owner, "fc1_gemm_order", False):
+            raise RuntimeError("the gradient owner expects fc1.weight's gradient in GEMM order but this module cannot produce it")
     try:
         if fuse_eng is not None:
             fuse_eng.fc1_grad_gemm_order = True
@@ -406,12 +418,26 @@ def train_minibatch(model, batch, optimizer=None, reducer=None, scene: Optional[
             loss = model.training_step(scene, batch.relationships, batch.subj_or_obj, reducer=reducer, **loss_kw)
         else:
             loss = _train_image_groups(model, cfg, batch, scene, groups, reducer, loss_kw, lanes=lanes)
+    except BaseException:
+        # a GEMM-order gradient that may already hang on fc1.weight is a view of the engine's scratch in an order nobody else reads
+        fc1 = getattr(model, "fc1", None)
+        if fuse_eng is not None and fc1 is not None and getattr(fc1.weight, "_sgc_grad_gemm_order", False):
+            fc1.weight.grad = None
+            fc1.weight._sgc_grad_gemm_order = False
+        raise
     finally:
         if fuse_eng is not None:
             fuse_eng.fc1_grad_gemm_order = False
     model.last_scene = scene
     if optimizer is not None:
-        optimizer.step()
+        try:
+            optimizer.step()
+        except BaseException:
+            fc1 = getattr(model, "fc1", None)
+            if fc1 is not None and getattr(fc1.weight, "_sgc_grad_gemm_order", False):
+                fc1.weight.grad = None
+                fc1.weight._sgc_grad_gemm_order = False
+            raise
     return loss
 
 
@@ -558,6 +584,8 @@ def _train_image_groups(model, cfg, batch, scene: DeviceScene, groups, reducer, 
             acc[name] = torch.zeros_like(p)
     # the minibatch's gradient = the sum over its image groups: mean-reduce it across ranks once, then accumulate like autograd
     if reducer is not None:
+        if getattr(reducer, "owns_grads", False) and bool(getattr(reducer, "fc1_gemm_order", False)) != bool(lane[0]["engine"].fc1_grad_gemm_order):
+            raise RuntimeError("fc1.weight's gradient order differs from what the sharded optimizer accumulates")
         if "fc1.weight" in acc:
             reducer.hook("fc1.weight", acc["fc1.weight"])
         reducer.finish_grads(acc)

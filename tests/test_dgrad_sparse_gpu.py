@@ -111,3 +111,44 @@ def test_sparse_patch_dgrad_matches_the_definition_and_the_dense_form(n_sparse, 
     assert torch.equal(dy3x_t, dy3x[e0 * 4096:])
     tail_ref = (dyf[e0:] * (code[e0:] < 4)).sum(0)
     assert float((bpart_t[:nparts_t.value].double().sum(0) - tail_ref).abs().max()) <= 1e-3 * float(bias_ref.abs().max())
+
+
+def test_sparse_patch_dgrad_beyond_two_to_the_twenty_windows():
+    """the packed rows of a list with more than 2^20 windows lie beyond the 2 GiB a buffer descriptor based at the set's
+    first row could address (the loads returned zeros: a silent zero gradient).  The tile's rows are now addressed from the tile's own
+    base; checked on the LAST M tile of a 1 049 088-window list (an OpenImages 4 x 100 minibatch with wide boxes gets there) against the
+    float64 definition.  Few distinct source rows, gathered many times: the list is long, the inputs small."""
+    from scene_graph_commonsense_amd import _lib
+    lib = _lib.load()
+    dev = "cuda:0"
+    g = torch.Generator(device=dev).manual_seed(5)
+    st = _lib.stream_ptr
+    E, n_rows = (1 << 20) + 512, 4096
+    dy = (torch.randn(n_rows, 1024, device=dev, generator=g) * 0.5).to(torch.bfloat16)
+    am = torch.randint(0, 5, (n_rows, 1024), device=dev, generator=g, dtype=torch.int32).to(torch.uint8)
+    gather = torch.randint(0, n_rows, (E,), device=dev, generator=g, dtype=torch.int32)
+    dest = torch.randint(0, n_rows, (E,), device=dev, generator=g, dtype=torch.int32)
+    w3 = (torch.randn(1024, 512, 3, 3, device=dev, generator=g) * 0.02).contiguous()
+    w3sp = torch.empty(20 * 512 * 2048, dtype=torch.bfloat16, device=dev)
+    _lib.check(lib.sgc_windows_dgrad_sparse_weights(_lib.ptr(w3), _lib.ptr(w3sp), st()), "weights")
+    pack_a = torch.empty(4 * E * 1024, dtype=torch.bfloat16, device=dev)                    # 8.6 GB
+    pack_i = torch.empty(4 * E * 64, dtype=torch.int32, device=dev)
+    patch16 = torch.full((E, 16, 512), float("nan"), dtype=torch.bfloat16, device=dev)      # 17 GB
+    _lib.check(lib.sgc_windows_dgrad_sparse_pack(_lib.ptr(dy), _lib.ptr(am), _lib.ptr(gather), _lib.ptr(dest), E, _lib.ptr(pack_a), _lib.ptr(pack_i),
+                                                 None, None, st()), "sparse pack")
+    _lib.check(lib.sgc_windows_dgrad_patches_sparse(_lib.ptr(pack_a), _lib.ptr(pack_i), E, _lib.ptr(w3sp), _lib.ptr(patch16), st()), "sparse dgrad")
+    torch.cuda.synchronize()
+    w3b = w3.to(torch.bfloat16).double()
+    pp_of = [pp for pp, _ in _slots()]
+    for e0 in (0, (1 << 20) - 256, E - 256):                    # first tile, the last one below the old limit, the last one
+        sl = slice(e0, e0 + 256)
+        dyf = dy.double()[dest[sl].long()]
+        code = am[gather[sl].long()].long()
+        ref16 = torch.zeros(256, 16, 512, dtype=torch.float64, device=dev)
+        for s_, (pp, combos) in enumerate(_slots()):
+            for q, tap in combos:
+                ref16[:, pp] += (dyf * (code == q)) @ w3b[:, :, tap // 3, tap % 3]
+        scale = float(ref16.abs().max())
+        got = patch16[sl].double()
+        assert torch.isfinite(got).all()
+        assert scale > 0 and float((got - ref16).abs().max()) <= 2.0 ** -8 * scale, e0

@@ -162,3 +162,43 @@ def test_gemm_order_gradient_through_image_groups_sharded_sgd_and_the_contrastiv
     for n in runs[0]:
         assert torch.equal(runs[0][n], runs[1][n]), n
     assert not torch.equal(runs[0]["fc1.weight"], sd["fc1.weight"].cuda())
+
+
+def test_sharded_sgd_through_image_groups_with_the_step_taken_by_the_caller():
+    """a ``ShardedSGD`` that ``attach`` switched to GEMM order must get that order on EVERY path - also a minibatch cut into
+    image groups with ``optimizer=None`` (the caller steps: gradient accumulation over two minibatches).  Bit-identical parameters
+    with the fusion off."""
+    from scene_graph_commonsense_amd import distributed as D
+    from scene_graph_commonsense_amd import engine as E
+    from scene_graph_commonsense_amd.model import BayesianRelationClassifier
+    from scene_graph_commonsense_amd.pair_loop import train_minibatch
+    from scene_graph_commonsense_amd.synthetic import HeadConfig, make_scene_batch, make_state_dict
+    cfg = HeadConfig()
+    sd = make_state_dict(cfg, seed=17, head_gain=4.0)
+    batches = [make_scene_batch(cfg, (6, 5, 7, 4), seed=90 + k, connect_frac=0.5) for k in range(2)]
+    runs = []
+    for fused in (True, False):
+        with E.tuning(fused_sgd=fused):
+            model = BayesianRelationClassifier(cfg.args(run_mode="train")).cuda()
+            model.load_state_dict(sd)
+            model.eval()
+            opt = D.ShardedSGD(model.named_parameters(), 1, 0, lr=2e-5, momentum=0.9, weight_decay=1e-4).attach(model)
+            assert opt.fc1_gemm_order == fused
+            opt.zero_grad()
+            for b in batches:
+                train_minibatch(model, b, optimizer=None, reducer=opt, workspace_budget=2.5e8)
+                assert len(model.last_image_groups) > 1
+                assert not model.engine().fc1_grad_gemm_order          # the switch is back off once the call returns
+            opt.step()
+            torch.cuda.synchronize()
+            runs.append({n: p.detach().clone() for n, p in model.named_parameters()})
+            del model, opt
+            torch.cuda.empty_cache()
+    for n in runs[0]:
+        assert torch.equal(runs[0][n], runs[1][n]), n
+    assert not torch.equal(runs[0]["fc1.weight"], sd["fc1.weight"].cuda())
+    with pytest.raises(ValueError):
+        model = BayesianRelationClassifier(cfg.args(run_mode="train")).cuda()
+        from scene_graph_commonsense_amd.optim import FusedSGD
+        red = D.ShardedSGD(model.named_parameters(), 1, 0, lr=2e-5).attach(model)
+        train_minibatch(model, batches[0], FusedSGD(model.parameters(), lr=2e-5), reducer=red)
