@@ -181,6 +181,29 @@ def expansion_bytes(pixrect, sub, obj, n_obj, bf16_copy):
     return live * (1024 + 256 + (1024 if bf16_copy else 0)) + reads, live
 
 
+def window_gemm_bytes(key, n_list, e_obj, live_rows, n_ps):
+    """ALGORITHMIC HBM bytes of one launch of a GEMM over the listed windows (what ``roofline.traffic`` is to be compared with; the
+    units are stated in DESIGN.md 7): every operand byte read once, every result byte written once.
+      conv3_fwd_windows:   the distinct z rows under the listed windows' 4 x 4 patches (1 KiB f16 each; ``live_rows`` of the real pairs
+                           from the expansion's pixel rectangles, at most 16 per per-object window / 256 per pseudo-pair map) + the 9.4 MB
+                           of weights; per listed window 2 KiB pooled y (f16) + 2 KiB bf16 copy + 1 KiB routing bytes written.
+      conv3_dgrad_windows: per listed window of the sparse launch 4 masked pooled rows of 2 KiB + 4 x 256 B index words read, 16 patch
+                           rows of 1 KiB written; 42 MB of weights.
+      conv3_wgrad_windows: per listed window of the sparse launch 16 patch rows of 1 KiB + 4 KiB packed gradient + 512 B index words
+                           read; the 18.9 MB f32 result written once (its split-K slabs are not algorithmic)."""
+    e_real = max(n_list - e_obj, 0)
+    if key == "conv3_fwd_windows":
+        rows = (live_rows if live_rows is not None else e_real * 16) + min(e_obj * 16, n_ps * 256)
+        return int(rows * 1024 + 1024 * 4608 * 2 + n_list * 5120)
+    if key == "conv3_dgrad_windows":
+        e = (e_real // 256) * 256
+        return int(e * (4 * 2048 + 4 * 256 + 16 * 1024) + 20 * 512 * 2048 * 2)
+    if key == "conv3_wgrad_windows":
+        e = (e_real // 16) * 16
+        return int(e * (16 * 1024 + 4096 + 512) + 1024 * 4608 * 4)
+    return None
+
+
 def scale_boxes(batch, factor):
     """Boxes of a synthetic minibatch scaled about their centres and clipped to the 32x32 grid (>= 100: the whole image).  The
     reference's cost does not depend on the boxes (``model.py:138-150`` runs every pixel of every pair); this implementation's does
@@ -465,6 +488,26 @@ def run_rank(args):
                                 "peak_memory_gb": round(r["peak_gb"], 1),
                                 "step_frac": round(sum(fl.values()) / (r["dt"] / 2) / 1e12 / MFMA_PEAK_TFLOPS, 4)})
 
+    # ---- the same step with every sharing identity off (SGC_SHARED_LEVEL=0: conv3 / fc1 per pair over whole maps): the ONLY form whose
+    # multiply-adds are SURVEY 8d's 8.99 GFLOP per ordered pair, so its rate is what "fraction of the MFMA peak on the survey's flop
+    # count" honestly means (``survey_equivalent_tflops`` of the headline exceeds the peak because most of that work is not executed)
+    survey_pass = None
+    if world == 1 and not args.no_sensitivity and not args.forward_only and args.box_scale == 1.0 and args.box_dist == "survey" \
+            and (args.streams or 1) == 1 and args.images * args.objects <= 1024:
+        eng.ws.bufs.clear()
+        model._weights_version = None
+        torch.cuda.empty_cache()
+        with _engine_mod.tuning(shared_conv3=False, shared_fc1=False, shared_objects=False, shared_linear=False, shared_conv2=False):
+            r0 = measure(batch, 2, 1)
+        survey_pass = {"ms_per_step": round(r0["dt"] / 2 * 1e3, 2), "pairs_per_s": round(r0["P"] * 2 / r0["dt"], 1),
+                       "survey_flops_step_frac": round(r0["P"] * 8.99e9 / (r0["dt"] / 2) / 1e12 / MFMA_PEAK_TFLOPS, 4),
+                       "peak_memory_gb": round(r0["peak_gb"], 1),
+                       "note": "two steps (after one warm-up) of the same minibatch on the per-pair kernels, every restructuring identity off; "
+                               "8.99 GFLOP per ordered pair (SURVEY 8d) / step time / 2.5 PFLOP/s"}
+        eng.ws.bufs.clear()
+        model._weights_version = None
+        torch.cuda.empty_cache()
+
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = P * world * args.steps / dt
@@ -502,10 +545,13 @@ def run_rank(args):
             names, what = WINDOW_GEMMS[key]
             ach = flops[key] / (ms * 1e-3) / 1e12
             traffic, rocprof_ms, tag = pmc_traffic(names) if (P == 32256 and args.box_scale == 1.0 and args.dataset == "vg") else (None, None, None)
+            alg = window_gemm_bytes(key, n_list, m["linear"][1] if m["linear"] else 0, m["exp_bytes"][1] if m.get("exp_bytes") else None,
+                                    2 * args.objects * args.images)
             return {"bound": "mfma", "kernel": "%s: %d listed windows x 4 pixels x 1024 x 4608 (the pair-specific windows of the %d per-pair windows + "
                                                "the per-object windows; the rest is shared)" % (what, n_list, P * 64),
                     "timer": key, "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
-                    "traffic": traffic,
+                    "traffic": traffic, "algorithmic_bytes": alg,
+                    "traffic_over_algorithmic": None if not (traffic and alg) else round(traffic / alg, 2),
                     "traffic_note": "bytes/launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from profiles/%s_pmc_{f,w}.csv (separate rocprofv3 --pmc passes "
                                     "at this workload)" % tag,
                     "ms_per_launch": round(ms, 3), "ms_source": source, "executed_tflop": round(flops[key] / 1e12, 3),
@@ -570,6 +616,8 @@ def run_rank(args):
             # SURVEY 8d priced the path at 2.996 (fwd) / 8.99 (fwd+bwd) GFLOP per ordered pair, taking conv3 / fc1 per pair as
             # irreducible; with the shared windows most of that is no longer executed, so this is an equivalence, not a rate
             "survey_equivalent_tflops": round(value / max(world, 1) * (2.996e9 if args.forward_only else 8.99e9) / 1e12, 1),
+            "survey_flops_pass": survey_pass,
+            "survey_flops_step_frac": None if survey_pass is None else survey_pass["survey_flops_step_frac"],
             "shared_windows": None if xw is None else {"pair_specific": n_x, "of": P * 64, "fraction": round(n_x / max(P * 64, 1), 4),
                                                        "combined_not_convolved": m["linear"][0] if m["linear"] else 0,
                                                        "note": "conv3 and fc1 run per pair only on these pooling windows; the rest is computed "

@@ -67,6 +67,17 @@ def test_bench_single_rank_line(capsys, monkeypatch):
     fr = [out["shared_windows"]["fraction"]] + [s["pair_specific_fraction"] for s in sens[3:]]
     assert fr == sorted(fr) and fr[-1] == 1.0 and sens[-1]["path"].startswith("per-pair")
     assert all(s["ms_per_step"] > 0 and s["peak_memory_gb"] > 1 for s in sens)
+    # self-auditing fields: algorithmic bytes beside the counter traffic for all three window GEMMs, and the step
+    # with every identity off priced on SURVEY 8d's own flop count - the honest counterpart of ``survey_equivalent_tflops``
+    for r in rk:
+        assert r["algorithmic_bytes"] > 1e9
+        if r["traffic"]:
+            assert r["traffic_over_algorithmic"] == round(r["traffic"] / r["algorithmic_bytes"], 2) and r["traffic_over_algorithmic"] >= 0.9
+    assert roof["algorithmic_bytes"] > 1e9
+    sp = out["survey_flops_pass"]
+    assert 0.2 < out["survey_flops_step_frac"] < 1 and out["survey_flops_step_frac"] == sp["survey_flops_step_frac"]
+    assert sp["ms_per_step"] > 3 * out["ms_per_step"]                  # the per-pair form is several times slower than the shipped step
+    assert out["survey_equivalent_tflops"] > 0
 
 
 def test_bench_refuses_a_world_size_that_is_not_gpus(capsys, monkeypatch):
