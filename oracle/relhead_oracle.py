@@ -87,18 +87,26 @@ def routed_relu_pool(c: Tensor, code: Tensor) -> Tensor:
 
 
 def conv_trunk(sd: Dict[str, Tensor], h_sub: Tensor, h_obj: Tensor, drop1: Optional[Tensor] = None,
-               routes: Optional[dict] = None) -> Tensor:
+               routes: Optional[dict] = None, capture: Optional[dict] = None) -> Tensor:
     """``routes`` (test hook, see ``routed_relu_pool``): dict(pool2 [b,512,16,16], pool3 [b,1024,8,8] window codes,
-    relu1 [b,4096] 0/1 pass mask of fc1's ReLU)."""
+    relu1 [b,4096] 0/1 pass mask of fc1's ReLU).  ``capture`` (test hook): dict that receives the PRE-activations in front of the
+    three routing decisions (conv2 / conv3 outputs before ReLU + max-pool, fc1 output before its ReLU), detached - how the tests
+    show that every route the device takes differently lies within the forward tolerance of the decision boundary."""
     a = torch.tanh(F.conv2d(h_sub, sd["conv1_1.weight"], sd["conv1_1.bias"]))
     b = torch.tanh(F.conv2d(h_obj, sd["conv1_2.weight"], sd["conv1_2.bias"]))
     h = torch.cat((a, b), dim=1)
     h = F.conv2d(h, sd["conv2_1.weight"], sd["conv2_1.bias"], padding=1)
+    if capture is not None:
+        capture["pool2"] = h.detach()
     h = F.max_pool2d(F.relu(h), 2, 2) if routes is None else routed_relu_pool(h, routes["pool2"])
     h = F.conv2d(h, sd["conv3_1.weight"], sd["conv3_1.bias"], padding=1)
+    if capture is not None:
+        capture["pool3"] = h.detach()
     h = F.max_pool2d(F.relu(h), 2, 2) if routes is None else routed_relu_pool(h, routes["pool3"])
     h = h.reshape(h.shape[0], -1)
     h = F.linear(h, sd["fc1.weight"], sd["fc1.bias"])
+    if capture is not None:
+        capture["relu1"] = h.detach()
     h = F.relu(h) if routes is None else h * routes["relu1"]
     if drop1 is not None:          # injected dropout mask already scaled by 1/(1-p)
         h = h * drop1
@@ -127,13 +135,16 @@ def bayes_head(sd: Dict[str, Tensor], p: Tensor, T=(1.0, 1.0, 1.0)):
 def classifier_forward(sd: Dict[str, Tensor], h_sub: Tensor, h_obj: Tensor, c1: Tensor, c2: Tensor, s1, s2,
                        num_classes: int = 150, num_super: int = 17, hierarchical: bool = True,
                        drop1: Optional[Tensor] = None, drop2: Optional[Tensor] = None, T=(1.0, 1.0, 1.0),
-                       routes: Optional[dict] = None):
+                       routes: Optional[dict] = None, capture: Optional[dict] = None):
     """Hierarchical: (rel1, rel2, rel3, super, connectivity[b,1], hidden[b,512]).
     Flat: (relation[b,R] raw logits, connectivity[b,1], hidden).
-    ``drop1``/``drop2``: injected dropout masks (already scaled); ``routes``: injected ReLU/max-pool routing (tests only)."""
-    h = conv_trunk(sd, h_sub, h_obj, drop1, routes)
+    ``drop1``/``drop2``: injected dropout masks (already scaled); ``routes``: injected ReLU/max-pool routing (tests only);
+    ``capture``: see ``conv_trunk`` (+ ``relu2``: fc2's output before its ReLU)."""
+    h = conv_trunk(sd, h_sub, h_obj, drop1, routes, capture)
     hc = concat_labels(h, c1, c2, s1, s2, num_classes, num_super)
     p = F.linear(hc, sd["fc2.weight"], sd["fc2.bias"])
+    if capture is not None:
+        capture["relu2"] = p.detach()
     p = F.relu(p) if routes is None else p * routes["relu2"]
     if drop2 is not None:
         p = p * drop2
@@ -319,7 +330,8 @@ def run_pair_loop(sd: Dict[str, Tensor], batch, cfg, mode: str = "eval", evaluat
                 bs, bo = (bb_g, bb_e) if first else (bb_e, bb_g)
                 inj = call_hook(len(records), len(keep)) if call_hook is not None else {}
                 out = classifier_forward(sd, hs, ho, cs, co, ss, so, cfg.num_classes, cfg.num_super_classes, hier,
-                                         drop1=inj.get("drop1"), drop2=inj.get("drop2"), routes=inj.get("routes"))
+                                         drop1=inj.get("drop1"), drop2=inj.get("drop2"), routes=inj.get("routes"),
+                                         **({"capture": inj["capture"]} if "capture" in inj else {}))
                 if hier:
                     r1, r2, r3, sup, conn, hidden = out
                     relation = torch.cat((r1, r2, r3), dim=1)

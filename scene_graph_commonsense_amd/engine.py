@@ -185,11 +185,10 @@ class Tuning:
     weight_kernels: bool = True       # 16-bit weight layouts by one gather + cast launch each (off: torch view / permute / flip / cat chains)
     fc1_own_sums: bool = True         # fc1 assembly reads S'_j[R_j] pre-summed per object (off: four corner vectors per pair; same bits)
     sparse_wgrad: bool = True         # conv3 weight gradient over the real pairs' listed windows on the sparse matrix cores (off: dense block)
-    fc1_x16: bool = False             # fc1's pair-specific products leave the grouped GEMM as f16 rows (the per-object rows stay f32): -0.8 ms
-                                      # per step and hidden error 7.0e-4 -> 7.03e-4, but one more rounding in front of fc1's ReLU: in the
-                                      # reference's small fixtures it flips single fc2 units (vg_flat: 18 pairs, one of 512 rows = 4.4e-2 of
-                                      # fc2's gradient) and the un-routed gradient fingerprints leave their 6e-2 bar - off by default
-                                      # (profiles/r05_fc1_x16_ab.txt)
+    fc1_x16: bool = True              # fc1's pair-specific products leave the grouped GEMM as f16 rows (the per-object rows stay f32): -0.8 ms
+                                      # per step, hidden error 7.0e-4 -> 7.03e-4 (profiles/r05_fc1_x16_ab.txt).  One more rounding in front of
+                                      # fc1's ReLU: like every other one it flips units whose pre-activation is within the forward tolerance of
+                                      # zero (held per unit by tests/test_backward_gpu.py::test_backward_matches_reference_fingerprints)
     assemble_by_subject: bool = True  # fc1 assembly walks the pairs sorted by subject (the subject's prefix table stays in the L2s; same bits)
     conv2_bwd_regions: bool = True    # conv2 data gradient only on the cells where an object's gradient can be non-zero (its pseudo-pair's pixel
                                       # rectangle + 1 cell; off: whole 32x32 maps; same bits)

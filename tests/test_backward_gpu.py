@@ -90,20 +90,55 @@ def test_backward_matches_oracle(hier):
         assert float(a @ b / (a.norm() * b.norm())) >= 0.997, k
 
 
+@pytest.mark.oracle_heavy
 @pytest.mark.parametrize("name", ["vg_full", "vg_flat", "oiv6_full"])
 def test_backward_matches_reference_fingerprints(name):
+    """The device's gradients against the fingerprints stored from the REAL reference (L2 norm + 509 strided samples per tensor), with
+    a bound that is derived in the test instead of calibrated (``profiles/r06_backward_attribution.txt``: an
+    exact float64 backward behind the f16 forward is already 2.6-4.5e-2 away on ``vg_full`` - routing flips, not arithmetic).  The chain:
+
+      (a) the oracle WITHOUT injected routes reproduces the stored samples (it is the reference; 1e-3 as in ``tests/test_oracle_golden.py``:
+          two f32 runs of one graph on different hosts / thread counts);
+      (b) every routing decision the device takes differently from the oracle lies within the forward tolerance of its decision boundary
+          (``train_case.route_flip_margins``: |pre-activation| <= 1e-3 of the layer's scale for a ReLU, the routed value within 2e-3 of the
+          window's maximum for a max-pool) - the forward parity statement of ``BASELINE.json`` applied to the routes;
+      (c) with those routes injected the oracle's gradient and the device's agree to the ARITHMETIC bound (5e-3; 7e-3 under conv3) on the
+          same samples and norms;
+      (d) therefore device vs stored fingerprint <= (c) + the distance the justified flips of (b) put between the oracle's two runs:
+          asserted as such - the un-routed distance itself (printed) needs no bar of its own, and a single flipped unit of an 18-pair
+          fixture (4.4e-2 of fc2's gradient) no longer decides whether an exact kernel change may ship."""
+    from tests.train_case import FORWARD_TOL, oracle_train, route_flip_margins, run_train_gpu
     cfg, sd, batch, gold = load_case(name)
-    loss, grads = run_train(cfg, sd, batch)
+    loss, grads, routes, sc = run_train_gpu(cfg, sd, batch, keep_ctx=True)
     assert abs(loss - gold["train_loss"][0]) <= 2e-3 * abs(gold["train_loss"][0])
+    pre = {}
+    _, g_ref, _ = oracle_train(cfg, sd, batch, sc, capture=pre)
+    _, g_routed, _ = oracle_train(cfg, sd, batch, sc, routes=routes)
+    margins = route_flip_margins(pre, routes)
+    print(name, {k: "%d of %d flipped, worst margin %.1e" % v for k, v in margins.items()})
+    for kind, (n_flip, n_all, worst) in margins.items():
+        assert worst <= (2 if kind.startswith("pool") else 1) * FORWARD_TOL, (kind, n_flip, worst)          # (b)
+        assert n_flip <= 0.01 * n_all, (kind, n_flip, n_all)
+    report = {}
     for k, g in grads.items():
         key = k.replace(".", "__")
-        flat = g.flatten()
-        stride = max(1, flat.numel() // 509)
-        ref_l2 = gold["grad_l2__" + key][0]
-        assert abs(float(flat.double().norm()) - ref_l2) <= _tol(k) * ref_l2, (k, float(flat.norm()), ref_l2)
-        samp, ref = flat[::stride][:509].double().numpy(), gold["grad_sample__" + key].astype(np.float64)
-        err = np.linalg.norm(samp - ref) / max(np.linalg.norm(ref), 1e-30)
-        assert err <= SAMPLE_TOL(k), (k, err)
+        stride = max(1, g.numel() // 509)
+        take = lambda t: t.flatten()[::stride][:509].double().numpy()
+        ref, ref_l2 = gold["grad_sample__" + key].astype(np.float64), float(gold["grad_l2__" + key][0])
+        nref = max(np.linalg.norm(ref), 1e-30)
+        d_host = np.linalg.norm(take(g_ref[k]) - ref) / nref
+        assert d_host <= 1e-3, (k, d_host)                                                                        # (a)
+        tol = _routed_tol(k) if _tol(k) == GRAD_TOL else HEAD_TOL
+        arith = np.linalg.norm(take(g) - take(g_routed[k])) / nref
+        assert arith <= 2 * tol, (k, arith)                       # (c) on 509 samples (twice the whole-tensor bound: a sample's share of the error fluctuates)
+        assert _fro(g, g_routed[k]) <= tol, (k, _fro(g, g_routed[k]))                                            # (c) whole tensor
+        d_route = np.linalg.norm(take(g_routed[k]) - ref) / nref
+        err = np.linalg.norm(take(g) - ref) / nref
+        assert err <= 2 * tol + d_route + 1e-4, (k, err, d_route)                                                 # (d): triangle inequality
+        d_l2 = _fro(g_routed[k], g_ref[k])
+        assert abs(float(g.double().norm()) - ref_l2) <= (tol + d_l2 + 1e-4) * ref_l2, (k, float(g.norm()), ref_l2)
+        report[k] = "%.1e (flips %.1e, arithmetic %.1e)" % (err, d_route, arith)
+    print(report)
 
 
 def _aug_features(batch, seed):

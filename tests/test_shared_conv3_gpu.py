@@ -217,19 +217,24 @@ def test_fc1_over_window_major_rows_matches_the_one_gemm_form(nobj, edge):
         for ws in (eng.ws, eng.scratch):
             if name in ws.bufs:
                 ws.bufs[name].view(torch.int16).fill_(0x7E00 if name in ("h1", "ywm", "oxh") else -1)      # NaN bit patterns
-    o1, h1 = _with_env({"SGC_SHARED_FC1": "1"}, run)
+    from scene_graph_commonsense_amd import engine as _engine
+    with _engine.tuning(fc1_x16=False):                        # every product row f32 (the form of rounds 3-5)
+        o1, h1 = _with_env({"SGC_SHARED_FC1": "1"}, run)
     assert torch.isfinite(h1).all()
     # second level (pseudo-pairs computed on their own windows only, the rest from the images' background maps): the same bits
-    o2, h2 = _with_env({"SGC_SHARED_FC1": "1", "SGC_SHARED_OBJECTS": "0"}, run)
+    with _engine.tuning(fc1_x16=False):
+        o2, h2 = _with_env({"SGC_SHARED_FC1": "1", "SGC_SHARED_OBJECTS": "0"}, run)
     assert torch.equal(h1, h2) and torch.equal(o1.relation, o2.relation) and torch.equal(o1.cand_pred, o2.cand_pred)
     scale = float(h0.abs().max())
     assert float((h1 - h0).abs().max()) <= 2e-3 * scale, (float((h1 - h0).abs().max()), scale)     # one f16 ulp at the top of the range
     assert float((h1 - h0).norm() / h0.norm().clamp(min=1e-30)) <= 2e-4
-    # engine.TUNING.fc1_x16 (off by default): the pair-specific products pass through f16 rows - ~7 of a pair's ~20 addends carry 2^-12
-    # each before the sum's own f16 rounding; measured 2.2e-4 here against 1.6e-4 with f32 rows
-    from scene_graph_commonsense_amd import engine as _engine
-    with _engine.tuning(fc1_x16=True):
-        o3, h3 = _with_env({"SGC_SHARED_FC1": "1"}, run)
+    # engine.TUNING.fc1_x16 (the default since round 6): the pair-specific products pass through f16 rows - ~7 of a pair's ~20 addends
+    # carry 2^-12 each before the sum's own f16 rounding; measured 2.2e-4 here against 1.6e-4 with f32 rows
+    assert _engine.TUNING.fc1_x16
+    o3, h3 = _with_env({"SGC_SHARED_FC1": "1"}, run)
+    with _engine.tuning(shared_objects=False):
+        o4, h4 = _with_env({"SGC_SHARED_FC1": "1"}, run)
+    assert torch.equal(h3, h4) and torch.equal(o3.relation, o4.relation)
     assert torch.isfinite(h3).all()
     assert float((h3 - h0).abs().max()) <= 2e-3 * scale
     assert float((h3 - h0).norm() / h0.norm().clamp(min=1e-30)) <= 3e-4

@@ -98,16 +98,22 @@ def device_routes(ctx, rows=None):
     return dict(pool2=pool2, pool3=pool3, relu1=relu1, relu2=relu2)
 
 
-def oracle_train(cfg, sd, batch, scene, dropout_seeds=None, routes=None):
-    """Oracle loss + autograd gradients; ``dropout_seeds`` injects the kernels' keep masks (x2), ``routes`` the device routing."""
+def oracle_train(cfg, sd, batch, scene, dropout_seeds=None, routes=None, capture=None):
+    """Oracle loss + autograd gradients; ``dropout_seeds`` injects the kernels' keep masks (x2), ``routes`` the device routing.
+    ``capture`` (a dict): filled with the oracle's PRE-activations in front of its four routing decisions, one row per ordered pair in
+    pair order - pool2 [P,512,32,32], pool3 [P,1024,16,16], relu1 [P,4096], relu2 [P,512] (``route_flip_margins``)."""
     from oracle import relhead_oracle as O
     from scene_graph_commonsense_amd.synthetic import dropout_keep_mask, predicate_counts
     start = np.concatenate([[0], np.cumsum(scene.pidx.call_sizes)])
+    caps = []
 
     def hook(t, b):
         r0 = int(start[t])
         assert int(start[t + 1]) - r0 == b
         inj = {}
+        if capture is not None:
+            caps.append({})
+            inj["capture"] = caps[-1]
         if dropout_seeds is not None:
             inj["drop1"] = torch.from_numpy(dropout_keep_mask(dropout_seeds[0], b, 4096, r0)).float() * 2
             inj["drop2"] = torch.from_numpy(dropout_keep_mask(dropout_seeds[1], b, 512, r0)).float() * 2
@@ -118,11 +124,50 @@ def oracle_train(cfg, sd, batch, scene, dropout_seeds=None, routes=None):
     sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
     out = O.run_pair_loop(sdr, batch, cfg, mode="train", weights=O.class_weights(predicate_counts(cfg)), call_hook=hook)
     out["losses"].backward()
+    if capture is not None:
+        for kind in ("pool2", "pool3", "relu1", "relu2"):
+            capture[kind] = torch.cat([c[kind] for c in caps])
     return float(out["losses"]), {k: p.grad for k, p in sdr.items()}, out
 
 
 def fro(a, b):
     return float((a.double() - b.double()).norm() / max(b.double().norm(), 1e-30))
+
+
+FORWARD_TOL = 1e-3          # BASELINE.json north_star: forward values within 1e-3 relative
+
+
+def route_flip_margins(pre, routes, keep1=None, keep2=None):
+    """How far from its decision boundary is every routing decision the device takes differently from the reference?
+
+    ``pre``: the oracle's pre-activations (``oracle_train(capture=...)``), ``routes``: the device's decisions (``device_routes``).
+    A ReLU unit the device passes and the reference kills (or the other way round) is a legitimate outcome of a forward that is
+    within the tolerance only if the reference's pre-activation lies within that tolerance of zero; a max-pool window routed to another
+    position only if the reference's value there is within (twice) the tolerance of the window's maximum.  Returns per decision kind
+    (flipped, total, worst margin / max |pre-activation| of the layer): the worst margin is what a test holds against ``FORWARD_TOL``
+    (ReLU) or 2 x ``FORWARD_TOL`` (arg-max: a difference of two values).  ``keep1`` / ``keep2``: dropout keep masks (bool [P,4096] /
+    [P,512]) - a dropped unit reads as "not passed" on the device whatever its pre-activation was, so it is not a decision."""
+    out = {}
+    for kind in ("pool2", "pool3"):
+        c = pre[kind].double()
+        Pn, C, H, W = c.shape
+        win = c.reshape(Pn, C, H // 2, 2, W // 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(Pn, C, H // 2, W // 2, 4)
+        m, am = win.max(dim=4)
+        own = torch.where(m > 0, am, torch.full_like(am, 4))
+        dev = routes[kind].long()
+        at_dev = torch.gather(win, 4, dev.clamp(max=3).unsqueeze(-1)).squeeze(-1)
+        # device killed the window: right if the maximum is <= 0; device routed to q: right if win[q] is the maximum and > 0
+        margin = torch.where(dev == 4, m.clamp(min=0), torch.maximum(m - at_dev, (-at_dev).clamp(min=0)))
+        flipped = (own != dev) & (margin > 0)             # equal maxima at two positions: either choice is the reference's
+        out[kind] = (int(flipped.sum()), flipped.numel(), float(margin[flipped].max() / c.abs().max()) if bool(flipped.any()) else 0.0)
+    for kind, keep in (("relu1", keep1), ("relu2", keep2)):
+        x = pre[kind].double()
+        dev = routes[kind].bool()
+        flipped = (x > 0) != dev
+        if keep is not None:
+            flipped &= torch.as_tensor(keep, dtype=torch.bool)
+        out[kind] = (int(flipped.sum()), flipped.numel(), float(x[flipped].abs().max() / x.abs().max()) if bool(flipped.any()) else 0.0)
+    return out
 
 
 def routed_model_step(model, scene, batch, step_kw=None, oracle_kw=None, aug=None):
