@@ -170,6 +170,12 @@ int sgc_windows_wgrad_patch(const void* dy3x, const void* zpatch, float* slabs, 
  * pack_ac (n_entries/16 * 64 KiB) / pack_ic (n_entries/16 * 8 KiB): scratch for the packed operand. */
 int sgc_windows_wgrad_patch_sparse(const void* dywm, const unsigned char* argmax, const int* gather, const int* dest, int n_entries,
                                    const void* zpatch, void* pack_ac, void* pack_ic, float* slabs, int splits, int* n_slabs, void* stream);
+/* ... with the second operand gathered from the forward's f16 maps z_pad_f16 [pairs][18][18][512] through the window list inside the GEMM
+ * block (no patch copy of these windows; f16 -> bf16 in registers: the same bits as sgc_windows_im2patch_f16 + the call above), and the
+ * patch copy of a TAIL of the list (entries e0 .. e0 + entries - 1, zpatch row 0 = entry e0) for the dense block behind it. */
+int sgc_windows_wgrad_gather_sparse(const void* dywm, const unsigned char* argmax, const int* gather, const int* dest, int n_entries,
+                                    const void* z_pad_f16, void* pack_ac, void* pack_ic, float* slabs, int splits, int* n_slabs, void* stream);
+int sgc_windows_im2patch_f16_from(const void* z_pad_f16, const int* gather, const int* gather_n, int e0, int entries, void* zpatch, void* stream);
 int sgc_windows_dgrad_cols(const void* dy3x, const void* w3col, void* col, int rows, void* stream);
 int sgc_windows_col2im(const void* col, const int* bbox, const int* sub_idx, const int* obj_idx, const int* count_incl, int n_pairs,
                        void* dz, void* stream);

@@ -165,6 +165,14 @@ __global__ __launch_bounds__(512) void unpool_pack_kernel(const u16* __restrict_
 // pixel kr of window kl >> 2 + tap at fixed per-lane offsets) instead of whole padded maps - the conv3 weight gradient over the
 // listed windows (csrc/kernels_shared.hip); the A operand is packed from the listed windows' pooled gradient rows by
 // windows_sparse_pack_kernel.
+// PATCH = 2 (round 6): the same product with NO patch copy - the rows of B come straight from the forward's f16 maps
+// z [pair][18][18][512] through the window list (p.gather[e] = pair * 64 + window).  A wave's load instruction covers ONE window (rows
+// kl = 4 (2 wid + q) .. + 3 of the K tile), so the window's base is wave-uniform: its list entry is fetched by a SCALAR load one K tile
+// ahead of the stage that needs it (requested before the tile's first counted wait, consumed behind it - round 3's gathered TN block
+// fetched it inside the stage and stalled there, 11.0 against 8.3 ms), the per-lane part (own pixel + tap on the 18-pixel pitch, column)
+// is fixed.  The maps are f16 and the instruction is bf16: a fragment is converted in registers (f16 -> f32 -> bf16, round to nearest
+// even: exactly what windows_im2patch_kernel<true> did on the way to the patch buffer - same bits) on the vector pipes, which this
+// operand-starved block leaves idle.  Deletes the 3.7 GB patch buffer and its 1.0 ms copy pass for the sparse part of the list.
 template <int PATCH = 0>
 __global__ __launch_bounds__(512, 2) void gemm_tn_sp_kernel(const TnParams p, const u16* __restrict__ Ac, const unsigned* __restrict__ Ic) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -214,14 +222,40 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_sp_kernel(const TnParams p, co
             const int tap = tap_raw > 8 ? 8 : tap_raw;
             const int ky = tap / 3, kx = tap - 3 * ky;
             long b;
-            if constexpr (PATCH) b = (long)((kl >> 2) * 16 + ((kr >> 1) + ky) * 4 + (kr & 1) + kx) * p.Cin + (col - tap_raw * p.Cin);
+            if constexpr (PATCH == 2) b = (long)(((kr >> 1) + ky) * 18 + (kr & 1) + kx) * p.Cin + (col - tap_raw * p.Cin);     // + the window's base (stage)
+            else if constexpr (PATCH == 1) b = (long)((kl >> 2) * 16 + ((kr >> 1) + ky) * 4 + (kr & 1) + kx) * p.Cin + (col - tap_raw * p.Cin);
             else b = conv_row_base(kl, p.lgS, p.Cin) + (long)(ky * ((1 << p.lgS) + 2) + kx) * p.Cin + (col - tap_raw * p.Cin);
             b_voff[h][q] = (int)((b + c8) * 2);
         }
     }
+    // PATCH == 2: bases of the two windows (q = 0, 1) this wave stages for the K tile whose B halves are issued next
+    const u16* gwin[2] = {p.B, p.B};
+    // The request is a scalar load by hand: inside the loop the compiler turns the plain C++ load into a VECTOR global_load (the LDS-DMA
+    // loads count as possible writers), which would join the in-order vmcnt queue the counted waits below are written against.  Issued
+    // right in front of close(), whose own s_waitcnt lgkmcnt(0) is the wait for it (nothing may be scheduled between the two volatile
+    // statements that could copy the destination registers before the data has landed).
+    auto window_codes = [&](int it) __attribute__((always_inline)) {
+        const int* src = p.gather + (long)(kt_begin + it) * 16 + wid * 2;
+        unsigned long long v;
+        asm volatile("s_load_dwordx2 %0, %1, 0x0" : "=s"(v) : "s"(src) : "memory");
+        return v;
+    };
+    auto window_bases = [&](unsigned long long code) __attribute__((always_inline)) {
+        asm volatile("" : "+s"(code));                                         // ordered behind the wait (volatile statements keep their order)
+        const int c0 = (int)(unsigned)code, c1 = (int)(unsigned)(code >> 32);
+        gwin[0] = p.B + ((long)((c0 >> 6) * 18 + 2 * ((c0 >> 3) & 7)) * 18 + 2 * (c0 & 7)) * 512;
+        gwin[1] = p.B + ((long)((c1 >> 6) * 18 + 2 * ((c1 >> 3) & 7)) * 18 + 2 * (c1 & 7)) * 512;
+    };
     auto stage = [&](int kind, int it) __attribute__((always_inline)) {      // kind 0 A0, 1 B0, 2 B1, 3 A1
         char* base = smem + (((it & 1) << 2) + kind) * HT;
         const int kt = kt_begin + it;
+        if constexpr (PATCH == 2) {
+            if (kind == 1 || kind == 2) {
+                buf_load_lds16(gwin[0], b_voff[kind - 1][0], 0, base + wid * 2048);
+                buf_load_lds16(gwin[1], b_voff[kind - 1][1], 0, base + wid * 2048 + 1024);
+                return;
+            }
+        }
         if (kind == 0 || kind == 3) {
             const int h = kind ? 1 : 0;
             buf_load_lds16(reinterpret_cast<const char*>(Ac) + (long)kt * (1024 * 64), a_voff[h], 0, base + wid * 1024);
@@ -276,6 +310,15 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_sp_kernel(const TnParams p, co
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // PATCH == 2: the B fragments arrive as f16 (the forward's maps): once per K tile (half 0: both halves of the tile use them) every
+    // fragment is converted f16 -> f32 -> bf16 in place, the (j, s) pair just ahead of its first instruction
+    auto to_bf16 = [&](s16x8& v) __attribute__((always_inline)) {
+        const unsigned* w = reinterpret_cast<const unsigned*>(&v);
+        unsigned o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = f32x2_to_bf16x2_bits(f16_bits_to_f32((u16)(w[k] & 0xffffu)), f16_bits_to_f32((u16)(w[k] >> 16)));
+        v = __builtin_bit_cast(s16x8, *reinterpret_cast<const uint4*>(o));
+    };
     auto half = [&](int a) __attribute__((always_inline)) {
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -284,6 +327,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_sp_kernel(const TnParams p, co
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
+                    if constexpr (PATCH == 2) {
+                        if (a == 0 && i == 0) { to_bf16(bfr[j][s][0]); to_bf16(bfr[j][s][1]); }
+                    }
                     const bf16x8_sp av = __builtin_bit_cast(bf16x8_sp, af[i][s]);
                     const s16x16_sp_t bw = __builtin_shufflevector(bfr[j][s][0], bfr[j][s][1], 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
                     const bf16x16_sp bv = __builtin_bit_cast(bf16x16_sp, bw);
@@ -294,8 +340,10 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_sp_kernel(const TnParams p, co
     };
 
     if (nk > 0) {
+        if constexpr (PATCH == 2) { const unsigned long long c = window_codes(0); SGC_WAIT_LGKM0(); window_bases(c); }
         stage(0, 0); stage(1, 0); stage(2, 0); stage(3, 0);
         if (nk > 1) {                                  // tile 0 must have landed: the loads of [A0 B0 B1](1) may stay in flight
+            if constexpr (PATCH == 2) { const unsigned long long c = window_codes(1); SGC_WAIT_LGKM0(); window_bases(c); }
             stage(0, 1); stage(1, 1); stage(2, 1);
             if (wid == 0) SGC_WAIT_VM(6); else SGC_WAIT_VM(5);
         } else SGC_WAIT_VM(0);
@@ -313,9 +361,12 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_sp_kernel(const TnParams p, co
     };
     auto tile = [&](int it, int par, auto steady_c) __attribute__((always_inline)) {
         constexpr bool STEADY = decltype(steady_c)::value;
+        unsigned long long codes = 0;
         read_a(0, par); read_b(par);
         if (it + 1 < nk) stage(3, it + 1);
+        if constexpr (PATCH == 2 && STEADY) codes = window_codes(it + 2);      // scalar request; lands during the counted wait of close()
         close(STEADY);
+        if constexpr (PATCH == 2 && STEADY) window_bases(codes);               // behind close()'s lgkmcnt(0): no wait of its own
         half(0);
         read_a(1, par);
         if (STEADY) { stage(0, it + 2); stage(1, it + 2); stage(2, it + 2); }
@@ -413,6 +464,7 @@ template <int PATCH = 0>
 static int launch_gemm_tn_sp(TnParams p, const u16* Ac, const unsigned* Ic, int splits, int* slabs_out, hipStream_t stream) {
     constexpr int LDS = 8 * 16384;
     if (p.M != 1024 || p.N != 9 * 512 || p.Cin != 512 || (!PATCH && p.lgS != 4) || (p.K & 63)) return SGC_ERR_ARG;
+    if (PATCH == 2 && p.gather == nullptr) return SGC_ERR_ARG;
     p.tiles_m = 4; p.tiles_n = 18;
     const int nk = p.K >> 6;
     if (splits <= 0) splits = tn_auto_splits(72, nk);

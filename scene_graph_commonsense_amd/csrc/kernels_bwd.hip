@@ -1058,6 +1058,23 @@ int sgc_windows_wgrad_patch_sparse(const void* dywm, const unsigned char* argmax
     p.ldc = 9 * 512; p.slab_stride = 1024L * 9 * 512; p.lgS = 4; p.Cin = 512; p.CinA = 1024;
     return launch_gemm_tn_sp<1>(p, (const u16*)pack_ac, (const unsigned*)pack_ic, splits, n_slabs, (hipStream_t)stream);
 }
+// The same product with the second operand read straight from the forward's f16 maps z_pad_f16 [pairs][18][18][512] through the window
+// list (gemm_tn_sp_kernel<2>: per-window bases by scalar loads one K tile ahead, f16 -> bf16 in registers): no patch copy of the
+// n_entries windows.  Same bits as sgc_windows_im2patch_f16 + sgc_windows_wgrad_patch_sparse (same conversion, same products, same order).
+// Every one of the n_entries list entries must be a window of a map whose 4 x 4 patch rows are written (the real pairs' windows are).
+int sgc_windows_wgrad_gather_sparse(const void* dywm, const unsigned char* argmax, const int* gather, const int* dest, int n_entries,
+                                    const void* z_pad_f16, void* pack_ac, void* pack_ic, float* slabs, int splits, int* n_slabs, void* stream) {
+    if (n_entries <= 0) { if (n_slabs) *n_slabs = 0; return SGC_OK; }
+    if (n_entries & 15) return SGC_ERR_ARG;
+    const int n_tiles = n_entries / 16;
+    SGC_LAUNCH(windows_sparse_pack_kernel, dim3((unsigned)n_tiles, 8), dim3(256), 0, (hipStream_t)stream, (const u16*)dywm, argmax, gather, dest,
+               n_entries, (u16*)pack_ac, (unsigned*)pack_ic, n_tiles);
+    SGC_CHECK_LAUNCH();
+    TnParams p{};
+    p.A = nullptr; p.B = (const u16*)z_pad_f16; p.C = slabs; p.M = 1024; p.N = 9 * 512; p.K = n_entries * 4;
+    p.ldc = 9 * 512; p.slab_stride = 1024L * 9 * 512; p.lgS = 4; p.Cin = 512; p.CinA = 1024; p.gather = gather;
+    return launch_gemm_tn_sp<2>(p, (const u16*)pack_ac, (const unsigned*)pack_ic, splits, n_slabs, (hipStream_t)stream);
+}
 // ---- expansion / contraction
 int sgc_pair_expand_train(const void* U, const void* V, const int* sub_idx, const int* obj_idx, void* z_pad_f16, void* z_pad_bf16,
                           unsigned char* amz, int n_pairs, void* stream) {

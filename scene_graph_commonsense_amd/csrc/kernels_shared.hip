@@ -357,11 +357,11 @@ __device__ __forceinline__ uint4 f16x8_to_bf16x8(uint4 v) {
 }
 template <bool SRC_F16>
 __global__ __launch_bounds__(256) void windows_im2patch_kernel(const u16* __restrict__ zbf, const int* __restrict__ gather,
-                                                               const int* __restrict__ gather_n, long n_rows, u16* __restrict__ zpatch) {
+                                                               const int* __restrict__ gather_n, long n_rows, u16* __restrict__ zpatch, int e0) {
     const int lane = threadIdx.x & 63;
     const int E = *gather_n;
     for (long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6); row < n_rows; row += (long)gridDim.x * 4) {
-        const int e = (int)(row >> 2), py = (int)(row & 3);
+        const int e = e0 + (int)(row >> 2), py = (int)(row & 3);             // output rows count from entry e0
         uint4 v[4];
         if (e < E) {
             const int g = gather[e];
@@ -1396,7 +1396,7 @@ int sgc_windows_im2patch(const void* z_pad_bf16, const int* gather, const int* g
     if (entries_pad <= 0) return SGC_OK;
     const long rows = (long)entries_pad * 4;
     SGC_LAUNCH(windows_im2patch_kernel<false>, dim3(grid_cap(rows, 4, 262144)), dim3(256), 0, (hipStream_t)stream, (const u16*)z_pad_bf16,
-               gather, gather_n, rows, (u16*)zpatch);
+               gather, gather_n, rows, (u16*)zpatch, 0);
     SGC_CHECK_LAUNCH();
     return SGC_OK;
 }
@@ -1405,7 +1405,17 @@ int sgc_windows_im2patch_f16(const void* z_pad_f16, const int* gather, const int
     if (entries_pad <= 0) return SGC_OK;
     const long rows = (long)entries_pad * 4;
     SGC_LAUNCH(windows_im2patch_kernel<true>, dim3(grid_cap(rows, 4, 262144)), dim3(256), 0, (hipStream_t)stream, (const u16*)z_pad_f16,
-               gather, gather_n, rows, (u16*)zpatch);
+               gather, gather_n, rows, (u16*)zpatch, 0);
+    SGC_CHECK_LAUNCH();
+    return SGC_OK;
+}
+// ... of the entries e0 .. e0 + entries - 1 only (zpatch row 0 = entry e0): the tail of the list behind the windows whose patches the sparse
+// weight gradient gathers itself (sgc_windows_wgrad_gather_sparse)
+int sgc_windows_im2patch_f16_from(const void* z_pad_f16, const int* gather, const int* gather_n, int e0, int entries, void* zpatch, void* stream) {
+    if (entries <= 0) return SGC_OK;
+    const long rows = (long)entries * 4;
+    SGC_LAUNCH(windows_im2patch_kernel<true>, dim3(grid_cap(rows, 4, 262144)), dim3(256), 0, (hipStream_t)stream, (const u16*)z_pad_f16,
+               gather, gather_n, rows, (u16*)zpatch, e0);
     SGC_CHECK_LAUNCH();
     return SGC_OK;
 }

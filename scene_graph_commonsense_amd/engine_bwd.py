@@ -408,6 +408,9 @@ class BackwardMixin:
                 _lib.check(lib.sgc_windows_linear_backward_bg(
                     _lib.ptr(lin["gather"]), _lib.ptr(lin["drow"]), _lib.ptr(lin["order"]), _lib.ptr(lin["seg"]), n_img, _lib.ptr(dy),
                     _lib.ptr(ctx.am), _lib.ptr(dy3_bg), _lib.ptr(bpart_l), st()), "sgc_windows_linear_backward_bg")))
+        # weight gradient of the sparse part with its second operand gathered from the forward's f16 maps (no patch copy): only where the
+        # patch copy would be made from those f16 maps anyway (``zb0``: no bf16 copy of the real pairs' z exists) - the same bits
+        gather_w = bool(TUNING.gather_wgrad and TUNING.patch_wgrad and zb0 and Epad and e_spw >= 4096)
         with side():
             gb = self._slab_sum(bpart, 1024, nparts.value)
             if nparts_x.value:
@@ -429,7 +432,13 @@ class BackwardMixin:
                 # im2col + plain ping-pong TN GEMM.  (Rows of z gathered by the window list inside the GEMM block - no column
                 # buffer, sgc_windows_wgrad_gather - measured 11.0 ms against 8.3 + 2.3 ms: the nine shifted re-reads of the z rows
                 # by different N tiles cost more than the im2col pass; kept in the C-ABI, not used by the step.)
-                if TUNING.patch_wgrad:
+                if gather_w:
+                    # the sparse launch gathers the real pairs' patches itself (gemm_tn_sp_kernel<2>): only the tail of the list behind
+                    # them (per-object entries + the boundary tile, on the dense block) gets a patch copy
+                    zcol = ws.get("zpatch_tail", max(Epad - e_spw, 16) * 16 * 512, torch.bfloat16)
+                    self._timed("im2col_windows", lambda: _lib.check(lib.sgc_windows_im2patch_f16_from(
+                        _lib.ptr(ctx.z), _lib.ptr(gather), _lib.ptr(gn), e_spw, Epad - e_spw, _lib.ptr(zcol), st()), "sgc_windows_im2patch_f16_from"))
+                elif TUNING.patch_wgrad:
                     # PATCH form: the 16 pixels of every listed window's input patch, read by the product at (own pixel + tap)
                     zcol = ws.get("zpatch", Epad * 16 * 512, torch.bfloat16)
                     if zb0:        # no bf16 copy of the real pairs' z: gather the f16 rows of the forward and convert
@@ -479,14 +488,20 @@ class BackwardMixin:
                     pack_a = ws.get("w3x_pack_a", (e_sp // 16) * 1024 * 64, torch.uint8)
                     pack_i = ws.get("w3x_pack_i", (e_sp // 16) * 1024 * 8, torch.uint8)
                     slx = sl[n_slabs * 1024 * 4608:]
-                    self._timed("conv3_wgrad_windows", lambda: _lib.check(lib.sgc_windows_wgrad_patch_sparse(
-                        _lib.ptr(dy), _lib.ptr(ctx.am), _lib.ptr(gather), _lib.ptr(dest), e_sp, _lib.ptr(zcol), _lib.ptr(pack_a), _lib.ptr(pack_i),
-                        _lib.ptr(slx), 0, ctypes.byref(slabs_x), st()), "sgc_windows_wgrad_patch_sparse"))
+                    if gather_w:
+                        self._timed("conv3_wgrad_windows", lambda: _lib.check(lib.sgc_windows_wgrad_gather_sparse(
+                            _lib.ptr(dy), _lib.ptr(ctx.am), _lib.ptr(gather), _lib.ptr(dest), e_sp, _lib.ptr(ctx.z), _lib.ptr(pack_a), _lib.ptr(pack_i),
+                            _lib.ptr(slx), 0, ctypes.byref(slabs_x), st()), "sgc_windows_wgrad_gather_sparse"))
+                    else:
+                        self._timed("conv3_wgrad_windows", lambda: _lib.check(lib.sgc_windows_wgrad_patch_sparse(
+                            _lib.ptr(dy), _lib.ptr(ctx.am), _lib.ptr(gather), _lib.ptr(dest), e_sp, _lib.ptr(zcol), _lib.ptr(pack_a), _lib.ptr(pack_i),
+                            _lib.ptr(slx), 0, ctypes.byref(slabs_x), st()), "sgc_windows_wgrad_patch_sparse"))
                     n_slabs += slabs_x.value
                     if Epad > e_sp:
                         slt = sl[n_slabs * 1024 * 4608:]
+                        ztail = zcol if gather_w else zcol[e_sp * 16 * 512:]
                         self._timed("conv3_wgrad_windows_tail", lambda: _lib.check(lib.sgc_windows_wgrad_patch(
-                            _lib.ptr(dy3x[e_sp * 4 * 1024:]), _lib.ptr(zcol[e_sp * 16 * 512:]), _lib.ptr(slt), (Epad - e_sp) * 4, 0,
+                            _lib.ptr(dy3x[e_sp * 4 * 1024:]), _lib.ptr(ztail), _lib.ptr(slt), (Epad - e_sp) * 4, 0,
                             ctypes.byref(slabs_t), st()), "sgc_windows_wgrad_patch"))
                         n_slabs += slabs_t.value
                 elif Epad:

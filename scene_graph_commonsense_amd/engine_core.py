@@ -186,6 +186,8 @@ class Tuning:
     conv2_bwd_regions: bool = True    # conv2 data gradient only on the cells where an object's gradient can be non-zero (its pseudo-pair's pixel
                                       # rectangle + 1 cell; off: whole 32x32 maps; same bits)
     sparse_dgrad: bool = True         # conv3 data gradient over the real pairs' listed windows on the sparse matrix cores (off: dense patch form)
+    gather_wgrad: bool = True         # sparse conv3 weight gradient over the listed windows reads its second operand straight from the forward's f16
+                                      # maps through the window list (f16 -> bf16 in registers; off: 3.7 GB patch copy first, +1.0 ms; same bits)
     fused_sgd: bool = True            # train_minibatch + optim.FusedSGD: fc1.weight's gradient stays in GEMM order, one pass un-permutes, updates and
                                       # writes the f16 copy (off: transposition + update + transposition; same bits)
 

@@ -410,6 +410,40 @@ def test_window_weight_gradient_on_the_sparse_matrix_cores_equals_the_dense_bloc
             assert torch.equal(a[n], b[n]), n
 
 
+def test_window_weight_gradient_gathered_from_the_f16_maps_keeps_every_bit():
+    """``TUNING.gather_wgrad`` (default, round 6): the sparse weight-gradient block reads the 4 x 4 input patches of the listed windows
+    straight from the forward's f16 maps through the window list (per-window bases by scalar loads, f16 -> bf16 in registers) instead of
+    from a 16 KB-per-window patch copy.  Same values (the copy pass converted the same way), same products in the same order: EVERY
+    gradient bit for bit, on ragged images with edge / duplicate / empty boxes, and with the contrastive branch's second engine."""
+    from scene_graph_commonsense_amd.engine import tuning
+    from scene_graph_commonsense_amd.model import BayesianRelationClassifier
+    from scene_graph_commonsense_amd.pairs import flatten_scene
+    from scene_graph_commonsense_amd.synthetic import HeadConfig, make_scene_batch, make_state_dict
+    cfg = HeadConfig()
+    model = BayesianRelationClassifier(cfg.args()).cuda()
+    model.load_state_dict(make_state_dict(cfg, seed=9, head_gain=4.0))
+    model.eval()
+    for nobj, seed, edge in (((40, 33, 27), 91, False), ((37, 22, 9, 31), 17, True)):
+        batch = make_scene_batch(cfg, nobj, seed=seed, connect_frac=0.05)
+        if edge:
+            batch = _edge_boxes(batch)
+        sc = flatten_scene(cfg, batch, "cuda:0")
+        assert sc.shared_windows >= 8192
+        grads = []
+        for on in (True, False):
+            with tuning(gather_wgrad=on):
+                _poison(model.engine())
+                model.zero_grad(set_to_none=True)
+                loss = model.training_step(sc, batch.relationships, batch.subj_or_obj)
+                torch.cuda.synchronize()
+                grads.append((float(loss), {n: p.grad.detach().clone() for n, p in model.named_parameters()}))
+        (la, a), (lb, b) = grads
+        assert la == lb
+        for n in a:
+            assert torch.isfinite(a[n]).all(), n
+            assert torch.equal(a[n], b[n]), n
+
+
 def test_window_data_gradient_on_the_sparse_matrix_cores_equals_the_dense_patch_form():
     """``TUNING.sparse_dgrad`` (default): the conv3 data gradient over the real pairs' listed windows runs on
     ``v_smfmac_f32_32x32x32_bf16`` (csrc/kernels_dgrad_sp.hip: the pooled rows masked to the own-pixel sets are the compressed operand),
