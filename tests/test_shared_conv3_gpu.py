@@ -423,12 +423,12 @@ def test_window_weight_gradient_gathered_from_the_f16_maps_keeps_every_bit():
     model = BayesianRelationClassifier(cfg.args()).cuda()
     model.load_state_dict(make_state_dict(cfg, seed=9, head_gain=4.0))
     model.eval()
-    for nobj, seed, edge in (((40, 33, 27), 91, False), ((37, 22, 9, 31), 17, True)):
+    for nobj, seed, edge in (((40, 33, 27), 91, False), ((48, 41, 9, 36), 17, True)):
         batch = make_scene_batch(cfg, nobj, seed=seed, connect_frac=0.05)
         if edge:
             batch = _edge_boxes(batch)
         sc = flatten_scene(cfg, batch, "cuda:0")
-        assert sc.shared_windows >= 8192
+        assert sc.shared_windows >= 6000, sc.shared_windows          # the sparse (gathering) launch takes lists of >= 4096 real windows
         grads = []
         for on in (True, False):
             with tuning(gather_wgrad=on):
