@@ -310,10 +310,11 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_sp_kernel(const TnParams p, co
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    // PATCH == 2: the B fragments arrive as f16 (the forward's maps): once per K tile every fragment is converted f16 -> f32 -> bf16 in
-    // place.  In the wave's LOAD phase - behind its fragment reads, in front of the counted wait for the next operands, i.e. while the
-    // partner wave row issues its matrix instructions and this one would only wait: converted just ahead of the instructions
-    // (first version) the 96 vector instructions per K tile sat in the compute phase and the launch ran 5.65 instead of 5.3 ms
+    // PATCH == 2: the B fragments arrive as f16 (the forward's maps): once per K tile (half 0: both halves of the tile use them) every
+    // fragment is converted f16 -> f32 -> bf16 in place, the (j, s) pair just ahead of its first instruction - the 96 vector instructions per
+    // K tile then issue between the matrix instructions of the compute phase.  Measured (profiles/r06_gather_wgrad_ab.txt): the launch
+    // 5.3 -> 5.65 ms for the 1.0 ms copy pass it deletes; with the conversions in the wave's LOAD phase instead (behind the fragment reads,
+    // in front of the counted wait) 6.45 ms - that phase is the longer one of the two already.
     auto to_bf16 = [&](s16x8& v) __attribute__((always_inline)) {
         const unsigned* w = reinterpret_cast<const unsigned*>(&v);
         unsigned o[4];
@@ -329,6 +330,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_sp_kernel(const TnParams p, co
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
+                    if constexpr (PATCH == 2) {
+                        if (a == 0 && i == 0) { to_bf16(bfr[j][s][0]); to_bf16(bfr[j][s][1]); }
+                    }
                     const bf16x8_sp av = __builtin_bit_cast(bf16x8_sp, af[i][s]);
                     const s16x16_sp_t bw = __builtin_shufflevector(bfr[j][s][0], bfr[j][s][1], 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
                     const bf16x16_sp bv = __builtin_bit_cast(bf16x16_sp, bw);
@@ -363,13 +367,6 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_sp_kernel(const TnParams p, co
         unsigned long long codes = 0;
         read_a(0, par); read_b(par);
         if (it + 1 < nk) stage(3, it + 1);
-        if constexpr (PATCH == 2) {
-            SGC_WAIT_LGKM0();
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int ss = 0; ss < 2; ++ss) { to_bf16(bfr[j][ss][0]); to_bf16(bfr[j][ss][1]); }
-        }
         if constexpr (PATCH == 2 && STEADY) codes = window_codes(it + 2);      // scalar request; lands during the counted wait of close()
         close(STEADY);
         if constexpr (PATCH == 2 && STEADY) window_bases(codes);               // behind close()'s lgkmcnt(0): no wait of its own

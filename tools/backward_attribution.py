@@ -91,6 +91,18 @@ def r16(t):
     return RoundST.apply(t) if FLAGS.fwd16 else t
 
 
+W16 = {}                   # rounded weights of the current optimisation step: ONE copy per step, not one per classifier call (fc1: 2.1 GB each)
+
+
+def w16(sd, name, cols=None):
+    if not FLAGS.fwd16:
+        return sd[name] if cols is None else sd[name][:, cols]
+    key = (name, cols.start if cols is not None else None, torch.is_grad_enabled())
+    if key not in W16:
+        W16[key] = RoundST.apply(sd[name] if cols is None else sd[name][:, cols])
+    return W16[key]
+
+
 class Layer(torch.autograd.Function):
     """conv2d / linear whose backward applies the flagged roundings to its three operands."""
     @staticmethod
@@ -138,20 +150,20 @@ def pool_codes(c):
 def trunk_and_fc2(sd, hs, ho, lab_fn, drop1, drop2, routes=None, collect=None):
     """(p, routes seen).  ``routes``: impose them (exact values, foreign decisions); ``collect``: dict filled with this pass's decisions."""
     hs, ho = r16(hs), r16(ho)
-    a = r16(torch.tanh(layer(hs, r16(sd["conv1_1.weight"]), sd["conv1_1.bias"])))
-    b = r16(torch.tanh(layer(ho, r16(sd["conv1_2.weight"]), sd["conv1_2.bias"])))
-    w2 = r16(sd["conv2_1.weight"])
+    a = r16(torch.tanh(layer(hs, w16(sd, "conv1_1.weight"), sd["conv1_1.bias"])))
+    b = r16(torch.tanh(layer(ho, w16(sd, "conv1_2.weight"), sd["conv1_2.bias"])))
+    w2 = w16(sd, "conv2_1.weight")
     U = r16(layer(a, w2[:, :128], None, 1))
     V = r16(layer(b, w2[:, 128:], sd["conv2_1.bias"], 1))
     c2 = U + V
     if collect is not None:
         collect["pool2"] = pool_codes(c2.detach())
     z = r16(F.max_pool2d(F.relu(c2), 2, 2) if routes is None else O.routed_relu_pool(c2, routes["pool2"]))
-    c3 = layer(z, r16(sd["conv3_1.weight"]), sd["conv3_1.bias"], 1)
+    c3 = layer(z, w16(sd, "conv3_1.weight"), sd["conv3_1.bias"], 1)
     if collect is not None:
         collect["pool3"] = pool_codes(c3.detach())
     y = r16(F.max_pool2d(F.relu(c3), 2, 2) if routes is None else O.routed_relu_pool(c3, routes["pool3"]))
-    f1 = layer(y.reshape(y.shape[0], -1), r16(sd["fc1.weight"]), sd["fc1.bias"], 0, True)
+    f1 = layer(y.reshape(y.shape[0], -1), w16(sd, "fc1.weight"), sd["fc1.bias"], 0, True)
     if collect is not None:
         collect["relu1"] = (f1.detach() > 0).to(f1.dtype)
     h1 = F.relu(f1) if routes is None else f1 * routes["relu1"]
@@ -160,7 +172,7 @@ def trunk_and_fc2(sd, hs, ho, lab_fn, drop1, drop2, routes=None, collect=None):
     h1 = r16(h1)
     w = sd["fc2.weight"]
     hc = lab_fn(h1)
-    wq = torch.cat((r16(w[:, :4096]), w[:, 4096:]), dim=1)             # the label columns are gathered in f32 on the device
+    wq = torch.cat((w16(sd, "fc2.weight", slice(0, 4096)), w[:, 4096:]), dim=1)             # the label columns are gathered in f32 on the device
     p = layer(hc, wq, sd["fc2.bias"])
     if collect is not None:
         collect["relu2"] = (p.detach() > 0).to(p.dtype)
@@ -240,6 +252,7 @@ def run(case, variant, K, lr, names, baseline=None):
 
         before = {n: sdr[n].detach().clone() for n in names}
         FC1_DEFERRED.clear()
+        W16.clear()
         out = O.run_pair_loop(sdr, batch, cfg, mode="train", weights=weights, call_hook=hook)
         opt.zero_grad(set_to_none=True)
         out["losses"].backward()
