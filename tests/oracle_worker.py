@@ -9,6 +9,7 @@ per step for trajectories).  The process never touches a GPU (the pool hides the
                     file with the device's own pool / ReLU routes of those pairs, injected into the oracle's graph.
 * ``trajectory``  - K SGD steps (momentum, weight decay as ``train_test.py:100``) on a golden case with the kernels' dropout masks:
                     per step the loss and every parameter's update, written as ``step_<k>.pt`` as soon as the step is done.
+                    ``routes_dir``: per step the device's routes of ITS step k (``routes_<k>.pt``), injected into the oracle's graph.
 """
 import os
 import sys
@@ -89,10 +90,17 @@ def _trajectory(spec, out_dir):
         s1 = (ds * 2654435761 + 2 * (k + 1)) & 0xFFFFFFFF              # model._next_seeds of training step k + 1
         s2 = (ds * 2654435761 + 2 * (k + 1) + 1) & 0xFFFFFFFF
 
-        def hook(t, b, s1=s1, s2=s2):
+        # ``routes_dir``: the device's own ReLU / max-pool decisions of its step k (tests/train_case.device_routes, one file per step),
+        # injected into this step's graph - the routed trajectory: what is left between the two runs is arithmetic
+        routes = torch.load(os.path.join(spec["routes_dir"], "routes_%d.pt" % k)) if spec.get("routes_dir") else None
+
+        def hook(t, b, s1=s1, s2=s2, routes=routes):
             r0 = int(start[t])
-            return dict(drop1=torch.from_numpy(dropout_keep_mask(s1, b, 4096, r0)).float() * 2,
-                        drop2=torch.from_numpy(dropout_keep_mask(s2, b, 512, r0)).float() * 2)
+            inj = dict(drop1=torch.from_numpy(dropout_keep_mask(s1, b, 4096, r0)).float() * 2,
+                       drop2=torch.from_numpy(dropout_keep_mask(s2, b, 512, r0)).float() * 2)
+            if routes is not None:
+                inj["routes"] = {k_: v[r0:r0 + b] for k_, v in routes.items()}
+            return inj
 
         before = {n: sdr[n].detach().clone() for n in names}
         out = O.run_pair_loop(sdr, batch, cfg, mode="train", weights=weights, call_hook=hook)

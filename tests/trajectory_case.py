@@ -17,12 +17,29 @@ CASES = {
     "vg_full_ref_lr": ("vg_full", 1e-5, 8),
 }
 
-# Steps whose weight updates are held to the cosine bar 0.99 (default: all K).  For the later steps of ``vg_full_ref_lr`` the bar is
-# LATE_COSINE: set from the measured run, see the comment above and DESIGN.md (numerics).
-# Measured (GPUTEST of round 4, profiles/README.md): smallest update cosine per step at 1e-5 = 0.9990, 0.9986, 0.9968, 0.9936, 0.9907 |
-# 0.9891, 0.9870, 0.9779 (losses within 0.6 % throughout); at 5e-6 it stays >= 0.994 for all ten steps.
-STRICT_STEPS = {"vg_full_ref_lr": 4}          # step 5 measures 0.9907 on every box so far: too close to 0.99 to gate a suite run with -x
-LATE_COSINE = 0.95
+# THE BARS (derived, not calibrated).  ``profiles/r06_backward_attribution.txt`` runs the ``vg_full_ref_lr`` trajectory
+# (vg_full, lr 1e-5, these dropout masks) in float64 with ONE rounding source of the device path injected at a time.  Smallest update
+# cosine over the parameter tensors against the float64 trajectory, steps 1 .. 8:
+#     routes of the f16 forward only (exact values, exact backward)   0.9990 0.9990 0.9973 0.9939 0.9912 0.9900 0.9875 0.9802
+#     bf16 backward only (exact forward)                              1.0000 0.9997 0.9986 0.9958 0.9942 0.9927 0.9902 0.9791
+#     both (the model of the device)                                  0.9990 0.9985 0.9964 0.9931 0.9899 0.9886 0.9862 0.9800
+#     the device itself (GPUTEST r4 / r6)                             0.9990 0.9986 0.9968 0.9936 0.9907 0.9891 0.9870 0.9779
+#     f16 (ideally scaled) instead of bf16 gradient tensors           0.9990 0.9986 0.9965 0.9934 0.9898 0.9866 0.9838 0.9797
+# Reading: in step 1 the f16 forward's ROUTES are the whole distance (4.5e-2 relative Frobenius on conv1's gradient against 5e-3 for all
+# bf16 roundings of the backward together).  From there on ANY perturbation of the weights - the 5e-3 of bf16 alone - flips routes of its
+# own in later steps, and this schedule amplifies whatever it is given to the same ~0.98 by step 8 (its loss overshoots at step 9): the
+# sources do not add up, and gradient tensors in f16 change nothing.  What separates arithmetic from routing is therefore a comparison in
+# which the oracle walks the DEVICE's routes of every step:
+#   * ROUTED_COSINE: with the device's own ReLU / max-pool decisions injected (``tests/test_trajectory_gpu.py``) only arithmetic is left -
+#     bf16 gradient tensors and operand copies, f16 forward values, f32 accumulation order: 5e-3 relative per step on the deepest tensor,
+#     i.e. a cosine of 1 - (5e-3)^2 / 2 = 0.99999 for one step; allowing the ten steps' differences to line up instead of averaging out
+#     (10 x 5e-3): 1 - (5e-2)^2 / 2 = 0.9988, rounded to 0.999.  One bar, every step, every tensor.  (Measured: >= 0.99997.)
+#   * FREE_COSINE: without injected routes no backward, however exact, stays closer to the reference than the table's first row - a float64
+#     backward behind the f16 forward.  The un-routed bar is that row's (equally the device model's) largest drift 1 - 0.980 = 0.020 with
+#     half of it again as allowance for what the model leaves out (f32 accumulation order, the kernels' exact rounding points): 0.97.  The
+#     same number for every case and every step (rounds 3-5: 0.99 on the first four steps, 0.95 later, both set from device measurements).
+ROUTED_COSINE = 0.999
+FREE_COSINE = 0.97
 
 _NAMES = {}
 
@@ -37,14 +54,17 @@ def param_names(case):
     return _NAMES[case]
 
 
-def job_name(name):
-    return "trajectory_" + name
+def job_name(name, routed=False):
+    return ("trajectory_routed_" if routed else "trajectory_") + name
 
 
-def job_spec(name):
+def job_spec(name, routes_dir=None):
     case, lr, K = CASES[name]
-    return dict(kind="trajectory", case=case, lr=lr, K=K, momentum=MOMENTUM, weight_decay=WEIGHT_DECAY, dropout_seed=DROPOUT_SEED,
+    spec = dict(kind="trajectory", case=case, lr=lr, K=K, momentum=MOMENTUM, weight_decay=WEIGHT_DECAY, dropout_seed=DROPOUT_SEED,
                 names=param_names(case))
+    if routes_dir is not None:
+        spec["routes_dir"] = routes_dir
+    return spec
 
 
 def prelaunch(names=None):
