@@ -168,6 +168,9 @@ int sgc_windows_wgrad_patch(const void* dy3x, const void* zpatch, float* slabs, 
  * pattern; model.py:145-147 backward).  Valid for the real pairs' windows only (the per-object entries behind them hold sums of
  * several windows' gradients: sgc_windows_wgrad_patch on that tail).  dywm: POOLED gradient rows, row dest[e]; argmax at gather[e];
  * pack_ac (n_entries/16 * 64 KiB) / pack_ic (n_entries/16 * 8 KiB): scratch for the packed operand. */
+/* splits: > 0 that many K ranges (split-K slabs); 0: chosen for whole rounds of blocks on the 256 CUs; -1: K ranges PER XCD (32 ranges, every
+ * XCD runs all tiles of one channel half for every fourth range - the operands leave the fabric once / twice instead of four / two times;
+ * needs n_entries >= 32768, else as 0).  *n_slabs returns the count written. */
 int sgc_windows_wgrad_patch_sparse(const void* dywm, const unsigned char* argmax, const int* gather, const int* dest, int n_entries,
                                    const void* zpatch, void* pack_ac, void* pack_ic, float* slabs, int splits, int* n_slabs, void* stream);
 /* ... with the second operand gathered from the forward's f16 maps z_pad_f16 [pairs][18][18][512] through the window list inside the GEMM

@@ -183,9 +183,21 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_sp_kernel(const TnParams p, co
     int split, tm, tn;
     {
         const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;       // conv3: 4 M tiles x 18 N tiles, as gemm_tn_pp_kernel's xcd_map
-        split = j / 9;
-        tm = xcd & 3;
-        tn = (j - split * 9) * 2 + (xcd >> 2);
+        if (p.xcd_map == 2) {
+            // K ranges per XCD (round 6): an XCD owns one channel half of B (N tiles of one parity) and every fourth K range, and runs ALL
+            // 36 tiles (4 M tiles x 9 taps) of a K range together - its 32 CUs then share the same rows of both operands through its L2,
+            // every byte of B leaves the fabric once (one XCD per (channel half, K range)) and every byte of A twice.  The walk above
+            // gives an XCD ONE M tile and one channel half for every K range: four XCDs fetch each half of B (8 x 1.85 GB per launch).
+            // 36 tiles on 32 CUs: the split count is chosen so that an XCD's 36 s tiles fill whole rounds (s = 8: 9 rounds).
+            const int ks = j / 36, t = j - ks * 36;
+            split = ks * 4 + (xcd & 3);
+            tm = t & 3;
+            tn = (t >> 2) * 2 + (xcd >> 2);
+        } else {
+            split = j / 9;
+            tm = xcd & 3;
+            tn = (j - split * 9) * 2 + (xcd >> 2);
+        }
     }
     const int m0 = tm * BM, n0 = tn * BN;
     const int kt_begin = split * p.ktiles_per_split;
@@ -470,10 +482,15 @@ static int launch_gemm_tn_sp(TnParams p, const u16* Ac, const unsigned* Ic, int 
     if (PATCH == 2 && p.gather == nullptr) return SGC_ERR_ARG;
     p.tiles_m = 4; p.tiles_n = 18;
     const int nk = p.K >> 6;
+    if (splits == -1 && nk >= 32 * 64) {          // K ranges per XCD: 32 ranges of >= 64 K tiles (engine_bwd mirrors this rule for its slab count)
+        splits = 32;
+        p.xcd_map = 2;
+    }
     if (splits <= 0) splits = tn_auto_splits(72, nk);
     if (splits > nk) splits = nk;
     p.ktiles_per_split = (nk + splits - 1) / splits;
     splits = (nk + p.ktiles_per_split - 1) / p.ktiles_per_split;
+    if (p.xcd_map == 2 && splits != 32) return SGC_ERR_ARG;
     auto kern = gemm_tn_sp_kernel<PATCH>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     p.splits = splits;

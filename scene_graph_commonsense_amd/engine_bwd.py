@@ -5,6 +5,9 @@ from __future__ import annotations
 from .engine_core import *          # noqa: F401,F403  (TUNING, Workspace, PairOutputs, TrainContext, _lib, torch, np, ... - see engine_core.__all__)
 
 
+SLAB_CAPACITY = 48          # f32 split-K slabs of [1024][4608] in the weight-gradient chain's buffer (0.9 GB)
+
+
 class BackwardMixin:
     def _slab_sum(self, slabs, n, count):
         out = torch.empty(n, dtype=torch.float32, device=self.device)
@@ -81,7 +84,7 @@ class BackwardMixin:
         # instead of co-residing; profiles/README.md); results bit-identical either way (tests/test_configs_gpu.py).
         # ``SGC_BWD_STREAMS=0`` = one stream (used for per-kernel profiles: durations of overlapped launches mean little).
         side = self._side_chain()
-        sl = ws.get("slabs", 32 * 1024 * 4608, torch.float32)      # split-K slabs of the weight-gradient chain (largest user: conv3)
+        sl = ws.get("slabs", SLAB_CAPACITY * 1024 * 4608, torch.float32)      # split-K slabs of the weight-gradient chain (largest user: conv3)
 
         # ---- head weights
         with side():
@@ -476,10 +479,13 @@ class BackwardMixin:
                 n_slabs = slabs_n.value
                 e_sp = e_spw
                 # slab capacity is checked BEFORE anything is launched into the 32-slab buffer (the launches' own counts are the mirror's)
-                need = n_slabs + ((auto_splits(e_sp * 4) + (auto_splits((Epad - e_sp) * 4) if Epad > e_sp else 0)) if (Epad and e_sp >= 4096)
+                # K ranges per XCD (csrc/gemm_tn_sp.h, xcd_map 2): 32 ranges when the sparse part of the list has >= 2048 K tiles
+                xcd_k = bool(TUNING.wgrad_xcd_k and Epad and e_sp >= 4096 and ((e_sp * 4) >> 6) >= 2048)
+                sp_splits = 32 if xcd_k else auto_splits(e_sp * 4)
+                need = n_slabs + ((sp_splits + (auto_splits((Epad - e_sp) * 4) if Epad > e_sp else 0)) if (Epad and e_sp >= 4096)
                                   else (auto_splits(Epad * 4) if Epad else 0))
-                if need > 32:
-                    raise RuntimeError("split-K slabs of the conv3 weight gradient (%d) exceed the 32-slab buffer" % need)
+                if need > SLAB_CAPACITY:
+                    raise RuntimeError("split-K slabs of the conv3 weight gradient (%d) exceed the %d-slab buffer" % (need, SLAB_CAPACITY))
                 if Epad and e_sp >= 4096:
                     # the real pairs' windows: their un-pooled gradient has ONE non-zero per window and channel (4 consecutive K indices)
                     # - the 2:4 pattern of the sparse matrix cores; packed straight from the pooled rows.  The per-object entries behind
@@ -491,11 +497,11 @@ class BackwardMixin:
                     if gather_w:
                         self._timed("conv3_wgrad_windows", lambda: _lib.check(lib.sgc_windows_wgrad_gather_sparse(
                             _lib.ptr(dy), _lib.ptr(ctx.am), _lib.ptr(gather), _lib.ptr(dest), e_sp, _lib.ptr(ctx.z), _lib.ptr(pack_a), _lib.ptr(pack_i),
-                            _lib.ptr(slx), 0, ctypes.byref(slabs_x), st()), "sgc_windows_wgrad_gather_sparse"))
+                            _lib.ptr(slx), -1 if xcd_k else 0, ctypes.byref(slabs_x), st()), "sgc_windows_wgrad_gather_sparse"))
                     else:
                         self._timed("conv3_wgrad_windows", lambda: _lib.check(lib.sgc_windows_wgrad_patch_sparse(
                             _lib.ptr(dy), _lib.ptr(ctx.am), _lib.ptr(gather), _lib.ptr(dest), e_sp, _lib.ptr(zcol), _lib.ptr(pack_a), _lib.ptr(pack_i),
-                            _lib.ptr(slx), 0, ctypes.byref(slabs_x), st()), "sgc_windows_wgrad_patch_sparse"))
+                            _lib.ptr(slx), -1 if xcd_k else 0, ctypes.byref(slabs_x), st()), "sgc_windows_wgrad_patch_sparse"))
                     n_slabs += slabs_x.value
                     if Epad > e_sp:
                         slt = sl[n_slabs * 1024 * 4608:]

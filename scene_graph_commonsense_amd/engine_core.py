@@ -188,6 +188,8 @@ class Tuning:
     sparse_dgrad: bool = True         # conv3 data gradient over the real pairs' listed windows on the sparse matrix cores (off: dense patch form)
     gather_wgrad: bool = True         # sparse conv3 weight gradient over the listed windows reads its second operand straight from the forward's f16
                                       # maps through the window list (f16 -> bf16 in registers; off: 3.7 GB patch copy first, +1.0 ms; same bits)
+    wgrad_xcd_k: bool = True          # sparse conv3 weight gradient: every XCD owns K ranges (all 36 tiles of a channel half) instead of one M tile
+                                      # for every K range: B leaves the fabric once instead of four times (32 split-K slabs instead of 7)
     fused_sgd: bool = True            # train_minibatch + optim.FusedSGD: fc1.weight's gradient stays in GEMM order, one pass un-permutes, updates and
                                       # writes the f16 copy (off: transposition + update + transposition; same bits)
 
