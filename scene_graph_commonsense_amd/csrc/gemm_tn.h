@@ -226,7 +226,16 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(const TnParams p) {
     const int wr = wid >> 2, wc = wid & 3;
     const int tiles = p.tiles_n * p.tiles_m;
     int split, tm, tn;
-    if (p.xcd_map) {
+    if (p.xcd_map == 3) {
+        // grouped form, 64 groups (window positions w = 8 row + col) of 64 tiles (round 6): ALL tiles of a group on ONE XCD - its 32 CUs share
+        // the group's rows of both operands through its L2 and every operand byte leaves the fabric once (tiles of a group dealt over the
+        // eight XCDs: every XCD fetched all of B and an eighth of A, 9.5 GB per step against 4.2 algorithmic).  Groups differ in length
+        // (centre windows are pair-specific more often than border windows): an XCD takes one window of every row and of every column.
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;          // j = 0 .. 511: the XCD's eight groups, 64 tiles each
+        const int i = j >> 6;
+        split = i * 8 + ((xcd - i) & 7);
+        supertile_map(j & 63, p.tiles_m, p.tiles_n, tm, tn);
+    } else if (p.xcd_map) {
         const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
         split = j / 9;
         tm = xcd & 3;

@@ -1743,6 +1743,7 @@ int sgc_fc1_windows_wgrad(const void* gwm, const void* ywm_bf16, const int* goff
     p.A = (const u16*)gwm; p.B = (const u16*)ywm_bf16; p.C = dw; p.M = 4096; p.N = 1024; p.K = rows;
     p.lda = 4096; p.ldb = 1024; p.ldc = 65536; p.goff = goff;
     p.tiles_m = 16; p.tiles_n = 4; p.ktiles_per_split = 0; p.splits = 64; p.xcd_map = 0; p.xcd_patch = 1;
+    if (sgc_tuning().fc1_wgrad_group_xcd) { p.xcd_map = 3; p.xcd_patch = 0; }       // a group's 64 tiles on one XCD (gemm_tn.h)
     auto kern = gemm_tn_pp_kernel<ELEM_BF16, BMODE_PLAIN, 0>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 16384);
     SGC_LAUNCH(kern, dim3(64 * 64), dim3(512), 8 * 16384, (hipStream_t)stream, p);

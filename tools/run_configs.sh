@@ -12,6 +12,11 @@ ARGS="" run "8x64 default (two-stream backward, GEMMs apart)" SGC_NOOP=1
 ARGS="" run "8x64 SGC_TUNING=gemms_apart=0 (round-2 order)" SGC_TUNING=gemms_apart=0
 ARGS="" run "8x64 SGC_BWD_STREAMS=0 (one stream)" SGC_BWD_STREAMS=0
 ARGS="" run "8x64 default again" SGC_NOOP=1
+ARGS="" run "8x64 round-6 switches off: fc1_x16=0" SGC_TUNING=fc1_x16=0
+ARGS="" run "8x64 round-6 switches off: wgrad_xcd_k=0 (one M tile per XCD for every K range)" SGC_TUNING=wgrad_xcd_k=0
+ARGS="" run "8x64 round-6 switches off: gather_wgrad=0 (patch copy for the whole list)" SGC_TUNING=gather_wgrad=0
+ARGS="" run "8x64 all three off (round 5's step)" SGC_TUNING=fc1_x16=0,wgrad_xcd_k=0,gather_wgrad=0
+ARGS="" run "8x64 default, third time" SGC_NOOP=1
 ARGS="" run "8x64 column forms of the conv3 window backward (rounds 1-2)" SGC_TUNING=patch_dgrad=0,patch_wgrad=0
 ARGS="" run "8x64 SGC_TUNING=shared_linear=0 (every pair convolves its own X windows)" SGC_TUNING=shared_linear=0
 ARGS="" run "8x64 SGC_SHARED_LEVEL=2 (no second level)" SGC_SHARED_LEVEL=2
