@@ -102,7 +102,7 @@ def test_bench_two_ranks_end_to_end_on_one_gpu_over_gloo():
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--objects", "20",
-                        "--images", "4", "--backend", "gloo", "--no-cpu-baseline"], capture_output=True, text=True, timeout=1200, env=env)
+                        "--images", "4", "--backend", "gloo", "--no-cpu-baseline"], capture_output=True, text=True, timeout=420, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout
@@ -120,7 +120,7 @@ def test_bench_eight_ranks_end_to_end_on_one_gpu_over_gloo():
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "1", "--objects", "6",
-                        "--images", "2", "--backend", "gloo", "--no-cpu-baseline"], capture_output=True, text=True, timeout=1500, env=env)
+                        "--images", "2", "--backend", "gloo", "--no-cpu-baseline"], capture_output=True, text=True, timeout=420, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout
