@@ -36,8 +36,10 @@ struct SgcTuning {
     int gather_pp = 1;       // SGC_GATHER_PP: ping-pong block for the gathered conv3 forward
     int owm_pitch = 4160;    // SGC_OWM_PITCH: row pitch (floats) of fc1's f32 products over the window-major rows; 4096 + 256 B (a power of two is 10 % slower)
     int f32_swap = 1;        // SGC_F32_SWAP: f32 products of fc1 over the window-major rows leave as 16-byte stores (operands swapped in the MFMA)
-    int fc1_wgrad_group_xcd = 1;   // SGC_FC1_WGRAD_XCD (read in every build: the A/B of profiles/r06_fc1_wgrad_xcd_ab.txt): fc1's grouped weight gradient
-                                   // runs all 64 tiles of a window-position group on one XCD (0: dealt over the eight XCDs)
+    int fc1_wgrad_group_xcd = 0;   // SGC_FC1_WGRAD_XCD (read in every build: the A/B of profiles/r06_fc1_wgrad_xcd_ab.txt): 1 = fc1's grouped weight gradient
+                                   // runs all 64 tiles of a window-position group on one XCD.  Measured and left OFF: the launch 2.39 -> 2.77 ms,
+                                   // the step +0.4 ms - eight sequences of eight groups of different length do not balance, and half of the fabric
+                                   // traffic it saves (9.5 -> 4.2 GB) was Infinity-Cache hits that cost the neighbours nothing
 };
 inline const SgcTuning& sgc_tuning() {
     static const SgcTuning t = [] {
