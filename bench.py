@@ -43,11 +43,12 @@ WINDOW_GEMMS = {
     "conv3_dgrad_windows": (("gemm_nt_sp_kernel", "gemm_nt_pp_kernel<1, 0, 0, 0, 1>"),
                             "gemm_nt_sp_kernel (sgc_windows_dgrad_patches_sparse: conv3 data gradient of the real pairs' listed windows in patch "
                             "form on the sparse matrix cores; executed = issued multiply-adds, 20 of the dense form's 36 per window)"),
-    "conv3_wgrad_windows": (("gemm_tn_sp_kernel<1>",),
-                            "gemm_tn_sp_kernel<patch> (sgc_windows_wgrad_patch_sparse: conv3 weight gradient of the real pairs' listed windows, "
-                            "2:4-sparse un-pooled gradient x 4x4 input patches; executed = non-zero multiply-adds only)"),
+    "conv3_wgrad_windows": (("gemm_tn_sp_kernel<2>", "gemm_tn_sp_kernel<1>"),
+                            "gemm_tn_sp_kernel<gather> (sgc_windows_wgrad_gather_sparse: conv3 weight gradient of the real pairs' listed windows, "
+                            "2:4-sparse un-pooled gradient x 4x4 input patches gathered from the forward's f16 maps, K ranges per XCD; "
+                            "executed = non-zero multiply-adds only)"),
 }
-PMC_TAGS = ("r05_final7", "r05_final6", "r05_final5", "r05_final3", "r05_final2", "r05_final", "r05_mid", "r04_final5", "r04_final4", "r04_final3", "r04_final2", "r04_final", "r03_final6")   # newest committed profile sets first
+PMC_TAGS = ("r06_final", "r05_final7", "r05_final6", "r05_final5", "r05_final3", "r05_final2", "r05_final", "r05_mid", "r04_final5", "r04_final4", "r04_final3", "r04_final2", "r04_final", "r03_final6")   # newest committed profile sets first
 
 
 BENCH_LR_SCALE = 1e-3
@@ -189,8 +190,9 @@ def window_gemm_bytes(key, n_list, e_obj, live_rows, n_ps):
                            of weights; per listed window 2 KiB pooled y (f16) + 2 KiB bf16 copy + 1 KiB routing bytes written.
       conv3_dgrad_windows: per listed window of the sparse launch 4 masked pooled rows of 2 KiB + 4 x 256 B index words read, 16 patch
                            rows of 1 KiB written; 42 MB of weights.
-      conv3_wgrad_windows: per listed window of the sparse launch 16 patch rows of 1 KiB + 4 KiB packed gradient + 512 B index words
-                           read; the 18.9 MB f32 result written once (its split-K slabs are not algorithmic)."""
+      conv3_wgrad_windows: the distinct z rows under the windows' 4 x 4 patches (1 KiB each, gathered from the forward's maps; at most 16 per
+                           window) + per listed window 4 KiB packed gradient + 512 B index words read; the 18.9 MB f32 result written
+                           once (its split-K slabs are not algorithmic)."""
     e_real = max(n_list - e_obj, 0)
     if key == "conv3_fwd_windows":
         rows = (live_rows if live_rows is not None else e_real * 16) + min(e_obj * 16, n_ps * 256)
@@ -200,7 +202,10 @@ def window_gemm_bytes(key, n_list, e_obj, live_rows, n_ps):
         return int(e * (4 * 2048 + 4 * 256 + 16 * 1024) + 20 * 512 * 2048 * 2)
     if key == "conv3_wgrad_windows":
         e = (e_real // 16) * 16
-        return int(e * (16 * 1024 + 4096 + 512) + 1024 * 4608 * 4)
+        # second operand: the distinct f16 z rows under the windows' patches (gathered from the maps: neighbouring windows share rows),
+        # at most 16 per window
+        rows = min(live_rows, e * 16) if live_rows is not None else e * 16
+        return int(rows * 1024 + e * (4096 + 512) + 1024 * 4608 * 4)
     return None
 
 
