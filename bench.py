@@ -591,9 +591,8 @@ def run_rank(args):
                    "bytes": int(eb), "ms_per_launch": round(kern["expand_dense"], 3), "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
                    "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                    "note": "algorithmic bytes: 1 KiB z row + 256 B routing codes per live item, 4 KiB per distinct (object, role, pixel) read "
-                           "once; the launch is bound by its vector instructions (~195 per lane and item: SQ_INSTS_VALU, vector pipes "
-                           "~55 % busy), not by these bytes (profiles/r05_expand_ab.txt: 308 -> 195 instructions per item took it from "
-                           "1.33 to 0.83 ms)"}
+                           "once; the launch is bound by its vector instructions (~156 per lane and item after round 6's v_fma_mix_f32 / "
+                           "v_max3_f32 form, ~200 before: profiles/r06_expand_ab.txt), not by these bytes"}
         ex = executed_flops(P, args.images, m["n_obj"], n_x, n_list, m["shared"], args.forward_only, linear=m["linear"])
         if roof is not None:
             # whole-step efficiency on EXECUTED matrix flops (the per-pair form SURVEY 8d prices is mostly not executed any more)

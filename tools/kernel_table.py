@@ -44,7 +44,7 @@ ROWS = [
     ("masks: per-object masked maps forward / backward, tanh backward, conv2 region fills", "engine_fwd.object_halves, engine_bwd", "sgc_object_masked_maps[_bwd], sgc_tanh_bwd, sgc_conv2_*regions*",
      "HBM / latency", [r"mask_objects", r"tanh_bwd", r"conv2_fill", r"conv2_regions", r"conv2_bwd_regions", r"fill_zero"]),
     ("scene tables + shared-window plan (pair tables, window lists, placement)", "pairs.flatten_scene, engine_plan", "sgc_scene_tables, sgc_shared_windows_*, sgc_bucket_place_seg, sgc_scan_rows",
-     "latency", [r"scene_", r"shared_", r"bucket_", r"scan_rows"]),
+     "latency", [r"scene_", r"shared_", r"bucket_", r"scan_rows", r"window_rows", r"pseudo_pair"]),
     ("torch-native elementwise / cat / reduce launches still issued from Python, memcpy / memset", "various", "-", "latency", [r"at::native", r"rocclr", r"cub::", r"rocprim"]),
 ]
 

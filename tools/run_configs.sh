@@ -15,7 +15,7 @@ ARGS="" run "8x64 default again" SGC_NOOP=1
 ARGS="" run "8x64 round-6 switches off: fc1_x16=0" SGC_TUNING=fc1_x16=0
 ARGS="" run "8x64 round-6 switches off: wgrad_xcd_k=0 (one M tile per XCD for every K range)" SGC_TUNING=wgrad_xcd_k=0
 ARGS="" run "8x64 round-6 switches off: gather_wgrad=0 (patch copy for the whole list)" SGC_TUNING=gather_wgrad=0
-ARGS="" run "8x64 all three off (round 5's step)" SGC_TUNING=fc1_x16=0,wgrad_xcd_k=0,gather_wgrad=0
+ARGS="" run "8x64 all three off (the step of round 5)" SGC_TUNING=fc1_x16=0,wgrad_xcd_k=0,gather_wgrad=0
 ARGS="" run "8x64 default, third time" SGC_NOOP=1
 ARGS="" run "8x64 column forms of the conv3 window backward (rounds 1-2)" SGC_TUNING=patch_dgrad=0,patch_wgrad=0
 ARGS="" run "8x64 SGC_TUNING=shared_linear=0 (every pair convolves its own X windows)" SGC_TUNING=shared_linear=0
