@@ -55,7 +55,8 @@ def test_dropout_training_step_matches_oracle(name):
         assert e <= (HEAD_TOL if k.split(".")[0] in HEAD else FREE_TOL), (k, e)
 
 
-@pytest.mark.parametrize("name,dropout", [("vg_full", False), ("vg_full", True), ("oiv6_full", True), ("vg_flat", False)])
+# (dropout off: the routed comparison of vg_full / vg_flat / oiv6_full is part of tests/test_backward_gpu.py::test_backward_matches_reference_fingerprints)
+@pytest.mark.parametrize("name,dropout", [("vg_full", True), ("oiv6_full", True)])
 def test_backward_with_device_routes_is_arithmetic_exact(name, dropout):
     cfg, sd, batch, _ = load_case(name)
     loss, grads, routes, sc = run_train_gpu(cfg, sd, batch, dropout=dropout, seeds=SEEDS, keep_ctx=True)

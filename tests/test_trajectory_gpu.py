@@ -11,8 +11,9 @@ oracle drawing the SAME dropout masks (``synthetic.dropout_keep_mask`` replicate
 * ROUTED - the oracle walks the device's own ReLU / max-pool decisions of every step (captured from the engine contexts,
   ``tests/train_case.device_routes``): what is left is arithmetic.  Every parameter tensor's update (w_k+1 - w_k = lr x momentum buffer)
   has cosine >= ROUTED_COSINE with the oracle's at EVERY step, its norm within 2 %, the loss within 2e-3.
-* FREE - no routes injected: the loss curves agree within 1e-2 relative at every step, update cosines >= FREE_COSINE (what a float64
-  backward behind an f16 forward does on this trajectory, see the table), norms within 10 %.
+* FREE - no routes injected (``FREE_CASES``: the VG case at the reference's rate - the hard one; the OpenImages case measured >= 0.998 at
+  every step in rounds 4-6 and its extra oracle job is not worth the host time): the loss curves agree within 1e-2 relative at every step,
+  update cosines >= FREE_COSINE (what a float64 backward behind an f16 forward does on this trajectory, see the table), norms within 10 %.
 
 The run must train (the oracle's loss falls by >= 10 % over the K steps), otherwise nothing is tested.  The oracle's K steps run as
 jobs of ``tests/oracle_pool.py`` (processes beside the GPU tests): the un-routed one starts when collection ends, the routed one as
@@ -28,7 +29,7 @@ import torch
 
 from tests import oracle_pool
 from tests.golden_cases import load_case
-from tests.trajectory_case import CASES, DROPOUT_SEED, FREE_COSINE, MOMENTUM, ROUTED_COSINE, WEIGHT_DECAY, job_name, job_spec, param_names
+from tests.trajectory_case import CASES, DROPOUT_SEED, FREE_CASES, FREE_COSINE, MOMENTUM, ROUTED_COSINE, WEIGHT_DECAY, job_name, job_spec, param_names
 
 pytestmark = pytest.mark.gpu
 _DEVICE = {}
@@ -90,7 +91,6 @@ def device_trajectory(name):
 
 
 @pytest.mark.oracle_launch
-@pytest.mark.oracle_jobs("trajectory")
 @pytest.mark.parametrize("name", list(CASES))
 def test_device_trajectory(name):
     d = device_trajectory(name)
@@ -136,7 +136,6 @@ def _compare(name, routed):
 
 
 @pytest.mark.oracle_join
-@pytest.mark.oracle_jobs("trajectory")
 @pytest.mark.parametrize("name", list(CASES))
 def test_training_trajectory_with_device_routes_is_arithmetic_exact(name):
     d, ref_losses, step_cos, worst_norm = _compare(name, routed=True)
@@ -151,7 +150,7 @@ def test_training_trajectory_with_device_routes_is_arithmetic_exact(name):
 
 @pytest.mark.oracle_join
 @pytest.mark.oracle_jobs("trajectory")
-@pytest.mark.parametrize("name", list(CASES))
+@pytest.mark.parametrize("name", FREE_CASES)
 def test_training_trajectory_matches_f32_oracle(name):
     d, ref_losses, step_cos, worst_norm = _compare(name, routed=False)
     for k in range(d["K"]):
