@@ -444,6 +444,39 @@ def test_window_weight_gradient_gathered_from_the_f16_maps_keeps_every_bit():
             assert torch.equal(a[n], b[n]), n
 
 
+def test_window_weight_gradient_with_k_ranges_per_xcd_is_the_same_sum():
+    """``TUNING.wgrad_xcd_k`` (default, round 6): for lists of >= 32 768 real windows the sparse weight-gradient launch cuts K into 32 ranges
+    and gives every XCD all 36 tiles of one channel half for every fourth range (``csrc/gemm_tn_sp.h``, xcd_map 2) instead of 7 ranges with one
+    M tile per XCD.  Same products, another partition of the f32 sums: conv3_1.weight's gradient to 1e-5, every other gradient bit for bit."""
+    from scene_graph_commonsense_amd.engine import tuning
+    from scene_graph_commonsense_amd.model import BayesianRelationClassifier
+    from scene_graph_commonsense_amd.pairs import flatten_scene
+    from scene_graph_commonsense_amd.synthetic import HeadConfig, make_scene_batch, make_state_dict
+    cfg = HeadConfig()
+    model = BayesianRelationClassifier(cfg.args()).cuda()
+    model.load_state_dict(make_state_dict(cfg, seed=9, head_gain=4.0))
+    model.eval()
+    batch = make_scene_batch(cfg, (64, 64, 64), seed=23, connect_frac=0.03)
+    sc = flatten_scene(cfg, batch, "cuda:0")
+    assert sc.shared_windows >= 40000, sc.shared_windows
+    grads = []
+    for on in (True, False):
+        with tuning(wgrad_xcd_k=on):
+            model.zero_grad(set_to_none=True)
+            loss = model.training_step(sc, batch.relationships, batch.subj_or_obj)
+            torch.cuda.synchronize()
+            grads.append((float(loss), {n: p.grad.detach().clone() for n, p in model.named_parameters()}))
+    (la, a), (lb, b) = grads
+    assert la == lb
+    for n in a:
+        if n == "conv3_1.weight":
+            e = float((a[n].double() - b[n].double()).norm() / b[n].double().norm())
+            print("conv3_1.weight, K ranges per XCD vs per M tile", e)
+            assert 0 < e <= 1e-5, e                      # 0 would mean the switch did not take (the list is long enough for it)
+        else:
+            assert torch.equal(a[n], b[n]), n
+
+
 def test_window_data_gradient_on_the_sparse_matrix_cores_equals_the_dense_patch_form():
     """``TUNING.sparse_dgrad`` (default): the conv3 data gradient over the real pairs' listed windows runs on
     ``v_smfmac_f32_32x32x32_bf16`` (csrc/kernels_dgrad_sp.hip: the pooled rows masked to the own-pixel sets are the compressed operand),
