@@ -146,9 +146,13 @@ class WeightsMixin:
         self._permute_cast(c3, wd3, 1, [512, 16, 9, 64], [9, 64 * 4608, -1, 4608], src_off=8)
         w["wd3"] = wd3.view(512, 9216)
         # [(tap, c_in)][c_out]: second operand of the column form of the data gradient over pair-specific windows
-        w3col = self.ws.get("w3col", 4608 * 1024, torch.bfloat16)
-        self._permute_cast(c3, w3col, 1, [9, 512, 1024], [1, 9, 4608])
-        w["w3col"] = w3col.view(4608, 1024)
+        # (only the column form reads it - ``TUNING.patch_dgrad`` off: made on first use, not on every step)
+        def make_w3col():
+            w3col = self.ws.get("w3col", 4608 * 1024, torch.bfloat16)
+            with torch.no_grad():
+                self._permute_cast(g("conv3_1.weight").contiguous(), w3col, 1, [9, 512, 1024], [1, 9, 4608])
+            return w3col.view(4608, 1024)
+        w.defer("w3col", make_w3col)
         # patch form of the same data gradient: per patch pixel pp = (py, px) the transposed tap matrices of its combinations, stacked along K
         opts = self._PATCH_OPTS
         d_off, d_ld, s_off, base = [], [], [], 0
