@@ -15,11 +15,11 @@ class BackwardMixin:
         return out
 
 
-    def _colsum(self, X, rows, cols, elem=ELEM_BF16, blocks=None):
+    def _colsum(self, X, rows, cols, elem=ELEM_BF16, blocks=None, part_name="colsum_part"):
         if blocks is None:
             blocks = max(1, min(512, rows // 64))
         blocks = int(max(1, min(blocks, rows)))
-        part = self.scratch.get("colsum_part", blocks * cols, torch.float32)
+        part = self.scratch.get(part_name, blocks * cols, torch.float32)
         _lib.check(self.lib.sgc_colsum(elem, _lib.ptr(X), _lib.ptr(part), _c_long(rows), cols, blocks, self._st()), "sgc_colsum")
         return self._slab_sum(part, cols, blocks)
 
@@ -163,6 +163,15 @@ class BackwardMixin:
             c2_n = ws.get("c2b_n", 4, torch.int32)
             _lib.check(lib.sgc_conv2_bwd_regions(_lib.ptr(ctx.bbox), n_obj, n_objx, 1, _lib.ptr(c2_list), _lib.ptr(c2_n), st()), "sgc_conv2_bwd_regions")
         mapU, mapA = 34 * 34 * 512, 34 * 34 * 128
+        # The conv2 / conv1 weight gradients (0.56 + 0.1 ms per role) and their slab / column sums.  On the side stream they queue up BEHIND
+        # the sparse conv3 weight gradient, which starts when the data-gradient GEMM ends and is that stream's long pole (5.7 ms alone,
+        # 8.4 beside this loop's passes): the caller's stream finished at 35.1 ms of the step and then waited 2.7 ms for the side stream's
+        # tail (tools/two_stream_timeline.py, profiles/r06_two_stream_timeline.txt).  ``TUNING.small_wgrads_main``: they run in line on
+        # the caller's stream - inside the time it would otherwise wait - with slabs / partial sums of their own.
+        in_line = bool(TUNING.small_wgrads_main and TUNING.bwd_streams)
+        small = contextlib.nullcontext if in_line else side
+        sl_s = ws.get("slabs_small", 32 * 512 * 1152, torch.float32) if in_line else sl
+        cpn = "colsum_part_main" if in_line else "colsum_part"
         for r, csr in ((0, sub_csr), (1, obj_csr)):
             dU = ws.get("dU_pad_%d" % r, n_objx * mapU, torch.bfloat16)
             if shared is not None:
@@ -173,15 +182,17 @@ class BackwardMixin:
             else:
                 self._timed("contract", lambda: _lib.check(lib.sgc_pair_contract(_lib.ptr(dz), _lib.ptr(ctx.amz), _lib.ptr(csr[0]), _lib.ptr(csr[1]), _lib.ptr(dU), n_obj, st()),
                            "sgc_pair_contract"))
-            with side():
+            with small():
                 a_pad = self.ws.get("a_pad_%d" % r, n_objx * mapA, torch.float16)      # kept by the forward
                 a_bf = self._to_bf16("a_pad_bf", a_pad, n_objx * mapA)
-                self._timed("conv2_wgrad", lambda: _lib.check(lib.sgc_conv2_wgrad(_lib.ptr(dU), _lib.ptr(a_bf), _lib.ptr(sl), n_objx, 0, ctypes.byref(slabs_n), st()),
+                self._timed("conv2_wgrad", lambda: _lib.check(lib.sgc_conv2_wgrad(_lib.ptr(dU), _lib.ptr(a_bf), _lib.ptr(sl_s), n_objx, 0, ctypes.byref(slabs_n), st()),
                            "sgc_conv2_wgrad"))
-                dW2r = self._slab_sum(sl, 512 * 1152, slabs_n.value)
+                if slabs_n.value > 32:
+                    raise RuntimeError("split-K slabs of the conv2 weight gradient (%d) exceed its 32-slab buffer" % slabs_n.value)
+                dW2r = self._slab_sum(sl_s, 512 * 1152, slabs_n.value)
                 gc2[:, r * 128:(r + 1) * 128] = dW2r.view(512, 3, 3, 128).permute(0, 3, 1, 2)
                 if r == 1:
-                    grads["conv2_1.bias"] = self._colsum(dU, n_objx * 34 * 34, 512)
+                    grads["conv2_1.bias"] = self._colsum(dU, n_objx * 34 * 34, 512, part_name=cpn)
             da = ws.get("da", n_objx * 1024 * 128, torch.bfloat16)
             if c2_list is not None:
                 Workspace._zero(da)                  # unlisted cells: the gradient there is exactly zero
@@ -201,18 +212,18 @@ class BackwardMixin:
             dp1 = ws.get("dpre1_%d" % r, n_img * 1024 * 128, torch.bfloat16)
             _lib.check(lib.sgc_tanh_bwd(_lib.ptr(dA), _lib.ptr(ctx.a_img[r]), _lib.ptr(dp1), _c_long(n_img * 1024 * 128), st()),
                        "sgc_tanh_bwd")
-            with side():
+            with small():
                 x_bf = self._to_bf16("x_bf", ctx.x[r], n_img * 1024 * XC)
-                _lib.check(lib.sgc_conv1_wgrad(_lib.ptr(dp1), _lib.ptr(x_bf), _lib.ptr(sl), n_img * 1024, XC, 16, ctypes.byref(slabs_n), st()),
+                _lib.check(lib.sgc_conv1_wgrad(_lib.ptr(dp1), _lib.ptr(x_bf), _lib.ptr(sl_s), n_img * 1024, XC, 16, ctypes.byref(slabs_n), st()),
                            "sgc_conv1_wgrad")
-                dW1 = self._slab_sum(sl, 128 * XC, slabs_n.value).view(128, XC)
+                dW1 = self._slab_sum(sl_s, 128 * XC, slabs_n.value).view(128, XC)
                 nm = "conv1_%d" % (r + 1)
                 grads[nm + ".weight"] = dW1[:, :257].reshape(128, 257, 1, 1).contiguous()
                 tb = torch.tanh(w["b1"][r])
                 dcst = self._slab_sum(cpart, 128, n_cst)
                 if dcst_bg is not None:
                     dcst = dcst + dcst_bg
-                grads[nm + ".bias"] = self._colsum(dp1, n_img * 1024, 128) + dcst * (1 - tb * tb)
+                grads[nm + ".bias"] = self._colsum(dp1, n_img * 1024, 128, part_name=cpn) + dcst * (1 - tb * tb)
         with side():
             grads["conv2_1.weight"] = gc2
         side.join()                              # the caller's stream continues only after every gradient is complete

@@ -190,6 +190,8 @@ class Tuning:
                                       # maps through the window list (f16 -> bf16 in registers; off: 3.7 GB patch copy first, +1.0 ms; same bits)
     wgrad_xcd_k: bool = True          # sparse conv3 weight gradient: every XCD owns K ranges (all 36 tiles of a channel half) instead of one M tile
                                       # for every K range: B leaves the fabric once instead of four times (32 split-K slabs instead of 7)
+    small_wgrads_main: bool = True    # two-stream backward: the conv2 / conv1 weight gradients run in line on the caller's stream instead of behind the
+                                      # side stream's long sparse conv3 weight gradient (the caller's stream waited 2.7 ms for that tail)
     fused_sgd: bool = True            # train_minibatch + optim.FusedSGD: fc1.weight's gradient stays in GEMM order, one pass un-permutes, updates and
                                       # writes the f16 copy (off: transposition + update + transposition; same bits)
 
