@@ -170,7 +170,7 @@ class BackwardMixin:
         # the caller's stream - inside the time it would otherwise wait - with slabs / partial sums of their own.
         in_line = bool(TUNING.small_wgrads_main and TUNING.bwd_streams)
         small = contextlib.nullcontext if in_line else side
-        sl_s = ws.get("slabs_small", 32 * 512 * 1152, torch.float32) if in_line else sl
+        sl_s = ws.get("slabs_small", 64 * 512 * 1152, torch.float32) if in_line else sl      # 64 = the most splits the launches choose (csrc/gemm_tn.h:tn_auto_splits)
         cpn = "colsum_part_main" if in_line else "colsum_part"
         for r, csr in ((0, sub_csr), (1, obj_csr)):
             dU = ws.get("dU_pad_%d" % r, n_objx * mapU, torch.bfloat16)
@@ -187,8 +187,7 @@ class BackwardMixin:
                 a_bf = self._to_bf16("a_pad_bf", a_pad, n_objx * mapA)
                 self._timed("conv2_wgrad", lambda: _lib.check(lib.sgc_conv2_wgrad(_lib.ptr(dU), _lib.ptr(a_bf), _lib.ptr(sl_s), n_objx, 0, ctypes.byref(slabs_n), st()),
                            "sgc_conv2_wgrad"))
-                if slabs_n.value > 32:
-                    raise RuntimeError("split-K slabs of the conv2 weight gradient (%d) exceed its 32-slab buffer" % slabs_n.value)
+                assert slabs_n.value <= 64
                 dW2r = self._slab_sum(sl_s, 512 * 1152, slabs_n.value)
                 gc2[:, r * 128:(r + 1) * 128] = dW2r.view(512, 3, 3, 128).permute(0, 3, 1, 2)
                 if r == 1:
