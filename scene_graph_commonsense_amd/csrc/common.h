@@ -37,9 +37,9 @@ struct SgcTuning {
     int owm_pitch = 4160;    // SGC_OWM_PITCH: row pitch (floats) of fc1's f32 products over the window-major rows; 4096 + 256 B (a power of two is 10 % slower)
     int f32_swap = 1;        // SGC_F32_SWAP: f32 products of fc1 over the window-major rows leave as 16-byte stores (operands swapped in the MFMA)
     int fc1_wgrad_group_xcd = 0;   // SGC_FC1_WGRAD_XCD (read in every build: the A/B of profiles/r06_fc1_wgrad_xcd_ab.txt): 1 = fc1's grouped weight gradient
-                                   // runs all 64 tiles of a window-position group on one XCD.  Measured and left OFF: the launch 2.39 -> 2.77 ms,
-                                   // the step +0.4 ms - eight sequences of eight groups of different length do not balance, and half of the fabric
-                                   // traffic it saves (9.5 -> 4.2 GB) was Infinity-Cache hits that cost the neighbours nothing
+                                   // runs half a window-position group (32 tiles) per XCD at a time.  Measured and left OFF: whole groups per XCD
+                                   // 2.39 -> 2.77 ms (eight sequences of unequal groups), half groups 2.37 -> 2.41 ms and the step unchanged -
+                                   // the fabric traffic it saves (9.5 -> ~4.8 GB) was Infinity-Cache hits that cost the neighbours nothing
 };
 inline const SgcTuning& sgc_tuning() {
     static const SgcTuning t = [] {

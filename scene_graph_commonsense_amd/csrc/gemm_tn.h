@@ -231,10 +231,14 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(const TnParams p) {
         // the group's rows of both operands through its L2 and every operand byte leaves the fabric once (tiles of a group dealt over the
         // eight XCDs: every XCD fetched all of B and an eighth of A, 9.5 GB per step against 4.2 algorithmic).  Groups differ in length
         // (centre windows are pair-specific more often than border windows): an XCD takes one window of every row and of every column.
-        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;          // j = 0 .. 511: the XCD's eight groups, 64 tiles each
-        const int i = j >> 6;
-        split = i * 8 + ((xcd - i) & 7);
-        supertile_map(j & 63, p.tiles_m, p.tiles_n, tm, tn);
+        // (second form, round 6: HALF a group - 8 M tiles x all 4 N tiles = 32 tiles, one round of the XCD's CUs - per unit, sixteen units
+        //  per XCD: the two halves of a group go to XCDs four apart, B leaves the fabric twice, A once.)
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;          // j = 0 .. 511: the XCD's sixteen units of 32 tiles
+        const int unit = j >> 5, t = j & 31;
+        const int half = unit & 1, row = unit >> 1;
+        split = row * 8 + ((xcd - row - 4 * half) & 7);
+        tm = half * 8 + (t >> 2);
+        tn = t & 3;
     } else if (p.xcd_map) {
         const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
         split = j / 9;
